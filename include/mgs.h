@@ -1,0 +1,200 @@
+/*
+ * mgs.h — C ABI of the MI355X-native VK3DGSR hot path ("mgs" = MI355X gaussian splatting).
+ *
+ * This header is the drop-in boundary.  The reference
+ * (nvpro-samples/vk_gaussian_splatting @ 2026.1.6) has no plugin/FFI API; the seam below is the
+ * narrowest set of C++ member calls through which its renderer is reached.  Every entry point
+ * cites the reference interface it replaces.  Plain pointers and sizes only; no exceptions
+ * cross this boundary; every function returns an MgsStatus (0 = ok, <0 = error) and the
+ * message is available from mgs_last_error() (thread-local).
+ *
+ * Matrix convention: float[16] in glm column-major memory order (m[col*4+row]), right-handed,
+ * clip z in [0,1]; proj[5] may be negative (Vulkan Y flip) — exactly what
+ * nvutils::CameraManipulator hands to GaussianSplatting::updateAndUploadFrameInfoUBO
+ * (src/gaussian_splatting.cpp:1162-1173).
+ *
+ * Threading: handle-level thread compatibility — one thread per MgsScene at a time
+ * (the reference has a single Vulkan submitter thread, src/gaussian_splatting.cpp:335).
+ */
+#ifndef MGS_H
+#define MGS_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGS_ABI_VERSION 1
+
+typedef enum MgsStatus {
+  MGS_OK              = 0,
+  MGS_ERR_INVALID_ARG = -1,
+  MGS_ERR_IO          = -2,  /* file missing / unreadable            (PlyLoaderAsync E_FAILURE, ply_loader_async.h:37-44) */
+  MGS_ERR_FORMAT      = -3,  /* not a valid 3DGS .ply/.spz/.splat    ("invalid 3DGS PLY file", ply_loader_async.cpp:449)  */
+  MGS_ERR_DEVICE      = -4,  /* HIP error                            (NVVK_CHECK, never aborts here)                     */
+  MGS_ERR_OOM         = -5,
+  MGS_ERR_STATE       = -6,  /* call order violated (e.g. render before commit)                                          */
+  MGS_ERR_OVERFLOW    = -7,  /* tile-pair capacity exceeded; frame is incomplete                                         */
+  MGS_ERR_UNSUPPORTED = -8
+} MgsStatus;
+
+/* storage formats — shaders/shaderio.h:60-62 (FORMAT_FLOAT32/16/UINT8), chosen at
+ * SplatSetVk::initDataStorage(shFormat, rgbaFormat) (src/splat_set_vk.h:112) */
+enum { MGS_FORMAT_FLOAT32 = 0, MGS_FORMAT_FLOAT16 = 1, MGS_FORMAT_UINT8 = 2 };
+/* sorting methods — shaders/shaderio.h SORTING_* / parameters.h:182 */
+enum { MGS_SORT_GPU_RADIX = 0, MGS_SORT_CPU_ASYNC = 1 };
+/* frustum culling — shaders/shaderio.h:84-86 / parameters.h:184 */
+enum { MGS_CULL_NONE = 0, MGS_CULL_AT_DIST = 1, MGS_CULL_AT_RASTER = 2 };
+/* colour target — src/gaussian_splatting.h:338-340 (RGBA16F default, RGBA32F optional) */
+enum { MGS_TARGET_RGBA16F = 0, MGS_TARGET_RGBA32F = 1 };
+/* alpha channel meaning: the reference's default back-to-front pipeline accumulates
+ * A = sum(alpha) (src/gaussian_splatting.cpp:2083-2084); its FTB pipeline yields 1-T (:2071-2076). */
+enum { MGS_ALPHA_COVERAGE = 0 /* 1-T */, MGS_ALPHA_SUM = 1 /* sum(alpha); disables early termination */ };
+
+typedef struct MgsSplatSet_t* MgsSplatSet; /* RAM model == struct SplatSet, src/splat_set.h:33-48 */
+typedef struct MgsScene_t*    MgsScene;    /* device scene == SplatSetManagerVk + renderer buffers  */
+
+/* The six SoA arrays of SplatSet (src/splat_set.h:36-42), INRIA semantics, ALREADY in the
+ * renderer's RUB frame (i.e. after SplatSet::convertCoordinates(RDF,RUB), splat_set.h:78-114):
+ * positions[3n], f_dc[3n], f_rest[f_rest_per_splat*n] channel-major (all R, all G, all B),
+ * opacity[n] (logit), scale[3n] (log), rotation[4n] (w,x,y,z). */
+typedef struct MgsSplatSetView {
+  const float* positions;
+  const float* f_dc;
+  const float* f_rest;
+  const float* opacity;
+  const float* scale;
+  const float* rotation;
+  uint64_t     splat_count;
+  uint32_t     f_rest_per_splat; /* 0, 9, 24 or 45 */
+  int32_t      sh_degree;        /* out only: SplatSet::maxShDegree(), splat_set.h:52-74 */
+} MgsSplatSetView;
+
+/* ---- errors ---- */
+const char* mgs_last_error(void);
+const char* mgs_version(void);
+
+/* ---- ingest: replaces PlyLoaderAsync::loadScene / innerLoad (src/ply_loader_async.h:62,
+ * src/ply_loader_async.cpp:291-453).  Synchronous; dispatches on the lower-cased extension
+ * (.ply via the INRIA property names, .spz = Niantic gzip "NGSP" v1-3, .splat = 32-byte records)
+ * and leaves the set in RUB coordinates exactly like the reference. */
+int  mgs_splatset_load(const char* path, MgsSplatSet* out);
+/* copies the arrays; caller keeps ownership of the host pointers (valid only during the call) */
+int  mgs_splatset_from_arrays(const MgsSplatSetView* view, MgsSplatSet* out);
+/* borrow the set's arrays (valid until mgs_splatset_destroy) */
+int  mgs_splatset_view(MgsSplatSet set, MgsSplatSetView* out);
+void mgs_splatset_destroy(MgsSplatSet set);
+
+/* ---- scene: replaces SplatSetManagerVk::createSplatSet/createInstance/updateInstanceTransform/
+ * processVramUpdates (src/splat_set_manager_vk.h:202,222-249,261).  `device` is the HIP ordinal. */
+int  mgs_scene_create(int device, MgsScene* out);
+void mgs_scene_destroy(MgsScene scene);
+/* run on a caller-owned hipStream_t (NULL = the scene's own stream) */
+int  mgs_scene_set_stream(MgsScene scene, void* hip_stream);
+/* instances are concatenated in creation order into the global splat id space
+ * (rebuildGlobalIndexTables, src/splat_set_manager_vk.cpp:2304-2360) */
+int  mgs_instance_add(MgsScene scene, MgsSplatSet set, const float transform[16], int* instance_id);
+int  mgs_instance_set_transform(MgsScene scene, int instance_id, const float transform[16]);
+/* SplatSetVk::initDataStorage + initDataBuffers (src/splat_set_vk.cpp:117-170,188-480): builds the
+ * device buffers (centres, 3D covariances, RGBA, interleaved SH) in the requested formats.
+ * Idempotent; call again after changing formats (the reference's --updateData). */
+int  mgs_scene_commit(MgsScene scene, int sh_format, int rgba_format);
+uint64_t mgs_scene_splat_count(MgsScene scene); /* getTotalGlobalSplatCount, gaussian_splatting.cpp:369 */
+/* test/debug hook: copy a committed device buffer of a splat set to the host, dequantised to
+ * fp32 exactly as the shaders would read it.  which: 0 centres[3n] 1 cov[6n] 2 rgba[4n] 3 sh[stride*n] */
+int  mgs_scene_download_set(MgsScene scene, int instance_id, int which, float* dst, size_t count);
+
+/* ---- per-frame parameters: shaderio::FrameInfo (shaders/shaderio.h:238-317) as filled by
+ * updateAndUploadFrameInfoUBO (src/gaussian_splatting.cpp:1150-1295) plus the raster knobs of
+ * parameters.h:86-201.  focal and basisViewport are derived inside, exactly as :1218-1250. */
+typedef struct MgsFrameParams {
+  float   view[16];
+  float   proj[16];
+  float   camera_pos[3];
+  int32_t width, height;
+  float   splat_scale;          /* default 1.0    shaderio.h:261 */
+  float   frustum_dilation;     /* default 0.2    shaderio.h:264 */
+  float   alpha_cull_threshold; /* default 1/255  shaderio.h:265 */
+  int32_t sh_degree;            /* default 3      shaderio.h:262 */
+  int32_t sort_mode;            /* MGS_SORT_*      */
+  int32_t frustum_culling;      /* MGS_CULL_*      (forced to AT_RASTER with CPU sort, gaussian_splatting_ui.cpp:1469-1479) */
+  int32_t target_format;        /* MGS_TARGET_*    */
+  int32_t alpha_mode;           /* MGS_ALPHA_*     */
+  int32_t ms_antialiasing;      /* 0/1            threedgs.h.slang:63-76 */
+  /* multi-GPU strip partition (no reference counterpart): this device renders
+   * 16-pixel tile rows [strip_row_begin, strip_row_end); 0,0 = whole frame */
+  int32_t strip_row_begin, strip_row_end;
+  int32_t collect_timings;      /* 1: bracket each stage with hipEvents on the render stream */
+  int32_t cpu_sort_blocking;    /* CPU_ASYNC only: 1 = wait for the sorter (deterministic tests) */
+  int32_t reserved[6];
+} MgsFrameParams;
+
+void mgs_frame_params_default(MgsFrameParams* p); /* fills the defaults cited above */
+
+enum { MGS_STAGE_PROJECT = 0, MGS_STAGE_SORT = 1, MGS_STAGE_BIN = 2, MGS_STAGE_PAIRSORT = 3,
+       MGS_STAGE_COMPOSITE = 4, MGS_STAGE_TOTAL = 5, MGS_STAGE_COUNT = 8 };
+
+typedef struct MgsFrameOut {
+  void*    rgba_device;     /* device pointer: [height][width][4] fp16 (or fp32), row 0 = NDC y -1, linear */
+  uint64_t rgba_bytes;
+  uint32_t frustum_count;   /* survivors of the dist-stage cull == IndirectParams.instanceCount (shaderio.h:343-356) */
+  uint32_t sorted_count;    /* elements actually sorted (after alpha/extent/off-screen rejection) */
+  uint64_t tile_pairs;      /* (tile, splat) records built by the binning stage */
+  uint32_t error_flags;     /* device-side diagnostics, 0 = clean */
+  uint32_t reserved;
+  float    stage_ms[MGS_STAGE_COUNT]; /* valid when collect_timings; HIP-event times on the render stream */
+} MgsFrameOut;
+
+/* GaussianSplatting::onRender -> renderHybridPipeline (src/gaussian_splatting.cpp:335,414,494):
+ * processSortingOnGPU (:1298-1367) + drawSplatPrimitives (:1369-1465) + blending (:2066-2087).
+ * Asynchronous on the scene's stream; counters in `out` are read back when the call returns
+ * only if collect_timings or MGS_SYNC_STATS were requested via mgs_frame_stats(). */
+int mgs_render(MgsScene scene, const MgsFrameParams* params, MgsFrameOut* out);
+/* waits for the last mgs_render and fills counters / timings (readBackIndirectParametersIfNeeded, :1536) */
+int mgs_frame_stats(MgsScene scene, MgsFrameOut* out);
+/* copy the last frame to the host (screenshot path, gaussian_splatting_ui.cpp:508-540, no tonemap) */
+int mgs_frame_download(MgsScene scene, void* host_dst, size_t bytes);
+/* copy this device's strip of the last frame into a caller-owned device buffer (all-gather staging) */
+int mgs_frame_copy_strip(MgsScene scene, void* device_dst, size_t bytes);
+int mgs_sync(MgsScene scene);
+
+/* ---- sort only (metric hook): vrdxCmdSortKeyValueIndirect (3rdparty/vrdx/include/vk_radix_sort.h:73-78)
+ * fed by dist.comp.slang, or SplatSorterAsync::sortAsync/consume (src/splat_sorter_async.h:84-128)
+ * when params->sort_mode == MGS_SORT_CPU_ASYNC. */
+typedef struct MgsSortOut {
+  uint32_t count;      /* number of sorted elements (visible count) */
+  float    key_ms;     /* dist stage */
+  float    sort_ms;    /* radix sort (GPU) / std::sort (CPU) */
+  float    hist_ms;    /* GPU: the up-front histogram kernel, included in sort_ms */
+  uint32_t passes;     /* GPU: radix passes executed */
+  uint32_t reserved[3];
+} MgsSortOut;
+int mgs_sort_keys(MgsScene scene, const MgsFrameParams* params, MgsSortOut* out);
+/* download the sorted keys (GPU mode: u32 encodeMinMaxFp32 keys; CPU mode: fp32 distances) and global ids */
+int mgs_sort_download(MgsScene scene, uint32_t* keys, uint32_t* ids, uint32_t capacity);
+
+/* sort an arbitrary device-resident (key,value) u32 array with the same onesweep kernels
+ * (keys_device/values_device are overwritten with the result) — used by the sort parity tests
+ * and the sorted-Gsplats/s microbenchmark. */
+int mgs_radix_sort_u32(MgsScene scene, void* keys_device, void* values_device, uint32_t count,
+                       int begin_bit, int end_bit, float* elapsed_ms);
+/* host convenience for the above: uploads, sorts, downloads */
+int mgs_radix_sort_host(MgsScene scene, uint32_t* keys, uint32_t* values, uint32_t count,
+                        int begin_bit, int end_bit, float* elapsed_ms);
+
+/* ---- camera helper (BUILD-DEFINED: nvutils::CameraManipulator lives in the absent nvpro_core2;
+ * SURVEY.md §8c "parity unpinned").  Right-handed lookAt + perspective with clip z in [0,1];
+ * flip_y != 0 negates proj[5] (Vulkan convention).  Defaults mirror src/camera_set.h:48-53. */
+void mgs_camera_lookat_perspective(const float eye[3], const float center[3], const float up[3],
+                                   float fov_y_degrees, float z_near, float z_far,
+                                   int width, int height, int flip_y,
+                                   float view_out[16], float proj_out[16]);
+/* T*R*S instance transform, computeTransform (src/utilities.h:170-199); rotation = Euler degrees */
+void mgs_compute_transform(const float scale[3], const float rotation_deg[3], const float translation[3],
+                           float transform_out[16], float inverse_out[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGS_H */

@@ -1,0 +1,726 @@
+/*
+ * mgs_oracle.cpp — TEST INFRASTRUCTURE ONLY (see mgs_oracle.h for the rules and pinning status).
+ *
+ * Plain fp32 CPU restatement of the reference's VK3DGSR path.  Compiled with
+ * -ffp-contract=off so every a*b+c rounds twice, i.e. "unfused fp32" is the oracle's
+ * arithmetic; GPU results are compared under the tolerances stated in tests/.
+ *
+ * Matrix convention: the Slang shaders are compiled row-major and use
+ * mul(v, M) over glm column-major memory (src/gaussian_splatting.cpp:125), which is the
+ * ordinary column-vector product  out = M * v  with  M(r,c) = mem[c*4 + r].
+ *
+ * Third-party arithmetic that is NOT under /root/reference (nvpro_core2 is an empty
+ * submodule, .gitmodules:1-3): glm (quat normalise, mat3_cast, inverse, packHalf1x16).
+ * Their published algorithms are restated below and marked [glm].
+ */
+#include "mgs_oracle.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <execution>
+#include <thread>
+#include <vector>
+
+namespace {
+
+inline float m_at(const float* m, int r, int c) { return m[c * 4 + r]; }
+
+// out = M * v (column vector), summation order x*col0 + y*col1 + z*col2 + w*col3
+inline void mat4_mul_vec4(const float* m, const float v[4], float out[4])
+{
+  for(int r = 0; r < 4; ++r)
+    out[r] = ((v[0] * m_at(m, r, 0) + v[1] * m_at(m, r, 1)) + v[2] * m_at(m, r, 2)) + v[3] * m_at(m, r, 3);
+}
+
+const float kSqrt8 = std::sqrt(8.0f);  // threedgs_particle_storage.h.slang:48
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------
+// src/splat_set.h:52-74
+int orc_max_sh_degree(size_t f_rest_len, size_t splat_count)
+{
+  if(splat_count == 0)
+    return -1;
+  const size_t total      = (uint32_t)f_rest_len / splat_count;
+  const size_t perChannel = total / 3;
+  int          degree     = 0;
+  if(perChannel >= 3)
+    degree = 1;
+  if(perChannel >= 8)
+    degree = 2;
+  if(perChannel == 15)
+    degree = 3;
+  return degree;
+}
+
+// 3rdparty/spz/src/cc/splat-types.h:55-83 evaluated for (from=RDF, to=RUB): x matches, y and z do not.
+void orc_flip_sh_rdf_to_rub(float out[15])
+{
+  const float x = 1.f, y = -1.f, z = -1.f;
+  const float f[15] = {y, z, x, x * y, y * z, 1.0f, x * z, 1.0f, y, x * y * z, y, z, x, z, x};
+  std::memcpy(out, f, sizeof(f));
+}
+
+// src/splat_set.h:78-114 with coordinateConverter(RDF, RUB): flipP=(1,-1,-1), flipQ=(y*z,x*z,x*y)=(1,-1,-1)
+void orc_convert_rdf_to_rub(float* positions, float* rotation, float* f_rest, size_t n, size_t coeffs_per_channel)
+{
+  float flipSh[15];
+  orc_flip_sh_rdf_to_rub(flipSh);
+  const float flipP[3] = {1.f, -1.f, -1.f};
+  const float flipQ[3] = {1.f, -1.f, -1.f};
+  for(size_t i = 0; i < n; ++i)
+  {
+    positions[3 * i + 0] *= flipP[0];
+    positions[3 * i + 1] *= flipP[1];
+    positions[3 * i + 2] *= flipP[2];
+    // scalar component (index 0) untouched
+    rotation[4 * i + 1] *= flipQ[0];
+    rotation[4 * i + 2] *= flipQ[1];
+    rotation[4 * i + 3] *= flipQ[2];
+  }
+  if(f_rest && coeffs_per_channel)
+  {
+    size_t idx = 0;
+    for(size_t i = 0; i < n; ++i)
+    {
+      for(size_t j = 0; j < coeffs_per_channel; ++j)
+      {
+        const float flip = flipSh[j];
+        f_rest[idx + j] *= flip;
+        f_rest[idx + coeffs_per_channel + j] *= flip;
+        f_rest[idx + 2 * coeffs_per_channel + j] *= flip;
+      }
+      idx += 3 * coeffs_per_channel;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// src/splat_set_vk.cpp:263-288.  [glm] normalize(quat): len=sqrt(dot); len<=0 -> (1,0,0,0); q*(1/len).
+// [glm] mat3_cast: the standard quaternion->matrix (column-major Result[col][row]).
+void orc_cov3d(const float* scale, const float* rotation, size_t n, float* cov6)
+{
+  for(size_t i = 0; i < n; ++i)
+  {
+    const float s[3] = {std::exp(scale[3 * i + 0]), std::exp(scale[3 * i + 1]), std::exp(scale[3 * i + 2])};
+    float       w = rotation[4 * i + 0], x = rotation[4 * i + 1], y = rotation[4 * i + 2], z = rotation[4 * i + 3];
+    const float len = std::sqrt(((w * w + x * x) + y * y) + z * z);
+    if(len <= 0.f)
+    {
+      w = 1.f;
+      x = y = z = 0.f;
+    }
+    else
+    {
+      const float inv = 1.f / len;
+      w *= inv;
+      x *= inv;
+      y *= inv;
+      z *= inv;
+    }
+    const float qxx = x * x, qyy = y * y, qzz = z * z, qxz = x * z, qxy = x * y, qyz = y * z, qwx = w * x,
+                qwy = w * y, qwz = w * z;
+    // R[col][row]
+    float R[3][3];
+    R[0][0] = 1.f - 2.f * (qyy + qzz);
+    R[0][1] = 2.f * (qxy + qwz);
+    R[0][2] = 2.f * (qxz - qwy);
+    R[1][0] = 2.f * (qxy - qwz);
+    R[1][1] = 1.f - 2.f * (qxx + qzz);
+    R[1][2] = 2.f * (qyz + qwx);
+    R[2][0] = 2.f * (qxz + qwy);
+    R[2][1] = 2.f * (qyz - qwx);
+    R[2][2] = 1.f - 2.f * (qxx + qyy);
+    // M = R * diag(s): column j scaled by s[j]
+    float M[3][3];
+    for(int c = 0; c < 3; ++c)
+      for(int r = 0; r < 3; ++r)
+        M[c][r] = R[c][r] * s[c];
+    // Sigma = M * M^T : Sigma(r,c) = sum_k M(r,k) M(c,k)
+    auto sig = [&](int r, int c) { return (M[0][r] * M[0][c] + M[1][r] * M[1][c]) + M[2][r] * M[2][c]; };
+    cov6[6 * i + 0] = sig(0, 0);
+    cov6[6 * i + 1] = sig(0, 1);
+    cov6[6 * i + 2] = sig(0, 2);
+    cov6[6 * i + 3] = sig(1, 1);
+    cov6[6 * i + 4] = sig(1, 2);
+    cov6[6 * i + 5] = sig(2, 2);
+  }
+}
+
+// src/splat_set_vk.cpp:313-345
+void orc_rgba(const float* f_dc, const float* opacity, size_t n, float* rgba)
+{
+  const float SH_C0 = 0.28209479177387814f;
+  auto        clamp01 = [](float v) { return std::min(std::max(v, 0.0f), 1.0f); };
+  for(size_t i = 0; i < n; ++i)
+  {
+    rgba[4 * i + 0] = clamp01(0.5f + SH_C0 * f_dc[3 * i + 0]);
+    rgba[4 * i + 1] = clamp01(0.5f + SH_C0 * f_dc[3 * i + 1]);
+    rgba[4 * i + 2] = clamp01(0.5f + SH_C0 * f_dc[3 * i + 2]);
+    rgba[4 * i + 3] = clamp01(1.0f / (1.0f + std::exp(-opacity[i])));
+  }
+}
+
+int orc_sh_stride(int cpc)
+{
+  int stride = 0;
+  if(cpc >= 3)
+    stride += 9;
+  if(cpc >= 8)
+    stride += 15;
+  if(cpc == 15)
+    stride += 21;
+  return stride;
+}
+
+// src/splat_set_vk.cpp:356-435: channel-major f_rest -> [coef][rgb] interleave
+void orc_sh_interleave(const float* f_rest, size_t n, int cpc, float* out)
+{
+  const int stride = orc_sh_stride(cpc);
+  const int ncoef  = stride / 3;
+  const int srcStride = 3 * cpc;
+  for(size_t i = 0; i < n; ++i)
+    for(int k = 0; k < ncoef; ++k)
+      for(int c = 0; c < 3; ++c)
+        out[i * stride + 3 * k + c] = f_rest[i * srcStride + cpc * c + k];
+}
+
+// [glm] packHalf1x16 / unpackHalf1x16: IEEE binary16, round-to-nearest-even
+uint16_t orc_float_to_half(float f)
+{
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  const uint32_t absx = x & 0x7fffffffu;
+  if(absx >= 0x7f800000u)  // inf / nan
+    return (uint16_t)(sign | 0x7c00u | ((absx > 0x7f800000u) ? 0x200u : 0u));
+  if(absx >= 0x477ff000u)  // rounds to >= 65520 -> inf
+    return (uint16_t)(sign | 0x7c00u);
+  if(absx < 0x33000001u)  // < 2^-25 (or exactly 2^-25 -> ties to even 0)
+    return (uint16_t)sign;
+  int32_t  exp  = (int32_t)(absx >> 23) - 127;
+  uint32_t mant = (absx & 0x7fffffu) | 0x800000u;
+  uint32_t shift;
+  uint32_t hexp;
+  if(exp < -14)
+  {  // subnormal half
+    shift = (uint32_t)(13 + (-14 - exp));
+    hexp  = 0;
+  }
+  else
+  {
+    shift = 13;
+    hexp  = (uint32_t)(exp + 15);
+  }
+  uint32_t hm        = mant >> shift;
+  uint32_t rem       = mant & ((1u << shift) - 1u);
+  uint32_t halfway   = 1u << (shift - 1);
+  if(rem > halfway || (rem == halfway && (hm & 1u)))
+    hm += 1;
+  uint32_t h;
+  if(hexp == 0)
+    h = hm;  // may carry into exponent 1: correct by construction
+  else
+    h = ((hexp << 10) + (hm - 0x400u));  // hm has implicit bit at 0x400; carry propagates
+  return (uint16_t)(sign | h);
+}
+
+float orc_half_to_float(uint16_t h)
+{
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  const uint32_t exp  = (h >> 10) & 0x1fu;
+  const uint32_t mant = h & 0x3ffu;
+  uint32_t       x;
+  if(exp == 0)
+  {
+    if(mant == 0)
+      x = sign;
+    else
+    {
+      float v = std::ldexp((float)mant, -24);
+      std::memcpy(&x, &v, 4);
+      x |= sign;
+    }
+  }
+  else if(exp == 31)
+    x = sign | 0x7f800000u | (mant << 13);
+  else
+    x = sign | ((exp + 112u) << 23) | (mant << 13);
+  float f;
+  std::memcpy(&f, &x, 4);
+  return f;
+}
+
+// src/splat_set_vk.cpp:85-112 (toUint8/storeSh) then the shader-side dequantisation
+// shaders/threedgs_particle_buffers.h.slang:72-90 (colour v/255), :112-131 (SH v/255*2-1)
+void orc_quantize_roundtrip(float* data, size_t count, int format, int is_sh)
+{
+  if(format == ORC_FORMAT_FLOAT32)
+    return;
+  if(format == ORC_FORMAT_FLOAT16)
+  {
+    for(size_t i = 0; i < count; ++i)
+      data[i] = orc_half_to_float(orc_float_to_half(data[i]));
+    return;
+  }
+  const float lo = is_sh ? -1.f : 0.f, hi = 1.f;
+  for(size_t i = 0; i < count; ++i)
+  {
+    const float   normalized = (data[i] - lo) / (hi - lo);
+    const uint8_t q          = (uint8_t)std::min(std::max(std::round(normalized * 255.0f), 0.0f), 255.0f);
+    if(is_sh)
+      data[i] = float(q) / 255.0f * 2.0f - 1.0f;
+    else
+      data[i] = float(q) / 255.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// [glm] inverse(mat4): cofactor expansion, as in glm/detail/func_matrix.inl compute_inverse<4,4>
+void orc_mat4_inverse(const float* m, float* out)
+{
+  auto  M      = [&](int c, int r) { return m[c * 4 + r]; };
+  float Coef00 = M(2, 2) * M(3, 3) - M(3, 2) * M(2, 3);
+  float Coef02 = M(1, 2) * M(3, 3) - M(3, 2) * M(1, 3);
+  float Coef03 = M(1, 2) * M(2, 3) - M(2, 2) * M(1, 3);
+  float Coef04 = M(2, 1) * M(3, 3) - M(3, 1) * M(2, 3);
+  float Coef06 = M(1, 1) * M(3, 3) - M(3, 1) * M(1, 3);
+  float Coef07 = M(1, 1) * M(2, 3) - M(2, 1) * M(1, 3);
+  float Coef08 = M(2, 1) * M(3, 2) - M(3, 1) * M(2, 2);
+  float Coef10 = M(1, 1) * M(3, 2) - M(3, 1) * M(1, 2);
+  float Coef11 = M(1, 1) * M(2, 2) - M(2, 1) * M(1, 2);
+  float Coef12 = M(2, 0) * M(3, 3) - M(3, 0) * M(2, 3);
+  float Coef14 = M(1, 0) * M(3, 3) - M(3, 0) * M(1, 3);
+  float Coef15 = M(1, 0) * M(2, 3) - M(2, 0) * M(1, 3);
+  float Coef16 = M(2, 0) * M(3, 2) - M(3, 0) * M(2, 2);
+  float Coef18 = M(1, 0) * M(3, 2) - M(3, 0) * M(1, 2);
+  float Coef19 = M(1, 0) * M(2, 2) - M(2, 0) * M(1, 2);
+  float Coef20 = M(2, 0) * M(3, 1) - M(3, 0) * M(2, 1);
+  float Coef22 = M(1, 0) * M(3, 1) - M(3, 0) * M(1, 1);
+  float Coef23 = M(1, 0) * M(2, 1) - M(2, 0) * M(1, 1);
+
+  const float Fac0[4] = {Coef00, Coef00, Coef02, Coef03};
+  const float Fac1[4] = {Coef04, Coef04, Coef06, Coef07};
+  const float Fac2[4] = {Coef08, Coef08, Coef10, Coef11};
+  const float Fac3[4] = {Coef12, Coef12, Coef14, Coef15};
+  const float Fac4[4] = {Coef16, Coef16, Coef18, Coef19};
+  const float Fac5[4] = {Coef20, Coef20, Coef22, Coef23};
+  const float Vec0[4] = {M(1, 0), M(0, 0), M(0, 0), M(0, 0)};
+  const float Vec1[4] = {M(1, 1), M(0, 1), M(0, 1), M(0, 1)};
+  const float Vec2[4] = {M(1, 2), M(0, 2), M(0, 2), M(0, 2)};
+  const float Vec3[4] = {M(1, 3), M(0, 3), M(0, 3), M(0, 3)};
+  float       Inv[4][4];
+  const float SignA[4] = {+1, -1, +1, -1};
+  const float SignB[4] = {-1, +1, -1, +1};
+  for(int i = 0; i < 4; ++i)
+  {
+    Inv[0][i] = (Vec1[i] * Fac0[i] - Vec2[i] * Fac1[i] + Vec3[i] * Fac2[i]) * SignA[i];
+    Inv[1][i] = (Vec0[i] * Fac0[i] - Vec2[i] * Fac3[i] + Vec3[i] * Fac4[i]) * SignB[i];
+    Inv[2][i] = (Vec0[i] * Fac1[i] - Vec1[i] * Fac3[i] + Vec3[i] * Fac5[i]) * SignA[i];
+    Inv[3][i] = (Vec0[i] * Fac2[i] - Vec1[i] * Fac4[i] + Vec2[i] * Fac5[i]) * SignB[i];
+  }
+  const float Dot1 = (M(0, 0) * Inv[0][0] + M(0, 1) * Inv[1][0]) + (M(0, 2) * Inv[2][0] + M(0, 3) * Inv[3][0]);
+  const float OneOverDet = 1.0f / Dot1;
+  for(int c = 0; c < 4; ++c)
+    for(int r = 0; r < 4; ++r)
+      out[c * 4 + r] = Inv[c][r] * OneOverDet;
+}
+
+// out = a * b (both glm column-major); [glm] operator*(mat4,mat4)
+void orc_mat4_mul(const float* a, const float* b, float* out)
+{
+  float tmp[16];
+  for(int c = 0; c < 4; ++c)
+    for(int r = 0; r < 4; ++r)
+      tmp[c * 4 + r] = ((a[0 * 4 + r] * b[c * 4 + 0] + a[1 * 4 + r] * b[c * 4 + 1]) + a[2 * 4 + r] * b[c * 4 + 2])
+                       + a[3 * 4 + r] * b[c * 4 + 3];
+  std::memcpy(out, tmp, sizeof(tmp));
+}
+
+// shaders/dist.comp.slang:33-38
+uint32_t orc_encode_key(float v)
+{
+  uint32_t bits;
+  std::memcpy(&bits, &v, 4);
+  bits ^= (uint32_t)((int32_t)bits >> 31) | 0x80000000u;
+  return bits;
+}
+
+// shaders/dist.comp.slang:40-171 (pinhole; size culling off = reference default parameters.h)
+// Global ids are the concatenation of instances in creation order
+// (src/splat_set_manager_vk.cpp:2319-2357).  Survivor order: ascending global id — a
+// deterministic refinement of the reference's atomic append order (dist.comp.slang:137-139).
+uint32_t orc_key_cull(const OrcFrame* f, const OrcInstance* inst, int n_inst, uint32_t* keys, uint32_t* ids)
+{
+  uint32_t v      = 0;
+  uint32_t offset = 0;
+  for(int k = 0; k < n_inst; ++k)
+  {
+    const OrcInstance& I = inst[k];
+    for(uint32_t i = 0; i < I.count; ++i)
+    {
+      const float p[4] = {I.centers[3 * i + 0], I.centers[3 * i + 1], I.centers[3 * i + 2], 1.0f};
+      float       world[4], view[4], clip[4];
+      mat4_mul_vec4(I.transform, p, world);  // mul(splatPos, desc.transform)          :58
+      mat4_mul_vec4(f->view, world, view);   // mul(..., frameInfo.viewMatrix)         :58
+      mat4_mul_vec4(f->proj, view, clip);    // mul(viewPos, projectionMatrix)         :60
+      const float ndc[3] = {clip[0] / clip[3], clip[1] / clip[3], clip[2] / clip[3]};  // :61
+      const float depth  = ndc[2];
+      if(f->frustum_culling == 1)
+      {
+        const float c = 1.0f + f->frustum_dilation;  // :71-73
+        if(std::fabs(ndc[0]) > c || std::fabs(ndc[1]) > c || ndc[2] < 0.f - f->frustum_dilation || ndc[2] > 1.0f)
+          continue;
+        // NaN compares false in every test above, exactly as in the shader: a NaN splat survives.
+      }
+      ids[v]  = offset + i;
+      keys[v] = f->front_to_back ? orc_encode_key(depth) : orc_encode_key(-depth);  // :163-167
+      ++v;
+    }
+    offset += I.count;
+  }
+  return v;
+}
+
+// 3rdparty/vrdx/src/vk_radix_sort.cc:262-416: stable ascending LSD radix sort, 8-bit digits, 4 passes
+void orc_sort_stable(uint32_t* keys, uint32_t* ids, uint32_t n)
+{
+  std::vector<uint32_t> k2(n), v2(n);
+  uint32_t *            ks = keys, *vs = ids, *kd = k2.data(), *vd = v2.data();
+  for(int pass = 0; pass < 4; ++pass)
+  {
+    size_t hist[257] = {0};
+    const int shift  = 8 * pass;
+    for(uint32_t i = 0; i < n; ++i)
+      hist[((ks[i] >> shift) & 0xffu) + 1]++;
+    for(int d = 0; d < 256; ++d)
+      hist[d + 1] += hist[d];
+    for(uint32_t i = 0; i < n; ++i)
+    {
+      const size_t dst = hist[(ks[i] >> shift) & 0xffu]++;
+      kd[dst]          = ks[i];
+      vd[dst]          = vs[i];
+    }
+    std::swap(ks, kd);
+    std::swap(vs, vd);
+  }
+  // even number of passes: result is back in keys/ids
+}
+
+// ---------------------------------------------------------------------------------------
+// shaders/threedgs_particle_storage.h.slang:48-52,103-159
+static void sh_radiance(const OrcInstance& I, uint32_t idx, int requested, const float d[3], float rgb[3])
+{
+  rgb[0] = rgb[1] = rgb[2] = 0.f;
+  const int degree = std::min(I.sh_degree, requested);
+  if(degree < 1 || !I.sh)
+    return;
+  const float  SH_C1    = 0.4886025119029199f;
+  const float  SH_C2[5] = {1.0925484f, -1.0925484f, 0.3153916f, -1.0925484f, 0.5462742f};
+  const float  SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                           -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+  const float* s        = I.sh + (size_t)idx * I.sh_stride;
+  const float  x = d[0], y = d[1], z = d[2];
+  for(int c = 0; c < 3; ++c)
+  {
+    auto  S = [&](int k) { return s[3 * k + c]; };
+    float r = SH_C1 * (-S(0) * y + S(1) * z - S(2) * x);
+    if(degree >= 2)
+    {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      r += (SH_C2[0] * xy) * S(3) + (SH_C2[1] * yz) * S(4) + (SH_C2[2] * (2.0f * zz - xx - yy)) * S(5)
+           + (SH_C2[3] * xz) * S(6) + (SH_C2[4] * (xx - yy)) * S(7);
+      if(degree >= 3)
+      {
+        r += SH_C3[0] * S(8) * (3.0f * x * x - y * y) * y + SH_C3[1] * S(9) * x * y * z
+             + SH_C3[2] * S(10) * (4.0f * z * z - x * x - y * y) * y
+             + SH_C3[3] * S(11) * z * (2.0f * z * z - 3.0f * x * x - 3.0f * y * y)
+             + SH_C3[4] * S(12) * x * (4.0f * z * z - x * x - y * y) + SH_C3[5] * S(13) * (x * x - y * y) * z
+             + SH_C3[6] * S(14) * x * (x * x - 3.0f * y * y);
+      }
+    }
+    rgb[c] = r;
+  }
+}
+
+// shaders/threedgs_raster.mesh.slang:111-291 + shaders/threedgs.h.slang:26-121
+void orc_project(const OrcFrame* f, const OrcInstance* Ip, uint32_t i, OrcProjected* out)
+{
+  const OrcInstance& I = *Ip;
+  std::memset(out, 0, sizeof(*out));
+  float rgba[4] = {I.rgba[4 * i + 0], I.rgba[4 * i + 1], I.rgba[4 * i + 2], I.rgba[4 * i + 3]};
+  if(rgba[3] < f->alpha_cull_threshold)  // mesh.slang:164-170
+    return;
+  const float p[4] = {I.centers[3 * i + 0], I.centers[3 * i + 1], I.centers[3 * i + 2], 1.0f};
+  float       MV[16];
+  orc_mat4_mul(f->view, I.transform, MV);  // mul(desc.transform, viewMatrix) == V*M      mesh.slang:175
+  float viewC[4], clip[4];
+  mat4_mul_vec4(MV, p, viewC);         // :178
+  mat4_mul_vec4(f->proj, viewC, clip);  // :179 (projectionMatrixJittered == projectionMatrix w/o DLSS)
+  if(f->frustum_culling == 2)
+  {  // mesh.slang:181-190
+    const float c = (1.0f + f->frustum_dilation) * clip[3];
+    if(std::fabs(clip[0]) > c || std::fabs(clip[1]) > c || clip[2] < (0.0f - f->frustum_dilation) * clip[3]
+       || clip[2] > clip[3])
+      return;
+  }
+  // SH: direction in model space                                                           :240-243
+  const float cam[4] = {f->camera_pos[0], f->camera_pos[1], f->camera_pos[2], 1.0f};
+  float       camM[4];
+  mat4_mul_vec4(I.transform_inv, cam, camM);
+  float       dir[3] = {p[0] - camM[0], p[1] - camM[1], p[2] - camM[2]};
+  const float dl     = std::sqrt((dir[0] * dir[0] + dir[1] * dir[1]) + dir[2] * dir[2]);
+  dir[0] /= dl;
+  dir[1] /= dl;
+  dir[2] /= dl;
+  float sh[3];
+  sh_radiance(I, i, f->sh_degree, dir, sh);
+  rgba[0] += sh[0];
+  rgba[1] += sh[1];
+  rgba[2] += sh[2];  // no clamp afterwards
+
+  // covariance projection                                                            threedgs.h.slang:26-56
+  const float* c6       = I.cov6 + (size_t)6 * i;
+  const float  S[3][3]  = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+  const float  focal[2] = {f->proj[0] * 0.5f * (float)f->width, f->proj[5] * 0.5f * (float)f->height};  // cpp:1248-1250
+  const float  tz = viewC[2];
+  const float  s  = 1.0f / (tz * tz);
+  const float  J[3][3] = {{focal[0] / tz, 0.f, -(focal[0] * viewC[0]) * s},
+                          {0.f, focal[1] / tz, -(focal[1] * viewC[1]) * s},
+                          {0.f, 0.f, 0.f}};
+  float        W[3][3];  // W(r,c) = MV(r,c)
+  for(int r = 0; r < 3; ++r)
+    for(int c = 0; c < 3; ++c)
+      W[r][c] = m_at(MV, r, c);
+  float T[3][3], TS[3][3];
+  for(int r = 0; r < 3; ++r)
+    for(int c = 0; c < 3; ++c)
+      T[r][c] = (J[r][0] * W[0][c] + J[r][1] * W[1][c]) + J[r][2] * W[2][c];
+  for(int r = 0; r < 3; ++r)
+    for(int c = 0; c < 3; ++c)
+      TS[r][c] = (T[r][0] * S[0][c] + T[r][1] * S[1][c]) + T[r][2] * S[2][c];
+  auto  c2  = [&](int r, int c) { return (TS[r][0] * T[c][0] + TS[r][1] * T[c][1]) + TS[r][2] * T[c][2]; };
+  float a = c2(0, 0), b = c2(0, 1), d = c2(1, 1);
+
+  // extent basis                                                                     threedgs.h.slang:60-121
+  float detOrig = 0.f;
+  if(f->ms_antialiasing)
+    detOrig = a * d - b * b;
+  a += 0.3f;
+  d += 0.3f;
+  if(f->ms_antialiasing)
+  {
+    const float detBlur = a * d - b * b;
+    rgba[3] *= std::sqrt(std::max(detOrig / detBlur, 0.0f));
+  }
+  const float D          = a * d - b * b;
+  const float traceOver2 = 0.5f * (a + d);
+  const float term2      = std::sqrt(std::max(0.1f, traceOver2 * traceOver2 - D));
+  const float ev1 = traceOver2 + term2, ev2 = traceOver2 - term2;
+  if(ev2 <= 0.0f)
+    return;
+  float       e1[2] = {(std::fabs(b) < 0.001f) ? 1.0f : b, ev1 - a};
+  const float el    = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1]);
+  e1[0] /= el;
+  e1[1] /= el;
+  const float e2[2] = {e1[1], -e1[0]};
+  const float l1    = std::min(kSqrt8 * std::sqrt(ev1), 2048.0f);
+  const float l2    = std::min(kSqrt8 * std::sqrt(ev2), 2048.0f);
+  out->basis1[0]    = e1[0] * f->splat_scale * l1;
+  out->basis1[1]    = e1[1] * f->splat_scale * l1;
+  out->basis2[0]    = e2[0] * f->splat_scale * l2;
+  out->basis2[1]    = e2[1] * f->splat_scale * l2;
+
+  const float ndc[3] = {clip[0] / clip[3], clip[1] / clip[3], clip[2] / clip[3]};  // :268
+  // Fixed-function clipping of the emitted quad (all four vertices carry z = ndc.z, w = 1):
+  // Vulkan's clip volume is 0 <= z <= w with depth clamp off (the pipeline never enables it,
+  // src/gaussian_splatting.cpp:2053-2181), which is also what emitDegeneratedQuad relies on
+  // when it parks rejected quads at z = 2 (mesh.slang:102-109).
+  if(!(ndc[2] >= 0.0f && ndc[2] <= 1.0f))
+    return;
+  out->ndc_z        = ndc[2];
+  out->center_px[0] = (ndc[0] + 1.0f) * 0.5f * (float)f->width;  // viewport transform, origin (0,0)
+  out->center_px[1] = (ndc[1] + 1.0f) * 0.5f * (float)f->height;
+  std::memcpy(out->rgba, rgba, sizeof(rgba));
+  out->valid = 1;
+}
+
+// fragments + blending: shaders/threedgs_raster.frag.slang:223-309, src/gaussian_splatting.cpp:2066-2087
+static uint64_t raster_one(const OrcFrame* f, const OrcProjected& P, float* img)
+{
+  const int   W = f->width, H = f->height;
+  const float ex = std::fabs(P.basis1[0]) + std::fabs(P.basis2[0]);
+  const float ey = std::fabs(P.basis1[1]) + std::fabs(P.basis2[1]);
+  // pixel centres (x+0.5) inside [cx-ex, cx+ex]
+  const float fx0 = P.center_px[0] - ex - 0.5f, fx1 = P.center_px[0] + ex - 0.5f;
+  const float fy0 = P.center_px[1] - ey - 0.5f, fy1 = P.center_px[1] + ey - 0.5f;
+  if(!(fx1 >= 0.f && fy1 >= 0.f && fx0 <= (float)(W - 1) && fy0 <= (float)(H - 1)))
+    return 0;
+  const int   x0 = (int)std::max(0.0f, std::floor(fx0)), x1 = (int)std::min((float)(W - 1), std::ceil(fx1));
+  const int   y0 = (int)std::max(0.0f, std::floor(fy0)), y1 = (int)std::min((float)(H - 1), std::ceil(fy1));
+  const float n1 = P.basis1[0] * P.basis1[0] + P.basis1[1] * P.basis1[1];
+  const float n2 = P.basis2[0] * P.basis2[0] + P.basis2[1] * P.basis2[1];
+  uint64_t    frags = 0;
+  for(int y = y0; y <= y1; ++y)
+  {
+    for(int x = x0; x <= x1; ++x)
+    {
+      const float dx = ((float)x + 0.5f) - P.center_px[0];
+      const float dy = ((float)y + 0.5f) - P.center_px[1];
+      // interpolated fragPos = sqrt8 * (u, v) with pixel = centre + u*b1 + v*b2 (b1 ⟂ b2)
+      const float u  = (dx * P.basis1[0] + dy * P.basis1[1]) / n1;
+      const float v  = (dx * P.basis2[0] + dy * P.basis2[1]) / n2;
+      const float px = u * kSqrt8, py = v * kSqrt8;
+      const float A  = px * px + py * py;  // frag.slang:236
+      if(A > 8.0f)                         // :242-245
+        continue;
+      const float opacity = std::exp(-0.5f * A) * P.rgba[3];  // :254
+      if(opacity <= 1.0f / 255.0f)                            // :258-262
+        continue;
+      float* dst = img + ((size_t)y * W + x) * 4;
+      if(f->front_to_back)
+      {  // src rgb premultiplied (:303); C = Cs*(1-Ad) + Cd ; A = As*(1-Ad) + Ad
+        const float oma = 1.0f - dst[3];
+        dst[0]          = (P.rgba[0] * opacity) * oma + dst[0];
+        dst[1]          = (P.rgba[1] * opacity) * oma + dst[1];
+        dst[2]          = (P.rgba[2] * opacity) * oma + dst[2];
+        dst[3]          = opacity * oma + dst[3];
+      }
+      else
+      {  // C = Cs*As + Cd*(1-As) ; A = As + Ad   (:308, cpp:2081-2086)
+        const float oma = 1.0f - opacity;
+        dst[0]          = P.rgba[0] * opacity + dst[0] * oma;
+        dst[1]          = P.rgba[1] * opacity + dst[1] * oma;
+        dst[2]          = P.rgba[2] * opacity + dst[2] * oma;
+        dst[3]          = opacity + dst[3];
+      }
+      if(f->target_fp16)  // RGBA16F colour target (gaussian_splatting.h:338,340)
+        for(int c = 0; c < 4; ++c)
+          dst[c] = orc_half_to_float(orc_float_to_half(dst[c]));
+      ++frags;
+    }
+  }
+  return frags;
+}
+
+uint64_t orc_render_order(const OrcFrame* f, const OrcInstance* inst, int n_inst, const uint32_t* ids, uint32_t v,
+                          float* rgba_out, uint64_t* stats)
+{
+  std::memset(rgba_out, 0, (size_t)f->width * f->height * 4 * sizeof(float));  // clear (0,0,0,0)
+  std::vector<uint32_t> offsets(n_inst + 1, 0);
+  for(int k = 0; k < n_inst; ++k)
+    offsets[k + 1] = offsets[k] + inst[k].count;
+  uint64_t frags = 0, quads = 0;
+  for(uint32_t s = 0; s < v; ++s)
+  {
+    const uint32_t g = ids[s];
+    int            k = 0;
+    while(k + 1 < n_inst && g >= offsets[k + 1])
+      ++k;
+    OrcProjected P;
+    orc_project(f, &inst[k], g - offsets[k], &P);
+    if(!P.valid)
+      continue;
+    ++quads;
+    frags += raster_one(f, P, rgba_out);
+  }
+  if(stats)
+  {
+    stats[0] = v;
+    stats[1] = quads;
+  }
+  return frags;
+}
+
+uint64_t orc_render(const OrcFrame* f, const OrcInstance* inst, int n_inst, float* rgba_out, uint64_t* stats)
+{
+  size_t total = 0;
+  for(int k = 0; k < n_inst; ++k)
+    total += inst[k].count;
+  std::vector<uint32_t> keys(total), ids(total);
+  const uint32_t        v = orc_key_cull(f, inst, n_inst, keys.data(), ids.data());
+  orc_sort_stable(keys.data(), ids.data(), v);
+  return orc_render_order(f, inst, n_inst, ids.data(), v, rgba_out, stats);
+}
+
+// shaders/image_compare_metric.comp.slang:116-130 ; src/image_compare.cpp:869-893
+double orc_psnr_rgb(const float* a, const float* b, int width, int height)
+{
+  double       se = 0.0;
+  const size_t n  = (size_t)width * height;
+  for(size_t i = 0; i < n; ++i)
+    for(int c = 0; c < 3; ++c)
+    {
+      const double d = (double)a[4 * i + c] - (double)b[4 * i + c];
+      se += d * d;
+    }
+  const double mse = se / ((double)n * 3.0);
+  if(mse <= 0.0)
+    return 99.99;
+  return std::min(99.99, 10.0 * std::log10(1.0 / mse));
+}
+
+// ---------------------------------------------------------------------------------------
+// src/splat_sorter_async.cpp:92-141 ; parallel loop = nvutils::parallel_batches_pooled<8192>
+// (src/utilities.h:52-59, nvpro_core2 absent: restated as fixed 8192-element batches handed
+// to a pool of `threads` workers).
+int orc_cpu_sort(const float dir[3], const float cop[3], const OrcSortInstance* inst, int n_inst, uint32_t total,
+                 int front_to_back, int threads, float* distances, uint32_t* indices, double* dist_ms, double* sort_ms)
+{
+  if(n_inst <= 0)
+    return -1;
+  const auto  t0       = std::chrono::high_resolution_clock::now();
+  const float plane[4] = {dir[0], dir[1], dir[2], -dir[0] * cop[0] - dir[1] * cop[1] - dir[2] * cop[2]};
+  const float divider  = 1.0f / std::sqrt(plane[0] * plane[0] + plane[1] * plane[1] + plane[2] * plane[2]);
+  if(threads <= 0)
+    threads = (int)std::max(1u, std::thread::hardware_concurrency());
+  for(int k = 0; k < n_inst; ++k)
+  {
+    const OrcSortInstance& I = inst[k];
+    if(!I.positions)
+      continue;
+    const uint32_t batch   = 8192;
+    const uint32_t nBatch  = (I.count + batch - 1) / batch;
+    auto           worker  = [&](int tid) {
+      for(uint32_t bi = (uint32_t)tid; bi < nBatch; bi += (uint32_t)threads)
+      {
+        const uint32_t b = bi * batch, e = std::min(I.count, b + batch);
+        for(uint32_t s = b; s < e; ++s)
+        {
+          const float v[4] = {I.positions[3 * s], I.positions[3 * s + 1], I.positions[3 * s + 2], 1.0f};
+          float       p[4];
+          mat4_mul_vec4(I.transform, v, p);
+          const float dist = std::fabs(plane[0] * p[0] + plane[1] * p[1] + plane[2] * p[2] + plane[3]) * divider;
+          distances[I.global_offset + s] = dist;
+          indices[I.global_offset + s]   = I.global_offset + s;
+        }
+      }
+    };
+    std::vector<std::thread> pool;
+    for(int t = 1; t < threads; ++t)
+      pool.emplace_back(worker, t);
+    worker(0);
+    for(auto& th : pool)
+      th.join();
+  }
+  const auto t1 = std::chrono::high_resolution_clock::now();
+  if(front_to_back)
+    std::sort(std::execution::par_unseq, indices, indices + total,
+              [&](uint32_t i, uint32_t j) { return distances[i] < distances[j]; });
+  else
+    std::sort(std::execution::par_unseq, indices, indices + total,
+              [&](uint32_t i, uint32_t j) { return distances[i] > distances[j]; });
+  const auto t2 = std::chrono::high_resolution_clock::now();
+  if(dist_ms)
+    *dist_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  if(sort_ms)
+    *sort_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+/*
+ * mgs_oracle.h — TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement of the VK3DGSR hot path of nvpro-samples/vk_gaussian_splatting
+ * (reference @ /root/reference, VERSION 2026.1.6).  Every function cites the
+ * reference file:line it follows.  Nothing in the product (vk_gaussian_splatting_amd/)
+ * may include, link or call this; only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it, and only as the checker.
+ *
+ * Pinning status:
+ *   - ingest (PLY/SPZ/.splat -> SplatSet, RDF->RUB, maxShDegree, flipSh): PINNED against
+ *     the reference's own miniply/spz/splat_set.h compiled unmodified into oracle/_ref/
+ *     (tests/golden/ingest_*.npz, generator tests/golden/make_golden.py).
+ *   - everything that lives in Slang shaders or in Vulkan-dependent .cpp files
+ *     (upload transform, keys/cull, sort order, projection, SH, raster, blend):
+ *     "parity unpinned" — the reference ships no tests/golden vectors for it and
+ *     cannot be built here (needs slangc, Vulkan, nvpro_core2, glm).
+ */
+#ifndef MGS_ORACLE_H
+#define MGS_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_FORMAT_FLOAT32 = 0, ORC_FORMAT_FLOAT16 = 1, ORC_FORMAT_UINT8 = 2 }; /* shaderio.h:60-62 */
+
+/* ---- ingest-side semantics (src/splat_set.h) ---- */
+int  orc_max_sh_degree(size_t f_rest_len, size_t splat_count);              /* splat_set.h:52-74   */
+void orc_flip_sh_rdf_to_rub(float out15[15]);                               /* splat-types.h:55-83 */
+void orc_convert_rdf_to_rub(float* positions, float* rotation, float* f_rest,
+                            size_t splat_count, size_t coeffs_per_channel); /* splat_set.h:78-114  */
+
+/* ---- load-time upload transform (src/splat_set_vk.cpp) ---- */
+void orc_cov3d(const float* scale, const float* rotation, size_t n, float* cov6);                 /* :263-288 */
+void orc_rgba(const float* f_dc, const float* opacity, size_t n, float* rgba);                    /* :313-345 */
+void orc_sh_interleave(const float* f_rest, size_t n, int coeffs_per_channel, float* sh_out);     /* :356-435 */
+int  orc_sh_stride(int coeffs_per_channel);
+/* in-place quantise then dequantise exactly as the shaders read it back
+ * (splat_set_vk.cpp:85-112 ; threedgs_particle_buffers.h.slang:72-90,112-207) */
+void orc_quantize_roundtrip(float* data, size_t count, int format, int is_sh);
+uint16_t orc_float_to_half(float f);
+float    orc_half_to_float(uint16_t h);
+
+/* ---- frame ---- */
+typedef struct OrcFrame {
+  float view[16];       /* glm column-major memory */
+  float proj[16];       /* glm column-major, RH, clip z in [0,1]; proj[5] may be negative */
+  float camera_pos[3];
+  int   width, height;
+  float splat_scale;          /* shaderio.h:261 */
+  float frustum_dilation;     /* shaderio.h:264 */
+  float alpha_cull_threshold; /* shaderio.h:265 */
+  int   sh_degree;            /* shaderio.h:262 */
+  int   front_to_back;        /* FRONT_TO_BACK macro: keys use +depth; blend uses "under" */
+  int   frustum_culling;      /* 0 none, 1 at dist (default), 2 at raster (shaderio.h:84-86) */
+  int   target_fp16;          /* 1: round the colour target to fp16 after every blend (RGBA16F) */
+  int   ms_antialiasing;      /* MS_ANTIALIASING macro (threedgs.h.slang:63-76) */
+} OrcFrame;
+
+typedef struct OrcInstance {
+  const float* centers;  /* [count*3] */
+  const float* cov6;     /* [count*6] */
+  const float* rgba;     /* [count*4], already dequantised */
+  const float* sh;       /* [count*sh_stride] interleaved [coef][rgb], may be NULL */
+  uint32_t count;
+  int      sh_degree;    /* of the splat set */
+  int      sh_stride;    /* 0, 9, 24, 45 */
+  float    transform[16];
+  float    transform_inv[16];
+} OrcInstance;
+
+typedef struct OrcProjected {
+  int   valid;          /* 0 => degenerate quad / discarded */
+  float center_px[2];
+  float ndc_z;
+  float basis1[2], basis2[2]; /* pixels */
+  float rgba[4];
+} OrcProjected;
+
+void orc_mat4_inverse(const float m[16], float out[16]);  /* glm::inverse restated (cofactors) */
+void orc_mat4_mul(const float a[16], const float b[16], float out[16]);
+
+uint32_t orc_encode_key(float v);                                               /* dist.comp.slang:33-38 */
+/* keys + ids of survivors in ascending global id; returns V.  dist.comp.slang:40-171 */
+uint32_t orc_key_cull(const OrcFrame* f, const OrcInstance* inst, int n_inst,
+                      uint32_t* keys, uint32_t* ids);
+/* stable ascending LSD radix sort, 4x8 bit — vrdx vk_radix_sort.cc:262-416 */
+void orc_sort_stable(uint32_t* keys, uint32_t* ids, uint32_t n);
+/* per-splat raster front end — threedgs_raster.mesh.slang:111-291 */
+void orc_project(const OrcFrame* f, const OrcInstance* inst, uint32_t local_idx, OrcProjected* out);
+/* whole frame; rgba_out is [height][width][4] floats, row 0 = NDC y -1.
+ * returns number of fragments blended.  stats[0]=V, stats[1]=valid quads */
+uint64_t orc_render(const OrcFrame* f, const OrcInstance* inst, int n_inst,
+                    float* rgba_out, uint64_t* stats);
+/* same, but consuming an externally supplied draw order (global ids) */
+uint64_t orc_render_order(const OrcFrame* f, const OrcInstance* inst, int n_inst,
+                          const uint32_t* ids, uint32_t v, float* rgba_out, uint64_t* stats);
+
+/* PSNR as the reference defines it: MSE over RGB / (W*H*3), 10*log10(1/MSE), cap 99.99
+ * image_compare_metric.comp.slang:116-130, image_compare.cpp:869-893 */
+double orc_psnr_rgb(const float* a, const float* b, int width, int height);
+
+/* ---- CPU async sorter semantics — src/splat_sorter_async.cpp:92-141 ---- */
+typedef struct OrcSortInstance {
+  const float* positions; uint32_t count; uint32_t global_offset; float transform[16];
+} OrcSortInstance;
+/* fills distances[total], indices[total]; returns 0 on success.  threads<=0 => hardware_concurrency */
+int orc_cpu_sort(const float dir[3], const float cop[3], const OrcSortInstance* inst, int n_inst,
+                 uint32_t total, int front_to_back, int threads,
+                 float* distances, uint32_t* indices, double* dist_ms, double* sort_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

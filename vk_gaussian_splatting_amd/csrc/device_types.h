@@ -1,0 +1,87 @@
+// device_types.h — structs shared between the host orchestration and the gfx950 kernels.
+#pragma once
+#include <cstdint>
+
+namespace mgs {
+
+constexpr int kMaxInlineInstances = 8;   // instances carried by value in the kernel argument block
+constexpr int kTilePx             = 16;  // binning tile edge in pixels (composite works on 8x8 wave quadrants)
+
+// error bits reported through MgsFrameOut.error_flags
+enum : uint32_t {
+  kErrPairOverflow  = 1u << 0,  // tile-pair capacity exceeded
+  kErrSpinTimeout   = 1u << 1,  // a bounded look-back spin gave up (never hangs the GPU)
+  kErrSortOverflow  = 1u << 2,
+};
+
+// per-instance constants (SplatSetDesc, shaders/shaderio.h:439-479, reduced to what the path reads)
+struct InstanceConst
+{
+  const float* centers;  // [count*3]
+  const float* cov6;     // [count*6]
+  const void*  rgba;     // [count*4] fp32 | fp16 | u8
+  const void*  sh;       // [count*shStride] fp32 | fp16 | u8, interleaved [coef][rgb]
+  float        model[16];      // M   (glm column-major)
+  float        modelView[16];  // V*M (host-computed with the same unfused fp32 products the shader does per thread)
+  float        camModel[3];    // M^-1 * cameraPosition
+  uint32_t     count;
+  uint32_t     globalOffset;   // first global splat id of this instance
+  uint32_t     blockBegin;     // first project-kernel partition of this instance
+  int32_t      shDegree;       // of the splat set
+  int32_t      shStride;       // 0 / 9 / 24 / 45 elements
+};
+
+// frame constants (shaderio::FrameInfo, shaders/shaderio.h:238-317, reduced)
+struct FrameConst
+{
+  float    view[16];
+  float    proj[16];
+  float    focal[2];      // (P00*W/2, P11*H/2), src/gaussian_splatting.cpp:1248-1250
+  int32_t  width, height;
+  int32_t  tilesX, tilesY;
+  int32_t  stripRow0, stripRow1;  // tile rows rendered by this device
+  float    splatScale, frustumDilation, alphaCull;
+  int32_t  shDegree;
+  int32_t  frontToBack;   // key sign
+  int32_t  cullMode;
+  int32_t  msAA;
+  int32_t  alphaMode;
+  int32_t  targetFormat;
+  int32_t  nInstances;
+  uint32_t totalSplats;
+  uint32_t totalPartitions;  // project-kernel partitions
+};
+
+struct FrameArgs
+{
+  FrameConst    f;
+  InstanceConst inst[kMaxInlineInstances];
+};
+
+// projected splat record consumed by the compositor (48 B, 16-B aligned)
+struct alignas(16) SplatRec
+{
+  float cx, cy;    // centre in pixels
+  float p1x, p1y;  // 2*b1/|b1|^2 : (d.p1)^2 + (d.p2)^2 == A/2 of threedgs_raster.frag.slang:236
+  float p2x, p2y;
+  float r, g, b, a;
+  float ex, ey;    // tight half extents of the visible footprint in pixels
+};
+
+// device-resident counters of one frame
+struct FrameCounters
+{
+  uint32_t frustumCount;   // survivors of the dist-stage cull
+  uint32_t sortedCount;    // V: elements handed to the radix sort
+  uint32_t pairCount;      // D: (tile, splat) records
+  uint32_t errorFlags;
+  uint32_t ticketProject;
+  uint32_t ticketBin;
+  uint32_t ticketSort[8];  // one per radix pass (4 key passes + up to 4 pair passes)
+  uint32_t sortSelect;     // which ping-pong buffer holds the current keys (0/1)
+  uint32_t pairSelect;
+  uint32_t passesRun;
+  uint32_t pad[13];
+};
+
+}  // namespace mgs

@@ -1,0 +1,403 @@
+// k_project.hip — fused "dist + cull + project" kernel for gfx950.
+//
+// Replaces, in ONE pass over the splats in storage (id) order:
+//   shaders/dist.comp.slang:40-171          depth key, frustum cull, survivor append
+//   shaders/threedgs_raster.mesh.slang:111-291  per-splat raster front end (colour fetch, alpha cull,
+//                                            SH -> RGB, covariance projection, extent basis)
+//   shaders/threedgs.h.slang:26-121         threedgsCovarianceProjection / threedgsProjectedExtentBasis
+//   shaders/threedgs_particle_storage.h.slang:103-159  fetchViewDependentRadiance
+// MI355X-first differences:
+//   * the reference runs dist in id order and the mesh shader in SORTED order, so its 232 B/splat
+//     attribute gather is uncoalesced; here the gather happens before the sort, in id order, and the
+//     sort only moves 8-byte (key,id) pairs.  The 48-byte projected record is indexed by global id.
+//   * survivors are compacted per 2048-splat partition into a fixed slot region (ascending id, so
+//     the order is deterministic); the radix sort's first pass consumes the slots directly — there
+//     is no global atomic append and no inter-workgroup chain.
+//   * splats that can never produce a fragment (alpha cull, lambda2<=0, clipped by z, footprint
+//     outside the strip) are dropped BEFORE the sort.
+#include "kernels_common.h"
+
+namespace mgs {
+
+constexpr int kPrjThreads = 256;
+constexpr int kPrjItems   = 8;
+constexpr int kPrjPart    = kPrjThreads * kPrjItems;  // 2048 splats per workgroup
+
+struct Projected
+{
+  SplatRec rec;
+  uint32_t rect;  // tile rectangle x0 | y0<<8 | x1<<16 | y1<<24 (inclusive, 16-px tiles)
+};
+
+template <int FMT>
+__device__ __forceinline__ float4 loadRgba(const void* base, uint32_t i)
+{
+  if constexpr(FMT == 0)
+  {
+    return reinterpret_cast<const float4*>(base)[i];
+  }
+  else if constexpr(FMT == 1)
+  {
+    const uint2  raw = reinterpret_cast<const uint2*>(base)[i];
+    const __half2 lo = *reinterpret_cast<const __half2*>(&raw.x), hi = *reinterpret_cast<const __half2*>(&raw.y);
+    const float2  a = __half22float2(lo), b = __half22float2(hi);
+    return make_float4(a.x, a.y, b.x, b.y);
+  }
+  else
+  {
+    const uint32_t raw = reinterpret_cast<const uint32_t*>(base)[i];
+    return make_float4((float)(raw & 255u) / 255.0f, (float)((raw >> 8) & 255u) / 255.0f,
+                       (float)((raw >> 16) & 255u) / 255.0f, (float)(raw >> 24) / 255.0f);
+  }
+}
+
+template <int FMT>
+__device__ __forceinline__ float loadSh(const void* base, size_t idx)
+{
+  if constexpr(FMT == 0)
+    return reinterpret_cast<const float*>(base)[idx];
+  else if constexpr(FMT == 1)
+    return __half2float(reinterpret_cast<const __half*>(base)[idx]);
+  else
+    return (float)reinterpret_cast<const uint8_t*>(base)[idx] / 255.0f * 2.0f - 1.0f;
+}
+
+// SH degrees 1..3 added to the base colour; constants and term order of
+// threedgs_particle_storage.h.slang:48-52,121-155
+template <int FMT>
+__device__ __forceinline__ void addShRadiance(const InstanceConst& I, uint32_t li, int degree, float x, float y, float z,
+                                              float& r, float& g, float& b)
+{
+  if(degree < 1 || I.sh == nullptr)
+    return;
+  const size_t o = (size_t)li * (size_t)I.shStride;
+  float        s[45];
+  const int    ncoef = degree == 1 ? 9 : (degree == 2 ? 24 : 45);
+#pragma unroll
+  for(int k = 0; k < 45; ++k)
+    s[k] = (k < ncoef) ? loadSh<FMT>(I.sh, o + k) : 0.f;
+  const float C1 = 0.4886025119029199f;
+  float       acc[3];
+#pragma unroll
+  for(int c = 0; c < 3; ++c)
+    acc[c] = C1 * (-s[0 + c] * y + s[3 + c] * z - s[6 + c] * x);
+  if(degree >= 2)
+  {
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    const float k0 = 1.0925484f * xy, k1 = -1.0925484f * yz, k2 = 0.3153916f * (2.0f * zz - xx - yy),
+                k3 = -1.0925484f * xz, k4 = 0.5462742f * (xx - yy);
+#pragma unroll
+    for(int c = 0; c < 3; ++c)
+      acc[c] += k0 * s[9 + c] + k1 * s[12 + c] + k2 * s[15 + c] + k3 * s[18 + c] + k4 * s[21 + c];
+    if(degree >= 3)
+    {
+      const float m0 = -0.5900435899266435f * (3.0f * xx - yy) * y, m1 = 2.890611442640554f * xy * z,
+                  m2 = -0.4570457994644658f * (4.0f * zz - xx - yy) * y,
+                  m3 = 0.3731763325901154f * z * (2.0f * zz - 3.0f * xx - 3.0f * yy),
+                  m4 = -0.4570457994644658f * x * (4.0f * zz - xx - yy), m5 = 1.445305721320277f * (xx - yy) * z,
+                  m6 = -0.5900435899266435f * x * (xx - 3.0f * yy);
+#pragma unroll
+      for(int c = 0; c < 3; ++c)
+        acc[c] += m0 * s[24 + c] + m1 * s[27 + c] + m2 * s[30 + c] + m3 * s[33 + c] + m4 * s[36 + c] + m5 * s[39 + c]
+                  + m6 * s[42 + c];
+    }
+  }
+  r += acc[0];
+  g += acc[1];
+  b += acc[2];
+}
+
+// The per-splat raster front end.  Returns false when the splat cannot produce a fragment.
+template <int SHF, int RGBAF>
+__device__ __forceinline__ bool projectSplat(const FrameConst& F, const InstanceConst& I, uint32_t li, Projected& out)
+{
+  float4 col = loadRgba<RGBAF>(I.rgba, li);
+  if(col.w < F.alphaCull)  // mesh.slang:164-170
+    return false;
+  const float px = I.centers[3 * (size_t)li + 0], py = I.centers[3 * (size_t)li + 1], pz = I.centers[3 * (size_t)li + 2];
+  const float* MV = I.modelView;
+  // view-space centre and clip position (mesh.slang:175-179)
+  const float tx = MV[0] * px + MV[4] * py + MV[8] * pz + MV[12];
+  const float ty = MV[1] * px + MV[5] * py + MV[9] * pz + MV[13];
+  const float tz = MV[2] * px + MV[6] * py + MV[10] * pz + MV[14];
+  const float tw = MV[3] * px + MV[7] * py + MV[11] * pz + MV[15];
+  const float* P  = F.proj;
+  const float  cx = P[0] * tx + P[4] * ty + P[8] * tz + P[12] * tw;
+  const float  cy = P[1] * tx + P[5] * ty + P[9] * tz + P[13] * tw;
+  const float  cz = P[2] * tx + P[6] * ty + P[10] * tz + P[14] * tw;
+  const float  cw = P[3] * tx + P[7] * ty + P[11] * tz + P[15] * tw;
+  if(F.cullMode == 2)
+  {  // FRUSTUM_CULLING_AT_RASTER, mesh.slang:181-190
+    const float c = (1.0f + F.frustumDilation) * cw;
+    if(fabsf(cx) > c || fabsf(cy) > c || cz < (0.0f - F.frustumDilation) * cw || cz > cw)
+      return false;
+  }
+  const float rw   = 1.0f / cw;
+  const float ndcx = cx * rw, ndcy = cy * rw, ndcz = cz * rw;
+  // fixed-function z clip of the emitted quad (all vertices at z = ndc.z, w = 1; no depth clamp)
+  if(!(ndcz >= 0.0f && ndcz <= 1.0f))
+    return false;
+
+  // covariance projection, threedgs.h.slang:26-56
+  const float* c6 = I.cov6 + 6 * (size_t)li;
+  const float  s00 = c6[0], s01 = c6[1], s02 = c6[2], s11 = c6[3], s12 = c6[4], s22 = c6[5];
+  const float  rz = 1.0f / tz, rz2 = rz * rz;
+  const float  j00 = F.focal[0] * rz, j02 = -(F.focal[0] * tx) * rz2;
+  const float  j11 = F.focal[1] * rz, j12 = -(F.focal[1] * ty) * rz2;
+  // W(r,c) = MV(r,c);  T = J * W (rows 0 and 1 only)
+  const float t00 = j00 * MV[0] + j02 * MV[2], t01 = j00 * MV[4] + j02 * MV[6], t02 = j00 * MV[8] + j02 * MV[10];
+  const float t10 = j11 * MV[1] + j12 * MV[2], t11 = j11 * MV[5] + j12 * MV[6], t12 = j11 * MV[9] + j12 * MV[10];
+  // cov2D = T * Sigma * T^T
+  const float u0 = t00 * s00 + t01 * s01 + t02 * s02, u1 = t00 * s01 + t01 * s11 + t02 * s12,
+              u2 = t00 * s02 + t01 * s12 + t02 * s22;
+  const float v0 = t10 * s00 + t11 * s01 + t12 * s02, v1 = t10 * s01 + t11 * s11 + t12 * s12,
+              v2 = t10 * s02 + t11 * s12 + t12 * s22;
+  float a = u0 * t00 + u1 * t01 + u2 * t02;
+  float b = u0 * t10 + u1 * t11 + u2 * t12;
+  float d = v0 * t10 + v1 * t11 + v2 * t12;
+
+  // extent basis, threedgs.h.slang:60-121
+  float detOrig = 0.f;
+  if(F.msAA)
+    detOrig = a * d - b * b;
+  a += 0.3f;
+  d += 0.3f;
+  if(F.msAA)
+  {
+    const float detBlur = a * d - b * b;
+    col.w *= sqrtf(fmaxf(detOrig / detBlur, 0.0f));
+  }
+  const float D     = a * d - b * b;
+  const float half  = 0.5f * (a + d);
+  const float term2 = sqrtf(fmaxf(0.1f, half * half - D));
+  const float ev1 = half + term2, ev2 = half - term2;
+  if(ev2 <= 0.0f)
+    return false;
+  float       e1x = (fabsf(b) < 0.001f) ? 1.0f : b, e1y = ev1 - a;
+  const float el  = rsqrtf(e1x * e1x + e1y * e1y);
+  e1x *= el;
+  e1y *= el;
+  const float kSqrt8 = 2.8284271247461903f;
+  const float l1     = F.splatScale * fminf(kSqrt8 * sqrtf(ev1), 2048.0f);
+  const float l2     = F.splatScale * fminf(kSqrt8 * sqrtf(ev2), 2048.0f);
+  if(!(l1 > 0.f && l2 > 0.f))
+    return false;
+  const float b1x = e1x * l1, b1y = e1y * l1;   // basisVector1 (pixels)
+  const float b2x = e1y * l2, b2y = -e1x * l2;  // basisVector2 = (e1.y, -e1.x) * l2
+
+  // a fragment survives iff q = (d.p1)^2+(d.p2)^2 <= 4 (A<=8) and a*exp(-q) > 1/255 (frag.slang:242-262)
+  const float a255 = col.w * 255.0f;
+  if(!(a255 > 1.0f))
+    return false;
+  const float qmax  = fminf(4.0f, __logf(a255) + 1e-3f);
+  const float shrink = sqrtf(qmax * 0.25f) * 1.0005f;
+  const float ex = shrink * sqrtf(b1x * b1x + b2x * b2x) + 0.01f;
+  const float ey = shrink * sqrtf(b1y * b1y + b2y * b2y) + 0.01f;
+
+  const float pcx = (ndcx + 1.0f) * 0.5f * (float)F.width;
+  const float pcy = (ndcy + 1.0f) * 0.5f * (float)F.height;
+  // pixel centres (x+0.5) within [pc-e, pc+e]
+  const float fx0 = ceilf(pcx - ex - 0.5f), fx1 = floorf(pcx + ex - 0.5f);
+  const float fy0 = ceilf(pcy - ey - 0.5f), fy1 = floorf(pcy + ey - 0.5f);
+  const float ymin = (float)(F.stripRow0 * kTilePx), ymax = (float)(min(F.stripRow1 * kTilePx, F.height) - 1);
+  if(!(fx1 >= fx0 && fy1 >= fy0 && fx1 >= 0.f && fx0 <= (float)(F.width - 1) && fy1 >= ymin && fy0 <= ymax))
+    return false;
+  const int x0 = (int)fmaxf(fx0, 0.f), x1 = (int)fminf(fx1, (float)(F.width - 1));
+  const int y0 = (int)fmaxf(fy0, ymin), y1 = (int)fminf(fy1, ymax);
+  out.rect = (uint32_t)(x0 >> 4) | ((uint32_t)(y0 >> 4) << 8) | ((uint32_t)(x1 >> 4) << 16) | ((uint32_t)(y1 >> 4) << 24);
+
+  // view-dependent colour (mesh.slang:240-243): direction in model space, no clamp afterwards
+  float dx = px - I.camModel[0], dy = py - I.camModel[1], dz = pz - I.camModel[2];
+  const float dl = rsqrtf(dx * dx + dy * dy + dz * dz);
+  dx *= dl;
+  dy *= dl;
+  dz *= dl;
+  const int degree = min(I.shDegree, F.shDegree);
+  addShRadiance<SHF>(I, li, degree, dx, dy, dz, col.x, col.y, col.z);
+
+  const float n1 = 2.0f / (b1x * b1x + b1y * b1y), n2 = 2.0f / (b2x * b2x + b2y * b2y);
+  out.rec.cx  = pcx;
+  out.rec.cy  = pcy;
+  out.rec.p1x = b1x * n1;
+  out.rec.p1y = b1y * n1;
+  out.rec.p2x = b2x * n2;
+  out.rec.p2y = b2y * n2;
+  out.rec.r   = col.x;
+  out.rec.g   = col.y;
+  out.rec.b   = col.z;
+  out.rec.a   = col.w;
+  out.rec.ex  = ex;
+  out.rec.ey  = ey;
+  return true;
+}
+
+// One workgroup = one partition of 2048 consecutive splats of one instance.
+// Output: survivors of partition p, ascending id, in keysSlot/idsSlot[p*2048 ...], count in slotCount[p].
+template <bool FULL, int SHF, int RGBAF>
+__global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, FrameCounters* __restrict__ ctr,
+                                                         uint32_t* __restrict__ keysSlot, uint32_t* __restrict__ idsSlot,
+                                                         uint32_t* __restrict__ slotCount, SplatRec* __restrict__ rec,
+                                                         uint32_t* __restrict__ rect)
+{
+  __shared__ uint16_t s_li[kPrjPart];
+  __shared__ uint32_t s_key[kPrjPart];
+  __shared__ uint32_t s_wc[2][4];
+
+  const int      t = threadIdx.x, lane = laneId(), w = t >> 6;
+  const uint32_t part = blockIdx.x;
+  int            k    = 0;
+#pragma unroll
+  for(int i = 1; i < kMaxInlineInstances; ++i)
+    if(i < A.f.nInstances && part >= A.inst[i].blockBegin)
+      k = i;
+  const InstanceConst& I      = A.inst[k];
+  const uint32_t       local0 = (part - I.blockBegin) * kPrjPart;
+
+  // ---- phase 1: key + frustum cull, compacted (ascending id) into LDS -------------------------
+  uint32_t running = 0;
+#pragma unroll
+  for(int it = 0; it < kPrjItems; ++it)
+  {
+    const uint32_t li    = local0 + it * kPrjThreads + t;
+    const bool     valid = li < I.count;
+    bool           vis   = false;
+    uint32_t       key   = 0;
+    if(valid)
+    {
+      const float x = I.centers[3 * (size_t)li], y = I.centers[3 * (size_t)li + 1], z = I.centers[3 * (size_t)li + 2];
+      float       wp[4], vp[4], cp[4];
+      mulMat4Exact(I.model, x, y, z, 1.0f, wp);               // dist.comp.slang:58
+      mulMat4Exact(A.f.view, wp[0], wp[1], wp[2], wp[3], vp);  // :58
+      mulMat4Exact(A.f.proj, vp[0], vp[1], vp[2], vp[3], cp);  // :60
+      const float nx = __fdiv_rn(cp[0], cp[3]), ny = __fdiv_rn(cp[1], cp[3]), nz = __fdiv_rn(cp[2], cp[3]);  // :61
+      vis = true;
+      if(A.f.cullMode == 1)
+      {  // :71-73 (NaN compares false everywhere, as in the shader)
+        const float c = __fadd_rn(1.0f, A.f.frustumDilation);
+        if(fabsf(nx) > c || fabsf(ny) > c || nz < __fsub_rn(0.f, A.f.frustumDilation) || nz > 1.0f)
+          vis = false;
+      }
+      key = A.f.frontToBack ? encodeKey(nz) : encodeKey(-nz);  // :163-167
+    }
+    const uint64_t bal = __ballot(vis);
+    if(lane == 0)
+      s_wc[it & 1][w] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    const uint32_t c0 = s_wc[it & 1][0], c1 = s_wc[it & 1][1], c2 = s_wc[it & 1][2], c3 = s_wc[it & 1][3];
+    uint32_t       wb = 0;
+    if(w > 0) wb += c0;
+    if(w > 1) wb += c1;
+    if(w > 2) wb += c2;
+    if(vis)
+    {
+      const uint32_t pos = running + wb + lanesBelow(bal);
+      s_li[pos]          = (uint16_t)(it * kPrjThreads + t);
+      s_key[pos]         = key;
+    }
+    running += c0 + c1 + c2 + c3;
+  }
+  const uint32_t M = running;
+  __syncthreads();
+  if(t == 0 && M)
+    atomicAdd(&ctr->frustumCount, M);
+
+  const size_t slotBase = (size_t)part * kPrjPart;
+  if constexpr(!FULL)
+  {
+    // sort-only hook: survivors of the dist stage, exactly dist.comp.slang's (key, id) stream
+    for(uint32_t j = t; j < M; j += kPrjThreads)
+    {
+      keysSlot[slotBase + j] = s_key[j];
+      idsSlot[slotBase + j]  = I.globalOffset + local0 + s_li[j];
+    }
+    if(t == 0)
+    {
+      slotCount[part] = M;
+      if(M)
+        atomicAdd(&ctr->sortedCount, M);
+    }
+    return;
+  }
+  else
+  {
+    // ---- phase 2: dense raster front end over the survivors, second ordered compaction ---------
+    uint32_t outCount = 0;
+    const int rounds  = (int)((M + kPrjThreads - 1) / kPrjThreads);
+    for(int r = 0; r < rounds; ++r)
+    {
+      const uint32_t j  = r * kPrjThreads + t;
+      bool           ok = false;
+      uint32_t       key = 0, gid = 0;
+      if(j < M)
+      {
+        const uint32_t li = local0 + s_li[j];
+        key               = s_key[j];
+        gid               = I.globalOffset + li;
+        Projected pr;
+        ok = projectSplat<SHF, RGBAF>(A.f, I, li, pr);
+        if(ok)
+        {
+          float4* dst = reinterpret_cast<float4*>(rec + gid);
+          dst[0]      = make_float4(pr.rec.cx, pr.rec.cy, pr.rec.p1x, pr.rec.p1y);
+          dst[1]      = make_float4(pr.rec.p2x, pr.rec.p2y, pr.rec.r, pr.rec.g);
+          dst[2]      = make_float4(pr.rec.b, pr.rec.a, pr.rec.ex, pr.rec.ey);
+          rect[gid]   = pr.rect;
+        }
+      }
+      const uint64_t bal = __ballot(ok);
+      if(lane == 0)
+        s_wc[r & 1][w] = (uint32_t)__popcll(bal);
+      __syncthreads();
+      const uint32_t c0 = s_wc[r & 1][0], c1 = s_wc[r & 1][1], c2 = s_wc[r & 1][2], c3 = s_wc[r & 1][3];
+      uint32_t       wb = 0;
+      if(w > 0) wb += c0;
+      if(w > 1) wb += c1;
+      if(w > 2) wb += c2;
+      if(ok)
+      {
+        const uint32_t pos      = outCount + wb + lanesBelow(bal);
+        keysSlot[slotBase + pos] = key;
+        idsSlot[slotBase + pos]  = gid;
+      }
+      outCount += c0 + c1 + c2 + c3;
+    }
+    if(t == 0)
+    {
+      slotCount[part] = outCount;
+      if(outCount)
+        atomicAdd(&ctr->sortedCount, outCount);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-callable launcher
+void launchProject(hipStream_t stream, const FrameArgs& args, bool full, int shFormat, int rgbaFormat, FrameCounters* ctr,
+                   uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, SplatRec* rec, uint32_t* rect)
+{
+  const dim3 grid(args.f.totalPartitions), block(kPrjThreads);
+  if(args.f.totalPartitions == 0)
+    return;
+#define MGS_LAUNCH(FULLV, S, R)                                                                                          \
+  hipLaunchKernelGGL((k_project<FULLV, S, R>), grid, block, 0, stream, args, ctr, keysSlot, idsSlot, slotCount, rec, rect)
+  if(!full)
+  {
+    MGS_LAUNCH(false, 0, 0);
+    return;
+  }
+  switch(shFormat * 3 + rgbaFormat)
+  {
+    case 0: MGS_LAUNCH(true, 0, 0); break;
+    case 1: MGS_LAUNCH(true, 0, 1); break;
+    case 2: MGS_LAUNCH(true, 0, 2); break;
+    case 3: MGS_LAUNCH(true, 1, 0); break;
+    case 4: MGS_LAUNCH(true, 1, 1); break;
+    case 5: MGS_LAUNCH(true, 1, 2); break;
+    case 6: MGS_LAUNCH(true, 2, 0); break;
+    case 7: MGS_LAUNCH(true, 2, 1); break;
+    default: MGS_LAUNCH(true, 2, 2); break;
+  }
+#undef MGS_LAUNCH
+}
+
+}  // namespace mgs

@@ -1,0 +1,342 @@
+// k_raster.hip — screen-tile binning and per-pixel compositing for gfx950.
+//
+// The reference has no counterpart for binning: it emits one quad per splat and lets the
+// fixed-function rasterizer + ROP blend in primitive (= sorted) order
+// (shaders/threedgs_raster.frag.slang:223-309, src/gaussian_splatting.cpp:2066-2087).
+// Contract kept here: every pixel centre inside the splat's ellipse
+// (A <= 8) with alpha > 1/255 is blended, in the global depth order produced by the sort.
+// The reference blends back-to-front ("over"); we walk the same order from the other end and
+// accumulate front-to-back with transmittance, which is the same sum in exact arithmetic:
+//   C = sum_i c_i a_i prod_{j nearer than i} (1 - a_j).
+#include "kernels_common.h"
+#include "sort_plan.h"
+
+namespace mgs {
+
+constexpr int kBinThreads = 256;
+constexpr int kBinItems   = 8;
+constexpr int kBinPart    = kBinThreads * kBinItems;  // 2048 sorted splats per workgroup
+
+__device__ __forceinline__ uint32_t rectTiles(uint32_t r)
+{
+  const uint32_t x0 = r & 255u, y0 = (r >> 8) & 255u, x1 = (r >> 16) & 255u, y1 = r >> 24;
+  return (x1 - x0 + 1u) * (y1 - y0 + 1u);
+}
+
+// ---- frame init: zero counters, both sort plans and the tile ranges -------------------------
+__global__ void k_frame_init(FrameCounters* ctr, SortPlan* planKeys, SortPlan* planPairs, uint2* ranges, uint32_t nTiles)
+{
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+  uint32_t*      c   = reinterpret_cast<uint32_t*>(ctr);
+  for(uint32_t i = gid; i < sizeof(FrameCounters) / 4; i += gsz)
+    c[i] = 0;
+  uint32_t* a = reinterpret_cast<uint32_t*>(planKeys);
+  uint32_t* b = reinterpret_cast<uint32_t*>(planPairs);
+  for(uint32_t i = gid; i < sizeof(SortPlan) / 4; i += gsz)
+  {
+    a[i] = 0;
+    b[i] = 0;
+  }
+  for(uint32_t i = gid; i < nTiles; i += gsz)
+    ranges[i] = make_uint2(0u, 0u);
+}
+
+// ---- binning, step 1: tile-pair count of each 2048-splat block of the sorted list -----------
+__global__ __launch_bounds__(kBinThreads) void k_bin_count(const uint32_t* __restrict__ idsX, const uint32_t* __restrict__ idsY,
+                                                           const SortPlan* __restrict__ plan, const uint32_t* __restrict__ rect,
+                                                           uint32_t* __restrict__ blockCount)
+{
+  __shared__ uint32_t s_tmp[4];
+  const uint32_t      n     = plan->n;
+  const uint32_t      parts = (n + kBinPart - 1) / kBinPart;
+  if(blockIdx.x >= parts)
+    return;
+  const uint32_t* ids = plan->finalSel ? idsY : idsX;
+  uint32_t        sum = 0;
+#pragma unroll
+  for(int i = 0; i < kBinItems; ++i)
+  {
+    const uint32_t e = blockIdx.x * kBinPart + i * kBinThreads + threadIdx.x;
+    if(e < n)
+      sum += rectTiles(rect[ids[e]]);
+  }
+  sum = waveSum(sum);
+  if(laneId() == 0)
+    s_tmp[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if(threadIdx.x == 0)
+    blockCount[blockIdx.x] = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+}
+
+// ---- binning, step 2: exclusive scan of the block counts (one workgroup; <= a few 10k entries)
+__global__ __launch_bounds__(256) void k_bin_scan(const SortPlan* __restrict__ plan, uint32_t* __restrict__ blockCount,
+                                                  FrameCounters* __restrict__ ctr, uint32_t capacity)
+{
+  __shared__ uint32_t s_tmp[4];
+  const uint32_t      n     = plan->n;
+  const uint32_t      parts = (n + kBinPart - 1) / kBinPart;
+  uint64_t            carry = 0;
+  for(uint32_t base = 0; base < parts; base += 256)
+  {
+    const uint32_t p = base + threadIdx.x;
+    const uint32_t v = (p < parts) ? blockCount[p] : 0u;
+    uint32_t       chunk;
+    const uint32_t ex = blockExclusiveScan256(v, s_tmp, &chunk);
+    if(p < parts)
+      blockCount[p] = (uint32_t)min(carry + ex, (uint64_t)0xFFFFFFFFull);
+    carry += chunk;
+  }
+  if(threadIdx.x == 0)
+  {
+    if(carry > capacity)
+    {
+      atomicOr(&ctr->errorFlags, kErrPairOverflow);
+      carry = capacity;
+    }
+    ctr->pairCount = (uint32_t)carry;
+  }
+}
+
+// ---- binning, step 3: cooperative expansion to (tile id, global splat id) records ------------
+// Written in sorted order, so a STABLE sort by tile id keeps every tile's list depth-ordered.
+__global__ __launch_bounds__(kBinThreads) void k_bin_expand(const uint32_t* __restrict__ idsX, const uint32_t* __restrict__ idsY,
+                                                            const SortPlan* __restrict__ plan, const uint32_t* __restrict__ rect,
+                                                            const uint32_t* __restrict__ blockOffset, uint32_t* __restrict__ pairKey,
+                                                            uint32_t* __restrict__ pairVal, uint32_t capacity, int tilesX)
+{
+  __shared__ uint32_t s_start[kBinPart];
+  __shared__ uint32_t s_rect[kBinPart];
+  __shared__ uint32_t s_gid[kBinPart];
+  __shared__ uint32_t s_tmp[4];
+  const uint32_t      n     = plan->n;
+  const uint32_t      parts = (n + kBinPart - 1) / kBinPart;
+  if(blockIdx.x >= parts)
+    return;
+  const uint32_t* ids = plan->finalSel ? idsY : idsX;
+  const int       t   = threadIdx.x;
+  // entry e (sorted order) = block*2048 + i : coalesced load, then thread t owns entries [8t, 8t+8)
+#pragma unroll
+  for(int i = 0; i < kBinItems; ++i)
+  {
+    const uint32_t le = i * kBinThreads + t;
+    const uint32_t e  = blockIdx.x * kBinPart + le;
+    uint32_t       g = 0, r = 0, c = 0;
+    if(e < n)
+    {
+      g = ids[e];
+      r = rect[g];
+      c = rectTiles(r);
+    }
+    s_gid[le]   = g;
+    s_rect[le]  = r;
+    s_start[le] = c;
+  }
+  __syncthreads();
+  uint32_t cnt[kBinItems], sum = 0;
+#pragma unroll
+  for(int i = 0; i < kBinItems; ++i)
+  {
+    cnt[i] = s_start[t * kBinItems + i];
+    sum += cnt[i];
+  }
+  uint32_t total;
+  uint32_t run = blockExclusiveScan256(sum, s_tmp, &total);
+#pragma unroll
+  for(int i = 0; i < kBinItems; ++i)
+  {
+    s_start[t * kBinItems + i] = run;
+    run += cnt[i];
+  }
+  __syncthreads();
+  const uint32_t base = blockOffset[blockIdx.x];
+  for(uint32_t o = t; o < total; o += kBinThreads)
+  {
+    // last entry whose start <= o
+    uint32_t lo = 0, hi = kBinPart;
+    while(hi - lo > 1)
+    {
+      const uint32_t mid = (lo + hi) >> 1;
+      if(s_start[mid] <= o)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    const uint32_t r  = s_rect[lo];
+    const uint32_t x0 = r & 255u, y0 = (r >> 8) & 255u, x1 = (r >> 16) & 255u;
+    const uint32_t wd = x1 - x0 + 1u;
+    const uint32_t k  = o - s_start[lo];
+    const uint32_t ty = y0 + k / wd, tx = x0 + k % wd;
+    const uint64_t dst = (uint64_t)base + o;
+    if(dst < capacity)
+    {
+      pairKey[dst] = ty * (uint32_t)tilesX + tx;
+      pairVal[dst] = s_gid[lo];
+    }
+  }
+}
+
+// ---- tile ranges over the tile-sorted pair list ------------------------------------------------
+__global__ void k_tile_ranges(const uint32_t* __restrict__ keyX, const uint32_t* __restrict__ keyY,
+                              const SortPlan* __restrict__ plan, uint2* __restrict__ ranges)
+{
+  const uint32_t  n    = plan->n;
+  const uint32_t* keys = plan->finalSel ? keyY : keyX;
+  for(uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+  {
+    const uint32_t k = keys[j];
+    if(j == 0 || keys[j - 1] != k)
+      ranges[k].x = j;
+    if(j == n - 1 || keys[j + 1] != k)
+      ranges[k].y = j + 1;
+  }
+}
+
+// ---- compositing ------------------------------------------------------------------------------
+// One workgroup per 16x16 tile, one wave per 8x8 quadrant (lane = pixel).  The tile's list is
+// walked nearest-first in batches of 256 records staged in LDS; every lane keeps transmittance T and
+// the premultiplied colour in registers.  A wave skips splats whose footprint misses its quadrant and
+// retires once all of its 64 pixels are saturated (T < 1e-4; not in MGS_ALPHA_SUM mode, where the
+// reference's additive alpha must see every fragment).
+template <bool HALF_OUT>
+__global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uint2* __restrict__ ranges,
+                                                   const uint32_t* __restrict__ valX, const uint32_t* __restrict__ valY,
+                                                   const SortPlan* __restrict__ plan, const SplatRec* __restrict__ rec,
+                                                   void* __restrict__ outImage)
+{
+  __shared__ float4 s_a[256];
+  __shared__ float4 s_b[256];
+  __shared__ float4 s_c[256];
+
+  const int      t = threadIdx.x, lane = laneId(), w = t >> 6;
+  const int      stripTiles = F.tilesX * (F.stripRow1 - F.stripRow0);
+  // XCD-aware tile mapping: workgroup b lands on XCD b%8 (observed dispatch rule); give each XCD a
+  // contiguous run of tiles so neighbouring tiles — which share most of their splats — share an L2.
+  const int per  = (stripTiles + 7) >> 3;
+  const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if(tile >= stripTiles || (int)(blockIdx.x >> 3) >= per)
+    return;
+  const int      tileId = F.stripRow0 * F.tilesX + tile;
+  const int      tx = tileId % F.tilesX, ty = tileId / F.tilesX;
+  const int      qx0 = tx * kTilePx + (w & 1) * 8, qy0 = ty * kTilePx + (w >> 1) * 8;
+  const int      px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+  const float    pcx = (float)px + 0.5f, pcy = (float)py + 0.5f;
+  const float    qcx = (float)qx0 + 4.0f, qcy = (float)qy0 + 4.0f;
+  const bool     inside = px < F.width && py < F.height;
+  const bool     early  = (F.alphaMode == 0);
+  const uint32_t* vals  = plan->finalSel ? valY : valX;
+  const uint2    range  = ranges[tileId];
+
+  float T = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, asum = 0.f;
+  bool  done = !inside;
+  bool  waveDone = (__ballot(!done) == 0ull);
+
+  uint32_t hi = range.y;
+  while(hi > range.x)
+  {
+    const uint32_t nb = min(256u, hi - range.x);
+    if((uint32_t)t < nb)
+    {
+      const uint32_t g = vals[hi - 1u - (uint32_t)t];
+      const float4*  r = reinterpret_cast<const float4*>(rec + g);
+      s_a[t]           = r[0];
+      s_b[t]           = r[1];
+      s_c[t]           = r[2];
+    }
+    __syncthreads();
+    if(!waveDone)
+    {
+      for(uint32_t j = 0; j < nb; ++j)
+      {
+        const float4 a = s_a[j];
+        const float4 c = s_c[j];
+        // footprint vs this wave's 8x8 quadrant (wave-uniform)
+        if(fabsf(a.x - qcx) > c.z + 3.5f || fabsf(a.y - qcy) > c.w + 3.5f)
+          continue;
+        const float4 b  = s_b[j];
+        const float  dx = pcx - a.x, dy = pcy - a.y;
+        const float  s  = dx * a.z + dy * a.w;
+        const float  u  = dx * b.x + dy * b.y;
+        const float  q  = s * s + u * u;              // == A/2 of frag.slang:236
+        const float  al = c.y * __expf(-q);           // frag.slang:254
+        if(q <= 4.0f && al > (1.0f / 255.0f) && !done)  // frag.slang:242-245,258-262
+        {
+          const float wgt = al * T;
+          cr += wgt * b.z;
+          cg += wgt * b.w;
+          cb += wgt * c.x;
+          asum += al;
+          T -= wgt;
+          if(early && T < 1.0e-4f)
+            done = true;
+        }
+        if((j & 15u) == 15u && early && __ballot(!done) == 0ull)
+        {
+          waveDone = true;
+          break;
+        }
+      }
+      if(early && __ballot(!done) == 0ull)
+        waveDone = true;
+    }
+    hi -= nb;
+    if(__syncthreads_and(waveDone ? 1 : 0))
+      break;
+  }
+
+  if(inside)
+  {
+    const float  aout = early ? (1.0f - T) : asum;
+    const size_t o    = (size_t)py * (size_t)F.width + (size_t)px;
+    if(HALF_OUT)
+    {
+      const __half2 lo = __floats2half2_rn(cr, cg), hi2 = __floats2half2_rn(cb, aout);
+      uint2         pk;
+      pk.x = *reinterpret_cast<const uint32_t*>(&lo);
+      pk.y = *reinterpret_cast<const uint32_t*>(&hi2);
+      reinterpret_cast<uint2*>(outImage)[o] = pk;
+    }
+    else
+      reinterpret_cast<float4*>(outImage)[o] = make_float4(cr, cg, cb, aout);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+void launchFrameInit(hipStream_t stream, FrameCounters* ctr, SortPlan* planKeys, SortPlan* planPairs, uint2* ranges,
+                     uint32_t nTiles)
+{
+  const uint32_t blocks = (nTiles + 255u) / 256u < 1u ? 1u : min((nTiles + 255u) / 256u, 256u);
+  hipLaunchKernelGGL(k_frame_init, dim3(blocks), dim3(256), 0, stream, ctr, planKeys, planPairs, ranges, nTiles);
+}
+
+void launchBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
+                   const uint32_t* rect, uint32_t* blockCount, uint32_t maxBlocks, FrameCounters* ctr, uint32_t* pairKey,
+                   uint32_t* pairVal, uint32_t capacity, int tilesX)
+{
+  if(maxBlocks == 0)
+    return;
+  hipLaunchKernelGGL(k_bin_count, dim3(maxBlocks), dim3(kBinThreads), 0, stream, idsX, idsY, planKeys, rect, blockCount);
+  hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(256), 0, stream, planKeys, blockCount, ctr, capacity);
+  hipLaunchKernelGGL(k_bin_expand, dim3(maxBlocks), dim3(kBinThreads), 0, stream, idsX, idsY, planKeys, rect, blockCount,
+                     pairKey, pairVal, capacity, tilesX);
+}
+
+void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* keyY, const SortPlan* planPairs,
+                      uint2* ranges)
+{
+  hipLaunchKernelGGL(k_tile_ranges, dim3(2048), dim3(256), 0, stream, keyX, keyY, planPairs, ranges);
+}
+
+void launchComposite(hipStream_t stream, const FrameConst& F, const uint2* ranges, const uint32_t* valX,
+                     const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, bool halfOut)
+{
+  const int stripTiles = F.tilesX * (F.stripRow1 - F.stripRow0);
+  if(stripTiles <= 0)
+    return;
+  const int per = (stripTiles + 7) >> 3;
+  if(halfOut)
+    hipLaunchKernelGGL((k_composite<true>), dim3(per * 8), dim3(256), 0, stream, F, ranges, valX, valY, planPairs, rec, image);
+  else
+    hipLaunchKernelGGL((k_composite<false>), dim3(per * 8), dim3(256), 0, stream, F, ranges, valX, valY, planPairs, rec, image);
+}
+
+}  // namespace mgs

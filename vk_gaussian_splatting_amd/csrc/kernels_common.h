@@ -1,0 +1,89 @@
+// kernels_common.h — wave64 helpers for the gfx950 kernels.  CDNA4 only: 64-lane wavefronts are
+// hard-coded on purpose (no 32-wide fallbacks, no portability macros).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cstdint>
+
+#include "device_types.h"
+
+namespace mgs {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int laneId() { return (int)__lane_id(); }
+
+// bits of `mask` strictly below this lane
+__device__ __forceinline__ uint32_t lanesBelow(uint64_t mask)
+{
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__device__ __forceinline__ uint32_t waveSum(uint32_t v)
+{
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1)
+    v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// inclusive prefix sum across the 64 lanes of a wave
+__device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v)
+{
+  const int lane = laneId();
+#pragma unroll
+  for(int o = 1; o < 64; o <<= 1)
+  {
+    const uint32_t t = __shfl_up(v, o, 64);
+    if(lane >= o)
+      v += t;
+  }
+  return v;
+}
+
+// Exclusive scan of one value per thread over a 256-thread block.  `s_tmp` needs 4 entries.
+// Returns the exclusive prefix; *total receives the block sum.
+__device__ __forceinline__ uint32_t blockExclusiveScan256(uint32_t v, uint32_t* s_tmp, uint32_t* total)
+{
+  const int      lane = laneId();
+  const int      w    = threadIdx.x >> 6;
+  const uint32_t inc  = waveInclusiveScan(v);
+  if(lane == 63)
+    s_tmp[w] = inc;
+  __syncthreads();
+  const uint32_t w0 = s_tmp[0], w1 = s_tmp[1], w2 = s_tmp[2], w3 = s_tmp[3];
+  uint32_t       base = 0;
+  if(w > 0) base += w0;
+  if(w > 1) base += w1;
+  if(w > 2) base += w2;
+  *total = w0 + w1 + w2 + w3;
+  __syncthreads();
+  return base + inc - v;
+}
+
+// encodeMinMaxFp32 (shaders/dist.comp.slang:33-38): order-preserving fp32 -> u32
+__device__ __forceinline__ uint32_t encodeKey(float v)
+{
+  uint32_t bits = __float_as_uint(v);
+  bits ^= (uint32_t)((int32_t)bits >> 31) | 0x80000000u;
+  return bits;
+}
+
+// out = M * v with the exact unfused evaluation order of the oracle / host:
+// ((x*c0 + y*c1) + z*c2) + w*c3, every product and sum rounded separately.
+__device__ __forceinline__ void mulMat4Exact(const float* m, float x, float y, float z, float w, float out[4])
+{
+#pragma clang fp contract(off)
+#pragma unroll
+  for(int r = 0; r < 4; ++r)
+  {
+    const float a = __fmul_rn(x, m[r]);
+    const float b = __fmul_rn(y, m[4 + r]);
+    const float c = __fmul_rn(z, m[8 + r]);
+    const float d = __fmul_rn(w, m[12 + r]);
+    out[r]        = __fadd_rn(__fadd_rn(__fadd_rn(a, b), c), d);
+  }
+}
+
+}  // namespace mgs

@@ -1,0 +1,1318 @@
+// mgs_api.hip — implementation of include/mgs.h: handles, device scene, frame orchestration.
+//
+// Host orchestration replaces GaussianSplatting::processSortingOnGPU / drawSplatPrimitives
+// (src/gaussian_splatting.cpp:1298-1465): everything after the parameter upload is GPU-driven —
+// counts stay on the device (IndirectParams, shaders/shaderio.h:343-356) and are read back only
+// for statistics, like readBackIndirectParametersIfNeeded (:1536).
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <execution>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mgs.h"
+#include "device_types.h"
+#include "host_model.h"
+#include "sort_plan.h"
+
+namespace mgs {
+// kernels_*.hip
+void launchProject(hipStream_t stream, const FrameArgs& args, bool full, int shFormat, int rgbaFormat, FrameCounters* ctr,
+                   uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, SplatRec* rec, uint32_t* rect);
+void launchFrameInit(hipStream_t stream, FrameCounters* ctr, SortPlan* planKeys, SortPlan* planPairs, uint2* ranges,
+                     uint32_t nTiles);
+void launchBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
+                   const uint32_t* rect, uint32_t* blockCount, uint32_t maxBlocks, FrameCounters* ctr, uint32_t* pairKey,
+                   uint32_t* pairVal, uint32_t capacity, int tilesX);
+void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* keyY, const SortPlan* planPairs,
+                      uint2* ranges);
+void launchComposite(hipStream_t stream, const FrameConst& F, const uint2* ranges, const uint32_t* valX,
+                     const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, bool halfOut);
+constexpr uint32_t kPart = 2048;  // == kPrjPart == kSortPart == kBinPart
+}  // namespace mgs
+
+using namespace mgs;
+
+#define HIPCHK(expr)                                                                                                    \
+  do                                                                                                                    \
+  {                                                                                                                     \
+    hipError_t e_ = (expr);                                                                                             \
+    if(e_ != hipSuccess)                                                                                                \
+    {                                                                                                                   \
+      setError(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr);                                      \
+      return MGS_ERR_DEVICE;                                                                                            \
+    }                                                                                                                   \
+  } while(0)
+
+struct MgsSplatSet_t
+{
+  std::shared_ptr<HostSplatSet> data;
+};
+
+namespace {
+
+struct DeviceSet
+{
+  std::shared_ptr<HostSplatSet> host;
+  float*   centers = nullptr;
+  float*   cov6    = nullptr;
+  void*    rgba    = nullptr;
+  void*    sh      = nullptr;
+  uint32_t count   = 0;
+  int      shDegree = 0, shStride = 0;
+  int      shFormat = -1, rgbaFormat = -1;
+};
+
+struct Instance
+{
+  int   set;  // index into sets
+  float M[16];
+};
+
+template <typename T>
+struct DevBuf
+{
+  T*     p = nullptr;
+  size_t n = 0;
+  int    ensure(size_t count)
+  {
+    if(count <= n)
+      return MGS_OK;
+    if(p)
+      (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+    if(hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess)
+    {
+      setError("device allocation failed (" + std::to_string(count * sizeof(T)) + " bytes)");
+      return MGS_ERR_OOM;
+    }
+    n = count;
+    return MGS_OK;
+  }
+  void release()
+  {
+    if(p)
+      (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+// CPU async sorter: same protocol as SplatSorterAsync (src/splat_sorter_async.h:41-48,84-128)
+struct CpuSorter
+{
+  enum State { READY, SORTING, SORTED, FAILURE, SHUTDOWN };
+  std::thread             worker;
+  std::mutex              mtx;
+  std::condition_variable cv;
+  State                   state = READY;
+  bool                    started = false;
+  // job
+  struct Job
+  {
+    float dir[3], cop[3];
+    bool  frontToBack;
+    struct Inst
+    {
+      std::shared_ptr<HostSplatSet> set;
+      float                         M[16];
+      uint32_t                      offset, count;
+    };
+    std::vector<Inst> inst;
+    uint32_t          total;
+  } job;
+  std::vector<float>    distances;
+  std::vector<uint32_t> indices;
+  double                distMs = 0, sortMs = 0;
+
+  void run()
+  {
+    std::unique_lock<std::mutex> lk(mtx);
+    for(;;)
+    {
+      cv.wait(lk, [&] { return state == SORTING || state == SHUTDOWN; });
+      if(state == SHUTDOWN)
+        return;
+      lk.unlock();
+      innerSort();
+      lk.lock();
+      if(state != SHUTDOWN)
+        state = SORTED;
+      cv.notify_all();
+    }
+  }
+  // SplatSorterAsync::innerSort (src/splat_sorter_async.cpp:92-141): plane distance keys, then
+  // std::sort(par_unseq) of the index array with a comparator on the distances.
+  void innerSort()
+  {
+    const auto  t0 = std::chrono::high_resolution_clock::now();
+    const float plane[4] = {job.dir[0], job.dir[1], job.dir[2],
+                            -job.dir[0] * job.cop[0] - job.dir[1] * job.cop[1] - job.dir[2] * job.cop[2]};
+    const float divider = 1.0f / std::sqrt(plane[0] * plane[0] + plane[1] * plane[1] + plane[2] * plane[2]);
+    distances.resize(job.total);
+    indices.resize(job.total);
+    for(const auto& I : job.inst)
+    {
+      const float* pos = I.set->positions.data();
+      parallelBatches(I.count, [&](size_t s) {
+        const float v[4] = {pos[3 * s], pos[3 * s + 1], pos[3 * s + 2], 1.0f};
+        float       p[4];
+        mat4MulVec4(I.M, v, p);
+        distances[I.offset + s] = std::fabs(plane[0] * p[0] + plane[1] * p[1] + plane[2] * p[2] + plane[3]) * divider;
+        indices[I.offset + s]   = I.offset + (uint32_t)s;
+      });
+    }
+    const auto   t1 = std::chrono::high_resolution_clock::now();
+    const float* d  = distances.data();
+    if(job.frontToBack)
+      std::sort(std::execution::par_unseq, indices.begin(), indices.end(), [d](uint32_t i, uint32_t j) { return d[i] < d[j]; });
+    else
+      std::sort(std::execution::par_unseq, indices.begin(), indices.end(), [d](uint32_t i, uint32_t j) { return d[i] > d[j]; });
+    const auto t2 = std::chrono::high_resolution_clock::now();
+    distMs        = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    sortMs        = std::chrono::duration<double, std::milli>(t2 - t1).count();
+  }
+  void ensureStarted()
+  {
+    if(!started)
+    {
+      started = true;
+      worker  = std::thread([this] { run(); });
+    }
+  }
+  void shutdown()
+  {
+    if(!started)
+      return;
+    {
+      std::lock_guard<std::mutex> lk(mtx);
+      state = SHUTDOWN;
+    }
+    cv.notify_all();
+    worker.join();
+    started = false;
+  }
+};
+
+}  // namespace
+
+struct MgsScene_t
+{
+  int         device = 0;
+  hipStream_t stream = nullptr, ownStream = nullptr;
+
+  std::vector<DeviceSet> sets;
+  std::vector<Instance>  instances;
+  bool                   committed = false;
+  int                    shFormat = 0, rgbaFormat = 0;
+  uint32_t               totalSplats = 0, totalParts = 0;
+
+  // frame buffers
+  DevBuf<uint32_t>      keysSlot, idsSlot, slotCount, keysA, idsA, keysB, idsB, rect, partHist, blockCount;
+  DevBuf<SplatRec>      rec;
+  DevBuf<uint32_t>      pairKey0, pairVal0, pairKey1, pairVal1;
+  DevBuf<uint2>         ranges;
+  DevBuf<uint8_t>       image;
+  DevBuf<FrameCounters> ctr;
+  DevBuf<SortPlan>      plans;  // [0] keys, [1] pairs
+  uint32_t              pairCapacity = 0, pStride = 0;
+
+  // pinned readback
+  FrameCounters* hCtr   = nullptr;
+  SortPlan*      hPlans = nullptr;
+
+  hipEvent_t ev[8] = {};
+  bool       evReady = false;
+
+  // last frame
+  MgsFrameParams lastParams{};
+  bool           haveFrame = false, lastTimed = false, lastWasSortOnly = false;
+  size_t         imageBytes = 0, imageRowBytes = 0;
+  MgsSortOut     lastSort{};
+
+  CpuSorter             cpu;
+  std::vector<uint32_t> cpuIndices;  // consumed result
+  bool                  cpuHaveIndices = false;
+  DevBuf<float>         cpuDistDev;
+};
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* mgs_last_error(void) { return lastError(); }
+const char* mgs_version(void) { return "mgs 0.1 (gfx950, ABI 1)"; }
+
+int mgs_splatset_load(const char* path, MgsSplatSet* out)
+{
+  if(!path || !out)
+  {
+    setError("mgs_splatset_load: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  std::string p(path), ext;
+  const auto  dot = p.find_last_of('.');
+  if(dot != std::string::npos)
+    ext = p.substr(dot);
+  for(auto& c : ext)
+    c = (char)std::tolower((unsigned char)c);  // hasExtension lower-cases, src/utilities.h:65-70
+  auto set = std::make_shared<HostSplatSet>();
+  int  rc;
+  if(ext == ".splat")
+    rc = loadSplat(p, *set);
+  else if(ext == ".spz")
+    rc = loadSpz(p, *set);
+  else
+    rc = loadPly(p, *set);  // the reference hands every other extension to miniply
+  if(rc != MGS_OK)
+    return rc;
+  *out = new MgsSplatSet_t{set};
+  return MGS_OK;
+}
+
+int mgs_splatset_from_arrays(const MgsSplatSetView* v, MgsSplatSet* out)
+{
+  if(!v || !out || !v->positions || !v->f_dc || !v->opacity || !v->scale || !v->rotation)
+  {
+    setError("mgs_splatset_from_arrays: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(v->splat_count == 0 || v->splat_count > 0xFFFFFFFFull)
+  {
+    setError("mgs_splatset_from_arrays: splat_count must be in [1, 2^32)");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(v->f_rest_per_splat != 0 && v->f_rest == nullptr)
+  {
+    setError("mgs_splatset_from_arrays: f_rest is null but f_rest_per_splat != 0");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(v->f_rest_per_splat % 3 != 0 || v->f_rest_per_splat > 45)
+  {
+    setError("mgs_splatset_from_arrays: f_rest_per_splat must be a multiple of 3, at most 45");
+    return MGS_ERR_INVALID_ARG;
+  }
+  const size_t n   = (size_t)v->splat_count;
+  auto         set = std::make_shared<HostSplatSet>();
+  set->positions.assign(v->positions, v->positions + 3 * n);
+  set->f_dc.assign(v->f_dc, v->f_dc + 3 * n);
+  if(v->f_rest_per_splat)
+    set->f_rest.assign(v->f_rest, v->f_rest + (size_t)v->f_rest_per_splat * n);
+  set->opacity.assign(v->opacity, v->opacity + n);
+  set->scale.assign(v->scale, v->scale + 3 * n);
+  set->rotation.assign(v->rotation, v->rotation + 4 * n);
+  *out = new MgsSplatSet_t{set};
+  return MGS_OK;
+}
+
+int mgs_splatset_view(MgsSplatSet set, MgsSplatSetView* out)
+{
+  if(!set || !out)
+  {
+    setError("mgs_splatset_view: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  const HostSplatSet& s = *set->data;
+  out->positions        = s.positions.data();
+  out->f_dc             = s.f_dc.data();
+  out->f_rest           = s.f_rest.empty() ? nullptr : s.f_rest.data();
+  out->opacity          = s.opacity.data();
+  out->scale            = s.scale.data();
+  out->rotation         = s.rotation.data();
+  out->splat_count      = s.size();
+  out->f_rest_per_splat = s.fRestPerSplat();
+  out->sh_degree        = s.maxShDegree();
+  return MGS_OK;
+}
+
+void mgs_splatset_destroy(MgsSplatSet set) { delete set; }
+
+// ------------------------------------------------------------------------------------------------
+int mgs_scene_create(int device, MgsScene* out)
+{
+  if(!out)
+  {
+    setError("mgs_scene_create: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  int count = 0;
+  if(hipGetDeviceCount(&count) != hipSuccess || count == 0)
+  {
+    setError("mgs_scene_create: no HIP device available — the MI355X path has no CPU fallback");
+    return MGS_ERR_DEVICE;
+  }
+  if(device < 0 || device >= count)
+  {
+    setError("mgs_scene_create: device ordinal out of range");
+    return MGS_ERR_INVALID_ARG;
+  }
+  HIPCHK(hipSetDevice(device));
+  auto* s   = new MgsScene_t();
+  s->device = device;
+  if(hipStreamCreateWithFlags(&s->ownStream, hipStreamNonBlocking) != hipSuccess)
+  {
+    delete s;
+    setError("mgs_scene_create: hipStreamCreate failed");
+    return MGS_ERR_DEVICE;
+  }
+  s->stream = s->ownStream;
+  if(hipHostMalloc((void**)&s->hCtr, sizeof(FrameCounters)) != hipSuccess
+     || hipHostMalloc((void**)&s->hPlans, 2 * sizeof(SortPlan)) != hipSuccess)
+  {
+    delete s;
+    setError("mgs_scene_create: pinned allocation failed");
+    return MGS_ERR_OOM;
+  }
+  std::memset(s->hCtr, 0, sizeof(FrameCounters));
+  std::memset(s->hPlans, 0, 2 * sizeof(SortPlan));
+  for(auto& e : s->ev)
+    if(hipEventCreate(&e) != hipSuccess)
+    {
+      setError("mgs_scene_create: hipEventCreate failed");
+      return MGS_ERR_DEVICE;
+    }
+  s->evReady = true;
+  *out       = s;
+  return MGS_OK;
+}
+
+static void freeSet(DeviceSet& d)
+{
+  if(d.centers) (void)hipFree(d.centers);
+  if(d.cov6) (void)hipFree(d.cov6);
+  if(d.rgba) (void)hipFree(d.rgba);
+  if(d.sh) (void)hipFree(d.sh);
+  d.centers = d.cov6 = nullptr;
+  d.rgba = d.sh = nullptr;
+}
+
+void mgs_scene_destroy(MgsScene s)
+{
+  if(!s)
+    return;
+  s->cpu.shutdown();
+  (void)hipSetDevice(s->device);
+  (void)hipStreamSynchronize(s->stream);  // like vkDeviceWaitIdle before destruction (gaussian_splatting.cpp:1096)
+  for(auto& d : s->sets)
+    freeSet(d);
+  s->keysSlot.release(); s->idsSlot.release(); s->slotCount.release(); s->keysA.release(); s->idsA.release();
+  s->keysB.release(); s->idsB.release(); s->rect.release(); s->partHist.release(); s->blockCount.release();
+  s->rec.release(); s->pairKey0.release(); s->pairVal0.release(); s->pairKey1.release(); s->pairVal1.release();
+  s->ranges.release(); s->image.release(); s->ctr.release(); s->plans.release(); s->cpuDistDev.release();
+  if(s->hCtr) (void)hipHostFree(s->hCtr);
+  if(s->hPlans) (void)hipHostFree(s->hPlans);
+  if(s->evReady)
+    for(auto& e : s->ev)
+      (void)hipEventDestroy(e);
+  if(s->ownStream)
+    (void)hipStreamDestroy(s->ownStream);
+  delete s;
+}
+
+int mgs_scene_set_stream(MgsScene s, void* stream)
+{
+  if(!s)
+  {
+    setError("mgs_scene_set_stream: null scene");
+    return MGS_ERR_INVALID_ARG;
+  }
+  s->stream = stream ? (hipStream_t)stream : s->ownStream;
+  return MGS_OK;
+}
+
+int mgs_instance_add(MgsScene s, MgsSplatSet set, const float m[16], int* id)
+{
+  if(!s || !set || !m)
+  {
+    setError("mgs_instance_add: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if((int)s->instances.size() >= kMaxInlineInstances)
+  {
+    setError("mgs_instance_add: at most " + std::to_string(kMaxInlineInstances) + " instances per scene in this build");
+    return MGS_ERR_UNSUPPORTED;
+  }
+  int idx = -1;
+  for(size_t i = 0; i < s->sets.size(); ++i)
+    if(s->sets[i].host == set->data)
+      idx = (int)i;
+  if(idx < 0)
+  {
+    DeviceSet d;
+    d.host = set->data;
+    s->sets.push_back(d);
+    idx = (int)s->sets.size() - 1;
+  }
+  uint64_t total = 0;
+  for(const auto& I : s->instances)
+    total += s->sets[I.set].host->size();
+  total += set->data->size();
+  if(total > 0xFFFFFFFFull)
+  {
+    setError("mgs_instance_add: more than 2^32 global splats (ids are u32, like the reference)");
+    return MGS_ERR_UNSUPPORTED;
+  }
+  Instance I;
+  I.set = idx;
+  std::memcpy(I.M, m, sizeof(I.M));
+  s->instances.push_back(I);
+  s->committed = false;
+  if(id)
+    *id = (int)s->instances.size() - 1;
+  return MGS_OK;
+}
+
+int mgs_instance_set_transform(MgsScene s, int id, const float m[16])
+{
+  if(!s || !m || id < 0 || id >= (int)s->instances.size())
+  {
+    setError("mgs_instance_set_transform: bad argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  std::memcpy(s->instances[id].M, m, sizeof(float) * 16);
+  return MGS_OK;  // transforms travel with every frame; no re-commit needed
+}
+
+uint64_t mgs_scene_splat_count(MgsScene s)
+{
+  if(!s)
+    return 0;
+  uint64_t total = 0;
+  for(const auto& I : s->instances)
+    total += s->sets[I.set].host->size();
+  return total;
+}
+
+static int uploadFormatted(const std::vector<float>& src, int format, bool isSh, void** dev)
+{
+  const size_t n = src.size();
+  if(n == 0)
+  {
+    *dev = nullptr;
+    return MGS_OK;
+  }
+  const size_t esz = format == MGS_FORMAT_FLOAT32 ? 4 : format == MGS_FORMAT_FLOAT16 ? 2 : 1;
+  if(hipMalloc(dev, n * esz) != hipSuccess)
+  {
+    setError("commit: device allocation failed");
+    return MGS_ERR_OOM;
+  }
+  if(format == MGS_FORMAT_FLOAT32)
+  {
+    HIPCHK(hipMemcpy(*dev, src.data(), n * 4, hipMemcpyHostToDevice));
+  }
+  else if(format == MGS_FORMAT_FLOAT16)
+  {
+    std::vector<uint16_t> tmp(n);
+    parallelBatches(n, [&](size_t i) { tmp[i] = floatToHalf(src[i]); });
+    HIPCHK(hipMemcpy(*dev, tmp.data(), n * 2, hipMemcpyHostToDevice));
+  }
+  else
+  {
+    std::vector<uint8_t> tmp(n);
+    const float          lo = isSh ? -1.f : 0.f;
+    parallelBatches(n, [&](size_t i) { tmp[i] = toUint8(src[i], lo, 1.f); });
+    HIPCHK(hipMemcpy(*dev, tmp.data(), n, hipMemcpyHostToDevice));
+  }
+  return MGS_OK;
+}
+
+int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
+{
+  if(!s)
+  {
+    setError("mgs_scene_commit: null scene");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(shFormat < 0 || shFormat > 2 || rgbaFormat < 0 || rgbaFormat > 2)
+  {
+    setError("mgs_scene_commit: formats must be MGS_FORMAT_FLOAT32/FLOAT16/UINT8");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(s->instances.empty())
+  {
+    setError("mgs_scene_commit: scene has no instances");
+    return MGS_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  for(auto& d : s->sets)
+  {
+    if(d.centers && d.shFormat == shFormat && d.rgbaFormat == rgbaFormat)
+      continue;  // idempotent
+    freeSet(d);
+    const HostSplatSet& h = *d.host;
+    const size_t        n = h.size();
+    d.count               = (uint32_t)n;
+    d.shDegree            = std::max(0, h.maxShDegree());
+    d.shStride            = shStride(h.fRestPerSplat());
+    // a4: SplatSetVk::initDataBuffers (src/splat_set_vk.cpp:188-480), host loops like the reference
+    HIPCHK(hipMalloc((void**)&d.centers, n * 3 * sizeof(float)));
+    HIPCHK(hipMemcpy(d.centers, h.positions.data(), n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    {
+      std::vector<float> cov;
+      buildCov6(h, cov);
+      HIPCHK(hipMalloc((void**)&d.cov6, n * 6 * sizeof(float)));
+      HIPCHK(hipMemcpy(d.cov6, cov.data(), n * 6 * sizeof(float), hipMemcpyHostToDevice));
+    }
+    {
+      std::vector<float> rgba;
+      buildRgba(h, rgba);
+      int rc = uploadFormatted(rgba, rgbaFormat, false, &d.rgba);
+      if(rc != MGS_OK)
+        return rc;
+    }
+    if(d.shStride)
+    {
+      std::vector<float> sh;
+      buildShInterleaved(h, sh);
+      int rc = uploadFormatted(sh, shFormat, true, &d.sh);
+      if(rc != MGS_OK)
+        return rc;
+    }
+    d.shFormat   = shFormat;
+    d.rgbaFormat = rgbaFormat;
+  }
+  s->shFormat   = shFormat;
+  s->rgbaFormat = rgbaFormat;
+
+  // global id space + partitions (a5: rebuildGlobalIndexTables, splat_set_manager_vk.cpp:2304-2360,
+  // here a closed-form prefix instead of an 8-byte-per-splat table)
+  uint64_t total = 0, parts = 0;
+  for(const auto& I : s->instances)
+  {
+    const uint32_t c = s->sets[I.set].count;
+    total += c;
+    parts += (c + kPart - 1) / kPart;
+  }
+  s->totalSplats = (uint32_t)total;
+  s->totalParts  = (uint32_t)parts;
+
+  int rc = MGS_OK;
+  const size_t slots = (size_t)parts * kPart;
+  if((rc = s->keysSlot.ensure(slots))) return rc;
+  if((rc = s->idsSlot.ensure(slots))) return rc;
+  if((rc = s->slotCount.ensure(parts))) return rc;
+  if((rc = s->keysA.ensure(total))) return rc;
+  if((rc = s->idsA.ensure(total))) return rc;
+  if((rc = s->keysB.ensure(total))) return rc;
+  if((rc = s->idsB.ensure(total))) return rc;
+  if((rc = s->rect.ensure(total))) return rc;
+  if((rc = s->rec.ensure(total))) return rc;
+  if((rc = s->ctr.ensure(1))) return rc;
+  if((rc = s->plans.ensure(2))) return rc;
+
+  uint64_t cap = std::max<uint64_t>(8ull * total, 16ull << 20);
+  if(const char* e = std::getenv("MGS_PAIR_CAPACITY"))
+    cap = std::strtoull(e, nullptr, 10);
+  cap = std::min<uint64_t>(std::max<uint64_t>(cap, kPart), 0xFFFFF000ull);
+  s->pairCapacity = (uint32_t)cap;
+  if((rc = s->pairKey0.ensure(cap))) return rc;
+  if((rc = s->pairVal0.ensure(cap))) return rc;
+  if((rc = s->pairKey1.ensure(cap))) return rc;
+  if((rc = s->pairVal1.ensure(cap))) return rc;
+  const uint64_t maxParts = std::max<uint64_t>((cap + kPart - 1) / kPart, parts);
+  s->pStride              = (uint32_t)maxParts;
+  if((rc = s->partHist.ensure(256ull * maxParts))) return rc;
+  if((rc = s->blockCount.ensure(std::max<uint64_t>((total + kPart - 1) / kPart, 1)))) return rc;
+  HIPCHK(hipMemset(s->ctr.p, 0, sizeof(FrameCounters)));
+  HIPCHK(hipMemset(s->plans.p, 0, 2 * sizeof(SortPlan)));
+  s->committed = true;
+  s->haveFrame = false;
+  return MGS_OK;
+}
+
+int mgs_scene_download_set(MgsScene s, int instance, int which, float* dst, size_t count)
+{
+  if(!s || !dst || instance < 0 || instance >= (int)s->instances.size())
+  {
+    setError("mgs_scene_download_set: bad argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(!s->committed)
+  {
+    setError("mgs_scene_download_set: scene not committed");
+    return MGS_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(s->device));
+  const DeviceSet& d = s->sets[s->instances[instance].set];
+  const size_t     n = d.count;
+  size_t           need;
+  const void*      src;
+  int              fmt = MGS_FORMAT_FLOAT32;
+  bool             isSh = false;
+  switch(which)
+  {
+    case 0: need = 3 * n; src = d.centers; break;
+    case 1: need = 6 * n; src = d.cov6; break;
+    case 2: need = 4 * n; src = d.rgba; fmt = d.rgbaFormat; break;
+    case 3: need = (size_t)d.shStride * n; src = d.sh; fmt = d.shFormat; isSh = true; break;
+    default: setError("mgs_scene_download_set: unknown buffer"); return MGS_ERR_INVALID_ARG;
+  }
+  if(count < need)
+  {
+    setError("mgs_scene_download_set: destination too small");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(need == 0)
+    return MGS_OK;
+  if(fmt == MGS_FORMAT_FLOAT32)
+  {
+    HIPCHK(hipMemcpy(dst, src, need * 4, hipMemcpyDeviceToHost));
+  }
+  else if(fmt == MGS_FORMAT_FLOAT16)
+  {
+    std::vector<uint16_t> tmp(need);
+    HIPCHK(hipMemcpy(tmp.data(), src, need * 2, hipMemcpyDeviceToHost));
+    for(size_t i = 0; i < need; ++i)
+      dst[i] = halfToFloat(tmp[i]);
+  }
+  else
+  {
+    std::vector<uint8_t> tmp(need);
+    HIPCHK(hipMemcpy(tmp.data(), src, need, hipMemcpyDeviceToHost));
+    for(size_t i = 0; i < need; ++i)
+      dst[i] = isSh ? ((float)tmp[i] / 255.0f * 2.0f - 1.0f) : ((float)tmp[i] / 255.0f);
+  }
+  return MGS_OK;
+}
+
+void mgs_frame_params_default(MgsFrameParams* p)
+{
+  if(!p)
+    return;
+  std::memset(p, 0, sizeof(*p));
+  const float id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  std::memcpy(p->view, id, sizeof(id));
+  std::memcpy(p->proj, id, sizeof(id));
+  p->width                = 1920;
+  p->height               = 1080;
+  p->splat_scale          = 1.0f;
+  p->frustum_dilation     = 0.2f;
+  p->alpha_cull_threshold = 1.0f / 255.0f;
+  p->sh_degree            = 3;
+  p->sort_mode            = MGS_SORT_GPU_RADIX;
+  p->frustum_culling      = MGS_CULL_AT_DIST;
+  p->target_format        = MGS_TARGET_RGBA16F;
+  p->alpha_mode           = MGS_ALPHA_COVERAGE;
+}
+
+// ------------------------------------------------------------------------------------------------
+static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
+{
+  if(p->width <= 0 || p->height <= 0 || p->width > 4096 || p->height > 4096)
+  {
+    setError("frame: width/height must be in [1,4096] (tile coordinates are 8-bit)");
+    return MGS_ERR_INVALID_ARG;
+  }
+  std::memset(&A, 0, sizeof(A));
+  FrameConst& F = A.f;
+  std::memcpy(F.view, p->view, sizeof(F.view));
+  std::memcpy(F.proj, p->proj, sizeof(F.proj));
+  F.focal[0] = p->proj[0] * 0.5f * (float)p->width;   // gaussian_splatting.cpp:1248-1250
+  F.focal[1] = p->proj[5] * 0.5f * (float)p->height;
+  F.width    = p->width;
+  F.height   = p->height;
+  F.tilesX   = (p->width + kTilePx - 1) / kTilePx;
+  F.tilesY   = (p->height + kTilePx - 1) / kTilePx;
+  int r0 = p->strip_row_begin, r1 = p->strip_row_end;
+  if(r0 == 0 && r1 == 0)
+    r1 = F.tilesY;
+  if(r0 < 0 || r1 > F.tilesY || r0 >= r1)
+  {
+    setError("frame: strip rows out of range");
+    return MGS_ERR_INVALID_ARG;
+  }
+  F.stripRow0       = r0;
+  F.stripRow1       = r1;
+  F.splatScale      = p->splat_scale;
+  F.frustumDilation = p->frustum_dilation;
+  F.alphaCull       = p->alpha_cull_threshold;
+  F.shDegree        = p->sh_degree;
+  F.frontToBack     = 0;  // keys of -depth: ascending = far to near, the reference's default order
+  F.cullMode        = p->frustum_culling;
+  if(p->sort_mode == MGS_SORT_CPU_ASYNC && F.cullMode == MGS_CULL_AT_DIST)
+    F.cullMode = MGS_CULL_AT_RASTER;  // gaussian_splatting_ui.cpp:1469-1479
+  F.msAA            = p->ms_antialiasing;
+  F.alphaMode       = p->alpha_mode;
+  F.targetFormat    = p->target_format;
+  F.nInstances      = (int)s->instances.size();
+  F.totalSplats     = s->totalSplats;
+  F.totalPartitions = s->totalParts;
+  uint32_t offset = 0, block = 0;
+  for(int k = 0; k < F.nInstances; ++k)
+  {
+    const Instance&  I = s->instances[k];
+    const DeviceSet& d = s->sets[I.set];
+    InstanceConst&   C = A.inst[k];
+    C.centers = d.centers;
+    C.cov6    = d.cov6;
+    C.rgba    = d.rgba;
+    C.sh      = d.sh;
+    std::memcpy(C.model, I.M, sizeof(C.model));
+    mat4Mul(p->view, I.M, C.modelView);  // mul(desc.transform, viewMatrix), mesh.slang:175
+    float inv[16], cam[4] = {p->camera_pos[0], p->camera_pos[1], p->camera_pos[2], 1.0f}, cm[4];
+    mat4Inverse(I.M, inv);
+    mat4MulVec4(inv, cam, cm);  // mesh.slang:240-241
+    C.camModel[0]  = cm[0];
+    C.camModel[1]  = cm[1];
+    C.camModel[2]  = cm[2];
+    C.count        = d.count;
+    C.globalOffset = offset;
+    C.blockBegin   = block;
+    C.shDegree     = d.shDegree;
+    C.shStride     = d.shStride;
+    offset += d.count;
+    block += (d.count + kPart - 1) / kPart;
+  }
+  return MGS_OK;
+}
+
+static int pairSortBits(int nTiles)
+{
+  int bits = 1;
+  while((1 << bits) < nTiles)
+    ++bits;
+  return ((bits + 7) / 8) * 8;
+}
+
+static void keySort(MgsScene s, hipStream_t st)
+{
+  SortLaunch L{};
+  L.keys0 = s->keysSlot.p;
+  L.vals0 = s->idsSlot.p;
+  L.keysX = s->keysA.p;
+  L.valsX = s->idsA.p;
+  L.keysY = s->keysB.p;
+  L.valsY = s->idsB.p;
+  L.slotCount    = s->slotCount.p;
+  L.partsSlotted = s->totalParts;
+  L.nPtr         = &s->ctr.p->sortedCount;
+  L.plan         = &s->plans.p[0];
+  L.partHist     = s->partHist.p;
+  L.pStride      = s->pStride;
+  L.maxParts     = std::max<uint32_t>(s->totalParts, (s->totalSplats + kPart - 1) / kPart);
+  L.beginBit     = 0;
+  L.endBit       = 32;
+  launchRadixSort(st, L);
+}
+
+// CPU_ASYNC path: tryConsumeAndUploadCpuSortingResult (src/splat_set_manager_vk.cpp:3334-3416)
+static int cpuSortStep(MgsScene s, const MgsFrameParams* p, bool blocking)
+{
+  CpuSorter& c = s->cpu;
+  c.ensureStarted();
+  std::unique_lock<std::mutex> lk(c.mtx);
+  auto submit = [&]() {
+    // view direction = -Z axis of the camera in world space; centre of projection = camera position
+    // (SplatSetManagerVk passes cameraManip's eye/centre; with matrices only, the third row of the
+    //  view matrix is the same direction)
+    c.job.dir[0] = -p->view[2];
+    c.job.dir[1] = -p->view[6];
+    c.job.dir[2] = -p->view[10];
+    std::memcpy(c.job.cop, p->camera_pos, sizeof(float) * 3);
+    c.job.frontToBack = false;
+    c.job.inst.clear();
+    uint32_t offset = 0;
+    for(const auto& I : s->instances)
+    {
+      CpuSorter::Job::Inst ji;
+      ji.set = s->sets[I.set].host;
+      std::memcpy(ji.M, I.M, sizeof(ji.M));
+      ji.offset = offset;
+      ji.count  = s->sets[I.set].count;
+      offset += ji.count;
+      c.job.inst.push_back(ji);
+    }
+    c.job.total = offset;
+    c.state     = CpuSorter::SORTING;
+    c.cv.notify_all();
+  };
+  if(c.state == CpuSorter::SORTED)
+  {
+    s->cpuIndices.swap(c.indices);  // consume()
+    s->cpuHaveIndices = true;
+    c.state           = CpuSorter::READY;
+  }
+  if(c.state == CpuSorter::READY)
+    submit();
+  if(blocking)
+  {
+    c.cv.wait(lk, [&] { return c.state == CpuSorter::SORTED; });
+    s->cpuIndices.swap(c.indices);
+    s->cpuHaveIndices = true;
+    c.state           = CpuSorter::READY;
+  }
+  s->lastSort.key_ms  = (float)c.distMs;
+  s->lastSort.sort_ms = (float)c.sortMs;
+  return MGS_OK;
+}
+
+__global__ void k_set_plan_n(SortPlan* plan, FrameCounters* ctr, uint32_t n)
+{
+  plan->n         = n;
+  plan->finalSel  = 0;
+  plan->passesRun = 0;
+  ctr->sortedCount = n;
+}
+__global__ void k_fill_u32(uint32_t* p, uint32_t v, uint32_t n)
+{
+  for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    p[i] = v;
+}
+__global__ void k_iota_u32(uint32_t* p, uint32_t n)
+{
+  for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    p[i] = i;
+}
+
+int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
+{
+  if(!s || !p)
+  {
+    setError("mgs_render: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(!s->committed)
+  {
+    setError("mgs_render: call mgs_scene_commit first");
+    return MGS_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(s->device));
+  FrameArgs A;
+  int       rc = buildFrameArgs(s, p, A);
+  if(rc != MGS_OK)
+    return rc;
+  const FrameConst& F      = A.f;
+  const uint32_t    nTiles = (uint32_t)(F.tilesX * F.tilesY);
+  const bool        half   = (p->target_format == MGS_TARGET_RGBA16F);
+  const size_t      pixB   = half ? 8 : 16;
+  s->imageRowBytes         = (size_t)F.width * pixB;
+  s->imageBytes            = s->imageRowBytes * (size_t)F.height;
+  if((rc = s->ranges.ensure(nTiles))) return rc;
+  if(s->image.n < s->imageBytes)
+  {
+    if((rc = s->image.ensure(s->imageBytes))) return rc;
+    HIPCHK(hipMemsetAsync(s->image.p, 0, s->imageBytes, s->stream));
+  }
+  hipStream_t st    = s->stream;
+  const bool  timed = p->collect_timings != 0;
+  FrameCounters* ctr = s->ctr.p;
+  SortPlan*      planK = &s->plans.p[0];
+  SortPlan*      planP = &s->plans.p[1];
+
+  if(timed) HIPCHK(hipEventRecord(s->ev[0], st));
+  launchFrameInit(st, ctr, planK, planP, s->ranges.p, nTiles);
+  const bool cpuMode = (p->sort_mode == MGS_SORT_CPU_ASYNC);
+  if(cpuMode)  // rejected splats must look empty to the binning stage: rect with x0 > x1
+    hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, st, s->rect.p, 1u, s->totalSplats);
+  launchProject(st, A, true, s->shFormat, s->rgbaFormat, ctr, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p,
+                s->rect.p);
+  if(timed) HIPCHK(hipEventRecord(s->ev[1], st));
+  if(!cpuMode)
+    keySort(s, st);
+  else
+  {
+    rc = cpuSortStep(s, p, p->cpu_sort_blocking != 0);
+    if(rc != MGS_OK)
+      return rc;
+    if(s->cpuHaveIndices && s->cpuIndices.size() == s->totalSplats)
+      HIPCHK(hipMemcpyAsync(s->idsA.p, s->cpuIndices.data(), (size_t)s->totalSplats * 4, hipMemcpyHostToDevice, st));
+    else  // no result yet: the reference draws with whatever the index buffer holds; we use identity order
+      hipLaunchKernelGGL(k_iota_u32, dim3(1024), dim3(256), 0, st, s->idsA.p, s->totalSplats);
+    hipLaunchKernelGGL(k_set_plan_n, dim3(1), dim3(1), 0, st, planK, ctr, s->totalSplats);
+  }
+  if(timed) HIPCHK(hipEventRecord(s->ev[2], st));
+  launchBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, s->blockCount.p, (s->totalSplats + kPart - 1) / kPart, ctr,
+                s->pairKey0.p, s->pairVal0.p, s->pairCapacity, F.tilesX);
+  if(timed) HIPCHK(hipEventRecord(s->ev[3], st));
+  {
+    SortLaunch L{};
+    L.keys0 = s->pairKey0.p;
+    L.vals0 = s->pairVal0.p;
+    L.keysX = s->pairKey1.p;
+    L.valsX = s->pairVal1.p;
+    L.keysY = s->pairKey0.p;
+    L.valsY = s->pairVal0.p;
+    L.slotCount = nullptr;
+    L.nPtr      = &ctr->pairCount;
+    L.plan      = planP;
+    L.partHist  = s->partHist.p;
+    L.pStride   = s->pStride;
+    L.maxParts  = (s->pairCapacity + kPart - 1) / kPart;
+    L.beginBit  = 0;
+    L.endBit    = pairSortBits((int)nTiles);
+    launchRadixSort(st, L);
+  }
+  launchTileRanges(st, s->pairKey1.p, s->pairKey0.p, planP, s->ranges.p);
+  if(timed) HIPCHK(hipEventRecord(s->ev[4], st));
+  launchComposite(st, F, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half);
+  if(timed) HIPCHK(hipEventRecord(s->ev[5], st));
+  HIPCHK(hipMemcpyAsync(s->hCtr, ctr, sizeof(FrameCounters), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(s->hPlans, s->plans.p, 2 * sizeof(SortPlan), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipGetLastError());
+  s->lastParams      = *p;
+  s->lastParams.strip_row_begin = F.stripRow0;
+  s->lastParams.strip_row_end   = F.stripRow1;
+  s->haveFrame       = true;
+  s->lastTimed       = timed;
+  s->lastWasSortOnly = false;
+  if(out)
+  {
+    std::memset(out, 0, sizeof(*out));
+    out->rgba_device = s->image.p;
+    out->rgba_bytes  = s->imageBytes;
+    if(timed)
+      return mgs_frame_stats(s, out);
+  }
+  return MGS_OK;
+}
+
+int mgs_frame_stats(MgsScene s, MgsFrameOut* out)
+{
+  if(!s || !out)
+  {
+    setError("mgs_frame_stats: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(!s->haveFrame)
+  {
+    setError("mgs_frame_stats: no frame rendered yet");
+    return MGS_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  std::memset(out->stage_ms, 0, sizeof(out->stage_ms));
+  out->rgba_device   = s->image.p;
+  out->rgba_bytes    = s->imageBytes;
+  out->frustum_count = s->hCtr->frustumCount;
+  out->sorted_count  = s->hCtr->sortedCount;
+  out->tile_pairs    = s->hCtr->pairCount;
+  out->error_flags   = s->hCtr->errorFlags;
+  if(s->lastTimed && !s->lastWasSortOnly)
+  {
+    float ms = 0;
+    for(int i = 0; i < 5; ++i)
+    {
+      HIPCHK(hipEventElapsedTime(&ms, s->ev[i], s->ev[i + 1]));
+      out->stage_ms[i] = ms;
+    }
+    HIPCHK(hipEventElapsedTime(&ms, s->ev[0], s->ev[5]));
+    out->stage_ms[MGS_STAGE_TOTAL] = ms;
+  }
+  if(out->error_flags & kErrPairOverflow)
+  {
+    setError("frame: tile-pair capacity exceeded (raise MGS_PAIR_CAPACITY); frame is incomplete");
+    return MGS_ERR_OVERFLOW;
+  }
+  return MGS_OK;
+}
+
+int mgs_frame_download(MgsScene s, void* dst, size_t bytes)
+{
+  if(!s || !dst)
+  {
+    setError("mgs_frame_download: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(!s->haveFrame || s->lastWasSortOnly)
+  {
+    setError("mgs_frame_download: no frame rendered yet");
+    return MGS_ERR_STATE;
+  }
+  if(bytes < s->imageBytes)
+  {
+    setError("mgs_frame_download: destination too small");
+    return MGS_ERR_INVALID_ARG;
+  }
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipMemcpyAsync(dst, s->image.p, s->imageBytes, hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  return MGS_OK;
+}
+
+int mgs_frame_copy_strip(MgsScene s, void* dst, size_t bytes)
+{
+  if(!s || !dst)
+  {
+    setError("mgs_frame_copy_strip: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(!s->haveFrame || s->lastWasSortOnly)
+  {
+    setError("mgs_frame_copy_strip: no frame rendered yet");
+    return MGS_ERR_STATE;
+  }
+  const int    y0 = s->lastParams.strip_row_begin * kTilePx;
+  const int    y1 = std::min(s->lastParams.strip_row_end * kTilePx, s->lastParams.height);
+  const size_t n  = (size_t)(y1 - y0) * s->imageRowBytes;
+  if(bytes < n)
+  {
+    setError("mgs_frame_copy_strip: destination too small");
+    return MGS_ERR_INVALID_ARG;
+  }
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipMemcpyAsync(dst, s->image.p + (size_t)y0 * s->imageRowBytes, n, hipMemcpyDeviceToDevice, s->stream));
+  return MGS_OK;
+}
+
+int mgs_sync(MgsScene s)
+{
+  if(!s)
+  {
+    setError("mgs_sync: null scene");
+    return MGS_ERR_INVALID_ARG;
+  }
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  return MGS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int mgs_sort_keys(MgsScene s, const MgsFrameParams* p, MgsSortOut* out)
+{
+  if(!s || !p || !out)
+  {
+    setError("mgs_sort_keys: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(!s->committed)
+  {
+    setError("mgs_sort_keys: call mgs_scene_commit first");
+    return MGS_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(s->device));
+  std::memset(out, 0, sizeof(*out));
+  if(p->sort_mode == MGS_SORT_CPU_ASYNC)
+  {
+    int rc = cpuSortStep(s, p, true);
+    if(rc != MGS_OK)
+      return rc;
+    out->count   = (uint32_t)s->cpuIndices.size();
+    out->key_ms  = s->lastSort.key_ms;
+    out->sort_ms = s->lastSort.sort_ms;
+    s->lastSort  = *out;
+    s->lastWasSortOnly = true;
+    s->haveFrame       = true;
+    s->lastParams      = *p;
+    return MGS_OK;
+  }
+  FrameArgs A;
+  int       rc = buildFrameArgs(s, p, A);
+  if(rc != MGS_OK)
+    return rc;
+  hipStream_t st = s->stream;
+  if((rc = s->ranges.ensure(1))) return rc;
+  HIPCHK(hipEventRecord(s->ev[0], st));
+  launchFrameInit(st, s->ctr.p, &s->plans.p[0], &s->plans.p[1], s->ranges.p, 0);
+  launchProject(st, A, false, 0, 0, s->ctr.p, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p, s->rect.p);
+  HIPCHK(hipEventRecord(s->ev[1], st));
+  keySort(s, st);
+  HIPCHK(hipEventRecord(s->ev[2], st));
+  HIPCHK(hipMemcpyAsync(s->hCtr, s->ctr.p, sizeof(FrameCounters), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(s->hPlans, s->plans.p, 2 * sizeof(SortPlan), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
+  out->key_ms = ms;
+  HIPCHK(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
+  out->sort_ms = ms;
+  out->count   = s->hCtr->sortedCount;
+  out->passes  = s->hPlans[0].passesRun;
+  s->lastSort  = *out;
+  s->lastWasSortOnly = true;
+  s->haveFrame       = true;
+  s->lastParams      = *p;
+  return MGS_OK;
+}
+
+int mgs_sort_download(MgsScene s, uint32_t* keys, uint32_t* ids, uint32_t capacity)
+{
+  if(!s || !ids)
+  {
+    setError("mgs_sort_download: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(!s->haveFrame)
+  {
+    setError("mgs_sort_download: nothing sorted yet");
+    return MGS_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(s->device));
+  if(s->lastParams.sort_mode == MGS_SORT_CPU_ASYNC)
+  {
+    const size_t n = s->cpuIndices.size();
+    if(capacity < n)
+    {
+      setError("mgs_sort_download: capacity too small");
+      return MGS_ERR_INVALID_ARG;
+    }
+    std::memcpy(ids, s->cpuIndices.data(), n * 4);
+    if(keys)
+      for(size_t i = 0; i < n; ++i)
+        std::memcpy(&keys[i], &s->cpu.distances[s->cpuIndices[i]], 4);
+    return MGS_OK;
+  }
+  HIPCHK(hipStreamSynchronize(s->stream));
+  const uint32_t n = s->hCtr->sortedCount;
+  if(capacity < n)
+  {
+    setError("mgs_sort_download: capacity too small");
+    return MGS_ERR_INVALID_ARG;
+  }
+  const bool y = s->hPlans[0].finalSel != 0;
+  if(n)
+  {
+    if(keys)
+      HIPCHK(hipMemcpy(keys, y ? s->keysB.p : s->keysA.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ids, y ? s->idsB.p : s->idsA.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  }
+  return MGS_OK;
+}
+
+int mgs_radix_sort_u32(MgsScene s, void* keysDev, void* valsDev, uint32_t count, int beginBit, int endBit, float* ms)
+{
+  if(!s || !keysDev || !valsDev || beginBit < 0 || endBit > 32 || beginBit >= endBit)
+  {
+    setError("mgs_radix_sort_u32: bad argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  HIPCHK(hipSetDevice(s->device));
+  if(count == 0)
+    return MGS_OK;
+  static thread_local DevBuf<uint32_t> kX, vX, hist, nDev;
+  static thread_local DevBuf<SortPlan> plan;
+  int rc;
+  const uint32_t parts = (count + kPart - 1) / kPart;
+  if((rc = kX.ensure(count))) return rc;
+  if((rc = vX.ensure(count))) return rc;
+  if((rc = hist.ensure(256ull * parts))) return rc;
+  if((rc = nDev.ensure(1))) return rc;
+  if((rc = plan.ensure(1))) return rc;
+  hipStream_t st = s->stream;
+  HIPCHK(hipMemcpyAsync(nDev.p, &count, 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipEventRecord(s->ev[6], st));
+  launchSortClearPlan(st, plan.p);
+  SortLaunch L{};
+  L.keys0 = (uint32_t*)keysDev;
+  L.vals0 = (uint32_t*)valsDev;
+  L.keysX = kX.p;
+  L.valsX = vX.p;
+  L.keysY = (uint32_t*)keysDev;
+  L.valsY = (uint32_t*)valsDev;
+  L.nPtr     = nDev.p;
+  L.plan     = plan.p;
+  L.partHist = hist.p;
+  L.pStride  = parts;
+  L.maxParts = parts;
+  L.beginBit = beginBit;
+  L.endBit   = endBit;
+  launchRadixSort(st, L);
+  HIPCHK(hipEventRecord(s->ev[7], st));
+  SortPlan hp;
+  HIPCHK(hipMemcpyAsync(&hp, plan.p, sizeof(SortPlan), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if(ms)
+    HIPCHK(hipEventElapsedTime(ms, s->ev[6], s->ev[7]));
+  if(hp.finalSel == 0)
+  {  // result is in X: bring it home (outside the timed region)
+    HIPCHK(hipMemcpyAsync(keysDev, kX.p, (size_t)count * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(valsDev, vX.p, (size_t)count * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  HIPCHK(hipGetLastError());
+  return MGS_OK;
+}
+
+int mgs_radix_sort_host(MgsScene s, uint32_t* keys, uint32_t* vals, uint32_t count, int beginBit, int endBit, float* ms)
+{
+  if(!s || !keys || !vals)
+  {
+    setError("mgs_radix_sort_host: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(count == 0)
+    return MGS_OK;
+  HIPCHK(hipSetDevice(s->device));
+  uint32_t *dk = nullptr, *dv = nullptr;
+  HIPCHK(hipMalloc((void**)&dk, (size_t)count * 4));
+  HIPCHK(hipMalloc((void**)&dv, (size_t)count * 4));
+  HIPCHK(hipMemcpy(dk, keys, (size_t)count * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dv, vals, (size_t)count * 4, hipMemcpyHostToDevice));
+  int rc = mgs_radix_sort_u32(s, dk, dv, count, beginBit, endBit, ms);
+  if(rc == MGS_OK)
+  {
+    HIPCHK(hipMemcpy(keys, dk, (size_t)count * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(vals, dv, (size_t)count * 4, hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(dk);
+  (void)hipFree(dv);
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// build-defined camera helper (nvutils::CameraManipulator is absent)
+void mgs_camera_lookat_perspective(const float eye[3], const float center[3], const float up[3], float fovDeg, float zn,
+                                   float zf, int width, int height, int flipY, float view[16], float proj[16])
+{
+  auto norm3 = [](float v[3]) {
+    const float l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    v[0] /= l; v[1] /= l; v[2] /= l;
+  };
+  float f[3] = {center[0] - eye[0], center[1] - eye[1], center[2] - eye[2]};
+  norm3(f);
+  float sx[3] = {f[1] * up[2] - f[2] * up[1], f[2] * up[0] - f[0] * up[2], f[0] * up[1] - f[1] * up[0]};
+  norm3(sx);
+  const float u[3] = {sx[1] * f[2] - sx[2] * f[1], sx[2] * f[0] - sx[0] * f[2], sx[0] * f[1] - sx[1] * f[0]};
+  // right-handed lookAt, column-major
+  view[0] = sx[0]; view[4] = sx[1]; view[8]  = sx[2]; view[12] = -(sx[0] * eye[0] + sx[1] * eye[1] + sx[2] * eye[2]);
+  view[1] = u[0];  view[5] = u[1];  view[9]  = u[2];  view[13] = -(u[0] * eye[0] + u[1] * eye[1] + u[2] * eye[2]);
+  view[2] = -f[0]; view[6] = -f[1]; view[10] = -f[2]; view[14] = (f[0] * eye[0] + f[1] * eye[1] + f[2] * eye[2]);
+  view[3] = 0; view[7] = 0; view[11] = 0; view[15] = 1;
+  // right-handed perspective, clip z in [0,1]
+  const float aspect = (float)width / (float)height;
+  const float t      = std::tan(fovDeg * 0.017453292519943295f * 0.5f);
+  std::memset(proj, 0, sizeof(float) * 16);
+  proj[0]  = 1.0f / (aspect * t);
+  proj[5]  = (flipY ? -1.0f : 1.0f) / t;
+  proj[10] = zf / (zn - zf);
+  proj[11] = -1.0f;
+  proj[14] = -(zf * zn) / (zf - zn);
+}
+
+// T*R*S with R from Euler angles (degrees) through a quaternion, computeTransform (src/utilities.h:170-199)
+void mgs_compute_transform(const float scale[3], const float rotDeg[3], const float tr[3], float M[16], float Minv[16])
+{
+  const float d2r = 0.017453292519943295f;
+  const float hx = rotDeg[0] * d2r * 0.5f, hy = rotDeg[1] * d2r * 0.5f, hz = rotDeg[2] * d2r * 0.5f;
+  const float cx = std::cos(hx), sx = std::sin(hx), cy = std::cos(hy), sy = std::sin(hy), cz = std::cos(hz),
+              sz = std::sin(hz);
+  // [glm] quat(eulerAngles): w = cx*cy*cz + sx*sy*sz, x = sx*cy*cz - cx*sy*sz, y = cx*sy*cz + sx*cy*sz, z = cx*cy*sz - sx*sy*cz
+  const float w = cx * cy * cz + sx * sy * sz, x = sx * cy * cz - cx * sy * sz, y = cx * sy * cz + sx * cy * sz,
+              z = cx * cy * sz - sx * sy * cz;
+  const float R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y + w * z),     2 * (x * z - w * y),
+                      2 * (x * y - w * z),     1 - 2 * (x * x + z * z), 2 * (y * z + w * x),
+                      2 * (x * z + w * y),     2 * (y * z - w * x),     1 - 2 * (x * x + y * y)};  // columns
+  for(int c = 0; c < 3; ++c)
+  {
+    for(int r = 0; r < 3; ++r)
+      M[c * 4 + r] = R[c * 3 + r] * scale[c];
+    M[c * 4 + 3] = 0.f;
+  }
+  M[12] = tr[0]; M[13] = tr[1]; M[14] = tr[2]; M[15] = 1.f;
+  if(Minv)
+    mat4Inverse(M, Minv);
+}
+
+}  // extern "C"

@@ -1,0 +1,41 @@
+// sort_plan.h — device-resident plan of one radix sort and the host-side launch descriptor.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace mgs {
+
+struct SortPlan
+{
+  uint32_t ghist[4][256];  // global digit histograms of every pass (order independent)
+  uint32_t skip[4];        // pass is the identity permutation (single occupied digit) -> skipped
+  uint32_t srcSel[4];      // pass reads from X (0) or Y (1); pass 0 always reads src0 and writes X
+  uint32_t finalSel;       // result lives in X (0) or Y (1)
+  uint32_t passesRun;
+  uint32_t n;
+  uint32_t pad[5];
+};
+
+struct SortLaunch
+{
+  const uint32_t* keys0;  // pass-0 source
+  const uint32_t* vals0;
+  uint32_t*       keysX;
+  uint32_t*       valsX;
+  uint32_t*       keysY;
+  uint32_t*       valsY;
+  const uint32_t* slotCount;     // non-null: pass 0 reads slotted partitions (stride 2048) with these counts
+  uint32_t        partsSlotted;  // number of slotted partitions
+  const uint32_t* nPtr;          // device-side element count (uniform partitions)
+  SortPlan*       plan;          // must be zeroed before the launch (launchSortClearPlan / frame init)
+  uint32_t*       partHist;      // [256][pStride]
+  uint32_t        pStride;
+  uint32_t        maxParts;      // host-side upper bound of the partition count (grid size)
+  int             beginBit, endBit;
+};
+
+void launchSortClearPlan(hipStream_t stream, SortPlan* plan);
+void launchRadixSort(hipStream_t stream, const SortLaunch& s);
+
+}  // namespace mgs
