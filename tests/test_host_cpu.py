@@ -1,0 +1,180 @@
+"""CPU tests of the product's host side: C-ABI surface, ingest (own PLY/SPZ/.splat readers) against
+the golden vectors made by the reference-compiled loaders, camera helpers, error behaviour.
+No compute call is made here (there is no GPU in this container)."""
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, lookat, persp
+import vk_gaussian_splatting_amd as mgs
+from vk_gaussian_splatting_amd import capi, synth
+
+FIELDS = ["positions", "f_dc", "f_rest", "opacity", "scale", "rotation"]
+
+
+def test_library_exports_every_symbol_declared_in_header():
+    lib = capi.load_library()
+    hdr = open(os.path.join(ROOT, "include", "mgs.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(mgs_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"libmgs.so does not export {name}"
+    assert sorted(capi.EXPORTED_SYMBOLS) == declared
+    assert b"gfx950" in lib.mgs_version()
+
+
+def test_struct_layouts_match_header_sizes():
+    # MgsFrameParams: 16+16+3 floats, 2 ints, 3 floats, 12 ints + 6 reserved
+
+    import ctypes
+    assert ctypes.sizeof(capi.FrameParams) == 224
+    assert ctypes.sizeof(capi.FrameOut) == 8 + 8 + 4 + 4 + 8 + 4 + 4 + 32
+    assert ctypes.sizeof(capi.SortOut) == 32
+    assert ctypes.sizeof(capi.SplatSetView) == 6 * 8 + 8 + 4 + 4
+
+
+@pytest.mark.parametrize("name", ["ply_sh3", "ply_sh0", "ply_ascii", "ply_be", "spz_sh3", "spz_sh1", "spz_sh0"])
+def test_ingest_matches_reference_loader_bit_for_bit(name, golden_meta):
+    ext = ".spz" if name.startswith("spz") else ".ply"
+    s = mgs.SplatSet.load(os.path.join(GOLDEN, f"ingest_{name}{ext}"))
+    a = s.arrays()
+    g = np.load(os.path.join(GOLDEN, f"ingest_{name}.npz"))
+    assert a["count"] == golden_meta[name]["n"]
+    assert a["sh_degree"] == int(g["sh_degree"])
+    for k in FIELDS:
+        assert a[k].shape == g[k].shape, k
+        assert np.array_equal(a[k].view(np.uint32), g[k].view(np.uint32)), k  # bit-exact, NaN/inf safe
+
+
+def test_uppercase_extension_and_ply_roundtrip(tmp_path):
+    sc = synth.make_scene(257, seed=3)
+    p = tmp_path / "Scene.PLY"
+    synth.write_ply(str(p), sc)
+    a = mgs.SplatSet.load(str(p)).arrays()
+    for k in FIELDS:
+        assert np.array_equal(a[k], sc[k].reshape(-1)), k  # write (RUB->RDF) then load (RDF->RUB) is the identity
+
+
+def test_ply_partial_f_rest_means_degree_zero(tmp_path):
+    """the reference keeps f_rest only if all 45 properties exist (ply_loader_async.cpp:383-396)"""
+    sc = synth.make_scene(50, seed=4, sh_coeffs_per_channel=8)  # 24 f_rest_* properties
+    p = tmp_path / "deg2.ply"
+    synth.write_ply(str(p), sc)
+    a = mgs.SplatSet.load(str(p)).arrays()
+    assert a["f_rest"].size == 0 and a["sh_degree"] == 0 and a["count"] == 50
+
+
+def test_splat_format_loader(tmp_path):
+    """32-byte records (ply_loader_async.cpp:43-50,113-166): log scale, logit alpha, f_dc from colour, RDF->RUB"""
+    rng = np.random.default_rng(5)
+    n = 100
+    pos = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    scl = np.exp(rng.normal(-3, 1, (n, 3))).astype(np.float32)
+    col = rng.integers(0, 256, (n, 4), dtype=np.uint8)
+    rot = rng.integers(0, 256, (n, 4), dtype=np.uint8)
+    p = tmp_path / "a.splat"
+    with open(p, "wb") as f:
+        for i in range(n):
+            f.write(pos[i].tobytes() + scl[i].tobytes() + col[i].tobytes() + rot[i].tobytes())
+    a = mgs.SplatSet.load(str(p)).arrays()
+    assert a["count"] == n and a["f_rest"].size == 0 and a["sh_degree"] == 0
+    assert np.array_equal(a["positions"].reshape(n, 3), pos * np.array([1, -1, -1], np.float32))
+    assert np.allclose(a["scale"].reshape(n, 3), np.log(scl), rtol=1e-6, atol=1e-6)
+    q = (rot.astype(np.float32) - 128) / 128
+    assert np.array_equal(a["rotation"].reshape(n, 4), q * np.array([1, 1, -1, -1], np.float32))
+    assert np.allclose(a["f_dc"].reshape(n, 3), (col[:, :3] / np.float32(255) - 0.5) / 0.28209479177387814, atol=1e-5)
+    al = np.clip(col[:, 3] / np.float32(255), 1e-6, 1 - 1e-6)
+    assert np.allclose(a["opacity"], -np.log(1 / al - 1), rtol=1e-4, atol=1e-4)
+
+
+def test_ingest_errors(tmp_path):
+    with pytest.raises(mgs.MgsError) as e:
+        mgs.SplatSet.load(str(tmp_path / "missing.ply"))
+    assert e.value.code == -2  # MGS_ERR_IO
+    bad = tmp_path / "bad.ply"
+    bad.write_bytes(b"not a ply\n")
+    with pytest.raises(mgs.MgsError) as e:
+        mgs.SplatSet.load(str(bad))
+    assert e.value.code == -3  # MGS_ERR_FORMAT
+    nov = tmp_path / "mesh.ply"  # a valid PLY without the 3DGS properties
+    nov.write_bytes(b"ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nproperty float y\nproperty float z\nend_header\n0 0 0\n")
+    with pytest.raises(mgs.MgsError) as e:
+        mgs.SplatSet.load(str(nov))
+    assert e.value.code == -3
+    sp = tmp_path / "odd.splat"
+    sp.write_bytes(b"\0" * 33)
+    with pytest.raises(mgs.MgsError) as e:
+        mgs.SplatSet.load(str(sp))
+    assert e.value.code == -3
+    z = tmp_path / "x.spz"
+    z.write_bytes(b"garbage")
+    with pytest.raises(mgs.MgsError) as e:
+        mgs.SplatSet.load(str(z))
+    assert e.value.code == -3
+    trunc = tmp_path / "trunc.ply"
+    full = open(os.path.join(GOLDEN, "ingest_ply_sh0.ply"), "rb").read()
+    trunc.write_bytes(full[: len(full) - 100])
+    with pytest.raises(mgs.MgsError) as e:
+        mgs.SplatSet.load(str(trunc))
+    assert e.value.code == -3
+
+
+def test_from_arrays_validation_and_roundtrip():
+    sc = synth.make_scene(33, seed=6)
+    a = mgs.SplatSet.from_arrays(**sc).arrays()
+    for k in FIELDS:
+        assert np.array_equal(a[k], sc[k].reshape(-1))
+    assert a["sh_degree"] == 3 and a["f_rest_per_splat"] == 45
+    sc0 = dict(sc, f_rest=None)
+    assert mgs.SplatSet.from_arrays(**sc0).arrays()["sh_degree"] == 0
+    with pytest.raises(mgs.MgsError):
+        mgs.SplatSet.from_arrays(**dict(sc, f_rest=np.zeros((33, 7), np.float32)))  # not a multiple of 3
+    with pytest.raises(mgs.MgsError):
+        mgs.SplatSet.from_arrays(np.zeros((0, 3)), np.zeros((0, 3)), None, np.zeros(0), np.zeros((0, 3)), np.zeros((0, 4)))
+
+
+def test_scene_creation_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(mgs.MgsError) as e:
+        mgs.Scene(0)
+    assert e.value.code == -4 and "no CPU fallback" in str(e.value)
+
+
+def test_camera_helper_matches_numpy():
+    eye = np.array([1.7, 1.5, 1.7], np.float32)  # default camera, camera_set.h:48-53
+    V, P = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, 1920, 1080)
+    assert np.allclose(V, lookat(eye, [0, 0, 0], [0, 1, 0]), atol=1e-6)
+    assert np.allclose(P, persp(60, 1920 / 1080, 0.1, 2000), rtol=1e-6, atol=1e-7)
+    _, Pf = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, 1920, 1080, flip_y=True)
+    assert Pf[1, 1] == -P[1, 1]
+    # a point on the near plane maps to z=0, far plane to z=1 (clip z in [0,1])
+    for zv, want in ((-0.1, 0.0), (-2000.0, 1.0)):
+        c = P @ np.array([0, 0, zv, 1], np.float32)
+        assert abs(c[2] / c[3] - want) < 1e-4
+
+
+def test_compute_transform_is_trs():
+    M, Mi = mgs.compute_transform([2, 1, 0.5], [0, 90, 0], [1, 2, 3])
+    # rotation of +90 deg about y maps +x to -z
+    assert np.allclose(M @ np.array([1, 0, 0, 1], np.float32), [1, 2, 3 - 2, 1], atol=1e-5)
+    assert np.allclose(M @ Mi, np.eye(4), atol=1e-5)
+
+
+def test_strip_partition_covers_all_rows():
+    from vk_gaussian_splatting_amd import multigpu
+    for h in (480, 1080, 2160, 17):
+        for ws in (1, 2, 3, 4, 8):
+            rows = multigpu.tile_rows(h)
+            cover = []
+            for r in range(ws):
+                b, e = multigpu.strip_rows(h, ws, r)
+                assert 0 <= b <= e <= rows
+                cover += list(range(b, e))
+            assert cover == list(range(rows))
+            assert multigpu.strip_pixel_rows(h, ws) * ws >= h

@@ -269,12 +269,12 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, Fram
       mulMat4Exact(I.model, x, y, z, 1.0f, wp);               // dist.comp.slang:58
       mulMat4Exact(A.f.view, wp[0], wp[1], wp[2], wp[3], vp);  // :58
       mulMat4Exact(A.f.proj, vp[0], vp[1], vp[2], vp[3], cp);  // :60
-      const float nx = __fdiv_rn(cp[0], cp[3]), ny = __fdiv_rn(cp[1], cp[3]), nz = __fdiv_rn(cp[2], cp[3]);  // :61
+      const float nx = divExact(cp[0], cp[3]), ny = divExact(cp[1], cp[3]), nz = divExact(cp[2], cp[3]);  // :61
       vis = true;
       if(A.f.cullMode == 1)
       {  // :71-73 (NaN compares false everywhere, as in the shader)
-        const float c = __fadd_rn(1.0f, A.f.frustumDilation);
-        if(fabsf(nx) > c || fabsf(ny) > c || nz < __fsub_rn(0.f, A.f.frustumDilation) || nz > 1.0f)
+        const float c = 1.0f + A.f.frustumDilation;
+        if(fabsf(nx) > c || fabsf(ny) > c || nz < 0.f - A.f.frustumDilation || nz > 1.0f)
           vis = false;
       }
       key = A.f.frontToBack ? encodeKey(nz) : encodeKey(-nz);  // :163-167

@@ -71,19 +71,28 @@ __device__ __forceinline__ uint32_t encodeKey(float v)
 }
 
 // out = M * v with the exact unfused evaluation order of the oracle / host:
-// ((x*c0 + y*c1) + z*c2) + w*c3, every product and sum rounded separately.
+// ((x*c0 + y*c1) + z*c2) + w*c3, every product and sum rounded separately.  The pragma only
+// affects operators written lexically inside the block (intrinsics like __fmul_rn are inlined with
+// the translation unit's default contract(fast) and WOULD be fused), hence plain * and +.
 __device__ __forceinline__ void mulMat4Exact(const float* m, float x, float y, float z, float w, float out[4])
 {
 #pragma clang fp contract(off)
 #pragma unroll
   for(int r = 0; r < 4; ++r)
   {
-    const float a = __fmul_rn(x, m[r]);
-    const float b = __fmul_rn(y, m[4 + r]);
-    const float c = __fmul_rn(z, m[8 + r]);
-    const float d = __fmul_rn(w, m[12 + r]);
-    out[r]        = __fadd_rn(__fadd_rn(__fadd_rn(a, b), c), d);
+    const float a = x * m[r];
+    const float b = y * m[4 + r];
+    const float c = z * m[8 + r];
+    const float d = w * m[12 + r];
+    out[r]        = ((a + b) + c) + d;
   }
+}
+
+// IEEE-correct fp32 division (hipcc default: -fhip-fp32-correctly-rounded-divide-sqrt)
+__device__ __forceinline__ float divExact(float a, float b)
+{
+#pragma clang fp contract(off)
+  return a / b;
 }
 
 }  // namespace mgs
