@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s @1920x1080 + sorted Gsplats/s on the garden-sized scene, 1..8 MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches one
+rank per GPU with torch.distributed.run.  A "step" is one frame = one pass of the hot path
+(key+cull+project -> radix sort -> tile binning -> per-pixel compositing) over the resident scene, on
+the next pose of the fixed 64-pose orbit.  Inputs are resident in HBM before the timed
+region.  W untimed warm-up frames, then EXACTLY K frames between barrier+synchronize pairs; rank 0
+prints ONE JSON line.
+
+N>1: screen-strip partition (tile rows) with replicated splat buffers and one RCCL all-gather of the
+strips per frame (strong scaling: the frame is fixed, the GPUs split it).
+
+The JSON line also carries
+  roofline      — the dominant kernel's algorithmic bytes / its mean HIP-event duration in the timed region
+  cpu_baseline  — the oracle's restatement of the reference's CPU sorter (splat_sorter_async.cpp:92-141),
+                  timed on this box's host cores (rank 0, N=1 only); a baseline, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+STAGES = ["project", "sort", "bin", "pairsort", "composite", "total"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--splats", type=int, default=5_830_000, help="scene size (default: garden-sized, configs[2])")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--sh-format", type=int, default=0, help="0 fp32 (benchmark setting), 1 fp16, 2 uint8")
+    ap.add_argument("--rgba-format", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sort-only", action="store_true", help="also report the isolated key+sort hook per pose")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+
+    import vk_gaussian_splatting_amd as mgs
+    from vk_gaussian_splatting_amd import capi, synth, multigpu
+
+    W, H, N = args.width, args.height, args.splats
+    t0 = time.time()
+    sc = synth.make_scene(N, seed=0xC0FFEE + 2)  # syn_garden; identical on every rank
+    ss = mgs.SplatSet.from_arrays(**sc)
+    scene = mgs.Scene(local)
+    scene.add_instance(ss)
+    scene.commit(args.sh_format, args.rgba_format)
+    stream = torch.cuda.Stream()          # a real (non-null) stream shared by the renderer and RCCL
+    torch.cuda.set_stream(stream)
+    scene.set_stream(stream.cuda_stream)
+    setup_s = time.time() - t0
+
+    poses = []
+    for i in range(64):
+        eye = synth.orbit_pose(i)
+        V, P = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, W, H)
+        p = capi.default_params(W, H)
+        capi.set_camera(p, V, P, eye)
+        p.strip_row_begin, p.strip_row_end = multigpu.strip_rows(H, world, rank) if world > 1 else (0, 0)
+        p.collect_timings = 2
+        poses.append(p)
+
+    R = multigpu.strip_pixel_rows(H, world)
+    strip = torch.zeros((R, W, 4), dtype=torch.float16, device="cuda") if world > 1 else None
+    strip_bytes = R * W * 8
+
+    def frame(i):
+        p = poses[i % 64]
+        if world > 1 and p.strip_row_begin == p.strip_row_end:
+            gathered = multigpu.gather_strips(strip, world)  # this rank owns no rows (more ranks than tile rows)
+            return gathered
+        scene.render(p)
+        if world > 1:
+            scene.copy_strip(strip.data_ptr(), strip_bytes)
+            return multigpu.gather_strips(strip, world)
+        return None
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        frame(i)
+    fence()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        frame(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- per-stage HIP-event times of the timed frames (ring of 128) + counters per pose --------
+    k = min(args.steps, 128)
+    st = np.array([scene.timings(b) for b in range(k)], np.float64)  # [k, 6] ms
+    stage_ms = st.mean(axis=0)
+    counts = []
+    for i in range(min(64, args.steps)):
+        pp = poses[(args.warmup + args.steps - 1 - i) % 64]
+        # counters are per pose; re-render untimed to read them back (outside the timed region)
+        pp.collect_timings = 0
+        o = scene.render(pp, want_stats=True)
+        counts.append((o.frustum_count, o.sorted_count, o.tile_pairs, o.error_flags))
+        pp.collect_timings = 2
+    counts = np.array(counts, np.float64)
+    Vf, Vs, D = counts[:, 0].mean(), counts[:, 1].mean(), counts[:, 2].mean()
+    err = int(counts[:, 3].max())
+    if world > 1:
+        agg = torch.tensor([Vs, D, Vf], dtype=torch.float64, device="cuda")
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        Vs_all = float(agg[0])
+    else:
+        Vs_all = Vs
+
+    fps = args.steps / elapsed
+    rows = (poses[0].strip_row_end - poses[0].strip_row_begin) if world > 1 else multigpu.tile_rows(H)
+    Ppix = W * min(rows * 16, H)
+    # algorithmic bytes per launch of each stage (SURVEY.md §8d per-unit figures)
+    alg = {
+        "project": 12 * N + 16 * Vf + (24 + 180) * Vs + (48 + 4 + 8) * Vs,
+        "sort": 68 * Vs,
+        "bin": 2 * 8 * Vs + 8 * D,
+        "pairsort": (4 + 2 * 16) * D,
+        "composite": 48 * Vs + 4 * D + 8 * Ppix,
+    }
+    dom = max(range(5), key=lambda j: stage_ms[j])
+    dom_name = STAGES[dom]
+    achieved = alg[dom_name] / (stage_ms[dom] * 1e-3) if stage_ms[dom] > 0 else 0.0
+    b_frame = 12 * N + Vs * (16 + 24 + 180) + 8 * Vs + 68 * Vs + 2 * 48 * Vs + 8 * Ppix
+    frame_gpu_ms = stage_ms[5]
+    sort_ms = stage_ms[1]
+
+    out = {
+        "metric": "frames/s @1920x1080 + sorted Gsplats/s, garden-sized scene",
+        "value": fps,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"syn_garden N={N} SH deg 3, storage sh/rgba format {args.sh_format}/{args.rgba_format}, "
+                               f"{W}x{H}, 64-pose orbit r=4 h=1.5 fov60, GPU radix sort, cull at dist (configs[2])",
+                   "partition": "single GPU" if world == 1 else f"{world} tile-row strips + RCCL all_gather"},
+        "sorted_gsplats_per_s": (Vs / (sort_ms * 1e-3)) / 1e9 if sort_ms > 0 else None,
+        "sorted_gsplats_per_s_in_frame_aggregate": Vs_all * fps / 1e9,
+        "visible_splats": {"frustum": Vf, "sorted": Vs, "tile_pairs": D},
+        "stage_ms": {STAGES[j]: float(stage_ms[j]) for j in range(6)},
+        "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg[dom_name], "launch_ms": float(stage_ms[dom]),
+                     "note": "composite is fp32-VALU bound (exp + blend per pixel-splat pair), not HBM bound; see DESIGN.md"
+                     if dom_name == "composite" else ""},
+        "roofline_sort": {"bound": "hbm", "achieved": (68 * Vs / (sort_ms * 1e-3)) / 1e9 if sort_ms > 0 else None,
+                          "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                          "frac": (68 * Vs / (sort_ms * 1e-3)) / HBM_PEAK if sort_ms > 0 else None},
+        "roofline_frame": {"bound": "hbm", "achieved": (b_frame / (frame_gpu_ms * 1e-3)) / 1e9 if frame_gpu_ms > 0 else None,
+                           "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                           "frac": (b_frame / (frame_gpu_ms * 1e-3)) / HBM_PEAK if frame_gpu_ms > 0 else None,
+                           "algorithmic_bytes_per_frame": b_frame},
+        "error_flags": err,
+        "setup_s": setup_s,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # CPU baseline: restated SplatSorterAsync::innerSort on a bounded sample of the same workload
+        from oracle import binding as ob
+        nb = min(N, 2_000_000)
+        V0 = np.array(poses[0].view, np.float32).reshape(4, 4).T
+        fwd = -V0[2, :3]
+        eye0 = synth.orbit_pose(0)
+        reps, best = 2, None
+        for _ in range(reps):
+            _, _, dms, sms = ob.cpu_sort(fwd, eye0, [(sc["positions"][:nb], None)], threads=0)
+            best = (dms + sms) if best is None else min(best, dms + sms)
+        out["cpu_baseline"] = {"value": nb / (best * 1e-3) / 1e9, "unit": "Gsplats/s (depth key + sort)",
+                               "cores": os.cpu_count(), "kind": "port",
+                               "sample": f"first {nb} splats of the workload, pose 0, best of {reps}; distance loop on all "
+                                         f"cores, std::sort(par_unseq) serial unless libstdc++ finds TBB",
+                               "ms": best}
+    if rank == 0:
+        print(json.dumps(out))
+    scene.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

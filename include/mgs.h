@@ -125,7 +125,8 @@ typedef struct MgsFrameParams {
   /* multi-GPU strip partition (no reference counterpart): this device renders
    * 16-pixel tile rows [strip_row_begin, strip_row_end); 0,0 = whole frame */
   int32_t strip_row_begin, strip_row_end;
-  int32_t collect_timings;      /* 1: bracket each stage with hipEvents on the render stream */
+  int32_t collect_timings;      /* 1: bracket each stage with hipEvents on the render stream and wait for them;
+                                   2: record the events but do not wait (query later with mgs_timings_query) */
   int32_t cpu_sort_blocking;    /* CPU_ASYNC only: 1 = wait for the sorter (deterministic tests) */
   int32_t reserved[6];
 } MgsFrameParams;
@@ -153,6 +154,9 @@ typedef struct MgsFrameOut {
 int mgs_render(MgsScene scene, const MgsFrameParams* params, MgsFrameOut* out);
 /* waits for the last mgs_render and fills counters / timings (readBackIndirectParametersIfNeeded, :1536) */
 int mgs_frame_stats(MgsScene scene, MgsFrameOut* out);
+/* per-stage HIP-event times of the timed frame rendered `frames_back` frames ago (0 = latest;
+ * a ring of 128 timed frames is kept).  Waits only for that frame's last event. */
+int mgs_timings_query(MgsScene scene, uint32_t frames_back, float stage_ms[MGS_STAGE_COUNT]);
 /* copy the last frame to the host (screenshot path, gaussian_splatting_ui.cpp:508-540, no tonemap) */
 int mgs_frame_download(MgsScene scene, void* host_dst, size_t bytes);
 /* copy this device's strip of the last frame into a caller-owned device buffer (all-gather staging) */

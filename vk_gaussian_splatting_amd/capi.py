@@ -92,6 +92,7 @@ def load_library():
         "mgs_frame_params_default": (None, [P(FrameParams)]),
         "mgs_render": (C.c_int, [vp, P(FrameParams), P(FrameOut)]),
         "mgs_frame_stats": (C.c_int, [vp, P(FrameOut)]),
+        "mgs_timings_query": (C.c_int, [vp, C.c_uint32, P(F)]),
         "mgs_frame_download": (C.c_int, [vp, vp, C.c_size_t]),
         "mgs_frame_copy_strip": (C.c_int, [vp, vp, C.c_size_t]),
         "mgs_sync": (C.c_int, [vp]),
@@ -114,7 +115,7 @@ EXPORTED_SYMBOLS = [
     "mgs_last_error", "mgs_version", "mgs_splatset_load", "mgs_splatset_from_arrays", "mgs_splatset_view",
     "mgs_splatset_destroy", "mgs_scene_create", "mgs_scene_destroy", "mgs_scene_set_stream", "mgs_instance_add",
     "mgs_instance_set_transform", "mgs_scene_commit", "mgs_scene_splat_count", "mgs_scene_download_set",
-    "mgs_frame_params_default", "mgs_render", "mgs_frame_stats", "mgs_frame_download", "mgs_frame_copy_strip",
+    "mgs_frame_params_default", "mgs_render", "mgs_frame_stats", "mgs_timings_query", "mgs_frame_download", "mgs_frame_copy_strip",
     "mgs_sync", "mgs_sort_keys", "mgs_sort_download", "mgs_radix_sort_u32", "mgs_radix_sort_host",
     "mgs_camera_lookat_perspective", "mgs_compute_transform"]
 
@@ -276,6 +277,11 @@ class Scene:
         out = FrameOut()
         _check(self._lib.mgs_frame_stats(self._h, C.byref(out)))
         return out
+
+    def timings(self, frames_back=0):
+        ms = (C.c_float * 8)()
+        _check(self._lib.mgs_timings_query(self._h, frames_back, ms))
+        return [float(x) for x in ms[:6]]
 
     def download_frame(self, params):
         if params.target_format == TARGET_RGBA16F:

@@ -231,7 +231,10 @@ struct MgsScene_t
   FrameCounters* hCtr   = nullptr;
   SortPlan*      hPlans = nullptr;
 
-  hipEvent_t ev[8] = {};
+  static constexpr int kRing = 128;
+  hipEvent_t ev[8] = {};              // [0..2] sort-only hook, [6..7] raw radix sort
+  hipEvent_t evRing[kRing][6] = {};   // per-frame stage brackets, so timed frames need no host sync
+  uint64_t   frameIndex = 0;          // frames rendered with collect_timings
   bool       evReady = false;
 
   // last frame
@@ -380,6 +383,13 @@ int mgs_scene_create(int device, MgsScene* out)
       setError("mgs_scene_create: hipEventCreate failed");
       return MGS_ERR_DEVICE;
     }
+  for(auto& set : s->evRing)
+    for(auto& e : set)
+      if(hipEventCreate(&e) != hipSuccess)
+      {
+        setError("mgs_scene_create: hipEventCreate failed");
+        return MGS_ERR_DEVICE;
+      }
   s->evReady = true;
   *out       = s;
   return MGS_OK;
@@ -411,8 +421,13 @@ void mgs_scene_destroy(MgsScene s)
   if(s->hCtr) (void)hipHostFree(s->hCtr);
   if(s->hPlans) (void)hipHostFree(s->hPlans);
   if(s->evReady)
+  {
     for(auto& e : s->ev)
       (void)hipEventDestroy(e);
+    for(auto& set : s->evRing)
+      for(auto& e : set)
+        (void)hipEventDestroy(e);
+  }
   if(s->ownStream)
     (void)hipStreamDestroy(s->ownStream);
   delete s;
@@ -910,14 +925,15 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
   SortPlan*      planK = &s->plans.p[0];
   SortPlan*      planP = &s->plans.p[1];
 
-  if(timed) HIPCHK(hipEventRecord(s->ev[0], st));
+  hipEvent_t* fev = s->evRing[s->frameIndex % MgsScene_t::kRing];
+  if(timed) HIPCHK(hipEventRecord(fev[0], st));
   launchFrameInit(st, ctr, planK, planP, s->ranges.p, nTiles);
   const bool cpuMode = (p->sort_mode == MGS_SORT_CPU_ASYNC);
   if(cpuMode)  // rejected splats must look empty to the binning stage: rect with x0 > x1
     hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, st, s->rect.p, 1u, s->totalSplats);
   launchProject(st, A, true, s->shFormat, s->rgbaFormat, ctr, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p,
                 s->rect.p);
-  if(timed) HIPCHK(hipEventRecord(s->ev[1], st));
+  if(timed) HIPCHK(hipEventRecord(fev[1], st));
   if(!cpuMode)
     keySort(s, st);
   else
@@ -931,10 +947,10 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
       hipLaunchKernelGGL(k_iota_u32, dim3(1024), dim3(256), 0, st, s->idsA.p, s->totalSplats);
     hipLaunchKernelGGL(k_set_plan_n, dim3(1), dim3(1), 0, st, planK, ctr, s->totalSplats);
   }
-  if(timed) HIPCHK(hipEventRecord(s->ev[2], st));
+  if(timed) HIPCHK(hipEventRecord(fev[2], st));
   launchBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, s->blockCount.p, (s->totalSplats + kPart - 1) / kPart, ctr,
                 s->pairKey0.p, s->pairVal0.p, s->pairCapacity, F.tilesX);
-  if(timed) HIPCHK(hipEventRecord(s->ev[3], st));
+  if(timed) HIPCHK(hipEventRecord(fev[3], st));
   {
     SortLaunch L{};
     L.keys0 = s->pairKey0.p;
@@ -954,9 +970,9 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
     launchRadixSort(st, L);
   }
   launchTileRanges(st, s->pairKey1.p, s->pairKey0.p, planP, s->ranges.p);
-  if(timed) HIPCHK(hipEventRecord(s->ev[4], st));
+  if(timed) HIPCHK(hipEventRecord(fev[4], st));
   launchComposite(st, F, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half);
-  if(timed) HIPCHK(hipEventRecord(s->ev[5], st));
+  if(timed) HIPCHK(hipEventRecord(fev[5], st));
   HIPCHK(hipMemcpyAsync(s->hCtr, ctr, sizeof(FrameCounters), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(s->hPlans, s->plans.p, 2 * sizeof(SortPlan), hipMemcpyDeviceToHost, st));
   HIPCHK(hipGetLastError());
@@ -966,14 +982,43 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
   s->haveFrame       = true;
   s->lastTimed       = timed;
   s->lastWasSortOnly = false;
+  if(timed)
+    ++s->frameIndex;
   if(out)
   {
     std::memset(out, 0, sizeof(*out));
     out->rgba_device = s->image.p;
     out->rgba_bytes  = s->imageBytes;
-    if(timed)
+    if(p->collect_timings == 1)
       return mgs_frame_stats(s, out);
   }
+  return MGS_OK;
+}
+
+int mgs_timings_query(MgsScene s, uint32_t framesBack, float* stageMs)
+{
+  if(!s || !stageMs)
+  {
+    setError("mgs_timings_query: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(framesBack >= (uint32_t)MgsScene_t::kRing || framesBack >= s->frameIndex)
+  {
+    setError("mgs_timings_query: no timed frame that far back (ring of 128)");
+    return MGS_ERR_INVALID_ARG;
+  }
+  HIPCHK(hipSetDevice(s->device));
+  hipEvent_t* fev = s->evRing[(s->frameIndex - 1 - framesBack) % MgsScene_t::kRing];
+  HIPCHK(hipEventSynchronize(fev[5]));
+  std::memset(stageMs, 0, sizeof(float) * MGS_STAGE_COUNT);
+  float ms = 0;
+  for(int i = 0; i < 5; ++i)
+  {
+    HIPCHK(hipEventElapsedTime(&ms, fev[i], fev[i + 1]));
+    stageMs[i] = ms;
+  }
+  HIPCHK(hipEventElapsedTime(&ms, fev[0], fev[5]));
+  stageMs[MGS_STAGE_TOTAL] = ms;
   return MGS_OK;
 }
 
@@ -1000,14 +1045,9 @@ int mgs_frame_stats(MgsScene s, MgsFrameOut* out)
   out->error_flags   = s->hCtr->errorFlags;
   if(s->lastTimed && !s->lastWasSortOnly)
   {
-    float ms = 0;
-    for(int i = 0; i < 5; ++i)
-    {
-      HIPCHK(hipEventElapsedTime(&ms, s->ev[i], s->ev[i + 1]));
-      out->stage_ms[i] = ms;
-    }
-    HIPCHK(hipEventElapsedTime(&ms, s->ev[0], s->ev[5]));
-    out->stage_ms[MGS_STAGE_TOTAL] = ms;
+    int rc = mgs_timings_query(s, 0, out->stage_ms);
+    if(rc != MGS_OK)
+      return rc;
   }
   if(out->error_flags & kErrPairOverflow)
   {
