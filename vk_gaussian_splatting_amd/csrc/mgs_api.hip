@@ -626,7 +626,7 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
   if((rc = s->ctr.ensure(1))) return rc;
   if((rc = s->plans.ensure(2))) return rc;
 
-  uint64_t cap = std::max<uint64_t>(8ull * total, 16ull << 20);
+  uint64_t cap = std::max<uint64_t>(32ull * total, 64ull << 20);  // 16 B per pair: 3 GB for a garden-sized scene
   if(const char* e = std::getenv("MGS_PAIR_CAPACITY"))
     cap = std::strtoull(e, nullptr, 10);
   cap = std::min<uint64_t>(std::max<uint64_t>(cap, kPart), 0xFFFFF000ull);
