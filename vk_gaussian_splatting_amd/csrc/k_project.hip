@@ -51,15 +51,60 @@ __device__ __forceinline__ float4 loadRgba(const void* base, uint32_t i)
   }
 }
 
+// SH storage: [coef][rgb] interleaved, one record per splat padded to a 16-byte multiple (pitch =
+// 48 elements for degree 3 in every format), so a lane fetches its record with aligned 16-byte loads:
+// 12 x dwordx4 (fp32), 6 (fp16) or 3 (uint8) instead of 45 scalar loads.  The texture-address unit, not
+// HBM, was the limiter with scalar loads at a 180-byte lane stride (profiles/r1_a: 0.92 ms).
 template <int FMT>
-__device__ __forceinline__ float loadSh(const void* base, size_t idx)
+__device__ __forceinline__ void loadShRecord(const void* base, size_t elemOffset, int ncoef, float (&s)[48])
 {
   if constexpr(FMT == 0)
-    return reinterpret_cast<const float*>(base)[idx];
+  {
+    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elemOffset);
+#pragma unroll
+    for(int v = 0; v < 12; ++v)
+    {
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if(4 * v < ncoef)
+        x = p[v];
+      s[4 * v] = x.x; s[4 * v + 1] = x.y; s[4 * v + 2] = x.z; s[4 * v + 3] = x.w;
+    }
+  }
   else if constexpr(FMT == 1)
-    return __half2float(reinterpret_cast<const __half*>(base)[idx]);
+  {
+    const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(base) + elemOffset);
+#pragma unroll
+    for(int v = 0; v < 6; ++v)
+    {
+      uint4 x = make_uint4(0u, 0u, 0u, 0u);
+      if(8 * v < ncoef)
+        x = p[v];
+      const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for(int q = 0; q < 4; ++q)
+      {
+        const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&w[q]));
+        s[8 * v + 2 * q] = f.x; s[8 * v + 2 * q + 1] = f.y;
+      }
+    }
+  }
   else
-    return (float)reinterpret_cast<const uint8_t*>(base)[idx] / 255.0f * 2.0f - 1.0f;
+  {
+    const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(base) + elemOffset);
+#pragma unroll
+    for(int v = 0; v < 3; ++v)
+    {
+      uint4 x = make_uint4(0u, 0u, 0u, 0u);
+      if(16 * v < ncoef)
+        x = p[v];
+      const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for(int q = 0; q < 4; ++q)
+#pragma unroll
+        for(int k = 0; k < 4; ++k)  // threedgs_particle_buffers.h.slang:128-131: v/255*2-1
+          s[16 * v + 4 * q + k] = (float)((w[q] >> (8 * k)) & 255u) / 255.0f * 2.0f - 1.0f;
+    }
+  }
 }
 
 // SH degrees 1..3 added to the base colour; constants and term order of
@@ -70,12 +115,9 @@ __device__ __forceinline__ void addShRadiance(const InstanceConst& I, uint32_t l
 {
   if(degree < 1 || I.sh == nullptr)
     return;
-  const size_t o = (size_t)li * (size_t)I.shStride;
-  float        s[45];
-  const int    ncoef = degree == 1 ? 9 : (degree == 2 ? 24 : 45);
-#pragma unroll
-  for(int k = 0; k < 45; ++k)
-    s[k] = (k < ncoef) ? loadSh<FMT>(I.sh, o + k) : 0.f;
+  float     s[48];
+  const int ncoef = degree == 1 ? 9 : (degree == 2 ? 24 : 45);
+  loadShRecord<FMT>(I.sh, (size_t)li * (size_t)I.shStride, ncoef, s);
   const float C1 = 0.4886025119029199f;
   float       acc[3];
 #pragma unroll
@@ -139,8 +181,9 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
     return false;
 
   // covariance projection, threedgs.h.slang:26-56
-  const float* c6 = I.cov6 + 6 * (size_t)li;
-  const float  s00 = c6[0], s01 = c6[1], s02 = c6[2], s11 = c6[3], s12 = c6[4], s22 = c6[5];
+  const float2* c6  = reinterpret_cast<const float2*>(I.cov6 + 6 * (size_t)li);  // 24-byte records: 8-byte aligned
+  const float2  c01 = c6[0], c23 = c6[1], c45 = c6[2];
+  const float   s00 = c01.x, s01 = c01.y, s02 = c23.x, s11 = c23.y, s12 = c45.x, s22 = c45.y;
   const float  rz = 1.0f / tz, rz2 = rz * rz;
   const float  j00 = F.focal[0] * rz, j02 = -(F.focal[0] * tx) * rz2;
   const float  j11 = F.focal[1] * rz, j12 = -(F.focal[1] * ty) * rz2;

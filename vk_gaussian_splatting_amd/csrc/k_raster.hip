@@ -41,10 +41,22 @@ __global__ void k_frame_init(FrameCounters* ctr, SortPlan* planKeys, SortPlan* p
     ranges[i] = make_uint2(0u, 0u);
 }
 
-// ---- binning, step 1: tile-pair count of each 2048-splat block of the sorted list -----------
+// ---- binning -------------------------------------------------------------------------------------
+// Contract: per 16x16 tile, the splats whose footprint box overlaps it, in global depth order.
+// Records (tile id, global id) are emitted in sorted-splat order; a STABLE sort by tile id then keeps
+// every tile's list depth-ordered.  The expansion is partitioned by OUTPUT range, not by splat: the
+// nearest splats are the largest on screen and sit together at the end of the sorted list, so a
+// splat-partitioned expansion leaves a ~1 ms tail on a handful of workgroups (profiles/r1_a).
+//   k_bin_count   : tile count of every sorted splat (+ its rect, re-laid out in sorted order) -> block sums
+//   k_bin_scan    : exclusive scan of the block sums, total D
+//   k_bin_offsets : per-splat exclusive offsets; marks, for every 2048-record output chunk, the sorted
+//                   splat that contains the chunk's first record
+//   k_bin_expand  : one workgroup per output chunk, balanced and fully coalesced writes
+constexpr int kChunk = 2048;  // output records per expand workgroup
+
 __global__ __launch_bounds__(kBinThreads) void k_bin_count(const uint32_t* __restrict__ idsX, const uint32_t* __restrict__ idsY,
                                                            const SortPlan* __restrict__ plan, const uint32_t* __restrict__ rect,
-                                                           uint32_t* __restrict__ blockCount)
+                                                           uint32_t* __restrict__ sortedRect, uint32_t* __restrict__ blockCount)
 {
   __shared__ uint32_t s_tmp[4];
   const uint32_t      n     = plan->n;
@@ -58,7 +70,11 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(const uint32_t* __res
   {
     const uint32_t e = blockIdx.x * kBinPart + i * kBinThreads + threadIdx.x;
     if(e < n)
-      sum += rectTiles(rect[ids[e]]);
+    {
+      const uint32_t r = rect[ids[e]];
+      sortedRect[e]    = r;
+      sum += rectTiles(r);
+    }
   }
   sum = waveSum(sum);
   if(laneId() == 0)
@@ -68,7 +84,6 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(const uint32_t* __res
     blockCount[blockIdx.x] = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
 }
 
-// ---- binning, step 2: exclusive scan of the block counts (one workgroup; <= a few 10k entries)
 __global__ __launch_bounds__(256) void k_bin_scan(const SortPlan* __restrict__ plan, uint32_t* __restrict__ blockCount,
                                                   FrameCounters* __restrict__ ctr, uint32_t capacity)
 {
@@ -97,97 +112,138 @@ __global__ __launch_bounds__(256) void k_bin_scan(const SortPlan* __restrict__ p
   }
 }
 
-// ---- binning, step 3: cooperative expansion to (tile id, global splat id) records ------------
-// Written in sorted order, so a STABLE sort by tile id keeps every tile's list depth-ordered.
-__global__ __launch_bounds__(kBinThreads) void k_bin_expand(const uint32_t* __restrict__ idsX, const uint32_t* __restrict__ idsY,
-                                                            const SortPlan* __restrict__ plan, const uint32_t* __restrict__ rect,
-                                                            const uint32_t* __restrict__ blockOffset, uint32_t* __restrict__ pairKey,
-                                                            uint32_t* __restrict__ pairVal, uint32_t capacity, int tilesX)
+__global__ __launch_bounds__(kBinThreads) void k_bin_offsets(const SortPlan* __restrict__ plan, const uint32_t* __restrict__ sortedRect,
+                                                             const uint32_t* __restrict__ blockOffset,
+                                                             uint32_t* __restrict__ splatOffset, uint32_t* __restrict__ chunkStart,
+                                                             uint32_t maxChunks)
 {
-  __shared__ uint32_t s_start[kBinPart];
-  __shared__ uint32_t s_rect[kBinPart];
-  __shared__ uint32_t s_gid[kBinPart];
   __shared__ uint32_t s_tmp[4];
   const uint32_t      n     = plan->n;
   const uint32_t      parts = (n + kBinPart - 1) / kBinPart;
   if(blockIdx.x >= parts)
     return;
-  const uint32_t* ids = plan->finalSel ? idsY : idsX;
-  const int       t   = threadIdx.x;
-  // entry e (sorted order) = block*2048 + i : coalesced load, then thread t owns entries [8t, 8t+8)
+  // thread t owns the 8 consecutive sorted entries [base + 8t, base + 8t + 8)
+  const uint32_t e0 = blockIdx.x * kBinPart + threadIdx.x * kBinItems;
+  uint32_t       cnt[kBinItems], sum = 0;
 #pragma unroll
   for(int i = 0; i < kBinItems; ++i)
   {
-    const uint32_t le = i * kBinThreads + t;
-    const uint32_t e  = blockIdx.x * kBinPart + le;
-    uint32_t       g = 0, r = 0, c = 0;
-    if(e < n)
-    {
-      g = ids[e];
-      r = rect[g];
-      c = rectTiles(r);
-    }
-    s_gid[le]   = g;
-    s_rect[le]  = r;
-    s_start[le] = c;
-  }
-  __syncthreads();
-  uint32_t cnt[kBinItems], sum = 0;
-#pragma unroll
-  for(int i = 0; i < kBinItems; ++i)
-  {
-    cnt[i] = s_start[t * kBinItems + i];
+    cnt[i] = (e0 + i < n) ? rectTiles(sortedRect[e0 + i]) : 0u;
     sum += cnt[i];
   }
   uint32_t total;
-  uint32_t run = blockExclusiveScan256(sum, s_tmp, &total);
+  uint32_t run = blockOffset[blockIdx.x] + blockExclusiveScan256(sum, s_tmp, &total);
 #pragma unroll
   for(int i = 0; i < kBinItems; ++i)
   {
-    s_start[t * kBinItems + i] = run;
+    if(e0 + i < n)
+    {
+      splatOffset[e0 + i] = run;
+      if(cnt[i])
+      {  // every multiple of kChunk inside [run, run+cnt) starts an output chunk inside this splat
+        const uint32_t first = (run + kChunk - 1) / kChunk, last = (run + cnt[i] - 1) / kChunk;
+        for(uint32_t m = first; m <= last && m < maxChunks; ++m)
+          chunkStart[m] = e0 + i;
+      }
+    }
     run += cnt[i];
   }
-  __syncthreads();
-  const uint32_t base = blockOffset[blockIdx.x];
-  for(uint32_t o = t; o < total; o += kBinThreads)
+}
+
+__global__ __launch_bounds__(kBinThreads) void k_bin_expand(const uint32_t* __restrict__ idsX, const uint32_t* __restrict__ idsY,
+                                                            const SortPlan* __restrict__ plan, const FrameCounters* __restrict__ ctr,
+                                                            const uint32_t* __restrict__ sortedRect,
+                                                            const uint32_t* __restrict__ splatOffset,
+                                                            const uint32_t* __restrict__ chunkStart, uint32_t* __restrict__ pairKey,
+                                                            uint32_t* __restrict__ pairVal, int tilesX)
+{
+  constexpr int       kWin = 2048;
+  __shared__ uint32_t s_off[kWin + 1];
+  __shared__ uint32_t s_rect[kWin];
+  __shared__ uint32_t s_gid[kWin];
+  const uint32_t      D = ctr->pairCount;  // already clamped to the capacity
+  const uint32_t      n = plan->n;
+  const uint32_t      o0 = blockIdx.x * (uint32_t)kChunk;
+  if(o0 >= D)
+    return;
+  const uint32_t  o1  = min(o0 + (uint32_t)kChunk, D);
+  const uint32_t* ids = plan->finalSel ? idsY : idsX;
+  const int       t   = threadIdx.x;
+  const uint32_t  s0  = chunkStart[blockIdx.x];
+  // the splat holding the next chunk's first record may also hold the tail of this chunk
+  const uint32_t s1 = (o1 < D) ? chunkStart[blockIdx.x + 1] : (n - 1);
+  for(uint32_t w0 = s0; w0 <= s1; w0 += kWin)
   {
-    // last entry whose start <= o
-    uint32_t lo = 0, hi = kBinPart;
-    while(hi - lo > 1)
+    const uint32_t wn = min((uint32_t)kWin, s1 + 1 - w0);
+    __syncthreads();
+    for(uint32_t i = t; i < wn; i += kBinThreads)
     {
-      const uint32_t mid = (lo + hi) >> 1;
-      if(s_start[mid] <= o)
-        lo = mid;
-      else
-        hi = mid;
+      s_off[i]  = splatOffset[w0 + i];
+      s_rect[i] = sortedRect[w0 + i];
+      s_gid[i]  = ids[w0 + i];
     }
-    const uint32_t r  = s_rect[lo];
-    const uint32_t x0 = r & 255u, y0 = (r >> 8) & 255u, x1 = (r >> 16) & 255u;
-    const uint32_t wd = x1 - x0 + 1u;
-    const uint32_t k  = o - s_start[lo];
-    const uint32_t ty = y0 + k / wd, tx = x0 + k % wd;
-    const uint64_t dst = (uint64_t)base + o;
-    if(dst < capacity)
+    if(t == 0)
+      s_off[wn] = (w0 + wn < n) ? splatOffset[w0 + wn] : 0xFFFFFFFFu;
+    __syncthreads();
+    const uint32_t lo = max(o0, s_off[0]), hi = min(o1, s_off[wn]);
+    for(uint32_t o = lo + t; o < hi; o += kBinThreads)
     {
-      pairKey[dst] = ty * (uint32_t)tilesX + tx;
-      pairVal[dst] = s_gid[lo];
+      // last window entry whose offset <= o
+      uint32_t a = 0, b = wn;
+      while(b - a > 1)
+      {
+        const uint32_t mid = (a + b) >> 1;
+        if(s_off[mid] <= o)
+          a = mid;
+        else
+          b = mid;
+      }
+      const uint32_t r  = s_rect[a];
+      const uint32_t x0 = r & 255u, y0 = (r >> 8) & 255u, x1 = (r >> 16) & 255u;
+      const uint32_t wd = x1 - x0 + 1u;
+      const uint32_t k  = o - s_off[a];
+      pairKey[o]        = (y0 + k / wd) * (uint32_t)tilesX + (x0 + k % wd);
+      pairVal[o]        = s_gid[a];
     }
   }
 }
 
 // ---- tile ranges over the tile-sorted pair list ------------------------------------------------
+// 4 keys per thread (one 16-byte load) + the two neighbours.
 __global__ void k_tile_ranges(const uint32_t* __restrict__ keyX, const uint32_t* __restrict__ keyY,
                               const SortPlan* __restrict__ plan, uint2* __restrict__ ranges)
 {
   const uint32_t  n    = plan->n;
   const uint32_t* keys = plan->finalSel ? keyY : keyX;
-  for(uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+  const uint32_t  n4   = (n + 3u) >> 2;
+  for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x)
   {
-    const uint32_t k = keys[j];
-    if(j == 0 || keys[j - 1] != k)
-      ranges[k].x = j;
-    if(j == n - 1 || keys[j + 1] != k)
-      ranges[k].y = j + 1;
+    const uint32_t j = i << 2;
+    uint32_t       k[6];
+    if(j + 4 <= n)
+    {
+      const uint4 v = *reinterpret_cast<const uint4*>(keys + j);
+      k[1] = v.x; k[2] = v.y; k[3] = v.z; k[4] = v.w;
+    }
+    else
+    {
+#pragma unroll
+      for(int q = 0; q < 4; ++q)
+        k[1 + q] = (j + q < n) ? keys[j + q] : 0xFFFFFFFFu;
+    }
+    k[0] = (j > 0) ? keys[j - 1] : 0xFFFFFFFFu;
+    k[5] = (j + 4 < n) ? keys[j + 4] : 0xFFFFFFFFu;
+#pragma unroll
+    for(int q = 0; q < 4; ++q)
+    {
+      if(j + q < n)
+      {
+        if(k[q] != k[q + 1] || (j + q) == 0)
+          ranges[k[q + 1]].x = j + q;
+        if(k[q + 2] != k[q + 1] || (j + q) == n - 1)
+          ranges[k[q + 1]].y = j + q + 1;
+      }
+    }
   }
 }
 
@@ -309,21 +365,26 @@ void launchFrameInit(hipStream_t stream, FrameCounters* ctr, SortPlan* planKeys,
 }
 
 void launchBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
-                   const uint32_t* rect, uint32_t* blockCount, uint32_t maxBlocks, FrameCounters* ctr, uint32_t* pairKey,
-                   uint32_t* pairVal, uint32_t capacity, int tilesX)
+                   const uint32_t* rect, uint32_t* blockCount, uint32_t maxBlocks, FrameCounters* ctr, uint32_t* sortedRect,
+                   uint32_t* splatOffset, uint32_t* chunkStart, uint32_t* pairKey, uint32_t* pairVal, uint32_t capacity,
+                   int tilesX)
 {
   if(maxBlocks == 0)
     return;
-  hipLaunchKernelGGL(k_bin_count, dim3(maxBlocks), dim3(kBinThreads), 0, stream, idsX, idsY, planKeys, rect, blockCount);
+  hipLaunchKernelGGL(k_bin_count, dim3(maxBlocks), dim3(kBinThreads), 0, stream, idsX, idsY, planKeys, rect, sortedRect,
+                     blockCount);
   hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(256), 0, stream, planKeys, blockCount, ctr, capacity);
-  hipLaunchKernelGGL(k_bin_expand, dim3(maxBlocks), dim3(kBinThreads), 0, stream, idsX, idsY, planKeys, rect, blockCount,
-                     pairKey, pairVal, capacity, tilesX);
+  const uint32_t chunks = (capacity + kChunk - 1) / kChunk;
+  hipLaunchKernelGGL(k_bin_offsets, dim3(maxBlocks), dim3(kBinThreads), 0, stream, planKeys, sortedRect, blockCount,
+                     splatOffset, chunkStart, chunks + 1);
+  hipLaunchKernelGGL(k_bin_expand, dim3(chunks), dim3(kBinThreads), 0, stream, idsX, idsY, planKeys, ctr, sortedRect,
+                     splatOffset, chunkStart, pairKey, pairVal, tilesX);
 }
 
 void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* keyY, const SortPlan* planPairs,
                       uint2* ranges)
 {
-  hipLaunchKernelGGL(k_tile_ranges, dim3(2048), dim3(256), 0, stream, keyX, keyY, planPairs, ranges);
+  hipLaunchKernelGGL(k_tile_ranges, dim3(4096), dim3(256), 0, stream, keyX, keyY, planPairs, ranges);
 }
 
 void launchComposite(hipStream_t stream, const FrameConst& F, const uint2* ranges, const uint32_t* valX,

@@ -19,41 +19,54 @@
 
 namespace mgs {
 
-constexpr int kSortThreads = 256;
-constexpr int kSortKpt     = 8;
-constexpr int kSortPart    = kSortThreads * kSortKpt;  // 2048 keys per partition (== project partition)
-constexpr int kSortWaves   = kSortThreads / 64;
+constexpr int kSlotPart = 2048;  // slotted pass-0 partitions == the project kernel's partitions
 
-__device__ __forceinline__ void partitionExtent(bool slotted, const uint32_t* slotCount, uint32_t n, uint32_t p,
-                                                uint32_t& count)
+// partition p: [p*part, p*part+count)
+__device__ __forceinline__ uint32_t partitionCount(bool slotted, const uint32_t* slotCount, uint32_t n, uint32_t p,
+                                                   uint32_t part)
 {
   if(slotted)
-    count = slotCount[p];
-  else
+    return slotCount[p];
+  const uint64_t base = (uint64_t)p * part;
+  return (n > base) ? (uint32_t)min((uint64_t)part, (uint64_t)n - base) : 0u;
+}
+
+// LDS histogram add with run aggregation: lanes holding the same digit as their left neighbour are
+// folded into the run's first lane, so long runs of equal digits (the high byte of a tile id, the top
+// bytes of depth keys) cost one LDS atomic instead of a 64-way serialised one.
+__device__ __forceinline__ void histAddRuns(uint32_t* hist, uint32_t digit, bool valid)
+{
+  const int      lane = laneId();
+  const uint32_t d    = valid ? digit : 0xFFFFFFFFu;
+  const uint32_t prev = __shfl_up(d, 1, 64);
+  const bool     lead = (lane == 0) || (prev != d);
+  const uint64_t mask = __ballot(lead);
+  if(lead && valid)
   {
-    const uint32_t base = p * kSortPart;
-    count               = (n > base) ? min((uint32_t)kSortPart, n - base) : 0u;
+    const uint64_t above = (lane == 63) ? 0ull : (mask >> (lane + 1));
+    const uint32_t len   = above ? (uint32_t)__builtin_ctzll(above) + 1u : (uint32_t)(64 - lane);
+    atomicAdd(&hist[digit], len);
   }
 }
 
 // (a) per-partition digit histogram.  FIRST additionally accumulates the global histogram of every
 // pass (order independent), flushed once per workgroup.
 template <bool FIRST>
-__global__ __launch_bounds__(kSortThreads) void k_sort_hist(const uint32_t* __restrict__ keysX, const uint32_t* __restrict__ keysY,
-                                                            const uint32_t* __restrict__ keys0, const uint32_t* __restrict__ slotCount,
-                                                            const uint32_t* __restrict__ nPtr, uint32_t partsSlotted,
-                                                            SortPlan* __restrict__ plan, uint32_t* __restrict__ partHist,
-                                                            uint32_t pStride, int pass, int beginBit, int nPasses)
+__global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ keysX, const uint32_t* __restrict__ keysY,
+                                                   const uint32_t* __restrict__ keys0, const uint32_t* __restrict__ slotCount,
+                                                   const uint32_t* __restrict__ nPtr, uint32_t partsSlotted,
+                                                   SortPlan* __restrict__ plan, uint32_t* __restrict__ partHist,
+                                                   uint32_t pStride, int pass, int beginBit, int nPasses, uint32_t part)
 {
   __shared__ uint32_t s_h[256];
   __shared__ uint32_t s_g[4][256];
-  const int  t       = threadIdx.x;
-  const bool slotted = FIRST && (slotCount != nullptr);
-  const uint32_t n   = *nPtr;
+  const int      t       = threadIdx.x;
+  const bool     slotted = FIRST && (slotCount != nullptr);
+  const uint32_t n       = *nPtr;
   if(!FIRST && plan->skip[pass])
     return;
   const uint32_t* keys  = FIRST ? keys0 : (plan->srcSel[pass] ? keysY : keysX);
-  const uint32_t  parts = slotted ? partsSlotted : (n + kSortPart - 1) / kSortPart;
+  const uint32_t  parts = slotted ? partsSlotted : (uint32_t)(((uint64_t)n + part - 1) / part);
   const int       shift = beginBit + 8 * pass;
   if(FIRST)
   {
@@ -65,27 +78,30 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_hist(const uint32_t* __re
   {
     s_h[t] = 0;
     __syncthreads();
-    uint32_t count;
-    partitionExtent(slotted, slotCount, n, p, count);
-    const uint32_t* src = keys + (size_t)p * kSortPart;
-    for(uint32_t i = t; i < count; i += kSortThreads)
+    const uint32_t  count = partitionCount(slotted, slotCount, n, p, part);
+    const uint32_t* src   = keys + (size_t)p * part;
+    const uint32_t  iters = (count + 255u) >> 8;
+    for(uint32_t it = 0; it < iters; ++it)
     {
-      const uint32_t key = src[i];
-      atomicAdd(&s_h[(key >> shift) & 255u], 1u);
+      const uint32_t i   = it * 256u + t;
+      const bool     in  = i < count;
+      const uint32_t key = in ? src[i] : 0u;
+      histAddRuns(s_h, (key >> shift) & 255u, in);
       if(FIRST)
       {
-        atomicAdd(&s_g[0][(key >> shift) & 255u], 1u);
         for(int q = 1; q < nPasses; ++q)
-          atomicAdd(&s_g[q][(key >> (shift + 8 * q)) & 255u], 1u);
+          histAddRuns(s_g[q], (key >> (shift + 8 * q)) & 255u, in);
       }
     }
     __syncthreads();
-    partHist[(size_t)t * pStride + p] = s_h[t];
+    const uint32_t c                  = s_h[t];
+    partHist[(size_t)t * pStride + p] = c;
+    if(FIRST)
+      s_g[0][t] += c;
     __syncthreads();
   }
   if(FIRST)
   {
-    __syncthreads();
     for(int q = 0; q < nPasses; ++q)
       if(s_g[q][t])
         atomicAdd(&plan->ghist[q][t], s_g[q][t]);
@@ -129,63 +145,92 @@ __global__ __launch_bounds__(256) void k_sort_plan(SortPlan* __restrict__ plan, 
 
 // (b) one workgroup per digit: exclusive scan of that digit's row of partition counts, offset by the
 // number of keys with a smaller digit.  In place: partHist[d][p] becomes the global destination of
-// the first key of partition p with digit d.
+// the first key of partition p with digit d.  8 consecutive entries per thread per step.
 __global__ __launch_bounds__(256) void k_sort_scan(const uint32_t* __restrict__ nPtr, const uint32_t* __restrict__ slotCount,
                                                    uint32_t partsSlotted, SortPlan* __restrict__ plan,
-                                                   uint32_t* __restrict__ partHist, uint32_t pStride, int pass)
+                                                   uint32_t* __restrict__ partHist, uint32_t pStride, int pass, uint32_t part)
 {
   __shared__ uint32_t s_tmp[4];
-  const int      t = threadIdx.x, d = blockIdx.x;
+  const int t = threadIdx.x, d = blockIdx.x;
   if(plan->skip[pass])
     return;
-  const uint32_t n     = *nPtr;
+  const uint32_t n       = *nPtr;
   const bool     slotted = (pass == 0) && (slotCount != nullptr);
-  const uint32_t parts = slotted ? partsSlotted : (n + kSortPart - 1) / kSortPart;
+  const uint32_t parts   = slotted ? partsSlotted : (uint32_t)(((uint64_t)n + part - 1) / part);
   uint32_t       total;
   const uint32_t below = (t < d) ? plan->ghist[pass][t] : 0u;
   (void)blockExclusiveScan256(below, s_tmp, &total);
   uint32_t  carry = total;  // keys with a smaller digit
   uint32_t* row   = partHist + (size_t)d * pStride;
-  for(uint32_t base = 0; base < parts; base += 256)
+  for(uint32_t base = 0; base < parts; base += 2048)
   {
-    const uint32_t p = base + t;
-    const uint32_t v = (p < parts) ? row[p] : 0u;
-    uint32_t       chunk;
-    const uint32_t ex = blockExclusiveScan256(v, s_tmp, &chunk);
-    if(p < parts)
-      row[p] = carry + ex;
+    const uint32_t p0 = base + t * 8;
+    uint32_t       v[8], sum = 0;
+#pragma unroll
+    for(int i = 0; i < 8; ++i)
+    {
+      v[i] = (p0 + i < parts) ? row[p0 + i] : 0u;
+      sum += v[i];
+    }
+    uint32_t chunk;
+    uint32_t run = carry + blockExclusiveScan256(sum, s_tmp, &chunk);
+#pragma unroll
+    for(int i = 0; i < 8; ++i)
+    {
+      if(p0 + i < parts)
+        row[p0 + i] = run;
+      run += v[i];
+    }
     carry += chunk;
   }
 }
 
-// (c) ranked scatter of one partition.
-template <bool FIRST>
-__global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint32_t* __restrict__ keys0, const uint32_t* __restrict__ vals0,
-                                                               uint32_t* __restrict__ keysX, uint32_t* __restrict__ valsX,
-                                                               uint32_t* __restrict__ keysY, uint32_t* __restrict__ valsY,
-                                                               const uint32_t* __restrict__ slotCount, const uint32_t* __restrict__ nPtr,
-                                                               uint32_t partsSlotted, const SortPlan* __restrict__ plan,
-                                                               const uint32_t* __restrict__ partHist, uint32_t pStride, int pass,
-                                                               int beginBit)
+// exclusive scan over the first 256 threads of a THREADS-wide block (one value per digit)
+template <int THREADS>
+__device__ __forceinline__ uint32_t digitExclusiveScan(uint32_t v, uint32_t* s_tmp /*THREADS/64*/)
 {
-  __shared__ uint32_t s_whist[kSortWaves][256];
-  __shared__ uint32_t s_k[kSortPart];
-  __shared__ uint32_t s_v[kSortPart];
+  const int      lane = laneId(), w = threadIdx.x >> 6;
+  const uint32_t inc  = waveInclusiveScan(v);
+  if(lane == 63)
+    s_tmp[w] = inc;
+  __syncthreads();
+  uint32_t base = 0;
+  if(w > 0) base += s_tmp[0];
+  if(w > 1) base += s_tmp[1];
+  if(w > 2) base += s_tmp[2];
+  __syncthreads();
+  return base + inc - v;  // meaningful for threads < 256 only
+}
+
+// (c) ranked scatter of one partition of THREADS*KPT keys.
+template <bool FIRST, int THREADS, int KPT>
+__global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __restrict__ keys0, const uint32_t* __restrict__ vals0,
+                                                          uint32_t* __restrict__ keysX, uint32_t* __restrict__ valsX,
+                                                          uint32_t* __restrict__ keysY, uint32_t* __restrict__ valsY,
+                                                          const uint32_t* __restrict__ slotCount, const uint32_t* __restrict__ nPtr,
+                                                          uint32_t partsSlotted, const SortPlan* __restrict__ plan,
+                                                          const uint32_t* __restrict__ partHist, uint32_t pStride, int pass,
+                                                          int beginBit)
+{
+  constexpr int PART  = THREADS * KPT;
+  constexpr int WAVES = THREADS / 64;
+  __shared__ uint32_t s_whist[WAVES][256];
+  __shared__ uint32_t s_k[PART];
+  __shared__ uint32_t s_v[PART];
   __shared__ uint32_t s_loff[256];
   __shared__ uint32_t s_gbase[256];
-  __shared__ uint32_t s_tmp[4];
+  __shared__ uint32_t s_tmp[WAVES];
 
   const int t = threadIdx.x, lane = laneId(), w = t >> 6;
   if(!FIRST && plan->skip[pass])
     return;
   const bool     slotted = FIRST && (slotCount != nullptr);
   const uint32_t n       = *nPtr;
-  const uint32_t parts   = slotted ? partsSlotted : (n + kSortPart - 1) / kSortPart;
+  const uint32_t parts   = slotted ? partsSlotted : (uint32_t)(((uint64_t)n + PART - 1) / PART);
   const uint32_t p       = blockIdx.x;
   if(p >= parts)
     return;
-  uint32_t count;
-  partitionExtent(slotted, slotCount, n, p, count);
+  const uint32_t count = partitionCount(slotted, slotCount, n, p, PART);
   const uint32_t *kin, *vin;
   uint32_t *      kout, *vout;
   if(FIRST)
@@ -211,17 +256,16 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint32_t* _
   }
   const int shift = beginBit + 8 * pass;
 
-#pragma unroll
-  for(int i = 0; i < kSortWaves; ++i)
-    s_whist[i][t] = 0;
+  for(int i = t; i < WAVES * 256; i += THREADS)
+    (&s_whist[0][0])[i] = 0;
 
-  // wave-striped load: wave w owns keys [w*512, w*512+512) of the partition, lane-interleaved, so
+  // wave-striped load: wave w owns keys [w*64*KPT, (w+1)*64*KPT) of the partition, lane-interleaved, so
   // (round i, lane) order == memory order inside the wave, and waves are in memory order too.
-  const size_t   base = (size_t)p * kSortPart + (size_t)w * (64 * kSortKpt);
-  const uint32_t wofs = w * (64 * kSortKpt);
-  uint32_t       key[kSortKpt], val[kSortKpt];
+  const uint32_t wofs = w * (64 * KPT);
+  const size_t   base = (size_t)p * PART + wofs;
+  uint32_t       key[KPT], val[KPT];
 #pragma unroll
-  for(int i = 0; i < kSortKpt; ++i)
+  for(int i = 0; i < KPT; ++i)
   {
     const uint32_t idx = wofs + i * 64 + lane;
     const bool     in  = idx < count;
@@ -231,11 +275,11 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint32_t* _
   __syncthreads();
 
   // per-wave multi-split: rank of each key among the keys of its wave with the same digit
-  uint32_t rank[kSortKpt];
+  uint32_t rank[KPT];
 #pragma unroll
-  for(int i = 0; i < kSortKpt; ++i)
+  for(int i = 0; i < KPT; ++i)
   {
-    // padding keys (idx >= count) use digit 255 of 0xFFFFFFFF shifted — they sort behind every real key
+    // padding keys (idx >= count) carry digit 255 and sit behind every real key of the partition
     const uint32_t d = (key[i] >> shift) & 255u;
     uint64_t       m = ~0ull;
 #pragma unroll
@@ -249,32 +293,38 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint32_t* _
     const uint32_t cnt   = (uint32_t)__popcll(m);
     const uint32_t pre   = s_whist[w][d];
     rank[i]              = pre + lower;
-    // make sure every lane of the group has read `pre` before the leader bumps it
-    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_wave_barrier();  // every lane of the group has read `pre` before the leader bumps it
     if(lower == 0)
       s_whist[w][d] = pre + cnt;
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
 
-  // thread t == digit t: wave offsets, partition-local exclusive scan over digits, global base
+  // thread t (< 256) == digit t: wave offsets, partition-local exclusive scan over digits, global base
+  uint32_t tot = 0;
+  if(t < 256)
   {
-    const uint32_t c0 = s_whist[0][t], c1 = s_whist[1][t], c2 = s_whist[2][t], c3 = s_whist[3][t];
-    s_whist[0][t] = 0;
-    s_whist[1][t] = c0;
-    s_whist[2][t] = c0 + c1;
-    s_whist[3][t] = c0 + c1 + c2;
-    const uint32_t tot = c0 + c1 + c2 + c3;
-    uint32_t       dummy;
-    const uint32_t loff = blockExclusiveScan256(tot, s_tmp, &dummy);
-    s_loff[t]           = loff;
-    s_gbase[t]          = partHist[(size_t)t * pStride + p] - loff;  // wraps are fine: only base+idx is used
+    uint32_t acc = 0;
+#pragma unroll
+    for(int q = 0; q < WAVES; ++q)
+    {
+      const uint32_t c = s_whist[q][t];
+      s_whist[q][t]    = acc;
+      acc += c;
+    }
+    tot = acc;
+  }
+  const uint32_t loff = digitExclusiveScan<THREADS>(tot, s_tmp);
+  if(t < 256)
+  {
+    s_loff[t]  = loff;
+    s_gbase[t] = partHist[(size_t)t * pStride + p] - loff;  // wraps are fine: only base+idx is used
   }
   __syncthreads();
 
   // re-order through LDS so that keys with equal digits are contiguous
 #pragma unroll
-  for(int i = 0; i < kSortKpt; ++i)
+  for(int i = 0; i < KPT; ++i)
   {
     const uint32_t d   = (key[i] >> shift) & 255u;
     const uint32_t pos = s_loff[d] + s_whist[w][d] + rank[i];
@@ -285,9 +335,9 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint32_t* _
 
   // coalesced scatter: consecutive threads write consecutive addresses inside each digit run
 #pragma unroll
-  for(int i = 0; i < kSortKpt; ++i)
+  for(int i = 0; i < KPT; ++i)
   {
-    const uint32_t idx = i * kSortThreads + t;
+    const uint32_t idx = i * THREADS + t;
     if(idx < count)
     {
       const uint32_t k   = s_k[idx];
@@ -317,27 +367,47 @@ void launchSortClearPlan(hipStream_t stream, SortPlan* plan)
 void launchRadixSort(hipStream_t stream, const SortLaunch& s)
 {
   const int nPasses = (s.endBit - s.beginBit + 7) / 8;
-  if(nPasses <= 0 || s.maxParts == 0)
+  if(nPasses <= 0 || s.maxElems == 0)
     return;
-  const uint32_t fatGrid = s.maxParts < 1024u ? s.maxParts : 1024u;
-  hipLaunchKernelGGL((k_sort_hist<true>), dim3(fatGrid), dim3(kSortThreads), 0, stream, s.keysX, s.keysY, s.keys0,
-                     s.slotCount, s.nPtr, s.partsSlotted, s.plan, s.partHist, s.pStride, 0, s.beginBit, nPasses);
+  const bool     slotted = s.slotCount != nullptr;
+  // big sorts use 8192-key partitions (digit runs of ~32 keys = 128-byte scatter segments, 4x shorter
+  // partition tables); small ones keep 2048 so that 256 CUs still see enough workgroups
+  const uint32_t bigPart = (s.maxElems >= (2u << 20)) ? 8192u : 2048u;
+  auto           partOf  = [&](int pass) { return (pass == 0 && slotted) ? (uint32_t)kSlotPart : bigPart; };
+  auto           partsOf = [&](int pass) {
+    return (pass == 0 && slotted) ? s.partsSlotted : (uint32_t)(((uint64_t)s.maxElems + partOf(pass) - 1) / partOf(pass));
+  };
+  const uint32_t p0      = partsOf(0);
+  const uint32_t fatGrid = p0 < 2048u ? p0 : 2048u;
+  hipLaunchKernelGGL((k_sort_hist<true>), dim3(fatGrid), dim3(256), 0, stream, s.keysX, s.keysY, s.keys0, s.slotCount, s.nPtr,
+                     s.partsSlotted, s.plan, s.partHist, s.pStride, 0, s.beginBit, nPasses, partOf(0));
   hipLaunchKernelGGL(k_sort_plan, dim3(1), dim3(256), 0, stream, s.plan, s.nPtr, nPasses);
   for(int pass = 0; pass < nPasses; ++pass)
   {
+    const uint32_t part = partOf(pass), parts = partsOf(pass);
     if(pass > 0)
-      hipLaunchKernelGGL((k_sort_hist<false>), dim3(s.maxParts), dim3(kSortThreads), 0, stream, s.keysX, s.keysY, s.keys0,
-                         (const uint32_t*)nullptr, s.nPtr, 0u, s.plan, s.partHist, s.pStride, pass, s.beginBit, nPasses);
+      hipLaunchKernelGGL((k_sort_hist<false>), dim3(parts), dim3(256), 0, stream, s.keysX, s.keysY, s.keys0,
+                         (const uint32_t*)nullptr, s.nPtr, 0u, s.plan, s.partHist, s.pStride, pass, s.beginBit, nPasses, part);
     hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, stream, s.nPtr, pass == 0 ? s.slotCount : nullptr,
-                       s.partsSlotted, s.plan, s.partHist, s.pStride, pass);
+                       s.partsSlotted, s.plan, s.partHist, s.pStride, pass, part);
+#define MGS_SCATTER(FIRSTV, TH, KP, SLOTS)                                                                                  \
+  hipLaunchKernelGGL((k_sort_scatter<FIRSTV, TH, KP>), dim3(parts), dim3(TH), 0, stream, s.keys0, s.vals0, s.keysX, s.valsX, \
+                     s.keysY, s.valsY, SLOTS, s.nPtr, s.partsSlotted, s.plan, s.partHist, s.pStride, pass, s.beginBit)
     if(pass == 0)
-      hipLaunchKernelGGL((k_sort_scatter<true>), dim3(s.maxParts), dim3(kSortThreads), 0, stream, s.keys0, s.vals0, s.keysX,
-                         s.valsX, s.keysY, s.valsY, s.slotCount, s.nPtr, s.partsSlotted, s.plan, s.partHist, s.pStride,
-                         pass, s.beginBit);
+    {
+      if(part == 2048u)
+        MGS_SCATTER(true, 256, 8, s.slotCount);
+      else
+        MGS_SCATTER(true, 512, 16, s.slotCount);
+    }
     else
-      hipLaunchKernelGGL((k_sort_scatter<false>), dim3(s.maxParts), dim3(kSortThreads), 0, stream, s.keys0, s.vals0, s.keysX,
-                         s.valsX, s.keysY, s.valsY, (const uint32_t*)nullptr, s.nPtr, 0u, s.plan, s.partHist, s.pStride,
-                         pass, s.beginBit);
+    {
+      if(part == 2048u)
+        MGS_SCATTER(false, 256, 8, (const uint32_t*)nullptr);
+      else
+        MGS_SCATTER(false, 512, 16, (const uint32_t*)nullptr);
+    }
+#undef MGS_SCATTER
   }
 }
 

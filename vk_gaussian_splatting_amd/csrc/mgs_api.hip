@@ -31,8 +31,9 @@ void launchProject(hipStream_t stream, const FrameArgs& args, bool full, int shF
 void launchFrameInit(hipStream_t stream, FrameCounters* ctr, SortPlan* planKeys, SortPlan* planPairs, uint2* ranges,
                      uint32_t nTiles);
 void launchBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
-                   const uint32_t* rect, uint32_t* blockCount, uint32_t maxBlocks, FrameCounters* ctr, uint32_t* pairKey,
-                   uint32_t* pairVal, uint32_t capacity, int tilesX);
+                   const uint32_t* rect, uint32_t* blockCount, uint32_t maxBlocks, FrameCounters* ctr, uint32_t* sortedRect,
+                   uint32_t* splatOffset, uint32_t* chunkStart, uint32_t* pairKey, uint32_t* pairVal, uint32_t capacity,
+                   int tilesX);
 void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* keyY, const SortPlan* planPairs,
                       uint2* ranges);
 void launchComposite(hipStream_t stream, const FrameConst& F, const uint2* ranges, const uint32_t* valX,
@@ -68,7 +69,8 @@ struct DeviceSet
   void*    rgba    = nullptr;
   void*    sh      = nullptr;
   uint32_t count   = 0;
-  int      shDegree = 0, shStride = 0;
+  int      shDegree = 0, shStride = 0;  // logical elements per splat (0/9/24/45)
+  int      shPitch = 0;                  // stored elements per splat: shStride padded to a 16-byte multiple
   int      shFormat = -1, rgbaFormat = -1;
 };
 
@@ -219,6 +221,7 @@ struct MgsScene_t
 
   // frame buffers
   DevBuf<uint32_t>      keysSlot, idsSlot, slotCount, keysA, idsA, keysB, idsB, rect, partHist, blockCount;
+  DevBuf<uint32_t>      sortedRect, splatOffset, chunkStart;
   DevBuf<SplatRec>      rec;
   DevBuf<uint32_t>      pairKey0, pairVal0, pairKey1, pairVal1;
   DevBuf<uint2>         ranges;
@@ -417,6 +420,7 @@ void mgs_scene_destroy(MgsScene s)
   s->keysSlot.release(); s->idsSlot.release(); s->slotCount.release(); s->keysA.release(); s->idsA.release();
   s->keysB.release(); s->idsB.release(); s->rect.release(); s->partHist.release(); s->blockCount.release();
   s->rec.release(); s->pairKey0.release(); s->pairVal0.release(); s->pairKey1.release(); s->pairVal1.release();
+  s->sortedRect.release(); s->splatOffset.release(); s->chunkStart.release();
   s->ranges.release(); s->image.release(); s->ctr.release(); s->plans.release(); s->cpuDistDev.release();
   if(s->hCtr) (void)hipHostFree(s->hCtr);
   if(s->hPlans) (void)hipHostFree(s->hPlans);
@@ -588,9 +592,15 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
     }
     if(d.shStride)
     {
-      std::vector<float> sh;
+      std::vector<float> sh, padded;
       buildShInterleaved(h, sh);
-      int rc = uploadFormatted(sh, shFormat, true, &d.sh);
+      const int per = shFormat == MGS_FORMAT_FLOAT32 ? 4 : shFormat == MGS_FORMAT_FLOAT16 ? 8 : 16;
+      d.shPitch     = (d.shStride + per - 1) / per * per;
+      padded.assign(n * (size_t)d.shPitch, 0.f);
+      parallelBatches(n, [&](size_t i) {
+        std::memcpy(padded.data() + i * (size_t)d.shPitch, sh.data() + i * (size_t)d.shStride, sizeof(float) * d.shStride);
+      });
+      int rc = uploadFormatted(padded, shFormat, true, &d.sh);
       if(rc != MGS_OK)
         return rc;
     }
@@ -623,6 +633,8 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
   if((rc = s->idsB.ensure(total))) return rc;
   if((rc = s->rect.ensure(total))) return rc;
   if((rc = s->rec.ensure(total))) return rc;
+  if((rc = s->sortedRect.ensure(total))) return rc;
+  if((rc = s->splatOffset.ensure(total))) return rc;
   if((rc = s->ctr.ensure(1))) return rc;
   if((rc = s->plans.ensure(2))) return rc;
 
@@ -635,6 +647,7 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
   if((rc = s->pairVal0.ensure(cap))) return rc;
   if((rc = s->pairKey1.ensure(cap))) return rc;
   if((rc = s->pairVal1.ensure(cap))) return rc;
+  if((rc = s->chunkStart.ensure(cap / kPart + 4))) return rc;
   const uint64_t maxParts = std::max<uint64_t>((cap + kPart - 1) / kPart, parts);
   s->pStride              = (uint32_t)maxParts;
   if((rc = s->partHist.ensure(256ull * maxParts))) return rc;
@@ -680,6 +693,31 @@ int mgs_scene_download_set(MgsScene s, int instance, int which, float* dst, size
   }
   if(need == 0)
     return MGS_OK;
+  if(isSh)
+  {  // stored with a padded pitch: fetch, dequantise, strip the padding
+    const size_t         tot = (size_t)d.shPitch * n;
+    const size_t         esz = fmt == MGS_FORMAT_FLOAT32 ? 4 : fmt == MGS_FORMAT_FLOAT16 ? 2 : 1;
+    std::vector<uint8_t> raw(tot * esz);
+    HIPCHK(hipMemcpy(raw.data(), src, raw.size(), hipMemcpyDeviceToHost));
+    for(size_t i = 0; i < n; ++i)
+      for(int k = 0; k < d.shStride; ++k)
+      {
+        const size_t j = i * (size_t)d.shPitch + k;
+        float        v;
+        if(fmt == MGS_FORMAT_FLOAT32)
+          std::memcpy(&v, raw.data() + 4 * j, 4);
+        else if(fmt == MGS_FORMAT_FLOAT16)
+        {
+          uint16_t hv;
+          std::memcpy(&hv, raw.data() + 2 * j, 2);
+          v = halfToFloat(hv);
+        }
+        else
+          v = (float)raw[j] / 255.0f * 2.0f - 1.0f;
+        dst[i * (size_t)d.shStride + k] = v;
+      }
+    return MGS_OK;
+  }
   if(fmt == MGS_FORMAT_FLOAT32)
   {
     HIPCHK(hipMemcpy(dst, src, need * 4, hipMemcpyDeviceToHost));
@@ -785,7 +823,7 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
     C.globalOffset = offset;
     C.blockBegin   = block;
     C.shDegree     = d.shDegree;
-    C.shStride     = d.shStride;
+    C.shStride     = d.shPitch;  // kernels index by the stored pitch
     offset += d.count;
     block += (d.count + kPart - 1) / kPart;
   }
@@ -815,7 +853,7 @@ static void keySort(MgsScene s, hipStream_t st)
   L.plan         = &s->plans.p[0];
   L.partHist     = s->partHist.p;
   L.pStride      = s->pStride;
-  L.maxParts     = std::max<uint32_t>(s->totalParts, (s->totalSplats + kPart - 1) / kPart);
+  L.maxElems     = s->totalSplats;
   L.beginBit     = 0;
   L.endBit       = 32;
   launchRadixSort(st, L);
@@ -949,7 +987,7 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
   }
   if(timed) HIPCHK(hipEventRecord(fev[2], st));
   launchBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, s->blockCount.p, (s->totalSplats + kPart - 1) / kPart, ctr,
-                s->pairKey0.p, s->pairVal0.p, s->pairCapacity, F.tilesX);
+                s->sortedRect.p, s->splatOffset.p, s->chunkStart.p, s->pairKey0.p, s->pairVal0.p, s->pairCapacity, F.tilesX);
   if(timed) HIPCHK(hipEventRecord(fev[3], st));
   {
     SortLaunch L{};
@@ -964,7 +1002,7 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
     L.plan      = planP;
     L.partHist  = s->partHist.p;
     L.pStride   = s->pStride;
-    L.maxParts  = (s->pairCapacity + kPart - 1) / kPart;
+    L.maxElems  = s->pairCapacity;
     L.beginBit  = 0;
     L.endBit    = pairSortBits((int)nTiles);
     launchRadixSort(st, L);
@@ -1255,7 +1293,7 @@ int mgs_radix_sort_u32(MgsScene s, void* keysDev, void* valsDev, uint32_t count,
   L.plan     = plan.p;
   L.partHist = hist.p;
   L.pStride  = parts;
-  L.maxParts = parts;
+  L.maxElems = count;
   L.beginBit = beginBit;
   L.endBit   = endBit;
   launchRadixSort(st, L);

@@ -29,9 +29,9 @@ struct SortLaunch
   uint32_t        partsSlotted;  // number of slotted partitions
   const uint32_t* nPtr;          // device-side element count (uniform partitions)
   SortPlan*       plan;          // must be zeroed before the launch (launchSortClearPlan / frame init)
-  uint32_t*       partHist;      // [256][pStride]
+  uint32_t*       partHist;      // [256][pStride], pStride >= max(partsSlotted, ceil(maxElems/2048))
   uint32_t        pStride;
-  uint32_t        maxParts;      // host-side upper bound of the partition count (grid size)
+  uint32_t        maxElems;      // host-side upper bound of the element count (sizes the grids)
   int             beginBit, endBit;
 };
 
