@@ -5,7 +5,7 @@
 namespace mgs {
 
 constexpr int kMaxInlineInstances = 8;   // instances carried by value in the kernel argument block
-constexpr int kTilePx             = 16;  // binning tile edge in pixels (composite works on 8x8 wave quadrants)
+constexpr int kTilePx             = 16;  // compositing tile edge in pixels (one workgroup; 8x8 pixels per wave)
 
 // error bits reported through MgsFrameOut.error_flags
 enum : uint32_t {
@@ -39,6 +39,8 @@ struct FrameConst
   float    focal[2];      // (P00*W/2, P11*H/2), src/gaussian_splatting.cpp:1248-1250
   int32_t  width, height;
   int32_t  tilesX, tilesY;
+  int32_t  binShiftX, binShiftY;  // a bin = (1<<shift) x (1<<shift) tiles; lists are built per bin
+  int32_t  binsX, binsY;
   int32_t  stripRow0, stripRow1;  // tile rows rendered by this device
   float    splatScale, frustumDilation, alphaCull;
   int32_t  shDegree;
@@ -62,10 +64,10 @@ struct FrameArgs
 struct alignas(16) SplatRec
 {
   float cx, cy;    // centre in pixels
+  float ex, ey;    // tight half extents of the visible footprint in pixels   -- first 16 B: all a cull test needs
   float p1x, p1y;  // 2*b1/|b1|^2 : (d.p1)^2 + (d.p2)^2 == A/2 of threedgs_raster.frag.slang:236
   float p2x, p2y;
   float r, g, b, a;
-  float ex, ey;    // tight half extents of the visible footprint in pixels
 };
 
 // device-resident counters of one frame

@@ -26,7 +26,7 @@ constexpr int kPrjPart    = kPrjThreads * kPrjItems;  // 2048 splats per workgro
 struct Projected
 {
   SplatRec rec;
-  uint32_t rect;  // tile rectangle x0 | y0<<8 | x1<<16 | y1<<24 (inclusive, 16-px tiles)
+  uint32_t rect;  // bin rectangle x0 | y0<<8 | x1<<16 | y1<<24 (inclusive, in bins)
 };
 
 template <int FMT>
@@ -247,7 +247,8 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
     return false;
   const int x0 = (int)fmaxf(fx0, 0.f), x1 = (int)fminf(fx1, (float)(F.width - 1));
   const int y0 = (int)fmaxf(fy0, ymin), y1 = (int)fminf(fy1, ymax);
-  out.rect = (uint32_t)(x0 >> 4) | ((uint32_t)(y0 >> 4) << 8) | ((uint32_t)(x1 >> 4) << 16) | ((uint32_t)(y1 >> 4) << 24);
+  const int sx = 4 + F.binShiftX, sy = 4 + F.binShiftY;
+  out.rect = (uint32_t)(x0 >> sx) | ((uint32_t)(y0 >> sy) << 8) | ((uint32_t)(x1 >> sx) << 16) | ((uint32_t)(y1 >> sy) << 24);
 
   // view-dependent colour (mesh.slang:240-243): direction in model space, no clamp afterwards
   float dx = px - I.camModel[0], dy = py - I.camModel[1], dz = pz - I.camModel[2];
@@ -381,9 +382,9 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, Fram
         if(ok)
         {
           float4* dst = reinterpret_cast<float4*>(rec + gid);
-          dst[0]      = make_float4(pr.rec.cx, pr.rec.cy, pr.rec.p1x, pr.rec.p1y);
-          dst[1]      = make_float4(pr.rec.p2x, pr.rec.p2y, pr.rec.r, pr.rec.g);
-          dst[2]      = make_float4(pr.rec.b, pr.rec.a, pr.rec.ex, pr.rec.ey);
+          dst[0]      = make_float4(pr.rec.cx, pr.rec.cy, pr.rec.ex, pr.rec.ey);
+          dst[1]      = make_float4(pr.rec.p1x, pr.rec.p1y, pr.rec.p2x, pr.rec.p2y);
+          dst[2]      = make_float4(pr.rec.r, pr.rec.g, pr.rec.b, pr.rec.a);
           rect[gid]   = pr.rect;
         }
       }

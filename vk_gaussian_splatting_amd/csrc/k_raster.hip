@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_expand(const uint32_t* __re
                                                             const uint32_t* __restrict__ sortedRect,
                                                             const uint32_t* __restrict__ splatOffset,
                                                             const uint32_t* __restrict__ chunkStart, uint32_t* __restrict__ pairKey,
-                                                            uint32_t* __restrict__ pairVal, int tilesX)
+                                                            uint32_t* __restrict__ pairVal, int binsX)
 {
   constexpr int       kWin = 2048;
   __shared__ uint32_t s_off[kWin + 1];
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_expand(const uint32_t* __re
       const uint32_t x0 = r & 255u, y0 = (r >> 8) & 255u, x1 = (r >> 16) & 255u;
       const uint32_t wd = x1 - x0 + 1u;
       const uint32_t k  = o - s_off[a];
-      pairKey[o]        = (y0 + k / wd) * (uint32_t)tilesX + (x0 + k % wd);
+      pairKey[o]        = (y0 + k / wd) * (uint32_t)binsX + (x0 + k % wd);
       pairVal[o]        = s_gid[a];
     }
   }
@@ -248,94 +248,182 @@ __global__ void k_tile_ranges(const uint32_t* __restrict__ keyX, const uint32_t*
 }
 
 // ---- compositing ------------------------------------------------------------------------------
-// One workgroup per 16x16 tile, one wave per 8x8 quadrant (lane = pixel).  The tile's list is
-// walked nearest-first in batches of 256 records staged in LDS; every lane keeps transmittance T and
-// the premultiplied colour in registers.  A wave skips splats whose footprint misses its quadrant and
-// retires once all of its 64 pixels are saturated (T < 1e-4; not in MGS_ALPHA_SUM mode, where the
-// reference's additive alpha must see every fragment).
+// One workgroup per 16x16 tile, one wave per 8x8 quadrant (lane = pixel).  Lists exist per BIN (a
+// block of tiles, e.g. 64x64 px), not per tile: duplicating every splat into every 16x16 tile it
+// touches costs ~13 records per splat and made the (tile,id) sort the most expensive stage
+// (profiles/r1_a/b).  Instead each workgroup walks its bin's depth-ordered list nearest-first and does
+// the fine culling on chip:
+//   stage A  every thread fetches 4 list entries (id -> first 16 bytes of the record: centre + extent),
+//            tests the footprint against the workgroup's 16x16 tile, and the survivors are compacted
+//            IN ORDER (ballot + mbcnt) into an LDS batch together with the rest of their record;
+//   stage B  each wave walks the batch, skips splats that miss its quadrant, and blends front-to-back:
+//            q=(d.p1)^2+(d.p2)^2 (== A/2, frag.slang:236), discard q>4, alpha=a*exp(-q), discard <=1/255.
+// A wave retires when all 64 pixels have T < 1e-4; the workgroup stops fetching when all 4 have
+// (not in MGS_ALPHA_SUM mode, where the reference's additive alpha must see every fragment).
+constexpr int kCmpEntries = 2;                  // list entries per thread per stage-A round
+constexpr int kCmpRound   = 256 * kCmpEntries;  // 512 entries scanned per round
+constexpr int kCmpCap     = 512;                // LDS batch capacity (records): 24 KB -> 6 workgroups per CU
+constexpr int kCmpGo      = 160;                // blend as soon as this many records are staged
+
 template <bool HALF_OUT>
 __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ valX, const uint32_t* __restrict__ valY,
                                                    const SortPlan* __restrict__ plan, const SplatRec* __restrict__ rec,
                                                    void* __restrict__ outImage)
 {
-  __shared__ float4 s_a[256];
-  __shared__ float4 s_b[256];
-  __shared__ float4 s_c[256];
+  __shared__ float4   s_a[kCmpCap];  // cx, cy, ex, ey
+  __shared__ float4   s_b[kCmpCap];  // p1, p2
+  __shared__ float4   s_c[kCmpCap];  // r, g, b, a
+  __shared__ uint32_t s_wc[2][kCmpEntries][4];
 
-  const int      t = threadIdx.x, lane = laneId(), w = t >> 6;
-  const int      stripTiles = F.tilesX * (F.stripRow1 - F.stripRow0);
+  const int t = threadIdx.x, lane = laneId(), w = t >> 6;
+  const int stripTiles = F.tilesX * (F.stripRow1 - F.stripRow0);
   // XCD-aware tile mapping: workgroup b lands on XCD b%8 (observed dispatch rule); give each XCD a
-  // contiguous run of tiles so neighbouring tiles — which share most of their splats — share an L2.
+  // contiguous run of tiles so the tiles of one bin — which read the same list — share an L2.
   const int per  = (stripTiles + 7) >> 3;
   const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if(tile >= stripTiles || (int)(blockIdx.x >> 3) >= per)
     return;
-  const int      tileId = F.stripRow0 * F.tilesX + tile;
-  const int      tx = tileId % F.tilesX, ty = tileId / F.tilesX;
+  // walk tiles bin by bin inside the strip so that consecutive workgroups share a list
+  const int bw = 1 << F.binShiftX, bh = 1 << F.binShiftY;
+  const int rowsInStrip = F.stripRow1 - F.stripRow0;
+  int       tx, ty;
+  {
+    // tiles are enumerated per bin-row band: band = group of bh tile rows
+    const int bandTiles = F.tilesX * bh;
+    const int band      = tile / bandTiles;
+    const int inBand    = tile - band * bandTiles;
+    const int bandRow0  = band * bh;
+    const int bandRows  = min(bh, rowsInStrip - bandRow0);
+    const int binCol    = inBand / (bw * bandRows);
+    const int inBin     = inBand - binCol * (bw * bandRows);
+    const int colsHere  = min(bw, F.tilesX - binCol * bw);
+    if(colsHere <= 0)
+      return;
+    // the last bin column may be narrower: re-derive with its true width
+    const int full = (F.tilesX / bw) * (bw * bandRows);
+    if(inBand < full || (F.tilesX % bw) == 0)
+    {
+      tx = binCol * bw + inBin % bw;
+      ty = F.stripRow0 + bandRow0 + inBin / bw;
+    }
+    else
+    {
+      const int rem = inBand - full, wlast = F.tilesX % bw;
+      tx            = (F.tilesX / bw) * bw + rem % wlast;
+      ty            = F.stripRow0 + bandRow0 + rem / wlast;
+    }
+  }
   const int      qx0 = tx * kTilePx + (w & 1) * 8, qy0 = ty * kTilePx + (w >> 1) * 8;
   const int      px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
   const float    pcx = (float)px + 0.5f, pcy = (float)py + 0.5f;
   const float    qcx = (float)qx0 + 4.0f, qcy = (float)qy0 + 4.0f;
+  const float    bcx = (float)(tx * kTilePx) + 8.0f, bcy = (float)(ty * kTilePx) + 8.0f;
   const bool     inside = px < F.width && py < F.height;
   const bool     early  = (F.alphaMode == 0);
   const uint32_t* vals  = plan->finalSel ? valY : valX;
-  const uint2    range  = ranges[tileId];
+  const int      bin    = (ty >> F.binShiftY) * F.binsX + (tx >> F.binShiftX);
+  const uint2    range  = ranges[bin];
 
   float T = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, asum = 0.f;
-  bool  done = !inside;
+  bool  done     = !inside;
   bool  waveDone = (__ballot(!done) == 0ull);
 
-  uint32_t hi = range.y;
-  while(hi > range.x)
+  uint32_t hi   = range.y;
+  uint32_t fill = 0;  // records currently in the LDS batch
+  int      rnd  = 0;
+  for(;;)
   {
-    const uint32_t nb = min(256u, hi - range.x);
-    if((uint32_t)t < nb)
+    // ---- stage A: scan list entries (nearest first) until enough records are staged or the list ends ----
+    while(hi > range.x && fill < (uint32_t)kCmpGo)
     {
-      const uint32_t g = vals[hi - 1u - (uint32_t)t];
-      const float4*  r = reinterpret_cast<const float4*>(rec + g);
-      s_a[t]           = r[0];
-      s_b[t]           = r[1];
-      s_c[t]           = r[2];
+      const uint32_t avail = hi - range.x;
+      uint32_t       g[kCmpEntries];
+      float4         a[kCmpEntries];
+      bool           ok[kCmpEntries];
+      uint64_t       bal[kCmpEntries];
+#pragma unroll
+      for(int k = 0; k < kCmpEntries; ++k)
+      {
+        const uint32_t e = k * 256u + (uint32_t)t;  // e-th nearest remaining entry
+        ok[k]            = e < avail;
+        g[k]             = ok[k] ? vals[hi - 1u - e] : 0u;
+      }
+#pragma unroll
+      for(int k = 0; k < kCmpEntries; ++k)
+        a[k] = ok[k] ? *reinterpret_cast<const float4*>(rec + g[k]) : make_float4(0.f, 0.f, -1.f, -1.f);
+#pragma unroll
+      for(int k = 0; k < kCmpEntries; ++k)
+      {
+        ok[k]  = ok[k] && fabsf(a[k].x - bcx) <= a[k].z + 7.5f && fabsf(a[k].y - bcy) <= a[k].w + 7.5f;
+        bal[k] = __ballot(ok[k]);
+        if(lane == 0)
+          s_wc[rnd & 1][k][w] = (uint32_t)__popcll(bal[k]);
+      }
+      __syncthreads();
+      uint32_t m = 0;
+#pragma unroll
+      for(int k = 0; k < kCmpEntries; ++k)
+        m += s_wc[rnd & 1][k][0] + s_wc[rnd & 1][k][1] + s_wc[rnd & 1][k][2] + s_wc[rnd & 1][k][3];
+      ++rnd;
+      if(fill + m > (uint32_t)kCmpCap)
+        break;  // would overflow the batch: blend first, rescan this round afterwards (fill > 0 here, m <= kCmpCap)
+      uint32_t base = fill;
+#pragma unroll
+      for(int k = 0; k < kCmpEntries; ++k)
+      {
+        const uint32_t* c  = s_wc[(rnd - 1) & 1][k];
+        uint32_t        wb = 0;
+        if(w > 0) wb += c[0];
+        if(w > 1) wb += c[1];
+        if(w > 2) wb += c[2];
+        if(ok[k])
+        {
+          const uint32_t pos = base + wb + lanesBelow(bal[k]);
+          const float4*  r   = reinterpret_cast<const float4*>(rec + g[k]);
+          s_a[pos]           = a[k];
+          s_b[pos]           = r[1];
+          s_c[pos]           = r[2];
+        }
+        base += c[0] + c[1] + c[2] + c[3];
+      }
+      fill = base;
+      hi -= min(avail, (uint32_t)kCmpRound);
     }
     __syncthreads();
+    // ---- stage B: blend the batch ------------------------------------------------------------------------
     if(!waveDone)
     {
-      for(uint32_t j = 0; j < nb; ++j)
+      for(uint32_t j = 0; j < fill; ++j)
       {
         const float4 a = s_a[j];
-        const float4 c = s_c[j];
-        // footprint vs this wave's 8x8 quadrant (wave-uniform)
-        if(fabsf(a.x - qcx) > c.z + 3.5f || fabsf(a.y - qcy) > c.w + 3.5f)
+        if(fabsf(a.x - qcx) > a.z + 3.5f || fabsf(a.y - qcy) > a.w + 3.5f)  // misses this wave's 8x8 quadrant
           continue;
         const float4 b  = s_b[j];
+        const float4 c  = s_c[j];
         const float  dx = pcx - a.x, dy = pcy - a.y;
-        const float  s  = dx * a.z + dy * a.w;
-        const float  u  = dx * b.x + dy * b.y;
-        const float  q  = s * s + u * u;              // == A/2 of frag.slang:236
-        const float  al = c.y * __expf(-q);           // frag.slang:254
+        const float  s  = dx * b.x + dy * b.y;
+        const float  u  = dx * b.z + dy * b.w;
+        const float  q  = s * s + u * u;         // == A/2 of frag.slang:236
+        const float  al = c.w * __expf(-q);      // frag.slang:254
         if(q <= 4.0f && al > (1.0f / 255.0f) && !done)  // frag.slang:242-245,258-262
         {
           const float wgt = al * T;
-          cr += wgt * b.z;
-          cg += wgt * b.w;
-          cb += wgt * c.x;
+          cr += wgt * c.x;
+          cg += wgt * c.y;
+          cb += wgt * c.z;
           asum += al;
           T -= wgt;
           if(early && T < 1.0e-4f)
             done = true;
         }
-        if((j & 15u) == 15u && early && __ballot(!done) == 0ull)
-        {
-          waveDone = true;
-          break;
-        }
       }
       if(early && __ballot(!done) == 0ull)
         waveDone = true;
     }
-    hi -= nb;
-    if(__syncthreads_and(waveDone ? 1 : 0))
+    fill = 0;
+    const int allDone = __syncthreads_and(waveDone ? 1 : 0);
+    if(allDone || hi <= range.x)
       break;
   }
 
@@ -367,7 +455,7 @@ void launchFrameInit(hipStream_t stream, FrameCounters* ctr, SortPlan* planKeys,
 void launchBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
                    const uint32_t* rect, uint32_t* blockCount, uint32_t maxBlocks, FrameCounters* ctr, uint32_t* sortedRect,
                    uint32_t* splatOffset, uint32_t* chunkStart, uint32_t* pairKey, uint32_t* pairVal, uint32_t capacity,
-                   int tilesX)
+                   int binsX)
 {
   if(maxBlocks == 0)
     return;
@@ -378,7 +466,7 @@ void launchBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* ids
   hipLaunchKernelGGL(k_bin_offsets, dim3(maxBlocks), dim3(kBinThreads), 0, stream, planKeys, sortedRect, blockCount,
                      splatOffset, chunkStart, chunks + 1);
   hipLaunchKernelGGL(k_bin_expand, dim3(chunks), dim3(kBinThreads), 0, stream, idsX, idsY, planKeys, ctr, sortedRect,
-                     splatOffset, chunkStart, pairKey, pairVal, tilesX);
+                     splatOffset, chunkStart, pairKey, pairVal, binsX);
 }
 
 void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* keyY, const SortPlan* planPairs,

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <execution>
@@ -787,6 +788,17 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
   }
   F.stripRow0       = r0;
   F.stripRow1       = r1;
+  // bins: lists are built per (16<<shift)-pixel bin; the compositor culls per 16x16 tile on chip.
+  // Default 128x128 px (MGS_BIN_SHIFT="x,y" overrides, 0..4 each; measured sweep in DESIGN.md §3.3).
+  int bsx = 3, bsy = 3;
+  if(const char* e = std::getenv("MGS_BIN_SHIFT"))
+    std::sscanf(e, "%d,%d", &bsx, &bsy);
+  bsx         = std::min(std::max(bsx, 0), 4);
+  bsy         = std::min(std::max(bsy, 0), 4);
+  F.binShiftX = bsx;
+  F.binShiftY = bsy;
+  F.binsX     = (F.tilesX + (1 << bsx) - 1) >> bsx;
+  F.binsY     = (F.tilesY + (1 << bsy) - 1) >> bsy;
   F.splatScale      = p->splat_scale;
   F.frustumDilation = p->frustum_dilation;
   F.alphaCull       = p->alpha_cull_threshold;
@@ -946,7 +958,7 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
   if(rc != MGS_OK)
     return rc;
   const FrameConst& F      = A.f;
-  const uint32_t    nTiles = (uint32_t)(F.tilesX * F.tilesY);
+  const uint32_t    nTiles = (uint32_t)(F.binsX * F.binsY);  // lists (and ranges) exist per bin
   const bool        half   = (p->target_format == MGS_TARGET_RGBA16F);
   const size_t      pixB   = half ? 8 : 16;
   s->imageRowBytes         = (size_t)F.width * pixB;
@@ -987,7 +999,7 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
   }
   if(timed) HIPCHK(hipEventRecord(fev[2], st));
   launchBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, s->blockCount.p, (s->totalSplats + kPart - 1) / kPart, ctr,
-                s->sortedRect.p, s->splatOffset.p, s->chunkStart.p, s->pairKey0.p, s->pairVal0.p, s->pairCapacity, F.tilesX);
+                s->sortedRect.p, s->splatOffset.p, s->chunkStart.p, s->pairKey0.p, s->pairVal0.p, s->pairCapacity, F.binsX);
   if(timed) HIPCHK(hipEventRecord(fev[3], st));
   {
     SortLaunch L{};
