@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
   __shared__ float4   s_b[kCmpCap];  // p1, p2
   __shared__ float4   s_c[kCmpCap];  // r, g, b, a
   __shared__ uint32_t s_wc[2][kCmpEntries][4];
+  __shared__ uint8_t  s_m[kCmpCap];  // which of the 4 quadrants (waves) the record's footprint touches
 
   const int t = threadIdx.x, lane = laneId(), w = t >> 6;
   const int stripTiles = F.tilesX * (F.stripRow1 - F.stripRow0);
@@ -317,7 +318,6 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
   const int      qx0 = tx * kTilePx + (w & 1) * 8, qy0 = ty * kTilePx + (w >> 1) * 8;
   const int      px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
   const float    pcx = (float)px + 0.5f, pcy = (float)py + 0.5f;
-  const float    qcx = (float)qx0 + 4.0f, qcy = (float)qy0 + 4.0f;
   const float    bcx = (float)(tx * kTilePx) + 8.0f, bcy = (float)(ty * kTilePx) + 8.0f;
   const bool     inside = px < F.width && py < F.height;
   const bool     early  = (F.alphaMode == 0);
@@ -384,6 +384,10 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
           s_a[pos]           = a[k];
           s_b[pos]           = r[1];
           s_c[pos]           = r[2];
+          // quadrant q covers pixel centres [x0+8(q&1)+0.5, +7.5]: centre bcx -4 / +4, half width 3.5
+          const bool xl = a[k].x - a[k].z <= bcx - 0.5f, xr = a[k].x + a[k].z >= bcx + 0.5f;
+          const bool yt = a[k].y - a[k].w <= bcy - 0.5f, yb = a[k].y + a[k].w >= bcy + 0.5f;
+          s_m[pos] = (uint8_t)((xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u));
         }
         base += c[0] + c[1] + c[2] + c[3];
       }
@@ -392,34 +396,53 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
     }
     __syncthreads();
     // ---- stage B: blend the batch ------------------------------------------------------------------------
+    // 64 records at a time: a ballot over the quadrant masks gives this wave's hit set; the hits are walked
+    // with scalar bit tricks (no per-record branch), the next record is fetched from LDS while the current
+    // one is blended, and the per-pixel discards are predicated instead of branched.
     if(!waveDone)
     {
-      for(uint32_t j = 0; j < fill; ++j)
+      for(uint32_t j0 = 0; j0 < fill; j0 += 64)
       {
-        const float4 a = s_a[j];
-        if(fabsf(a.x - qcx) > a.z + 3.5f || fabsf(a.y - qcy) > a.w + 3.5f)  // misses this wave's 8x8 quadrant
+        const uint32_t jl   = j0 + (uint32_t)lane;
+        const bool     mine = jl < fill && ((s_m[jl] >> w) & 1u);
+        uint64_t       hits = __ballot(mine);
+        if(hits == 0ull)
           continue;
-        const float4 b  = s_b[j];
-        const float4 c  = s_c[j];
-        const float  dx = pcx - a.x, dy = pcy - a.y;
-        const float  s  = dx * b.x + dy * b.y;
-        const float  u  = dx * b.z + dy * b.w;
-        const float  q  = s * s + u * u;         // == A/2 of frag.slang:236
-        const float  al = c.w * __expf(-q);      // frag.slang:254
-        if(q <= 4.0f && al > (1.0f / 255.0f) && !done)  // frag.slang:242-245,258-262
+        uint32_t j = j0 + (uint32_t)__builtin_ctzll(hits);
+        hits &= hits - 1ull;
+        float4 a = s_a[j], b = s_b[j], c = s_c[j];
+        for(;;)
         {
-          const float wgt = al * T;
+          const bool   more = hits != 0ull;
+          const uint32_t jn = j0 + (uint32_t)__builtin_ctzll(hits | (1ull << 63));
+          hits &= hits - 1ull;
+          const float4 an = s_a[jn], bn = s_b[jn], cn = s_c[jn];  // prefetch (harmless re-read when !more)
+          const float  dx = pcx - a.x, dy = pcy - a.y;
+          const float  sv = dx * b.x + dy * b.y;
+          const float  uv = dx * b.z + dy * b.w;
+          const float  q  = sv * sv + uv * uv;     // == A/2 of frag.slang:236
+          const float  al = c.w * __expf(-q);      // frag.slang:254
+          const bool   hit = q <= 4.0f && al > (1.0f / 255.0f) && !done;  // frag.slang:242-245,258-262
+          const float  ah  = hit ? al : 0.0f;
+          const float  wgt = ah * T;
           cr += wgt * c.x;
           cg += wgt * c.y;
           cb += wgt * c.z;
-          asum += al;
+          asum += ah;
           T -= wgt;
-          if(early && T < 1.0e-4f)
-            done = true;
+          done = done || (early && T < 1.0e-4f);
+          if(!more)
+            break;
+          a = an;
+          b = bn;
+          c = cn;
+        }
+        if(early && __ballot(!done) == 0ull)
+        {
+          waveDone = true;
+          break;
         }
       }
-      if(early && __ballot(!done) == 0ull)
-        waveDone = true;
     }
     fill = 0;
     const int allDone = __syncthreads_and(waveDone ? 1 : 0);
