@@ -18,9 +18,9 @@ enum : uint32_t {
 struct InstanceConst
 {
   const float* centers;  // [count*3]
-  const float* cov6;     // [count*6]
+  const float* cov6;     // planar: float4 covA[count] = (S00,S01,S02,S11) then float2 covB[count] = (S12,S22)
   const void*  rgba;     // [count*4] fp32 | fp16 | u8
-  const void*  sh;       // [count*shStride] fp32 | fp16 | u8, interleaved [coef][rgb]
+  const void*  sh;       // vector-planar: plane v holds 16 bytes of every splat's [coef][rgb] record: [planes][count][16 B]
   float        model[16];      // M   (glm column-major)
   float        modelView[16];  // V*M (host-computed with the same unfused fp32 products the shader does per thread)
   float        camModel[3];    // M^-1 * cameraPosition
@@ -28,7 +28,7 @@ struct InstanceConst
   uint32_t     globalOffset;   // first global splat id of this instance
   uint32_t     blockBegin;     // first project-kernel partition of this instance
   int32_t      shDegree;       // of the splat set
-  int32_t      shStride;       // 0 / 9 / 24 / 45 elements
+  int32_t      shStride;       // stored elements per splat (logical 0/9/24/45 padded to a 16-byte multiple)
 };
 
 // frame constants (shaderio::FrameInfo, shaders/shaderio.h:238-317, reduced)

@@ -51,34 +51,37 @@ __device__ __forceinline__ float4 loadRgba(const void* base, uint32_t i)
   }
 }
 
-// SH storage: [coef][rgb] interleaved, one record per splat padded to a 16-byte multiple (pitch =
-// 48 elements for degree 3 in every format), so a lane fetches its record with aligned 16-byte loads:
-// 12 x dwordx4 (fp32), 6 (fp16) or 3 (uint8) instead of 45 scalar loads.  The texture-address unit, not
-// HBM, was the limiter with scalar loads at a 180-byte lane stride (profiles/r1_a: 0.92 ms).
+// SH storage is VECTOR-PLANAR: the [coef][rgb] record of a splat (padded to 48 elements) is cut into
+// 16-byte vectors and vector v of all splats forms one contiguous plane: sh[v][splat] (12 planes fp32,
+// 6 fp16, 3 uint8).  Lanes process (mostly) consecutive splats, so every load instruction of a wave
+// covers one contiguous ~1 KB run of full cache lines.  With per-splat 192-byte records each
+// instruction touched 64 different lines and the 16 KB-per-wave footprint thrashed the 32 KB L1
+// (k_project 0.43 ms, profiles/r1_b); the reference's AoS layout (threedgs_particle_buffers.h.slang:112-207)
+// is kept only as the logical order inside a record.
 template <int FMT>
-__device__ __forceinline__ void loadShRecord(const void* base, size_t elemOffset, int ncoef, float (&s)[48])
+__device__ __forceinline__ void loadShRecord(const void* base, uint32_t li, uint32_t count, int ncoef, float (&s)[48])
 {
   if constexpr(FMT == 0)
   {
-    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elemOffset);
+    const float4* p = reinterpret_cast<const float4*>(base) + li;
 #pragma unroll
     for(int v = 0; v < 12; ++v)
     {
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
       if(4 * v < ncoef)
-        x = p[v];
+        x = p[(size_t)v * count];
       s[4 * v] = x.x; s[4 * v + 1] = x.y; s[4 * v + 2] = x.z; s[4 * v + 3] = x.w;
     }
   }
   else if constexpr(FMT == 1)
   {
-    const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(base) + elemOffset);
+    const uint4* p = reinterpret_cast<const uint4*>(base) + li;
 #pragma unroll
     for(int v = 0; v < 6; ++v)
     {
       uint4 x = make_uint4(0u, 0u, 0u, 0u);
       if(8 * v < ncoef)
-        x = p[v];
+        x = p[(size_t)v * count];
       const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
       for(int q = 0; q < 4; ++q)
@@ -90,13 +93,13 @@ __device__ __forceinline__ void loadShRecord(const void* base, size_t elemOffset
   }
   else
   {
-    const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(base) + elemOffset);
+    const uint4* p = reinterpret_cast<const uint4*>(base) + li;
 #pragma unroll
     for(int v = 0; v < 3; ++v)
     {
       uint4 x = make_uint4(0u, 0u, 0u, 0u);
       if(16 * v < ncoef)
-        x = p[v];
+        x = p[(size_t)v * count];
       const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
       for(int q = 0; q < 4; ++q)
@@ -117,7 +120,7 @@ __device__ __forceinline__ void addShRadiance(const InstanceConst& I, uint32_t l
     return;
   float     s[48];
   const int ncoef = degree == 1 ? 9 : (degree == 2 ? 24 : 45);
-  loadShRecord<FMT>(I.sh, (size_t)li * (size_t)I.shStride, ncoef, s);
+  loadShRecord<FMT>(I.sh, li, I.count, ncoef, s);
   const float C1 = 0.4886025119029199f;
   float       acc[3];
 #pragma unroll
@@ -181,9 +184,9 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
     return false;
 
   // covariance projection, threedgs.h.slang:26-56
-  const float2* c6  = reinterpret_cast<const float2*>(I.cov6 + 6 * (size_t)li);  // 24-byte records: 8-byte aligned
-  const float2  c01 = c6[0], c23 = c6[1], c45 = c6[2];
-  const float   s00 = c01.x, s01 = c01.y, s02 = c23.x, s11 = c23.y, s12 = c45.x, s22 = c45.y;
+  const float4 cA  = reinterpret_cast<const float4*>(I.cov6)[li];                              // planar: 16 B per lane
+  const float2 cB  = reinterpret_cast<const float2*>(I.cov6 + 4 * (size_t)I.count)[li];         //         8 B per lane
+  const float  s00 = cA.x, s01 = cA.y, s02 = cA.z, s11 = cA.w, s12 = cB.x, s22 = cB.y;
   const float  rz = 1.0f / tz, rz2 = rz * rz;
   const float  j00 = F.focal[0] * rz, j02 = -(F.focal[0] * tx) * rz2;
   const float  j11 = F.focal[1] * rz, j12 = -(F.focal[1] * ty) * rz2;
@@ -275,17 +278,39 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   return true;
 }
 
+// Ordered compaction of up to 8 rounds x 256 flags without a barrier per round: every wave posts its
+// per-round popcounts, ONE barrier, 32 lanes scan the 8x4 table, second barrier, then every thread knows
+// the base of its (round, wave).  Returns the total; bases land in s_base[round*4 + wave].
+__device__ __forceinline__ uint32_t scanRoundWaveCounts(uint32_t* s_cnt /*32*/, uint32_t* s_base /*33*/)
+{
+  __syncthreads();
+  if(threadIdx.x < 64)
+  {
+    const uint32_t v   = threadIdx.x < 32 ? s_cnt[threadIdx.x] : 0u;
+    const uint32_t inc = waveInclusiveScan(v);
+    if(threadIdx.x < 32)
+      s_base[threadIdx.x] = inc - v;
+    if(threadIdx.x == 31)
+      s_base[32] = inc;
+  }
+  __syncthreads();
+  return s_base[32];
+}
+
 // One workgroup = one partition of 2048 consecutive splats of one instance.
 // Output: survivors of partition p, ascending id, in keysSlot/idsSlot[p*2048 ...], count in slotCount[p].
+// No barrier sits inside a loop that waits on memory: all 8 centre loads of a thread are issued up front,
+// and the heavy per-survivor loop runs barrier-free (waves drift apart and overlap each other's loads).
 template <bool FULL, int SHF, int RGBAF>
 __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, FrameCounters* __restrict__ ctr,
                                                          uint32_t* __restrict__ keysSlot, uint32_t* __restrict__ idsSlot,
                                                          uint32_t* __restrict__ slotCount, SplatRec* __restrict__ rec,
                                                          uint32_t* __restrict__ rect)
 {
-  __shared__ uint16_t s_li[kPrjPart];
+  __shared__ uint16_t s_li[kPrjPart];   // bit 15: survived phase 2
   __shared__ uint32_t s_key[kPrjPart];
-  __shared__ uint32_t s_wc[2][4];
+  __shared__ uint32_t s_cnt[32];
+  __shared__ uint32_t s_base[33];
 
   const int      t = threadIdx.x, lane = laneId(), w = t >> 6;
   const uint32_t part = blockIdx.x;
@@ -297,50 +322,51 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, Fram
   const InstanceConst& I      = A.inst[k];
   const uint32_t       local0 = (part - I.blockBegin) * kPrjPart;
 
-  // ---- phase 1: key + frustum cull, compacted (ascending id) into LDS -------------------------
-  uint32_t running = 0;
+  // ---- phase 1: key + frustum cull for 8 splats per thread -------------------------------------------
+  float px[kPrjItems], py[kPrjItems], pz[kPrjItems];
 #pragma unroll
   for(int it = 0; it < kPrjItems; ++it)
   {
-    const uint32_t li    = local0 + it * kPrjThreads + t;
-    const bool     valid = li < I.count;
-    bool           vis   = false;
-    uint32_t       key   = 0;
-    if(valid)
-    {
-      const float x = I.centers[3 * (size_t)li], y = I.centers[3 * (size_t)li + 1], z = I.centers[3 * (size_t)li + 2];
-      float       wp[4], vp[4], cp[4];
-      mulMat4Exact(I.model, x, y, z, 1.0f, wp);               // dist.comp.slang:58
-      mulMat4Exact(A.f.view, wp[0], wp[1], wp[2], wp[3], vp);  // :58
-      mulMat4Exact(A.f.proj, vp[0], vp[1], vp[2], vp[3], cp);  // :60
-      const float nx = divExact(cp[0], cp[3]), ny = divExact(cp[1], cp[3]), nz = divExact(cp[2], cp[3]);  // :61
-      vis = true;
-      if(A.f.cullMode == 1)
-      {  // :71-73 (NaN compares false everywhere, as in the shader)
-        const float c = 1.0f + A.f.frustumDilation;
-        if(fabsf(nx) > c || fabsf(ny) > c || nz < 0.f - A.f.frustumDilation || nz > 1.0f)
-          vis = false;
-      }
-      key = A.f.frontToBack ? encodeKey(nz) : encodeKey(-nz);  // :163-167
-    }
-    const uint64_t bal = __ballot(vis);
-    if(lane == 0)
-      s_wc[it & 1][w] = (uint32_t)__popcll(bal);
-    __syncthreads();
-    const uint32_t c0 = s_wc[it & 1][0], c1 = s_wc[it & 1][1], c2 = s_wc[it & 1][2], c3 = s_wc[it & 1][3];
-    uint32_t       wb = 0;
-    if(w > 0) wb += c0;
-    if(w > 1) wb += c1;
-    if(w > 2) wb += c2;
-    if(vis)
-    {
-      const uint32_t pos = running + wb + lanesBelow(bal);
-      s_li[pos]          = (uint16_t)(it * kPrjThreads + t);
-      s_key[pos]         = key;
-    }
-    running += c0 + c1 + c2 + c3;
+    const uint32_t li = local0 + it * kPrjThreads + t;
+    const bool     in = li < I.count;
+    px[it] = in ? I.centers[3 * (size_t)li] : 0.f;
+    py[it] = in ? I.centers[3 * (size_t)li + 1] : 0.f;
+    pz[it] = in ? I.centers[3 * (size_t)li + 2] : 0.f;
   }
-  const uint32_t M = running;
+  uint32_t key[kPrjItems];
+  uint64_t bal[kPrjItems];
+  bool     vis[kPrjItems];
+#pragma unroll
+  for(int it = 0; it < kPrjItems; ++it)
+  {
+    const uint32_t li = local0 + it * kPrjThreads + t;
+    float          wp[4], vp[4], cp[4];
+    mulMat4Exact(I.model, px[it], py[it], pz[it], 1.0f, wp);  // dist.comp.slang:58
+    mulMat4Exact(A.f.view, wp[0], wp[1], wp[2], wp[3], vp);   // :58
+    mulMat4Exact(A.f.proj, vp[0], vp[1], vp[2], vp[3], cp);   // :60
+    const float nx = divExact(cp[0], cp[3]), ny = divExact(cp[1], cp[3]), nz = divExact(cp[2], cp[3]);  // :61
+    bool        v  = li < I.count;
+    if(A.f.cullMode == 1)
+    {  // :71-73 (NaN compares false everywhere, as in the shader)
+      const float c = 1.0f + A.f.frustumDilation;
+      if(fabsf(nx) > c || fabsf(ny) > c || nz < 0.f - A.f.frustumDilation || nz > 1.0f)
+        v = false;
+    }
+    vis[it] = v;
+    key[it] = A.f.frontToBack ? encodeKey(nz) : encodeKey(-nz);  // :163-167
+    bal[it] = __ballot(v);
+    if(lane == 0)
+      s_cnt[it * 4 + w] = (uint32_t)__popcll(bal[it]);
+  }
+  const uint32_t M = scanRoundWaveCounts(s_cnt, s_base);
+#pragma unroll
+  for(int it = 0; it < kPrjItems; ++it)
+    if(vis[it])
+    {
+      const uint32_t pos = s_base[it * 4 + w] + lanesBelow(bal[it]);
+      s_li[pos]          = (uint16_t)(it * kPrjThreads + t);
+      s_key[pos]         = key[it];
+    }
   __syncthreads();
   if(t == 0 && M)
     atomicAdd(&ctr->frustumCount, M);
@@ -364,47 +390,43 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, Fram
   }
   else
   {
-    // ---- phase 2: dense raster front end over the survivors, second ordered compaction ---------
-    uint32_t outCount = 0;
-    const int rounds  = (int)((M + kPrjThreads - 1) / kPrjThreads);
-    for(int r = 0; r < rounds; ++r)
+    // ---- phase 2: dense raster front end over the survivors (no barriers inside) ------------------------
+    for(uint32_t j = t; j < M; j += kPrjThreads)
     {
-      const uint32_t j  = r * kPrjThreads + t;
-      bool           ok = false;
-      uint32_t       key = 0, gid = 0;
-      if(j < M)
+      const uint32_t li = local0 + s_li[j];
+      Projected      pr;
+      if(projectSplat<SHF, RGBAF>(A.f, I, li, pr))
       {
-        const uint32_t li = local0 + s_li[j];
-        key               = s_key[j];
-        gid               = I.globalOffset + li;
-        Projected pr;
-        ok = projectSplat<SHF, RGBAF>(A.f, I, li, pr);
-        if(ok)
-        {
-          float4* dst = reinterpret_cast<float4*>(rec + gid);
-          dst[0]      = make_float4(pr.rec.cx, pr.rec.cy, pr.rec.ex, pr.rec.ey);
-          dst[1]      = make_float4(pr.rec.p1x, pr.rec.p1y, pr.rec.p2x, pr.rec.p2y);
-          dst[2]      = make_float4(pr.rec.r, pr.rec.g, pr.rec.b, pr.rec.a);
-          rect[gid]   = pr.rect;
-        }
+        const uint32_t gid = I.globalOffset + li;
+        float4*        dst = reinterpret_cast<float4*>(rec + gid);
+        dst[0]             = make_float4(pr.rec.cx, pr.rec.cy, pr.rec.ex, pr.rec.ey);
+        dst[1]             = make_float4(pr.rec.p1x, pr.rec.p1y, pr.rec.p2x, pr.rec.p2y);
+        dst[2]             = make_float4(pr.rec.r, pr.rec.g, pr.rec.b, pr.rec.a);
+        rect[gid]          = pr.rect;
+        s_li[j] |= 0x8000u;  // own entry only: no race
       }
-      const uint64_t bal = __ballot(ok);
-      if(lane == 0)
-        s_wc[r & 1][w] = (uint32_t)__popcll(bal);
-      __syncthreads();
-      const uint32_t c0 = s_wc[r & 1][0], c1 = s_wc[r & 1][1], c2 = s_wc[r & 1][2], c3 = s_wc[r & 1][3];
-      uint32_t       wb = 0;
-      if(w > 0) wb += c0;
-      if(w > 1) wb += c1;
-      if(w > 2) wb += c2;
-      if(ok)
-      {
-        const uint32_t pos      = outCount + wb + lanesBelow(bal);
-        keysSlot[slotBase + pos] = key;
-        idsSlot[slotBase + pos]  = gid;
-      }
-      outCount += c0 + c1 + c2 + c3;
     }
+    // ---- second ordered compaction straight into the partition's slot region ---------------------------
+    __syncthreads();
+#pragma unroll
+    for(int r = 0; r < kPrjItems; ++r)
+    {
+      const uint32_t j = r * kPrjThreads + t;
+      vis[r]           = (j < M) && (s_li[j] & 0x8000u);
+      bal[r]           = __ballot(vis[r]);
+      if(lane == 0)
+        s_cnt[r * 4 + w] = (uint32_t)__popcll(bal[r]);
+    }
+    const uint32_t outCount = scanRoundWaveCounts(s_cnt, s_base);
+#pragma unroll
+    for(int r = 0; r < kPrjItems; ++r)
+      if(vis[r])
+      {
+        const uint32_t j         = r * kPrjThreads + t;
+        const uint32_t pos       = s_base[r * 4 + w] + lanesBelow(bal[r]);
+        keysSlot[slotBase + pos] = s_key[j];
+        idsSlot[slotBase + pos]  = I.globalOffset + local0 + (s_li[j] & 0x7FFFu);
+      }
     if(t == 0)
     {
       slotCount[part] = outCount;

@@ -579,10 +579,15 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
     HIPCHK(hipMalloc((void**)&d.centers, n * 3 * sizeof(float)));
     HIPCHK(hipMemcpy(d.centers, h.positions.data(), n * 3 * sizeof(float), hipMemcpyHostToDevice));
     {
-      std::vector<float> cov;
+      std::vector<float> cov, planar(n * 6);
       buildCov6(h, cov);
+      // HBM layout: float4 covA[n] = (S00,S01,S02,S11) followed by float2 covB[n] = (S12,S22)
+      parallelBatches(n, [&](size_t i) {
+        std::memcpy(&planar[4 * i], &cov[6 * i], 16);
+        std::memcpy(&planar[4 * n + 2 * i], &cov[6 * i + 4], 8);
+      });
       HIPCHK(hipMalloc((void**)&d.cov6, n * 6 * sizeof(float)));
-      HIPCHK(hipMemcpy(d.cov6, cov.data(), n * 6 * sizeof(float), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(d.cov6, planar.data(), n * 6 * sizeof(float), hipMemcpyHostToDevice));
     }
     {
       std::vector<float> rgba;
@@ -597,10 +602,14 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
       buildShInterleaved(h, sh);
       const int per = shFormat == MGS_FORMAT_FLOAT32 ? 4 : shFormat == MGS_FORMAT_FLOAT16 ? 8 : 16;
       d.shPitch     = (d.shStride + per - 1) / per * per;
+      // vector-planar: element k of splat i lives in plane k/per at [plane][i][k%per]
       padded.assign(n * (size_t)d.shPitch, 0.f);
+      const int stride = d.shStride, pitch = d.shPitch;
       parallelBatches(n, [&](size_t i) {
-        std::memcpy(padded.data() + i * (size_t)d.shPitch, sh.data() + i * (size_t)d.shStride, sizeof(float) * d.shStride);
+        for(int k = 0; k < stride; ++k)
+          padded[((size_t)(k / per) * n + i) * per + (k % per)] = sh[i * (size_t)stride + k];
       });
+      (void)pitch;
       int rc = uploadFormatted(padded, shFormat, true, &d.sh);
       if(rc != MGS_OK)
         return rc;
@@ -678,11 +687,11 @@ int mgs_scene_download_set(MgsScene s, int instance, int which, float* dst, size
   size_t           need;
   const void*      src;
   int              fmt = MGS_FORMAT_FLOAT32;
-  bool             isSh = false;
+  bool             isSh = false, isCov = false;
   switch(which)
   {
     case 0: need = 3 * n; src = d.centers; break;
-    case 1: need = 6 * n; src = d.cov6; break;
+    case 1: need = 6 * n; src = d.cov6; isCov = true; break;
     case 2: need = 4 * n; src = d.rgba; fmt = d.rgbaFormat; break;
     case 3: need = (size_t)d.shStride * n; src = d.sh; fmt = d.shFormat; isSh = true; break;
     default: setError("mgs_scene_download_set: unknown buffer"); return MGS_ERR_INVALID_ARG;
@@ -694,16 +703,28 @@ int mgs_scene_download_set(MgsScene s, int instance, int which, float* dst, size
   }
   if(need == 0)
     return MGS_OK;
+  if(isCov)
+  {  // planar (float4 covA[n], float2 covB[n]) -> the reference's 6 floats per splat
+    std::vector<float> raw(need);
+    HIPCHK(hipMemcpy(raw.data(), src, need * 4, hipMemcpyDeviceToHost));
+    for(size_t i = 0; i < n; ++i)
+    {
+      std::memcpy(dst + 6 * i, &raw[4 * i], 16);
+      std::memcpy(dst + 6 * i + 4, &raw[4 * n + 2 * i], 8);
+    }
+    return MGS_OK;
+  }
   if(isSh)
-  {  // stored with a padded pitch: fetch, dequantise, strip the padding
+  {  // vector-planar with a padded pitch: fetch, dequantise, restore [splat][coef][rgb]
     const size_t         tot = (size_t)d.shPitch * n;
     const size_t         esz = fmt == MGS_FORMAT_FLOAT32 ? 4 : fmt == MGS_FORMAT_FLOAT16 ? 2 : 1;
+    const int            per = (int)(16 / esz);
     std::vector<uint8_t> raw(tot * esz);
     HIPCHK(hipMemcpy(raw.data(), src, raw.size(), hipMemcpyDeviceToHost));
     for(size_t i = 0; i < n; ++i)
       for(int k = 0; k < d.shStride; ++k)
       {
-        const size_t j = i * (size_t)d.shPitch + k;
+        const size_t j = ((size_t)(k / per) * n + i) * per + (k % per);
         float        v;
         if(fmt == MGS_FORMAT_FLOAT32)
           std::memcpy(&v, raw.data() + 4 * j, 4);
