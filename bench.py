@@ -42,7 +42,11 @@ def main():
     ap.add_argument("--sh-format", type=int, default=0, help="0 fp32 (benchmark setting), 1 fp16, 2 uint8")
     ap.add_argument("--rgba-format", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sort-only", action="store_true", help="also report the isolated key+sort hook per pose")
+    ap.add_argument("--inflight", type=int, default=1, help="frames in flight per GPU (each on its own HIP stream with "
+                    "its own working buffers); >1 overlaps one frame's tails/launch gaps/all-gather with the next frame")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (functional check of the N>1 path "
+                    "when all ranks share one GPU; strips are staged through host memory)")
+    ap.add_argument("--check-gather", action="store_true", help="N>1: verify the gathered frame == a full-frame render")
     args = ap.parse_args()
 
     import torch
@@ -52,7 +56,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)   # gloo functional check: several ranks may share one GPU
     torch.cuda.set_device(local)
 
     import vk_gaussian_splatting_amd as mgs
@@ -62,12 +71,17 @@ def main():
     t0 = time.time()
     sc = synth.make_scene(N, seed=0xC0FFEE + 2)  # syn_garden; identical on every rank
     ss = mgs.SplatSet.from_arrays(**sc)
-    scene = mgs.Scene(local)
-    scene.add_instance(ss)
-    scene.commit(args.sh_format, args.rgba_format)
-    stream = torch.cuda.Stream()          # a real (non-null) stream shared by the renderer and RCCL
-    torch.cuda.set_stream(stream)
-    scene.set_stream(stream.cuda_stream)
+    K = max(1, args.inflight)
+    scenes, streams = [], []
+    for _ in range(K):
+        sc_k = mgs.Scene(local)
+        sc_k.add_instance(ss)
+        sc_k.commit(args.sh_format, args.rgba_format)
+        st_k = torch.cuda.Stream()        # a real (non-null) stream shared by this context's renderer and RCCL
+        sc_k.set_stream(st_k.cuda_stream)
+        scenes.append(sc_k)
+        streams.append(st_k)
+    scene = scenes[0]
     setup_s = time.time() - t0
 
     poses = []
@@ -81,18 +95,21 @@ def main():
         poses.append(p)
 
     R = multigpu.strip_pixel_rows(H, world)
-    strip = torch.zeros((R, W, 4), dtype=torch.float16, device="cuda") if world > 1 else None
+    strips = [torch.zeros((R, W, 4), dtype=torch.float16, device="cuda") if world > 1 else None for _ in range(K)]
     strip_bytes = R * W * 8
 
     def frame(i):
         p = poses[i % 64]
-        if world > 1 and p.strip_row_begin == p.strip_row_end:
-            gathered = multigpu.gather_strips(strip, world)  # this rank owns no rows (more ranks than tile rows)
-            return gathered
-        scene.render(p)
-        if world > 1:
-            scene.copy_strip(strip.data_ptr(), strip_bytes)
-            return multigpu.gather_strips(strip, world)
+        c = i % K
+        with torch.cuda.stream(streams[c]):
+            if world > 1 and p.strip_row_begin == p.strip_row_end:
+                return multigpu.gather_strips(strips[c], world)  # this rank owns no rows (more ranks than tile rows)
+            scenes[c].render(p)
+            if world > 1:
+                scenes[c].copy_strip(strips[c].data_ptr(), strip_bytes)
+                if args.backend != "nccl":  # functional path: stage through the host
+                    return multigpu.gather_strips(strips[c].cpu(), world)
+                return multigpu.gather_strips(strips[c], world)
         return None
 
     def fence():
@@ -104,6 +121,19 @@ def main():
     for i in range(args.warmup):
         frame(i)
     fence()
+    if world > 1 and args.check_gather:
+        g = frame(0)
+        torch.cuda.synchronize()
+        pf = capi.default_params(W, H)
+        for kk in range(16):
+            pf.view[kk], pf.proj[kk] = poses[0].view[kk], poses[0].proj[kk]
+        for kk in range(3):
+            pf.camera_pos[kk] = poses[0].camera_pos[kk]
+        scene.render(pf)
+        full = torch.from_numpy(scene.download_frame(pf).view(np.int16))
+        same = torch.equal(g[:H].cpu().view(torch.int16), full)
+        print(f"[rank {rank}] gathered frame == full frame: {same}", file=sys.stderr)
+        assert same, "strip all-gather does not reproduce the single-GPU frame"
     t1 = time.perf_counter()
     for i in range(args.steps):
         frame(args.warmup + i)
@@ -115,8 +145,8 @@ def main():
         elapsed = float(tt.item())
 
     # ---- per-stage HIP-event times of the timed frames (ring of 128) + counters per pose --------
-    k = min(args.steps, 128)
-    st = np.array([scene.timings(b) for b in range(k)], np.float64)  # [k, 6] ms
+    k = min(args.steps // K, 128)
+    st = np.array([scenes[c].timings(b) for c in range(K) for b in range(k)], np.float64)  # [K*k, 6] ms
     stage_ms = st.mean(axis=0)
     counts = []
     for i in range(min(64, args.steps)):
@@ -167,6 +197,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
+        "frames_in_flight": K,
         "config": {"workload": f"syn_garden N={N} SH deg 3, storage sh/rgba format {args.sh_format}/{args.rgba_format}, "
                                f"{W}x{H}, 64-pose orbit r=4 h=1.5 fov60, GPU radix sort, cull at dist (configs[2])",
                    "partition": "single GPU" if world == 1 else f"{world} tile-row strips + RCCL all_gather"},
@@ -208,7 +239,8 @@ def main():
                                "ms": best}
     if rank == 0:
         print(json.dumps(out))
-    scene.close()
+    for sc_k in scenes:
+        sc_k.close()
     if world > 1:
         dist.destroy_process_group()
 
