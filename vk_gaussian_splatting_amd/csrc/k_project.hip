@@ -15,6 +15,8 @@
 //     is no global atomic append and no inter-workgroup chain.
 //   * splats that can never produce a fragment (alpha cull, lambda2<=0, clipped by z, footprint
 //     outside the strip) are dropped BEFORE the sort.
+#include <type_traits>
+
 #include "kernels_common.h"
 
 namespace mgs {
@@ -58,75 +60,62 @@ __device__ __forceinline__ float4 loadRgba(const void* base, uint32_t i)
 // instruction touched 64 different lines and the 16 KB-per-wave footprint thrashed the 32 KB L1
 // (k_project 0.43 ms, profiles/r1_b); the reference's AoS layout (threedgs_particle_buffers.h.slang:112-207)
 // is kept only as the logical order inside a record.
-template <int FMT>
-__device__ __forceinline__ void loadShRecord(const void* base, uint32_t li, uint32_t count, int ncoef, float (&s)[48])
+// NV = number of 16-byte vectors to fetch (compile time: the loads must be straight-line code — a
+// run-time guard per vector turns each load into its own branch + s_waitcnt vmcnt(0), i.e. 12
+// serialized round trips; that was the real cost of this kernel in profiles/r1_a..b).
+template <int FMT, int NV>
+__device__ __forceinline__ void loadShVectors(const void* base, uint32_t li, uint32_t count, float (&s)[48])
 {
-  if constexpr(FMT == 0)
-  {
-    const float4* p = reinterpret_cast<const float4*>(base) + li;
+  constexpr int PER = FMT == 0 ? 4 : (FMT == 1 ? 8 : 16);
+  const uint4*  p   = reinterpret_cast<const uint4*>(base) + li;
+  uint4         x[NV];
 #pragma unroll
-    for(int v = 0; v < 12; ++v)
+  for(int v = 0; v < NV; ++v)
+    x[v] = p[(size_t)v * count];
+#pragma unroll
+  for(int v = 0; v < NV; ++v)
+  {
+    const uint32_t w[4] = {x[v].x, x[v].y, x[v].z, x[v].w};
+    if constexpr(FMT == 0)
     {
-      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if(4 * v < ncoef)
-        x = p[(size_t)v * count];
-      s[4 * v] = x.x; s[4 * v + 1] = x.y; s[4 * v + 2] = x.z; s[4 * v + 3] = x.w;
+#pragma unroll
+      for(int q = 0; q < 4; ++q)
+        s[PER * v + q] = __uint_as_float(w[q]);
     }
-  }
-  else if constexpr(FMT == 1)
-  {
-    const uint4* p = reinterpret_cast<const uint4*>(base) + li;
-#pragma unroll
-    for(int v = 0; v < 6; ++v)
+    else if constexpr(FMT == 1)
     {
-      uint4 x = make_uint4(0u, 0u, 0u, 0u);
-      if(8 * v < ncoef)
-        x = p[(size_t)v * count];
-      const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
       for(int q = 0; q < 4; ++q)
       {
         const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&w[q]));
-        s[8 * v + 2 * q] = f.x; s[8 * v + 2 * q + 1] = f.y;
+        s[PER * v + 2 * q]     = f.x;
+        s[PER * v + 2 * q + 1] = f.y;
       }
     }
-  }
-  else
-  {
-    const uint4* p = reinterpret_cast<const uint4*>(base) + li;
-#pragma unroll
-    for(int v = 0; v < 3; ++v)
+    else
     {
-      uint4 x = make_uint4(0u, 0u, 0u, 0u);
-      if(16 * v < ncoef)
-        x = p[(size_t)v * count];
-      const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
       for(int q = 0; q < 4; ++q)
 #pragma unroll
         for(int k = 0; k < 4; ++k)  // threedgs_particle_buffers.h.slang:128-131: v/255*2-1
-          s[16 * v + 4 * q + k] = (float)((w[q] >> (8 * k)) & 255u) / 255.0f * 2.0f - 1.0f;
+          s[PER * v + 4 * q + k] = (float)((w[q] >> (8 * k)) & 255u) / 255.0f * 2.0f - 1.0f;
     }
   }
 }
 
-// SH degrees 1..3 added to the base colour; constants and term order of
-// threedgs_particle_storage.h.slang:48-52,121-155
-template <int FMT>
-__device__ __forceinline__ void addShRadiance(const InstanceConst& I, uint32_t li, int degree, float x, float y, float z,
-                                              float& r, float& g, float& b)
+// SH degrees 1..3 (constants and term order of threedgs_particle_storage.h.slang:48-52,121-155) from an
+// already-fetched record
+template <int degree>
+__device__ __forceinline__ void shRadiance(const float (&s)[48], float x, float y, float z, float& r, float& g, float& b)
 {
-  if(degree < 1 || I.sh == nullptr)
+  if constexpr(degree < 1)
     return;
-  float     s[48];
-  const int ncoef = degree == 1 ? 9 : (degree == 2 ? 24 : 45);
-  loadShRecord<FMT>(I.sh, li, I.count, ncoef, s);
   const float C1 = 0.4886025119029199f;
   float       acc[3];
 #pragma unroll
   for(int c = 0; c < 3; ++c)
     acc[c] = C1 * (-s[0 + c] * y + s[3 + c] * z - s[6 + c] * x);
-  if(degree >= 2)
+  if constexpr(degree >= 2)
   {
     const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
     const float k0 = 1.0925484f * xy, k1 = -1.0925484f * yz, k2 = 0.3153916f * (2.0f * zz - xx - yy),
@@ -134,7 +123,7 @@ __device__ __forceinline__ void addShRadiance(const InstanceConst& I, uint32_t l
 #pragma unroll
     for(int c = 0; c < 3; ++c)
       acc[c] += k0 * s[9 + c] + k1 * s[12 + c] + k2 * s[15 + c] + k3 * s[18 + c] + k4 * s[21 + c];
-    if(degree >= 3)
+    if constexpr(degree >= 3)
     {
       const float m0 = -0.5900435899266435f * (3.0f * xx - yy) * y, m1 = 2.890611442640554f * xy * z,
                   m2 = -0.4570457994644658f * (4.0f * zz - xx - yy) * y,
@@ -153,19 +142,33 @@ __device__ __forceinline__ void addShRadiance(const InstanceConst& I, uint32_t l
 }
 
 // The per-splat raster front end.  Returns false when the splat cannot produce a fragment.
-template <int SHF, int RGBAF>
+// Written BRANCH-FREE with every load issued first: rocprof showed the waves of this kernel waiting on
+// memory 70 % of their cycles when the fetches were staged behind the early-outs (rgba -> centre -> cov
+// -> SH, four dependent round trips).  ~96 % of the frustum survivors pass every test, so the
+// speculative SH fetch of the rest costs ~4 % extra traffic and buys one round trip instead of four.
+template <int SHF, int RGBAF, int DEG>
 __device__ __forceinline__ bool projectSplat(const FrameConst& F, const InstanceConst& I, uint32_t li, Projected& out)
 {
-  float4 col = loadRgba<RGBAF>(I.rgba, li);
-  if(col.w < F.alphaCull)  // mesh.slang:164-170
-    return false;
-  const float px = I.centers[3 * (size_t)li + 0], py = I.centers[3 * (size_t)li + 1], pz = I.centers[3 * (size_t)li + 2];
+  // ---- all fetches --------------------------------------------------------------------------------------
+  float4       col = loadRgba<RGBAF>(I.rgba, li);
+  const float  px = I.centers[3 * (size_t)li + 0], py = I.centers[3 * (size_t)li + 1], pz = I.centers[3 * (size_t)li + 2];
+  const float4 cA = reinterpret_cast<const float4*>(I.cov6)[li];                       // planar: 16 B per lane
+  const float2 cB = reinterpret_cast<const float2*>(I.cov6 + 4 * (size_t)I.count)[li];  //          8 B per lane
+  float        sh[48];
+  if constexpr(DEG >= 1)
+  {
+    constexpr int PER = SHF == 0 ? 4 : (SHF == 1 ? 8 : 16);
+    constexpr int NEL = DEG == 1 ? 9 : (DEG == 2 ? 24 : 45);
+    loadShVectors<SHF, (NEL + PER - 1) / PER>(I.sh, li, I.count, sh);
+  }
+
+  // ---- mesh.slang:164-190 ---------------------------------------------------------------------------------
+  bool         ok = !(col.w < F.alphaCull);
   const float* MV = I.modelView;
-  // view-space centre and clip position (mesh.slang:175-179)
-  const float tx = MV[0] * px + MV[4] * py + MV[8] * pz + MV[12];
-  const float ty = MV[1] * px + MV[5] * py + MV[9] * pz + MV[13];
-  const float tz = MV[2] * px + MV[6] * py + MV[10] * pz + MV[14];
-  const float tw = MV[3] * px + MV[7] * py + MV[11] * pz + MV[15];
+  const float  tx = MV[0] * px + MV[4] * py + MV[8] * pz + MV[12];
+  const float  ty = MV[1] * px + MV[5] * py + MV[9] * pz + MV[13];
+  const float  tz = MV[2] * px + MV[6] * py + MV[10] * pz + MV[14];
+  const float  tw = MV[3] * px + MV[7] * py + MV[11] * pz + MV[15];
   const float* P  = F.proj;
   const float  cx = P[0] * tx + P[4] * ty + P[8] * tz + P[12] * tw;
   const float  cy = P[1] * tx + P[5] * ty + P[9] * tz + P[13] * tw;
@@ -174,22 +177,18 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   if(F.cullMode == 2)
   {  // FRUSTUM_CULLING_AT_RASTER, mesh.slang:181-190
     const float c = (1.0f + F.frustumDilation) * cw;
-    if(fabsf(cx) > c || fabsf(cy) > c || cz < (0.0f - F.frustumDilation) * cw || cz > cw)
-      return false;
+    ok            = ok && !(fabsf(cx) > c || fabsf(cy) > c || cz < (0.0f - F.frustumDilation) * cw || cz > cw);
   }
   const float rw   = 1.0f / cw;
   const float ndcx = cx * rw, ndcy = cy * rw, ndcz = cz * rw;
   // fixed-function z clip of the emitted quad (all vertices at z = ndc.z, w = 1; no depth clamp)
-  if(!(ndcz >= 0.0f && ndcz <= 1.0f))
-    return false;
+  ok = ok && (ndcz >= 0.0f && ndcz <= 1.0f);
 
-  // covariance projection, threedgs.h.slang:26-56
-  const float4 cA  = reinterpret_cast<const float4*>(I.cov6)[li];                              // planar: 16 B per lane
-  const float2 cB  = reinterpret_cast<const float2*>(I.cov6 + 4 * (size_t)I.count)[li];         //         8 B per lane
-  const float  s00 = cA.x, s01 = cA.y, s02 = cA.z, s11 = cA.w, s12 = cB.x, s22 = cB.y;
-  const float  rz = 1.0f / tz, rz2 = rz * rz;
-  const float  j00 = F.focal[0] * rz, j02 = -(F.focal[0] * tx) * rz2;
-  const float  j11 = F.focal[1] * rz, j12 = -(F.focal[1] * ty) * rz2;
+  // ---- covariance projection, threedgs.h.slang:26-56 ---------------------------------------------------------
+  const float s00 = cA.x, s01 = cA.y, s02 = cA.z, s11 = cA.w, s12 = cB.x, s22 = cB.y;
+  const float rz = 1.0f / tz, rz2 = rz * rz;
+  const float j00 = F.focal[0] * rz, j02 = -(F.focal[0] * tx) * rz2;
+  const float j11 = F.focal[1] * rz, j12 = -(F.focal[1] * ty) * rz2;
   // W(r,c) = MV(r,c);  T = J * W (rows 0 and 1 only)
   const float t00 = j00 * MV[0] + j02 * MV[2], t01 = j00 * MV[4] + j02 * MV[6], t02 = j00 * MV[8] + j02 * MV[10];
   const float t10 = j11 * MV[1] + j12 * MV[2], t11 = j11 * MV[5] + j12 * MV[6], t12 = j11 * MV[9] + j12 * MV[10];
@@ -202,7 +201,7 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   float b = u0 * t10 + u1 * t11 + u2 * t12;
   float d = v0 * t10 + v1 * t11 + v2 * t12;
 
-  // extent basis, threedgs.h.slang:60-121
+  // ---- extent basis, threedgs.h.slang:60-121 -------------------------------------------------------------------
   float detOrig = 0.f;
   if(F.msAA)
     detOrig = a * d - b * b;
@@ -217,25 +216,22 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   const float half  = 0.5f * (a + d);
   const float term2 = sqrtf(fmaxf(0.1f, half * half - D));
   const float ev1 = half + term2, ev2 = half - term2;
-  if(ev2 <= 0.0f)
-    return false;
+  ok              = ok && !(ev2 <= 0.0f);
   float       e1x = (fabsf(b) < 0.001f) ? 1.0f : b, e1y = ev1 - a;
   const float el  = rsqrtf(e1x * e1x + e1y * e1y);
   e1x *= el;
   e1y *= el;
   const float kSqrt8 = 2.8284271247461903f;
   const float l1     = F.splatScale * fminf(kSqrt8 * sqrtf(ev1), 2048.0f);
-  const float l2     = F.splatScale * fminf(kSqrt8 * sqrtf(ev2), 2048.0f);
-  if(!(l1 > 0.f && l2 > 0.f))
-    return false;
+  const float l2     = F.splatScale * fminf(kSqrt8 * sqrtf(fmaxf(ev2, 0.f)), 2048.0f);
+  ok                 = ok && (l1 > 0.f && l2 > 0.f);
   const float b1x = e1x * l1, b1y = e1y * l1;   // basisVector1 (pixels)
   const float b2x = e1y * l2, b2y = -e1x * l2;  // basisVector2 = (e1.y, -e1.x) * l2
 
   // a fragment survives iff q = (d.p1)^2+(d.p2)^2 <= 4 (A<=8) and a*exp(-q) > 1/255 (frag.slang:242-262)
   const float a255 = col.w * 255.0f;
-  if(!(a255 > 1.0f))
-    return false;
-  const float qmax  = fminf(4.0f, __logf(a255) + 1e-3f);
+  ok               = ok && (a255 > 1.0f);
+  const float qmax   = fminf(4.0f, __logf(fmaxf(a255, 1.0f)) + 1e-3f);
   const float shrink = sqrtf(qmax * 0.25f) * 1.0005f;
   const float ex = shrink * sqrtf(b1x * b1x + b2x * b2x) + 0.01f;
   const float ey = shrink * sqrtf(b1y * b1y + b2y * b2y) + 0.01f;
@@ -246,8 +242,9 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   const float fx0 = ceilf(pcx - ex - 0.5f), fx1 = floorf(pcx + ex - 0.5f);
   const float fy0 = ceilf(pcy - ey - 0.5f), fy1 = floorf(pcy + ey - 0.5f);
   const float ymin = (float)(F.stripRow0 * kTilePx), ymax = (float)(min(F.stripRow1 * kTilePx, F.height) - 1);
-  if(!(fx1 >= fx0 && fy1 >= fy0 && fx1 >= 0.f && fx0 <= (float)(F.width - 1) && fy1 >= ymin && fy0 <= ymax))
-    return false;
+  ok = ok && (fx1 >= fx0 && fy1 >= fy0 && fx1 >= 0.f && fx0 <= (float)(F.width - 1) && fy1 >= ymin && fy0 <= ymax);
+  if(!ok)
+    return false;  // nothing below touches memory except the caller's stores
   const int x0 = (int)fmaxf(fx0, 0.f), x1 = (int)fminf(fx1, (float)(F.width - 1));
   const int y0 = (int)fmaxf(fy0, ymin), y1 = (int)fminf(fy1, ymax);
   const int sx = 4 + F.binShiftX, sy = 4 + F.binShiftY;
@@ -259,8 +256,7 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   dx *= dl;
   dy *= dl;
   dz *= dl;
-  const int degree = min(I.shDegree, F.shDegree);
-  addShRadiance<SHF>(I, li, degree, dx, dy, dz, col.x, col.y, col.z);
+  shRadiance<DEG>(sh, dx, dy, dz, col.x, col.y, col.z);
 
   const float n1 = 2.0f / (b1x * b1x + b1y * b1y), n2 = 2.0f / (b2x * b2x + b2y * b2y);
   out.rec.cx  = pcx;
@@ -327,11 +323,11 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, Fram
 #pragma unroll
   for(int it = 0; it < kPrjItems; ++it)
   {
-    const uint32_t li = local0 + it * kPrjThreads + t;
-    const bool     in = li < I.count;
-    px[it] = in ? I.centers[3 * (size_t)li] : 0.f;
-    py[it] = in ? I.centers[3 * (size_t)li + 1] : 0.f;
-    pz[it] = in ? I.centers[3 * (size_t)li + 2] : 0.f;
+    // clamped, not predicated: a predicated load becomes a branch + wait and serialises the 8 fetches
+    const uint32_t li = min(local0 + it * kPrjThreads + t, I.count - 1u);
+    px[it] = I.centers[3 * (size_t)li];
+    py[it] = I.centers[3 * (size_t)li + 1];
+    pz[it] = I.centers[3 * (size_t)li + 2];
   }
   uint32_t key[kPrjItems];
   uint64_t bal[kPrjItems];
@@ -391,21 +387,34 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, Fram
   else
   {
     // ---- phase 2: dense raster front end over the survivors (no barriers inside) ------------------------
-    for(uint32_t j = t; j < M; j += kPrjThreads)
-    {
-      const uint32_t li = local0 + s_li[j];
-      Projected      pr;
-      if(projectSplat<SHF, RGBAF>(A.f, I, li, pr))
+    // SH degree is uniform per instance: dispatch once so that the record fetch is straight-line code
+    const int degree = (I.sh == nullptr) ? 0 : min(I.shDegree, A.f.shDegree);
+    auto      body   = [&](auto degTag) {
+      constexpr int DEG = decltype(degTag)::value;
+      for(uint32_t j = t; j < M; j += kPrjThreads)
       {
-        const uint32_t gid = I.globalOffset + li;
-        float4*        dst = reinterpret_cast<float4*>(rec + gid);
-        dst[0]             = make_float4(pr.rec.cx, pr.rec.cy, pr.rec.ex, pr.rec.ey);
-        dst[1]             = make_float4(pr.rec.p1x, pr.rec.p1y, pr.rec.p2x, pr.rec.p2y);
-        dst[2]             = make_float4(pr.rec.r, pr.rec.g, pr.rec.b, pr.rec.a);
-        rect[gid]          = pr.rect;
-        s_li[j] |= 0x8000u;  // own entry only: no race
+        const uint32_t li = local0 + s_li[j];
+        Projected      pr;
+        if(projectSplat<SHF, RGBAF, DEG>(A.f, I, li, pr))
+        {
+          const uint32_t gid = I.globalOffset + li;
+          float4*        dst = reinterpret_cast<float4*>(rec + gid);
+          dst[0]             = make_float4(pr.rec.cx, pr.rec.cy, pr.rec.ex, pr.rec.ey);
+          dst[1]             = make_float4(pr.rec.p1x, pr.rec.p1y, pr.rec.p2x, pr.rec.p2y);
+          dst[2]             = make_float4(pr.rec.r, pr.rec.g, pr.rec.b, pr.rec.a);
+          rect[gid]          = pr.rect;
+          s_li[j] |= 0x8000u;  // own entry only: no race
+        }
       }
-    }
+    };
+    if(degree >= 3)
+      body(std::integral_constant<int, 3>{});
+    else if(degree == 2)
+      body(std::integral_constant<int, 2>{});
+    else if(degree == 1)
+      body(std::integral_constant<int, 1>{});
+    else
+      body(std::integral_constant<int, 0>{});
     // ---- second ordered compaction straight into the partition's slot region ---------------------------
     __syncthreads();
 #pragma unroll
