@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--sh-format", type=int, default=0, help="0 fp32 (benchmark setting), 1 fp16, 2 uint8")
     ap.add_argument("--rgba-format", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=1, help="frames in flight per GPU (each on its own HIP stream with "
+    ap.add_argument("--inflight", type=int, default=2, help="frames in flight per GPU (each on its own HIP stream with "
                     "its own working buffers); >1 overlaps one frame's tails/launch gaps/all-gather with the next frame")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (functional check of the N>1 path "
                     "when all ranks share one GPU; strips are staged through host memory)")
@@ -184,6 +184,16 @@ def main():
     frame_gpu_ms = stage_ms[5]
     sort_ms = stage_ms[1]
 
+    # HBM traffic of the dominant kernel from the PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    # runs of this same command, corrected as MI355X_MICROARCH.md prescribes; see profiles/*.json)
+    traffic = None
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r1_c_pmc_hbm_traffic.json")))
+        if dom_name == "project" and "k_project" in pj["kernel"] and world == 1 and N == 5_830_000:
+            traffic = pj["traffic_bytes_per_launch_corrected"]
+    except Exception:
+        pass
+
     out = {
         "metric": "frames/s @1920x1080 + sorted Gsplats/s, garden-sized scene",
         "value": fps,
@@ -206,7 +216,7 @@ def main():
         "visible_splats": {"frustum": Vf, "sorted": Vs, "tile_pairs": D},
         "stage_ms": {STAGES[j]: float(stage_ms[j]) for j in range(6)},
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg[dom_name], "launch_ms": float(stage_ms[dom]),
                      "note": "composite is fp32-VALU bound (exp + blend per pixel-splat pair), not HBM bound; see DESIGN.md"
                      if dom_name == "composite" else ""},

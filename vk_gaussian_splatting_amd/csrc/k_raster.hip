@@ -260,10 +260,10 @@ __global__ void k_tile_ranges(const uint32_t* __restrict__ keyX, const uint32_t*
 //            q=(d.p1)^2+(d.p2)^2 (== A/2, frag.slang:236), discard q>4, alpha=a*exp(-q), discard <=1/255.
 // A wave retires when all 64 pixels have T < 1e-4; the workgroup stops fetching when all 4 have
 // (not in MGS_ALPHA_SUM mode, where the reference's additive alpha must see every fragment).
-constexpr int kCmpEntries = 2;                  // list entries per thread per stage-A round
-constexpr int kCmpRound   = 256 * kCmpEntries;  // 512 entries scanned per round
+constexpr int kCmpEntries = 4;                  // list entries per thread per stage-A round (4 gathers in flight per lane)
+constexpr int kCmpRound   = 256 * kCmpEntries;  // 1024 entries scanned per round
 constexpr int kCmpCap     = 512;                // LDS batch capacity (records): 24 KB -> 6 workgroups per CU
-constexpr int kCmpGo      = 160;                // blend as soon as this many records are staged
+constexpr int kCmpGo      = 192;                // blend as soon as this many records are staged (<= kCmpCap-256)
 
 template <bool HALF_OUT>
 __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uint2* __restrict__ ranges,
@@ -332,9 +332,18 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
   uint32_t hi   = range.y;
   uint32_t fill = 0;  // records currently in the LDS batch
   int      rnd  = 0;
+  uint32_t gNext[kCmpEntries];
+  bool     prefValid = false;
+#pragma unroll
+  for(int k = 0; k < kCmpEntries; ++k)
+    gNext[k] = 0u;
   for(;;)
   {
     // ---- stage A: scan list entries (nearest first) until enough records are staged or the list ends ----
+    // A round looks at up to 1024 entries as 4 sub-groups of 256 (k-th sub-group = entries k*256+t).  The
+    // sub-groups are accepted in order while they fit into the batch; since fill < kCmpGo <= cap-256 on
+    // entry, sub-group 0 always fits, so every round makes progress and the batch can never overflow.
+    // The ids of the NEXT round are fetched before this round's barrier (one dependent trip instead of two).
     while(hi > range.x && fill < (uint32_t)kCmpGo)
     {
       const uint32_t avail = hi - range.x;
@@ -347,11 +356,22 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
       {
         const uint32_t e = k * 256u + (uint32_t)t;  // e-th nearest remaining entry
         ok[k]            = e < avail;
-        g[k]             = ok[k] ? vals[hi - 1u - e] : 0u;
+        g[k]             = prefValid ? gNext[k] : (ok[k] ? vals[hi - 1u - e] : 0u);
       }
 #pragma unroll
       for(int k = 0; k < kCmpEntries; ++k)
         a[k] = ok[k] ? *reinterpret_cast<const float4*>(rec + g[k]) : make_float4(0.f, 0.f, -1.f, -1.f);
+      // speculative prefetch of the next round's ids (valid if this round is consumed completely)
+      {
+        const uint32_t hiN = hi - min(avail, (uint32_t)kCmpRound);
+        const uint32_t avN = hiN - range.x;
+#pragma unroll
+        for(int k = 0; k < kCmpEntries; ++k)
+        {
+          const uint32_t e = k * 256u + (uint32_t)t;
+          gNext[k]         = (e < avN) ? vals[hiN - 1u - e] : 0u;
+        }
+      }
 #pragma unroll
       for(int k = 0; k < kCmpEntries; ++k)
       {
@@ -361,38 +381,42 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
           s_wc[rnd & 1][k][w] = (uint32_t)__popcll(bal[k]);
       }
       __syncthreads();
-      uint32_t m = 0;
-#pragma unroll
-      for(int k = 0; k < kCmpEntries; ++k)
-        m += s_wc[rnd & 1][k][0] + s_wc[rnd & 1][k][1] + s_wc[rnd & 1][k][2] + s_wc[rnd & 1][k][3];
+      const uint32_t(*cnt)[4] = s_wc[rnd & 1];
       ++rnd;
-      if(fill + m > (uint32_t)kCmpCap)
-        break;  // would overflow the batch: blend first, rescan this round afterwards (fill > 0 here, m <= kCmpCap)
       uint32_t base = fill;
+      int      used = 0;  // sub-groups consumed
 #pragma unroll
       for(int k = 0; k < kCmpEntries; ++k)
       {
-        const uint32_t* c  = s_wc[(rnd - 1) & 1][k];
-        uint32_t        wb = 0;
-        if(w > 0) wb += c[0];
-        if(w > 1) wb += c[1];
-        if(w > 2) wb += c[2];
-        if(ok[k])
+        const uint32_t m = cnt[k][0] + cnt[k][1] + cnt[k][2] + cnt[k][3];
+        if(used == k && base + m <= (uint32_t)kCmpCap)
         {
-          const uint32_t pos = base + wb + lanesBelow(bal[k]);
-          const float4*  r   = reinterpret_cast<const float4*>(rec + g[k]);
-          s_a[pos]           = a[k];
-          s_b[pos]           = r[1];
-          s_c[pos]           = r[2];
-          // quadrant q covers pixel centres [x0+8(q&1)+0.5, +7.5]: centre bcx -4 / +4, half width 3.5
-          const bool xl = a[k].x - a[k].z <= bcx - 0.5f, xr = a[k].x + a[k].z >= bcx + 0.5f;
-          const bool yt = a[k].y - a[k].w <= bcy - 0.5f, yb = a[k].y + a[k].w >= bcy + 0.5f;
-          s_m[pos] = (uint8_t)((xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u));
+          uint32_t wb = 0;
+          if(w > 0) wb += cnt[k][0];
+          if(w > 1) wb += cnt[k][1];
+          if(w > 2) wb += cnt[k][2];
+          if(ok[k])
+          {
+            const uint32_t pos = base + wb + lanesBelow(bal[k]);
+            const float4*  r   = reinterpret_cast<const float4*>(rec + g[k]);
+            s_a[pos]           = a[k];
+            s_b[pos]           = r[1];
+            s_c[pos]           = r[2];
+            // quadrant q covers pixel centres [x0+8(q&1)+0.5, +7.5]: centre bcx -4 / +4, half width 3.5
+            const bool xl = a[k].x - a[k].z <= bcx - 0.5f, xr = a[k].x + a[k].z >= bcx + 0.5f;
+            const bool yt = a[k].y - a[k].w <= bcy - 0.5f, yb = a[k].y + a[k].w >= bcy + 0.5f;
+            s_m[pos] = (uint8_t)((xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u));
+          }
+          base += m;
+          used = k + 1;
         }
-        base += c[0] + c[1] + c[2] + c[3];
       }
-      fill = base;
-      hi -= min(avail, (uint32_t)kCmpRound);
+      fill                    = base;
+      const uint32_t consumed = min(avail, (uint32_t)used * 256u);
+      prefValid               = (used == kCmpEntries);
+      hi -= consumed;
+      if(used < kCmpEntries)
+        break;  // batch full: blend, then rescan the unconsumed sub-groups
     }
     __syncthreads();
     // ---- stage B: blend the batch ------------------------------------------------------------------------
@@ -408,34 +432,38 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
         uint64_t       hits = __ballot(mine);
         if(hits == 0ull)
           continue;
-        uint32_t j = j0 + (uint32_t)__builtin_ctzll(hits);
-        hits &= hits - 1ull;
-        float4 a = s_a[j], b = s_b[j], c = s_c[j];
-        for(;;)
+        // two hits per iteration: their alpha evaluations are independent (ILP), the blend is sequential
+        while(hits != 0ull)
         {
-          const bool   more = hits != 0ull;
-          const uint32_t jn = j0 + (uint32_t)__builtin_ctzll(hits | (1ull << 63));
+          const uint32_t j1 = j0 + (uint32_t)__builtin_ctzll(hits);
           hits &= hits - 1ull;
-          const float4 an = s_a[jn], bn = s_b[jn], cn = s_c[jn];  // prefetch (harmless re-read when !more)
-          const float  dx = pcx - a.x, dy = pcy - a.y;
-          const float  sv = dx * b.x + dy * b.y;
-          const float  uv = dx * b.z + dy * b.w;
-          const float  q  = sv * sv + uv * uv;     // == A/2 of frag.slang:236
-          const float  al = c.w * __expf(-q);      // frag.slang:254
-          const bool   hit = q <= 4.0f && al > (1.0f / 255.0f) && !done;  // frag.slang:242-245,258-262
-          const float  ah  = hit ? al : 0.0f;
-          const float  wgt = ah * T;
-          cr += wgt * c.x;
-          cg += wgt * c.y;
-          cb += wgt * c.z;
-          asum += ah;
-          T -= wgt;
+          const bool     two = hits != 0ull;
+          const uint32_t j2  = two ? j0 + (uint32_t)__builtin_ctzll(hits) : j1;
+          hits &= hits - 1ull;  // no-op on 0
+          const float4 a1 = s_a[j1], b1 = s_b[j1], c1 = s_c[j1];
+          const float4 a2 = s_a[j2], b2 = s_b[j2], c2 = s_c[j2];
+          const float  dx1 = pcx - a1.x, dy1 = pcy - a1.y, dx2 = pcx - a2.x, dy2 = pcy - a2.y;
+          const float  s1 = dx1 * b1.x + dy1 * b1.y, u1 = dx1 * b1.z + dy1 * b1.w;
+          const float  s2 = dx2 * b2.x + dy2 * b2.y, u2 = dx2 * b2.z + dy2 * b2.w;
+          const float  q1 = s1 * s1 + u1 * u1, q2 = s2 * s2 + u2 * u2;  // == A/2 of frag.slang:236
+          const float  al1 = c1.w * __expf(-q1), al2 = c2.w * __expf(-q2);  // frag.slang:254
+          // frag.slang:242-245,258-262, predicated
+          const float ah1 = (q1 <= 4.0f && al1 > (1.0f / 255.0f) && !done) ? al1 : 0.0f;
+          const float w1  = ah1 * T;
+          cr += w1 * c1.x;
+          cg += w1 * c1.y;
+          cb += w1 * c1.z;
+          asum += ah1;
+          T -= w1;
           done = done || (early && T < 1.0e-4f);
-          if(!more)
-            break;
-          a = an;
-          b = bn;
-          c = cn;
+          const float ah2 = (two && q2 <= 4.0f && al2 > (1.0f / 255.0f) && !done) ? al2 : 0.0f;
+          const float w2  = ah2 * T;
+          cr += w2 * c2.x;
+          cg += w2 * c2.y;
+          cb += w2 * c2.z;
+          asum += ah2;
+          T -= w2;
+          done = done || (early && T < 1.0e-4f);
         }
         if(early && __ballot(!done) == 0ull)
         {
