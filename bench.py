@@ -121,6 +121,15 @@ def main():
     for i in range(args.warmup):
         frame(i)
     fence()
+    # calibration (untimed, single stream): which stage dominates a frame when nothing else shares the GPU
+    calib = []
+    for i in range(8):
+        with torch.cuda.stream(streams[0]):
+            scenes[0].render(poses[i % 64])
+        torch.cuda.synchronize()
+        calib.append(scenes[0].timings(0))
+    calib_ms = np.array(calib[2:], np.float64).mean(axis=0)
+    fence()
     if world > 1 and args.check_gather:
         g = frame(0)
         torch.cuda.synchronize()
@@ -177,12 +186,12 @@ def main():
         "pairsort": (4 + 2 * 16) * D,
         "composite": 48 * Vs + 4 * D + 8 * Ppix,
     }
-    dom = max(range(5), key=lambda j: stage_ms[j])
+    dom = max(range(5), key=lambda j: calib_ms[j])  # dominant stage of an un-overlapped frame
     dom_name = STAGES[dom]
     achieved = alg[dom_name] / (stage_ms[dom] * 1e-3) if stage_ms[dom] > 0 else 0.0
     b_frame = 12 * N + Vs * (16 + 24 + 180) + 8 * Vs + 68 * Vs + 2 * 48 * Vs + 8 * Ppix
     frame_gpu_ms = stage_ms[5]
-    sort_ms = stage_ms[1]
+    sort_ms = calib_ms[1] if K > 1 else stage_ms[1]  # isolated sort time: overlapped spans are not kernel time
 
     # HBM traffic of the dominant kernel from the PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # runs of this same command, corrected as MI355X_MICROARCH.md prescribes; see profiles/*.json)
@@ -215,9 +224,11 @@ def main():
         "sorted_gsplats_per_s_in_frame_aggregate": Vs_all * fps / 1e9,
         "visible_splats": {"frustum": Vf, "sorted": Vs, "tile_pairs": D},
         "stage_ms": {STAGES[j]: float(stage_ms[j]) for j in range(6)},
+        "stage_ms_single_stream": {STAGES[j]: float(calib_ms[j]) for j in range(6)},
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg[dom_name], "launch_ms": float(stage_ms[dom]),
+                     "launch_ms_single_stream": float(calib_ms[dom]),
                      "note": "composite is fp32-VALU bound (exp + blend per pixel-splat pair), not HBM bound; see DESIGN.md"
                      if dom_name == "composite" else ""},
         "roofline_sort": {"bound": "hbm", "achieved": (68 * Vs / (sort_ms * 1e-3)) / 1e9 if sort_ms > 0 else None,
