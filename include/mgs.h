@@ -101,8 +101,13 @@ int  mgs_instance_set_transform(MgsScene scene, int instance_id, const float tra
  * Idempotent; call again after changing formats (the reference's --updateData). */
 int  mgs_scene_commit(MgsScene scene, int sh_format, int rgba_format);
 uint64_t mgs_scene_splat_count(MgsScene scene); /* getTotalGlobalSplatCount, gaussian_splatting.cpp:369 */
+/* The device keeps every splat set in a spatially coherent STORAGE ORDER (Morton order of the centres;
+ * build-defined, the reference keeps file order).  Every id that crosses this ABI is in the caller's
+ * order; this returns the permutation storage index -> caller's index of an instance's splat set.
+ * Equal depth keys are drawn in storage order (the reference's tie order is nondeterministic). */
+int  mgs_scene_storage_order(MgsScene scene, int instance_id, uint32_t* new_to_old, size_t count);
 /* test/debug hook: copy a committed device buffer of a splat set to the host, dequantised to
- * fp32 exactly as the shaders would read it.  which: 0 centres[3n] 1 cov[6n] 2 rgba[4n] 3 sh[stride*n] */
+ * fp32 exactly as the shaders would read it, in the caller's splat order.  which: 0 centres[3n] 1 cov[6n] 2 rgba[4n] 3 sh[stride*n] */
 int  mgs_scene_download_set(MgsScene scene, int instance_id, int which, float* dst, size_t count);
 
 /* ---- per-frame parameters: shaderio::FrameInfo (shaders/shaderio.h:238-317) as filled by

@@ -32,6 +32,22 @@ def scene_small():
     scene.close()
 
 
+def oracle_sorted_stream(ob, scene, sc, frame_kw, transforms=(None,)):
+    """oracle (key, id) stream with ties resolved in the library's documented order: STORAGE order
+    (mgs_scene_storage_order).  The oracle is fed the arrays in storage order and its ids are mapped
+    back to the caller's ids — keys and ids can then be compared bit for bit."""
+    n = sc["positions"].shape[0]
+    perm = scene.storage_order(0, n)                       # storage index -> caller's index
+    sc_p = {k: (v[perm] if v is not None else None) for k, v in sc.items()}
+    ps = ob.PreparedSet(sc_p)
+    inst = ob.make_instances([(ps, m) for m in transforms])
+    fr = ob.make_frame(**frame_kw)
+    ok, oi = ob.key_cull(fr, inst)
+    oks, ois = ob.sort_stable(ok, oi)
+    k = ois // n
+    return oks, (k * n + perm[ois % n]).astype(np.uint32)
+
+
 def camera(i, W, H, flip=False):
     eye = synth.orbit_pose(i)
     V, P = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, W, H, flip_y=flip)
@@ -102,16 +118,18 @@ def test_upload_transform_matches_oracle_bitwise(scene_small, ob):
 def test_depth_keys_cull_and_sort_bit_exact(scene_small, ob, pose, flip):
     scene, sc = scene_small
     p, V, P, eye = camera(pose, 640, 480, flip)
-    ps = ob.PreparedSet(sc)
-    inst = ob.make_instances([(ps, None)])
-    fr = ob.make_frame(V, P, eye, 640, 480)
-    ok, oi = ob.key_cull(fr, inst)
-    oks, ois = ob.sort_stable(ok, oi)
+    oks, ois = oracle_sorted_stream(ob, scene, sc, dict(view=V, proj=P, camera_pos=eye, width=640, height=480))
     so = scene.sort_keys(p)
     gk, gi = scene.sort_download(so.count)
-    assert so.count == ok.size
+    assert so.count == oks.size
     assert np.array_equal(gk, oks)   # encodeMinMaxFp32(-ndc.z) bit for bit
-    assert np.array_equal(gi, ois)   # same survivors, same stable order
+    assert np.array_equal(gi, ois)   # same survivors, same stable order (ties in storage order)
+    # and against the oracle's own (ascending caller id) tie order: identical up to the order inside tie runs
+    ps = ob.PreparedSet(sc)
+    k2, i2 = ob.sort_stable(*ob.key_cull(ob.make_frame(V, P, eye, 640, 480), ob.make_instances([(ps, None)])))
+    assert np.array_equal(k2, gk)
+    assert np.array_equal(np.lexsort((i2, k2)), np.lexsort((i2, k2))) and np.array_equal(
+        i2[np.lexsort((i2, k2))], gi[np.lexsort((gi, gk))])
 
 
 def test_cull_modes_and_dilation(scene_small, ob):
@@ -121,9 +139,8 @@ def test_cull_modes_and_dilation(scene_small, ob):
     for cull, dil in ((capi.CULL_NONE, 0.2), (capi.CULL_AT_DIST, 0.0), (capi.CULL_AT_DIST, 1.0)):
         p, V, P, eye = camera(9, 320, 240)
         p.frustum_culling, p.frustum_dilation = cull, dil
-        fr = ob.make_frame(V, P, eye, 320, 240, frustum_culling=cull, frustum_dilation=dil)
-        ok, oi = ob.key_cull(fr, inst)
-        oks, ois = ob.sort_stable(ok, oi)
+        oks, ois = oracle_sorted_stream(ob, scene, sc, dict(view=V, proj=P, camera_pos=eye, width=320, height=240,
+                                                            frustum_culling=cull, frustum_dilation=dil))
         so = scene.sort_keys(p)
         gk, gi = scene.sort_download(so.count)
         assert np.array_equal(gk, oks) and np.array_equal(gi, ois)
@@ -137,13 +154,15 @@ def test_frame_matches_oracle(scene_small, ob, pose, W, H):
     img = scene.download_frame(p).astype(np.float32)
     ps = ob.PreparedSet(sc)
     inst = ob.make_instances([(ps, None)])
-    oimg, st = ob.render(ob.make_frame(V, P, eye, W, H, target_fp16=1), inst)   # reference default: BTF, RGBA16F
+    # draw order = the oracle's sorted stream with ties in the library's storage order (see oracle_sorted_stream)
+    _, order = oracle_sorted_stream(ob, scene, sc, dict(view=V, proj=P, camera_pos=eye, width=W, height=H))
+    oimg, st = ob.render(ob.make_frame(V, P, eye, W, H, target_fp16=1), inst, order=order)   # reference default: BTF, RGBA16F
     assert out.error_flags == 0
     assert out.frustum_count == st["visible"]
     assert ob.psnr_rgb(img, oimg) >= PSNR_MIN
     assert np.abs(img[..., :3] - oimg[..., :3]).max() <= ABS_TOL
     # alpha: ours is 1-T (MGS_ALPHA_COVERAGE) == the reference's FTB alpha
-    fimg, _ = ob.render(ob.make_frame(V, P, eye, W, H, front_to_back=1), inst)
+    fimg, _ = ob.render(ob.make_frame(V, P, eye, W, H, front_to_back=1), inst, order=order[::-1].copy())
     assert np.abs(img[..., 3] - fimg[..., 3]).max() <= ABS_TOL
 
 
@@ -156,7 +175,8 @@ def test_alpha_sum_mode_and_fp32_target(scene_small, ob):
     assert img.dtype == np.float32
     ps = ob.PreparedSet(sc)
     inst = ob.make_instances([(ps, None)])
-    oimg, _ = ob.render(ob.make_frame(V, P, eye, 320, 240), inst)   # fp32 target, BTF: alpha = sum(alpha)
+    _, order = oracle_sorted_stream(ob, scene, sc, dict(view=V, proj=P, camera_pos=eye, width=320, height=240))
+    oimg, _ = ob.render(ob.make_frame(V, P, eye, 320, 240), inst, order=order)   # fp32 target, BTF: alpha = sum(alpha)
     assert ob.psnr_rgb(img, oimg) >= PSNR_MIN + 5
     big = np.maximum(oimg[..., 3], 1.0)
     assert (np.abs(img[..., 3] - oimg[..., 3]) / big).max() <= 2e-2
@@ -178,7 +198,8 @@ def test_storage_formats_match_oracle_with_same_quantisation(ob, shf, rgbaf, tol
     scene.render(p)
     img = scene.download_frame(p).astype(np.float32)
     inst = ob.make_instances([(ps, None)])
-    oimg, _ = ob.render(ob.make_frame(V, P, eye, 480, 360, target_fp16=1), inst)
+    _, order = oracle_sorted_stream(ob, scene, sc, dict(view=V, proj=P, camera_pos=eye, width=480, height=360))
+    oimg, _ = ob.render(ob.make_frame(V, P, eye, 480, 360, target_fp16=1), inst, order=order)
     assert ob.psnr_rgb(img, oimg) >= tol_db
     # idempotent commit, and re-commit in another format (--updateData)
     scene.commit(shf, rgbaf)
@@ -200,7 +221,12 @@ def test_multi_instance_unified_sort_and_golden_frame(ob):
     capi.set_camera(p, g["view"], g["proj"], g["eye"])
     so = scene.sort_keys(p)
     gk, gi = scene.sort_download(so.count)
-    assert np.array_equal(gi, g["sorted_ids"]) and np.array_equal(gk, g["sorted_keys"])
+    assert np.array_equal(gk, g["sorted_keys"])
+    # the fixture's ids carry the oracle's tie order (ascending id); ours is storage order: equal per tie run
+    assert np.array_equal(gi[np.lexsort((gi, gk))], g["sorted_ids"][np.lexsort((g["sorted_ids"], g["sorted_keys"]))])
+    oks, ois = oracle_sorted_stream(ob, scene, sc, dict(view=g["view"], proj=g["proj"], camera_pos=g["eye"], width=160,
+                                                        height=120), transforms=(None, g["transform1"]))
+    assert np.array_equal(gk, oks) and np.array_equal(gi, ois)
     scene.render(p)
     img = scene.download_frame(p).astype(np.float32)
     assert ob.psnr_rgb(img, g["image"].astype(np.float32)) >= PSNR_MIN
@@ -211,7 +237,9 @@ def test_multi_instance_unified_sort_and_golden_frame(ob):
     img2 = scene.download_frame(p).astype(np.float32)
     ps = ob.PreparedSet(sc)
     inst = ob.make_instances([(ps, None), (ps, M)])
-    oimg, _ = ob.render(ob.make_frame(g["view"], g["proj"], g["eye"], 160, 120, target_fp16=1), inst)
+    _, order = oracle_sorted_stream(ob, scene, sc, dict(view=g["view"], proj=g["proj"], camera_pos=g["eye"], width=160,
+                                                        height=120), transforms=(None, M))
+    oimg, _ = ob.render(ob.make_frame(g["view"], g["proj"], g["eye"], 160, 120, target_fp16=1), inst, order=order)
     assert ob.psnr_rgb(img2, oimg) >= PSNR_MIN
     scene.close()
 
@@ -317,7 +345,9 @@ def test_full_size_properties(n):
     assert np.all(keys[1:] >= keys[:-1])                                   # sorted
     assert np.unique(ids).size == ids.size and ids.max() < n              # a permutation of survivors
     same = keys[1:] == keys[:-1]
-    assert np.all(ids[1:][same] > ids[:-1][same])                         # ties in ascending id: stable
+    inv = np.empty(n, np.uint32); inv[scene.storage_order(0, n)] = np.arange(n, dtype=np.uint32)
+    st = inv[ids]
+    assert np.all(st[1:][same] > st[:-1][same])                           # ties in ascending STORAGE id: stable
     # survivors == fp64 restatement of the cull, up to borderline rounding
     pos = np.c_[sc["positions"].astype(np.float64), np.ones(n)]
     clip = pos @ (P.astype(np.float64) @ V.astype(np.float64)).T

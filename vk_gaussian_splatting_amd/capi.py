@@ -89,6 +89,7 @@ def load_library():
         "mgs_scene_commit": (C.c_int, [vp, C.c_int, C.c_int]),
         "mgs_scene_splat_count": (C.c_uint64, [vp]),
         "mgs_scene_download_set": (C.c_int, [vp, C.c_int, C.c_int, P(F), C.c_size_t]),
+        "mgs_scene_storage_order": (C.c_int, [vp, C.c_int, P(C.c_uint32), C.c_size_t]),
         "mgs_frame_params_default": (None, [P(FrameParams)]),
         "mgs_render": (C.c_int, [vp, P(FrameParams), P(FrameOut)]),
         "mgs_frame_stats": (C.c_int, [vp, P(FrameOut)]),
@@ -114,7 +115,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "mgs_last_error", "mgs_version", "mgs_splatset_load", "mgs_splatset_from_arrays", "mgs_splatset_view",
     "mgs_splatset_destroy", "mgs_scene_create", "mgs_scene_destroy", "mgs_scene_set_stream", "mgs_instance_add",
-    "mgs_instance_set_transform", "mgs_scene_commit", "mgs_scene_splat_count", "mgs_scene_download_set",
+    "mgs_instance_set_transform", "mgs_scene_commit", "mgs_scene_splat_count", "mgs_scene_storage_order", "mgs_scene_download_set",
     "mgs_frame_params_default", "mgs_render", "mgs_frame_stats", "mgs_timings_query", "mgs_frame_download", "mgs_frame_copy_strip",
     "mgs_sync", "mgs_sort_keys", "mgs_sort_download", "mgs_radix_sort_u32", "mgs_radix_sort_host",
     "mgs_camera_lookat_perspective", "mgs_compute_transform"]
@@ -260,6 +261,12 @@ class Scene:
     @property
     def splat_count(self):
         return int(self._lib.mgs_scene_splat_count(self._h))
+
+    def storage_order(self, instance, count):
+        """permutation storage index -> caller's index of the instance's splat set"""
+        out = np.zeros(count, np.uint32)
+        _check(self._lib.mgs_scene_storage_order(self._h, instance, out.ctypes.data_as(C.POINTER(C.c_uint32)), count))
+        return out
 
     def download_set(self, instance, which, count):
         out = np.zeros(count, np.float32)

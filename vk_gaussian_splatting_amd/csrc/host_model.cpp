@@ -736,6 +736,92 @@ void buildShInterleaved(const HostSplatSet& s, std::vector<float>& sh)
   });
 }
 
+// ---- Morton (Z-curve) storage order ------------------------------------------------------------------
+// Build-defined, no reference counterpart: the reference keeps file order.  Splats that are close in
+// space become close in memory, so a frustum (or a screen strip) keeps or drops whole 2048-splat
+// partitions and the survivors of a partition are dense in every cache line of the planar buffers.
+static inline uint64_t spread21(uint64_t v)
+{
+  v &= 0x1fffffull;
+  v = (v | (v << 32)) & 0x1f00000000ffffull;
+  v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+  v = (v | (v << 8)) & 0x100f00f00f00f00full;
+  v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+
+void mortonOrder(const HostSplatSet& s, const std::vector<float>* radius, std::vector<uint32_t>& newToOld)
+{
+  const size_t n = s.size();
+  newToOld.resize(n);
+  if(n == 0)
+    return;
+  // quantisation window: mean +- 4 sigma per axis (outliers clamp to the border cells)
+  double mean[3] = {0, 0, 0}, var[3] = {0, 0, 0};
+  for(size_t i = 0; i < n; ++i)
+    for(int a = 0; a < 3; ++a)
+      mean[a] += s.positions[3 * i + a];
+  for(int a = 0; a < 3; ++a)
+    mean[a] /= (double)n;
+  for(size_t i = 0; i < n; ++i)
+    for(int a = 0; a < 3; ++a)
+    {
+      const double d = s.positions[3 * i + a] - mean[a];
+      var[a] += d * d;
+    }
+  double lo[3], inv[3];
+  for(int a = 0; a < 3; ++a)
+  {
+    const double sd = std::sqrt(var[a] / (double)n) + 1e-12;
+    lo[a]           = mean[a] - 4.0 * sd;
+    inv[a]          = 1048575.0 / (8.0 * sd);  // 20 bits per axis, the top bits carry the size class
+  }
+  // size classes: octaves of the footprint radius around the median (16 classes in the top 4 code bits).
+  // Footprints are log-normally distributed over ~2 orders of magnitude; inside a class they differ by < 2x,
+  // so a partition's radius bound (and with it the strip-level culling) is tight for the small splats that
+  // make up the bulk of a scene.
+  float rRef = 0.f;
+  if(radius && radius->size() == n && n >= 16)
+  {
+    std::vector<float> tmp(*radius);
+    std::nth_element(tmp.begin(), tmp.begin() + n / 2, tmp.end());
+    rRef = tmp[n / 2];
+  }
+  struct Item
+  {
+    uint64_t code;
+    uint32_t idx;
+  };
+  std::vector<Item> items(n);
+  parallelBatches(n, [&](size_t i) {
+    uint64_t q[3];
+    for(int a = 0; a < 3; ++a)
+    {
+      double v = ((double)s.positions[3 * i + a] - lo[a]) * inv[a];
+      v        = std::isfinite(v) ? std::min(std::max(v, 0.0), 1048575.0) : 0.0;
+      q[a]     = (uint64_t)v;
+    }
+    uint64_t cls = 0;
+    if(radius && radius->size() == n)
+    {
+      const float r = (*radius)[i];
+      int         o = 8;
+      if(rRef > 0.f && r > 0.f && std::isfinite(r))
+        o = 8 + (int)std::floor(std::log2(r / rRef));
+      else if(!(r > 0.f))
+        o = 0;
+      else
+        o = 15;
+      cls = (uint64_t)std::min(std::max(o, 0), 15);
+    }
+    items[i].code = (cls << 60) | spread21(q[0]) | (spread21(q[1]) << 1) | (spread21(q[2]) << 2);
+    items[i].idx  = (uint32_t)i;
+  });
+  std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.code < b.code || (a.code == b.code && a.idx < b.idx); });
+  parallelBatches(n, [&](size_t i) { newToOld[i] = items[i].idx; });
+}
+
 uint8_t toUint8(float v, float lo, float hi)
 {
   const float t = (v - lo) / (hi - lo);

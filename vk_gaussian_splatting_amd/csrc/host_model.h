@@ -46,6 +46,12 @@ uint16_t floatToHalf(float f);
 float    halfToFloat(uint16_t h);
 uint8_t  toUint8(float v, float lo, float hi);  // src/splat_set_vk.cpp:85-89
 
+// spatially coherent storage order: permutation newToOld sorted by the 63-bit Morton code of the centre
+// `radius` (optional, one per splat): splats are first split into 16 size classes (octaves of the radius
+// around the median), then Morton-sorted inside each class, so that a partition's footprint bound is not
+// set by a few outliers.
+void mortonOrder(const HostSplatSet& s, const std::vector<float>* radius, std::vector<uint32_t>& newToOld);
+
 // parallel-for over [0,n) in batches of 8192 (START_PAR_LOOP, src/utilities.h:52-59)
 template <typename F>
 void parallelBatches(size_t n, F&& fn);

@@ -301,8 +301,14 @@ template <bool FULL, int SHF, int RGBAF>
 __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, FrameCounters* __restrict__ ctr,
                                                          uint32_t* __restrict__ keysSlot, uint32_t* __restrict__ idsSlot,
                                                          uint32_t* __restrict__ slotCount, SplatRec* __restrict__ rec,
-                                                         uint32_t* __restrict__ rect)
+                                                         uint32_t* __restrict__ rect, const uint32_t* __restrict__ partSkip)
 {
+  if(partSkip != nullptr && partSkip[blockIdx.x] != 0u)
+  {  // k_partition_cull proved that no splat of this partition can survive the cull / reach the strip
+    if(threadIdx.x == 0)
+      slotCount[blockIdx.x] = 0u;
+    return;
+  }
   __shared__ uint16_t s_li[kPrjPart];   // bit 15: survived phase 2
   __shared__ uint32_t s_key[kPrjPart];
   __shared__ uint32_t s_cnt[32];
@@ -445,16 +451,99 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, Fram
   }
 }
 
+// ---- partition-level culling ---------------------------------------------------------------------------
+// One thread per 2048-splat partition.  Storage order is Morton order, so a partition is a compact
+// cell of space; its 8 AABB corners go through the same P*V*M.  The per-splat test of dist.comp.slang
+// (:71-73) culls on ndc = clip/w; for points with w > 0 every one of its conditions is LINEAR in the
+// point (x > c*w, -x > c*w, ..., z > w, z < -d*w), so if all 8 corners satisfy the same condition every
+// centre inside the box does too.  Margins make the test conservative against fp32 rounding: a
+// partition is skipped only if every splat in it would certainly be culled.  For strips the footprint
+// of a splat of the partition is bounded by R = s*(k*fmax*S*rmax/zmin + 3.2) + 1 px (derivation in
+// DESIGN.md §3.1), and the partition is skipped when [ymin-R, ymax+R] misses the strip's pixel rows.
+__global__ __launch_bounds__(256) void k_partition_cull(const FrameArgs A, uint32_t* __restrict__ partSkip)
+{
+  const uint32_t part = blockIdx.x * blockDim.x + threadIdx.x;
+  if(part >= A.f.totalPartitions)
+    return;
+  int k = 0;
+#pragma unroll
+  for(int i = 1; i < kMaxInlineInstances; ++i)
+    if(i < A.f.nInstances && part >= A.inst[i].blockBegin)
+      k = i;
+  const InstanceConst& I  = A.inst[k];
+  const float*         bx = I.partBox + 8 * (size_t)(part - I.blockBegin);
+  uint32_t             skip = 0;
+  if(bx[7] == 0.0f)
+  {
+    const float c = 1.0f + A.f.frustumDilation, dl = A.f.frustumDilation;
+    const float m = 1.0e-3f;  // relative safety margin
+    bool  allWpos = true;
+    bool  outXp = true, outXn = true, outYp = true, outYn = true, outZf = true, outZn = true;
+    float ymin = 3.4e38f, ymax = -3.4e38f, zvmin = 3.4e38f, rx = 0.f, ry = 0.f;
+    for(int q = 0; q < 8; ++q)
+    {
+      const float x = bx[(q & 1) ? 3 : 0], y = bx[(q & 2) ? 4 : 1], z = bx[(q & 4) ? 5 : 2];
+      const float* MV = I.modelView;
+      const float  tx = MV[0] * x + MV[4] * y + MV[8] * z + MV[12];
+      const float  ty = MV[1] * x + MV[5] * y + MV[9] * z + MV[13];
+      const float  tz = MV[2] * x + MV[6] * y + MV[10] * z + MV[14];
+      const float  tw = MV[3] * x + MV[7] * y + MV[11] * z + MV[15];
+      const float* P  = A.f.proj;
+      const float  cx = P[0] * tx + P[4] * ty + P[8] * tz + P[12] * tw;
+      const float  cy = P[1] * tx + P[5] * ty + P[9] * tz + P[13] * tw;
+      const float  cz = P[2] * tx + P[6] * ty + P[10] * tz + P[14] * tw;
+      const float  cw = P[3] * tx + P[7] * ty + P[11] * tz + P[15] * tw;
+      const float  aw = fabsf(cw), tol = m * (aw + fabsf(cx) + fabsf(cy) + fabsf(cz)) + 1e-6f;
+      allWpos = allWpos && (cw > tol);
+      outXp   = outXp && (cx > c * cw + tol);
+      outXn   = outXn && (-cx > c * cw + tol);
+      outYp   = outYp && (cy > c * cw + tol);
+      outYn   = outYn && (-cy > c * cw + tol);
+      outZf   = outZf && (cz > cw + tol);
+      outZn   = outZn && (cz < -dl * cw - tol);
+      const float yp = (cy / cw + 1.0f) * 0.5f * (float)A.f.height;
+      ymin  = fminf(ymin, yp);
+      ymax  = fmaxf(ymax, yp);
+      zvmin = fminf(zvmin, -tz);  // view depth (camera looks down -z)
+      rx    = fmaxf(rx, fabsf(tx / tz));
+      ry    = fmaxf(ry, fabsf(ty / tz));
+    }
+    if(allWpos && (outXp || outXn || outYp || outYn || outZf || outZn))
+      skip = 1;
+    const bool strip = (A.f.stripRow1 - A.f.stripRow0) < A.f.tilesY;
+    if(!skip && strip && allWpos && zvmin > 1e-4f)
+    {
+      const float S    = I.modelScale;  // largest singular value of the model 3x3 (host, per frame)
+      const float fmx  = fmaxf(fabsf(A.f.focal[0]), fabsf(A.f.focal[1]));
+      const float kk   = sqrtf(2.0f + rx * rx + ry * ry);
+      float       R    = A.f.splatScale * (kk * fmx * S * bx[6] / zvmin + 3.2f);
+      R                = fminf(R, 2897.0f * A.f.splatScale) * 1.01f + 2.0f;  // both bases are clamped at 2048 px
+      const float y0   = (float)(A.f.stripRow0 * kTilePx), y1 = (float)(min(A.f.stripRow1 * kTilePx, A.f.height));
+      if(ymax + R < y0 || ymin - R > y1)
+        skip = 1;
+    }
+  }
+  partSkip[part] = skip;
+}
+
+void launchPartitionCull(hipStream_t stream, const FrameArgs& args, uint32_t* partSkip)
+{
+  if(args.f.totalPartitions == 0)
+    return;
+  hipLaunchKernelGGL(k_partition_cull, dim3((args.f.totalPartitions + 255) / 256), dim3(256), 0, stream, args, partSkip);
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-callable launcher
 void launchProject(hipStream_t stream, const FrameArgs& args, bool full, int shFormat, int rgbaFormat, FrameCounters* ctr,
-                   uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, SplatRec* rec, uint32_t* rect)
+                   uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, SplatRec* rec, uint32_t* rect,
+                   const uint32_t* partSkip)
 {
   const dim3 grid(args.f.totalPartitions), block(kPrjThreads);
   if(args.f.totalPartitions == 0)
     return;
 #define MGS_LAUNCH(FULLV, S, R)                                                                                          \
-  hipLaunchKernelGGL((k_project<FULLV, S, R>), grid, block, 0, stream, args, ctr, keysSlot, idsSlot, slotCount, rec, rect)
+  hipLaunchKernelGGL((k_project<FULLV, S, R>), grid, block, 0, stream, args, ctr, keysSlot, idsSlot, slotCount, rec, rect, partSkip)
   if(!full)
   {
     MGS_LAUNCH(false, 0, 0);

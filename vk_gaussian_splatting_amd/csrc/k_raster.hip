@@ -56,7 +56,8 @@ constexpr int kChunk = 2048;  // output records per expand workgroup
 
 __global__ __launch_bounds__(kBinThreads) void k_bin_count(const uint32_t* __restrict__ idsX, const uint32_t* __restrict__ idsY,
                                                            const SortPlan* __restrict__ plan, const uint32_t* __restrict__ rect,
-                                                           uint32_t* __restrict__ sortedRect, uint32_t* __restrict__ blockCount)
+                                                           uint32_t* __restrict__ sortedRect, uint32_t* __restrict__ blockCount,
+                                                           int gather)
 {
   __shared__ uint32_t s_tmp[4];
   const uint32_t      n     = plan->n;
@@ -71,8 +72,14 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(const uint32_t* __res
     const uint32_t e = blockIdx.x * kBinPart + i * kBinThreads + threadIdx.x;
     if(e < n)
     {
-      const uint32_t r = rect[ids[e]];
-      sortedRect[e]    = r;
+      uint32_t r;
+      if(gather)  // CPU-sort mode: nothing has produced sortedRect yet
+      {
+        r             = rect[ids[e]];
+        sortedRect[e] = r;
+      }
+      else  // GPU sort: the last radix pass wrote the rects in sorted order (fused gather)
+        r = sortedRect[e];
       sum += rectTiles(r);
     }
   }
@@ -506,12 +513,12 @@ void launchFrameInit(hipStream_t stream, FrameCounters* ctr, SortPlan* planKeys,
 void launchBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
                    const uint32_t* rect, uint32_t* blockCount, uint32_t maxBlocks, FrameCounters* ctr, uint32_t* sortedRect,
                    uint32_t* splatOffset, uint32_t* chunkStart, uint32_t* pairKey, uint32_t* pairVal, uint32_t capacity,
-                   int binsX)
+                   int binsX, bool gatherRects)
 {
   if(maxBlocks == 0)
     return;
   hipLaunchKernelGGL(k_bin_count, dim3(maxBlocks), dim3(kBinThreads), 0, stream, idsX, idsY, planKeys, rect, sortedRect,
-                     blockCount);
+                     blockCount, gatherRects ? 1 : 0);
   hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(256), 0, stream, planKeys, blockCount, ctr, capacity);
   const uint32_t chunks = (capacity + kChunk - 1) / kChunk;
   hipLaunchKernelGGL(k_bin_offsets, dim3(maxBlocks), dim3(kBinThreads), 0, stream, planKeys, sortedRect, blockCount,

@@ -14,6 +14,8 @@
 //     fuses the stream compaction into the sort.
 //   * a pass whose digit is identical for every key (the top byte of a depth key, typically) is
 //     skipped on the device; the ping-pong selection lives in a device-side plan.
+#include <cstdlib>
+
 #include "kernels_common.h"
 #include "sort_plan.h"
 
@@ -21,12 +23,10 @@ namespace mgs {
 
 constexpr int kSlotPart = 2048;  // slotted pass-0 partitions == the project kernel's partitions
 
-// partition p: [p*part, p*part+count)
-__device__ __forceinline__ uint32_t partitionCount(bool slotted, const uint32_t* slotCount, uint32_t n, uint32_t p,
-                                                   uint32_t part)
+// Uniform partition p covers [p*part, p*part+count).  A slotted partition covers part/2048 consecutive
+// slots of the project kernel (each a 2048-entry region holding slotCount[slot] compacted survivors).
+__device__ __forceinline__ uint32_t partitionCount(const uint32_t* slotCount, uint32_t n, uint32_t p, uint32_t part)
 {
-  if(slotted)
-    return slotCount[p];
   const uint64_t base = (uint64_t)p * part;
   return (n > base) ? (uint32_t)min((uint64_t)part, (uint64_t)n - base) : 0u;
 }
@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ 
   if(!FIRST && plan->skip[pass])
     return;
   const uint32_t* keys  = FIRST ? keys0 : (plan->srcSel[pass] ? keysY : keysX);
-  const uint32_t  parts = slotted ? partsSlotted : (uint32_t)(((uint64_t)n + part - 1) / part);
+  const uint32_t  parts = slotted ? (partsSlotted + part / kSlotPart - 1) / (part / kSlotPart)
+                                  : (uint32_t)(((uint64_t)n + part - 1) / part);
   const int       shift = beginBit + 8 * pass;
   if(FIRST)
   {
@@ -74,23 +75,39 @@ __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ 
     for(int q = 0; q < 4; ++q)
       s_g[q][t] = 0;
   }
+  const uint32_t spp = part / kSlotPart;  // slots per slotted partition
   for(uint32_t p = blockIdx.x; p < parts; p += gridDim.x)
   {
     s_h[t] = 0;
     __syncthreads();
-    const uint32_t  count = partitionCount(slotted, slotCount, n, p, part);
-    const uint32_t* src   = keys + (size_t)p * part;
-    const uint32_t  iters = (count + 255u) >> 8;
-    for(uint32_t it = 0; it < iters; ++it)
+    const uint32_t nseg = slotted ? spp : 1u;
+    for(uint32_t sg = 0; sg < nseg; ++sg)
     {
-      const uint32_t i   = it * 256u + t;
-      const bool     in  = i < count;
-      const uint32_t key = in ? src[i] : 0u;
-      histAddRuns(s_h, (key >> shift) & 255u, in);
-      if(FIRST)
+      uint32_t        count;
+      const uint32_t* src;
+      if(slotted)
       {
-        for(int q = 1; q < nPasses; ++q)
-          histAddRuns(s_g[q], (key >> (shift + 8 * q)) & 255u, in);
+        const uint32_t slot = p * spp + sg;
+        count               = slot < partsSlotted ? slotCount[slot] : 0u;
+        src                 = keys + (size_t)slot * kSlotPart;
+      }
+      else
+      {
+        count = partitionCount(nullptr, n, p, part);
+        src   = keys + (size_t)p * part;
+      }
+      const uint32_t iters = (count + 255u) >> 8;
+      for(uint32_t it = 0; it < iters; ++it)
+      {
+        const uint32_t i   = it * 256u + t;
+        const bool     in  = i < count;
+        const uint32_t key = in ? src[i] : 0u;
+        histAddRuns(s_h, (key >> shift) & 255u, in);
+        if(FIRST)
+        {
+          for(int q = 1; q < nPasses; ++q)
+            histAddRuns(s_g[q], (key >> (shift + 8 * q)) & 255u, in);
+        }
       }
     }
     __syncthreads();
@@ -124,7 +141,7 @@ __global__ __launch_bounds__(256) void k_sort_plan(SortPlan* __restrict__ plan, 
   if(t == 0)
   {
     uint32_t cur = 0;  // after pass 0 the data is in X (sel 0)
-    uint32_t run = 1;
+    uint32_t run = 1, last = 0;
     plan->skip[0]   = 0;
     plan->srcSel[0] = 0;
     for(int q = 1; q < nPasses; ++q)
@@ -135,10 +152,12 @@ __global__ __launch_bounds__(256) void k_sort_plan(SortPlan* __restrict__ plan, 
       {
         cur ^= 1u;
         ++run;
+        last = (uint32_t)q;
       }
     }
     plan->finalSel  = cur;
     plan->passesRun = run;
+    plan->lastPass  = last;
     plan->n         = n;
   }
 }
@@ -156,7 +175,8 @@ __global__ __launch_bounds__(256) void k_sort_scan(const uint32_t* __restrict__ 
     return;
   const uint32_t n       = *nPtr;
   const bool     slotted = (pass == 0) && (slotCount != nullptr);
-  const uint32_t parts   = slotted ? partsSlotted : (uint32_t)(((uint64_t)n + part - 1) / part);
+  const uint32_t parts   = slotted ? (partsSlotted + part / kSlotPart - 1) / (part / kSlotPart)
+                                   : (uint32_t)(((uint64_t)n + part - 1) / part);
   uint32_t       total;
   const uint32_t below = (t < d) ? plan->ghist[pass][t] : 0u;
   (void)blockExclusiveScan256(below, s_tmp, &total);
@@ -210,9 +230,11 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
                                                           const uint32_t* __restrict__ slotCount, const uint32_t* __restrict__ nPtr,
                                                           uint32_t partsSlotted, const SortPlan* __restrict__ plan,
                                                           const uint32_t* __restrict__ partHist, uint32_t pStride, int pass,
-                                                          int beginBit)
+                                                          int beginBit, const uint32_t* __restrict__ gatherSrc,
+                                                          uint32_t* __restrict__ gatherDst)
 {
   constexpr int PART  = THREADS * KPT;
+  constexpr int SPP   = PART / kSlotPart;  // slots per slotted partition
   constexpr int WAVES = THREADS / 64;
   __shared__ uint32_t s_whist[WAVES][256];
   __shared__ uint32_t s_k[PART];
@@ -226,11 +248,23 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
     return;
   const bool     slotted = FIRST && (slotCount != nullptr);
   const uint32_t n       = *nPtr;
-  const uint32_t parts   = slotted ? partsSlotted : (uint32_t)(((uint64_t)n + PART - 1) / PART);
+  const uint32_t parts   = slotted ? (partsSlotted + SPP - 1) / SPP : (uint32_t)(((uint64_t)n + PART - 1) / PART);
   const uint32_t p       = blockIdx.x;
   if(p >= parts)
     return;
-  const uint32_t count = partitionCount(slotted, slotCount, n, p, PART);
+  // slotted: prefix of the SPP slot counts -> compact index inside the partition maps to (slot, offset)
+  uint32_t pre[SPP + 1];
+  pre[0] = 0;
+  if(slotted)
+  {
+#pragma unroll
+    for(int q = 0; q < SPP; ++q)
+    {
+      const uint32_t slot = p * SPP + q;
+      pre[q + 1]          = pre[q] + (slot < partsSlotted ? slotCount[slot] : 0u);
+    }
+  }
+  const uint32_t count = slotted ? pre[SPP] : partitionCount(nullptr, n, p, PART);
   const uint32_t *kin, *vin;
   uint32_t *      kout, *vout;
   if(FIRST)
@@ -262,15 +296,27 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
   // wave-striped load: wave w owns keys [w*64*KPT, (w+1)*64*KPT) of the partition, lane-interleaved, so
   // (round i, lane) order == memory order inside the wave, and waves are in memory order too.
   const uint32_t wofs = w * (64 * KPT);
-  const size_t   base = (size_t)p * PART + wofs;
   uint32_t       key[KPT], val[KPT];
 #pragma unroll
   for(int i = 0; i < KPT; ++i)
   {
     const uint32_t idx = wofs + i * 64 + lane;
     const bool     in  = idx < count;
-    key[i]             = in ? kin[base + i * 64 + lane] : 0xFFFFFFFFu;
-    val[i]             = in ? vin[base + i * 64 + lane] : 0u;
+    size_t         src = (size_t)p * PART + idx;
+    if(slotted)
+    {
+      uint32_t q = 0;
+#pragma unroll
+      for(int z = 1; z < SPP; ++z)
+        q += (idx >= pre[z]) ? 1u : 0u;
+      uint32_t pq = pre[0];
+#pragma unroll
+      for(int z = 1; z < SPP; ++z)
+        pq = (q >= (uint32_t)z) ? pre[z] : pq;
+      src = ((size_t)p * SPP + q) * kSlotPart + (idx - pq);
+    }
+    key[i] = in ? kin[src] : 0xFFFFFFFFu;
+    val[i] = in ? vin[src] : 0u;
   }
   __syncthreads();
 
@@ -333,7 +379,11 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
   }
   __syncthreads();
 
-  // coalesced scatter: consecutive threads write consecutive addresses inside each digit run
+  // coalesced scatter: consecutive threads write consecutive addresses inside each digit run.
+  // On the LAST executed pass the caller may ask for a fused gather: gatherDst[dst] = gatherSrc[value]
+  // (the binning stage needs the splat's bin rect in sorted order; doing the random 4-byte gather here
+  // overlaps it with the scatter instead of paying a separate latency-bound kernel).
+  const bool fuse = gatherSrc != nullptr && (uint32_t)pass == plan->lastPass;
 #pragma unroll
   for(int i = 0; i < KPT; ++i)
   {
@@ -341,10 +391,13 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
     if(idx < count)
     {
       const uint32_t k   = s_k[idx];
+      const uint32_t v   = s_v[idx];
       const uint32_t d   = (k >> shift) & 255u;
       const uint32_t dst = s_gbase[d] + idx;
       kout[dst]          = k;
-      vout[dst]          = s_v[idx];
+      vout[dst]          = v;
+      if(fuse)
+        gatherDst[dst] = gatherSrc[v];
     }
   }
 }
@@ -371,11 +424,15 @@ void launchRadixSort(hipStream_t stream, const SortLaunch& s)
     return;
   const bool     slotted = s.slotCount != nullptr;
   // big sorts use 8192-key partitions (digit runs of ~32 keys = 128-byte scatter segments, 4x shorter
-  // partition tables); small ones keep 2048 so that 256 CUs still see enough workgroups
-  const uint32_t bigPart = (s.maxElems >= (2u << 20)) ? 8192u : 2048u;
-  auto           partOf  = [&](int pass) { return (pass == 0 && slotted) ? (uint32_t)kSlotPart : bigPart; };
-  auto           partsOf = [&](int pass) {
-    return (pass == 0 && slotted) ? s.partsSlotted : (uint32_t)(((uint64_t)s.maxElems + partOf(pass) - 1) / partOf(pass));
+  // partition tables); small ones keep 2048 so that 256 CUs still see enough workgroups.  A slotted pass 0
+  // takes part/2048 of the project kernel's slots per partition.
+  const uint32_t part    = (s.maxElems >= (2u << 20)) ? 8192u : 2048u;
+  static const uint32_t kSlotPartOverride = [] { const char* e = std::getenv("MGS_SLOT_PART"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+  auto partOf  = [&](int pass) { return (pass == 0 && slotted && kSlotPartOverride) ? kSlotPartOverride : part; };
+  auto partsOf = [&](int pass) {
+    const uint32_t pp = partOf(pass);
+    return (pass == 0 && slotted) ? (s.partsSlotted + pp / 2048u - 1) / (pp / 2048u)
+                                  : (uint32_t)(((uint64_t)s.maxElems + pp - 1) / pp);
   };
   const uint32_t p0      = partsOf(0);
   // few, fat workgroups: each flushes up to nPasses*256 global atomics once (profiles/r1_b: 2048 groups cost 39 us)
@@ -385,25 +442,26 @@ void launchRadixSort(hipStream_t stream, const SortLaunch& s)
   hipLaunchKernelGGL(k_sort_plan, dim3(1), dim3(256), 0, stream, s.plan, s.nPtr, nPasses);
   for(int pass = 0; pass < nPasses; ++pass)
   {
-    const uint32_t part = partOf(pass), parts = partsOf(pass);
+    const uint32_t parts = partsOf(pass), pp = partOf(pass);
     if(pass > 0)
       hipLaunchKernelGGL((k_sort_hist<false>), dim3(parts), dim3(256), 0, stream, s.keysX, s.keysY, s.keys0,
-                         (const uint32_t*)nullptr, s.nPtr, 0u, s.plan, s.partHist, s.pStride, pass, s.beginBit, nPasses, part);
+                         (const uint32_t*)nullptr, s.nPtr, 0u, s.plan, s.partHist, s.pStride, pass, s.beginBit, nPasses, pp);
     hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, stream, s.nPtr, pass == 0 ? s.slotCount : nullptr,
-                       s.partsSlotted, s.plan, s.partHist, s.pStride, pass, part);
+                       s.partsSlotted, s.plan, s.partHist, s.pStride, pass, pp);
 #define MGS_SCATTER(FIRSTV, TH, KP, SLOTS)                                                                                  \
   hipLaunchKernelGGL((k_sort_scatter<FIRSTV, TH, KP>), dim3(parts), dim3(TH), 0, stream, s.keys0, s.vals0, s.keysX, s.valsX, \
-                     s.keysY, s.valsY, SLOTS, s.nPtr, s.partsSlotted, s.plan, s.partHist, s.pStride, pass, s.beginBit)
+                     s.keysY, s.valsY, SLOTS, s.nPtr, s.partsSlotted, s.plan, s.partHist, s.pStride, pass, s.beginBit,      \
+                     s.gatherSrc, s.gatherDst)
     if(pass == 0)
     {
-      if(part == 2048u)
+      if(pp == 2048u)
         MGS_SCATTER(true, 256, 8, s.slotCount);
       else
         MGS_SCATTER(true, 512, 16, s.slotCount);
     }
     else
     {
-      if(part == 2048u)
+      if(pp == 2048u)
         MGS_SCATTER(false, 256, 8, (const uint32_t*)nullptr);
       else
         MGS_SCATTER(false, 512, 16, (const uint32_t*)nullptr);

@@ -28,13 +28,15 @@
 namespace mgs {
 // kernels_*.hip
 void launchProject(hipStream_t stream, const FrameArgs& args, bool full, int shFormat, int rgbaFormat, FrameCounters* ctr,
-                   uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, SplatRec* rec, uint32_t* rect);
+                   uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, SplatRec* rec, uint32_t* rect,
+                   const uint32_t* partSkip);
+void launchPartitionCull(hipStream_t stream, const FrameArgs& args, uint32_t* partSkip);
 void launchFrameInit(hipStream_t stream, FrameCounters* ctr, SortPlan* planKeys, SortPlan* planPairs, uint2* ranges,
                      uint32_t nTiles);
 void launchBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
                    const uint32_t* rect, uint32_t* blockCount, uint32_t maxBlocks, FrameCounters* ctr, uint32_t* sortedRect,
                    uint32_t* splatOffset, uint32_t* chunkStart, uint32_t* pairKey, uint32_t* pairVal, uint32_t capacity,
-                   int tilesX);
+                   int binsX, bool gatherRects);
 void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* keyY, const SortPlan* planPairs,
                       uint2* ranges);
 void launchComposite(hipStream_t stream, const FrameConst& F, const uint2* ranges, const uint32_t* valX,
@@ -73,6 +75,8 @@ struct DeviceSet
   int      shDegree = 0, shStride = 0;  // logical elements per splat (0/9/24/45)
   int      shPitch = 0;                  // stored elements per splat: shStride padded to a 16-byte multiple
   int      shFormat = -1, rgbaFormat = -1;
+  float*   partBox = nullptr;              // [ceil(count/2048)][8]: AABB of the centres + footprint radius bound
+  std::vector<uint32_t> newToOld, oldToNew;  // storage order (Morton) <-> caller's order
 };
 
 struct Instance
@@ -222,7 +226,7 @@ struct MgsScene_t
 
   // frame buffers
   DevBuf<uint32_t>      keysSlot, idsSlot, slotCount, keysA, idsA, keysB, idsB, rect, partHist, blockCount;
-  DevBuf<uint32_t>      sortedRect, splatOffset, chunkStart;
+  DevBuf<uint32_t>      sortedRect, splatOffset, chunkStart, partSkip;
   DevBuf<SplatRec>      rec;
   DevBuf<uint32_t>      pairKey0, pairVal0, pairKey1, pairVal1;
   DevBuf<uint2>         ranges;
@@ -248,7 +252,8 @@ struct MgsScene_t
   MgsSortOut     lastSort{};
 
   CpuSorter             cpu;
-  std::vector<uint32_t> cpuIndices;  // consumed result
+  std::vector<uint32_t> cpuIndices;  // consumed result (caller's id space)
+  std::vector<uint32_t> cpuStorageIds;
   bool                  cpuHaveIndices = false;
   DevBuf<float>         cpuDistDev;
 };
@@ -405,7 +410,8 @@ static void freeSet(DeviceSet& d)
   if(d.cov6) (void)hipFree(d.cov6);
   if(d.rgba) (void)hipFree(d.rgba);
   if(d.sh) (void)hipFree(d.sh);
-  d.centers = d.cov6 = nullptr;
+  if(d.partBox) (void)hipFree(d.partBox);
+  d.centers = d.cov6 = d.partBox = nullptr;
   d.rgba = d.sh = nullptr;
 }
 
@@ -421,7 +427,7 @@ void mgs_scene_destroy(MgsScene s)
   s->keysSlot.release(); s->idsSlot.release(); s->slotCount.release(); s->keysA.release(); s->idsA.release();
   s->keysB.release(); s->idsB.release(); s->rect.release(); s->partHist.release(); s->blockCount.release();
   s->rec.release(); s->pairKey0.release(); s->pairVal0.release(); s->pairKey1.release(); s->pairVal1.release();
-  s->sortedRect.release(); s->splatOffset.release(); s->chunkStart.release();
+  s->sortedRect.release(); s->splatOffset.release(); s->chunkStart.release(); s->partSkip.release();
   s->ranges.release(); s->image.release(); s->ctr.release(); s->plans.release(); s->cpuDistDev.release();
   if(s->hCtr) (void)hipHostFree(s->hCtr);
   if(s->hPlans) (void)hipHostFree(s->hPlans);
@@ -575,24 +581,82 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
     d.count               = (uint32_t)n;
     d.shDegree            = std::max(0, h.maxShDegree());
     d.shStride            = shStride(h.fRestPerSplat());
-    // a4: SplatSetVk::initDataBuffers (src/splat_set_vk.cpp:188-480), host loops like the reference
-    HIPCHK(hipMalloc((void**)&d.centers, n * 3 * sizeof(float)));
-    HIPCHK(hipMemcpy(d.centers, h.positions.data(), n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    // storage order: Morton order of the centres (MGS_REORDER=0 keeps the caller's order).  Global ids
+    // used inside the pipeline are STORAGE ids; the API maps them back (mgs_sort_download,
+    // mgs_scene_download_set, mgs_scene_storage_order).  Ties between equal depth keys resolve in
+    // storage order — the reference's tie order is nondeterministic (dist.comp.slang:137-139).
+    static const bool kReorder = [] { const char* e = std::getenv("MGS_REORDER"); return e ? std::atoi(e) != 0 : true; }();
+    std::vector<float> cov;
+    buildCov6(h, cov);
+    if(kReorder)
     {
-      std::vector<float> cov, planar(n * 6);
-      buildCov6(h, cov);
+      std::vector<float> radius(n);
+      parallelBatches(n, [&](size_t i) { radius[i] = std::sqrt(8.0f * (cov[6 * i] + cov[6 * i + 3] + cov[6 * i + 5])); });
+      mortonOrder(h, &radius, d.newToOld);
+    }
+    else
+    {
+      d.newToOld.resize(n);
+      for(size_t i = 0; i < n; ++i)
+        d.newToOld[i] = (uint32_t)i;
+    }
+    d.oldToNew.resize(n);
+    parallelBatches(n, [&](size_t i) { d.oldToNew[d.newToOld[i]] = (uint32_t)i; });
+    const uint32_t* perm = d.newToOld.data();
+    // a4: SplatSetVk::initDataBuffers (src/splat_set_vk.cpp:188-480), host loops like the reference
+    {
+      std::vector<float> pos(n * 3);
+      parallelBatches(n, [&](size_t i) { std::memcpy(&pos[3 * i], &h.positions[3 * (size_t)perm[i]], 12); });
+      HIPCHK(hipMalloc((void**)&d.centers, n * 3 * sizeof(float)));
+      HIPCHK(hipMemcpy(d.centers, pos.data(), n * 3 * sizeof(float), hipMemcpyHostToDevice));
+      // per-partition bounds (model space): AABB of the centres and rmax = sqrt(8 * max trace(Sigma3D)),
+      // an upper bound of the sqrt(8)-sigma footprint radius of any splat of the partition
+      const size_t       np = (n + kPart - 1) / kPart;
+      std::vector<float> box(np * 8);
+      parallelBatches(np, [&](size_t pIdx) {
+        float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f}, tr = 0.f;
+        bool  bad = false;
+        for(size_t i = pIdx * kPart; i < std::min(n, (pIdx + 1) * kPart); ++i)
+        {
+          for(int a = 0; a < 3; ++a)
+          {
+            const float v = pos[3 * i + a];
+            if(!std::isfinite(v)) bad = true;
+            mn[a] = std::min(mn[a], v);
+            mx[a] = std::max(mx[a], v);
+          }
+          const float* c = &cov[6 * (size_t)perm[i]];
+          const float  t = c[0] + c[3] + c[5];
+          if(!std::isfinite(t)) bad = true;
+          tr = std::max(tr, t);
+        }
+        float* b = &box[8 * pIdx];
+        for(int a = 0; a < 3; ++a)
+        {
+          b[a]     = mn[a];
+          b[3 + a] = mx[a];
+        }
+        b[6] = std::sqrt(8.0f * tr);
+        b[7] = bad ? 1.0f : 0.0f;  // non-finite data: never cull this partition
+      });
+      HIPCHK(hipMalloc((void**)&d.partBox, np * 8 * sizeof(float)));
+      HIPCHK(hipMemcpy(d.partBox, box.data(), np * 8 * sizeof(float), hipMemcpyHostToDevice));
+    }
+    {
+      std::vector<float> planar(n * 6);
       // HBM layout: float4 covA[n] = (S00,S01,S02,S11) followed by float2 covB[n] = (S12,S22)
       parallelBatches(n, [&](size_t i) {
-        std::memcpy(&planar[4 * i], &cov[6 * i], 16);
-        std::memcpy(&planar[4 * n + 2 * i], &cov[6 * i + 4], 8);
+        std::memcpy(&planar[4 * i], &cov[6 * (size_t)perm[i]], 16);
+        std::memcpy(&planar[4 * n + 2 * i], &cov[6 * (size_t)perm[i] + 4], 8);
       });
       HIPCHK(hipMalloc((void**)&d.cov6, n * 6 * sizeof(float)));
       HIPCHK(hipMemcpy(d.cov6, planar.data(), n * 6 * sizeof(float), hipMemcpyHostToDevice));
     }
     {
-      std::vector<float> rgba;
+      std::vector<float> rgba, re(n * 4);
       buildRgba(h, rgba);
-      int rc = uploadFormatted(rgba, rgbaFormat, false, &d.rgba);
+      parallelBatches(n, [&](size_t i) { std::memcpy(&re[4 * i], &rgba[4 * (size_t)perm[i]], 16); });
+      int rc = uploadFormatted(re, rgbaFormat, false, &d.rgba);
       if(rc != MGS_OK)
         return rc;
     }
@@ -602,14 +666,14 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
       buildShInterleaved(h, sh);
       const int per = shFormat == MGS_FORMAT_FLOAT32 ? 4 : shFormat == MGS_FORMAT_FLOAT16 ? 8 : 16;
       d.shPitch     = (d.shStride + per - 1) / per * per;
-      // vector-planar: element k of splat i lives in plane k/per at [plane][i][k%per]
+      // vector-planar: element k of (storage) splat i lives in plane k/per at [plane][i][k%per]
       padded.assign(n * (size_t)d.shPitch, 0.f);
-      const int stride = d.shStride, pitch = d.shPitch;
+      const int stride = d.shStride;
       parallelBatches(n, [&](size_t i) {
+        const float* src = &sh[(size_t)perm[i] * (size_t)stride];
         for(int k = 0; k < stride; ++k)
-          padded[((size_t)(k / per) * n + i) * per + (k % per)] = sh[i * (size_t)stride + k];
+          padded[((size_t)(k / per) * n + i) * per + (k % per)] = src[k];
       });
-      (void)pitch;
       int rc = uploadFormatted(padded, shFormat, true, &d.sh);
       if(rc != MGS_OK)
         return rc;
@@ -637,6 +701,8 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
   if((rc = s->keysSlot.ensure(slots))) return rc;
   if((rc = s->idsSlot.ensure(slots))) return rc;
   if((rc = s->slotCount.ensure(parts))) return rc;
+  if((rc = s->partSkip.ensure(parts))) return rc;
+  HIPCHK(hipMemset(s->partSkip.p, 0, parts * sizeof(uint32_t)));
   if((rc = s->keysA.ensure(total))) return rc;
   if((rc = s->idsA.ensure(total))) return rc;
   if((rc = s->keysB.ensure(total))) return rc;
@@ -666,6 +732,28 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
   HIPCHK(hipMemset(s->plans.p, 0, 2 * sizeof(SortPlan)));
   s->committed = true;
   s->haveFrame = false;
+  return MGS_OK;
+}
+
+int mgs_scene_storage_order(MgsScene s, int instance, uint32_t* newToOld, size_t count)
+{
+  if(!s || !newToOld || instance < 0 || instance >= (int)s->instances.size())
+  {
+    setError("mgs_scene_storage_order: bad argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(!s->committed)
+  {
+    setError("mgs_scene_storage_order: scene not committed");
+    return MGS_ERR_STATE;
+  }
+  const DeviceSet& d = s->sets[s->instances[instance].set];
+  if(count < d.count)
+  {
+    setError("mgs_scene_storage_order: destination too small");
+    return MGS_ERR_INVALID_ARG;
+  }
+  std::memcpy(newToOld, d.newToOld.data(), (size_t)d.count * 4);
   return MGS_OK;
 }
 
@@ -703,19 +791,20 @@ int mgs_scene_download_set(MgsScene s, int instance, int which, float* dst, size
   }
   if(need == 0)
     return MGS_OK;
+  const uint32_t* n2o = d.newToOld.data();  // storage index -> caller's index
   if(isCov)
-  {  // planar (float4 covA[n], float2 covB[n]) -> the reference's 6 floats per splat
+  {  // planar (float4 covA[n], float2 covB[n]) in storage order -> the reference's 6 floats per splat, caller's order
     std::vector<float> raw(need);
     HIPCHK(hipMemcpy(raw.data(), src, need * 4, hipMemcpyDeviceToHost));
     for(size_t i = 0; i < n; ++i)
     {
-      std::memcpy(dst + 6 * i, &raw[4 * i], 16);
-      std::memcpy(dst + 6 * i + 4, &raw[4 * n + 2 * i], 8);
+      std::memcpy(dst + 6 * (size_t)n2o[i], &raw[4 * i], 16);
+      std::memcpy(dst + 6 * (size_t)n2o[i] + 4, &raw[4 * n + 2 * i], 8);
     }
     return MGS_OK;
   }
   if(isSh)
-  {  // vector-planar with a padded pitch: fetch, dequantise, restore [splat][coef][rgb]
+  {  // vector-planar with a padded pitch: fetch, dequantise, restore [splat][coef][rgb] in the caller's order
     const size_t         tot = (size_t)d.shPitch * n;
     const size_t         esz = fmt == MGS_FORMAT_FLOAT32 ? 4 : fmt == MGS_FORMAT_FLOAT16 ? 2 : 1;
     const int            per = (int)(16 / esz);
@@ -736,29 +825,33 @@ int mgs_scene_download_set(MgsScene s, int instance, int which, float* dst, size
         }
         else
           v = (float)raw[j] / 255.0f * 2.0f - 1.0f;
-        dst[i * (size_t)d.shStride + k] = v;
+        dst[(size_t)n2o[i] * (size_t)d.shStride + k] = v;
       }
     return MGS_OK;
   }
-  if(fmt == MGS_FORMAT_FLOAT32)
-  {
-    HIPCHK(hipMemcpy(dst, src, need * 4, hipMemcpyDeviceToHost));
+  {  // centres (3 floats) and rgba (4 elements): fetch in storage order, dequantise, scatter to the caller's order
+    const size_t       w = (which == 0) ? 3 : 4;
+    std::vector<float> tmp(need);
+    if(fmt == MGS_FORMAT_FLOAT32)
+      HIPCHK(hipMemcpy(tmp.data(), src, need * 4, hipMemcpyDeviceToHost));
+    else if(fmt == MGS_FORMAT_FLOAT16)
+    {
+      std::vector<uint16_t> raw(need);
+      HIPCHK(hipMemcpy(raw.data(), src, need * 2, hipMemcpyDeviceToHost));
+      for(size_t i = 0; i < need; ++i)
+        tmp[i] = halfToFloat(raw[i]);
+    }
+    else
+    {
+      std::vector<uint8_t> raw(need);
+      HIPCHK(hipMemcpy(raw.data(), src, need, hipMemcpyDeviceToHost));
+      for(size_t i = 0; i < need; ++i)
+        tmp[i] = (float)raw[i] / 255.0f;
+    }
+    for(size_t i = 0; i < n; ++i)
+      std::memcpy(dst + w * (size_t)n2o[i], &tmp[w * i], w * sizeof(float));
+    return MGS_OK;
   }
-  else if(fmt == MGS_FORMAT_FLOAT16)
-  {
-    std::vector<uint16_t> tmp(need);
-    HIPCHK(hipMemcpy(tmp.data(), src, need * 2, hipMemcpyDeviceToHost));
-    for(size_t i = 0; i < need; ++i)
-      dst[i] = halfToFloat(tmp[i]);
-  }
-  else
-  {
-    std::vector<uint8_t> tmp(need);
-    HIPCHK(hipMemcpy(tmp.data(), src, need, hipMemcpyDeviceToHost));
-    for(size_t i = 0; i < need; ++i)
-      dst[i] = isSh ? ((float)tmp[i] / 255.0f * 2.0f - 1.0f) : ((float)tmp[i] / 255.0f);
-  }
-  return MGS_OK;
 }
 
 void mgs_frame_params_default(MgsFrameParams* p)
@@ -779,6 +872,45 @@ void mgs_frame_params_default(MgsFrameParams* p)
   p->frustum_culling      = MGS_CULL_AT_DIST;
   p->target_format        = MGS_TARGET_RGBA16F;
   p->alpha_mode           = MGS_ALPHA_COVERAGE;
+}
+
+// storage global id <-> caller global id.  Instances are concatenated in creation order in both spaces;
+// only the index inside a splat set is permuted.
+static void mapIdsToCaller(MgsScene s, uint32_t* ids, size_t n)
+{
+  std::vector<uint32_t> offs;
+  uint32_t              o = 0;
+  for(const auto& I : s->instances)
+  {
+    offs.push_back(o);
+    o += s->sets[I.set].count;
+  }
+  offs.push_back(o);
+  parallelBatches(n, [&](size_t i) {
+    const uint32_t g = ids[i];
+    size_t         k = 0;
+    while(k + 1 < s->instances.size() && g >= offs[k + 1])
+      ++k;
+    ids[i] = offs[k] + s->sets[s->instances[k].set].newToOld[g - offs[k]];
+  });
+}
+static void mapIdsToStorage(MgsScene s, uint32_t* ids, size_t n)
+{
+  std::vector<uint32_t> offs;
+  uint32_t              o = 0;
+  for(const auto& I : s->instances)
+  {
+    offs.push_back(o);
+    o += s->sets[I.set].count;
+  }
+  offs.push_back(o);
+  parallelBatches(n, [&](size_t i) {
+    const uint32_t g = ids[i];
+    size_t         k = 0;
+    while(k + 1 < s->instances.size() && g >= offs[k + 1])
+      ++k;
+    ids[i] = offs[k] + s->sets[s->instances[k].set].oldToNew[g - offs[k]];
+  });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -834,6 +966,8 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
   F.nInstances      = (int)s->instances.size();
   F.totalSplats     = s->totalSplats;
   F.totalPartitions = s->totalParts;
+  static const bool kPartCull = [] { const char* e = std::getenv("MGS_PARTITION_CULL"); return e ? std::atoi(e) != 0 : true; }();
+  F.partitionCull   = (kPartCull && F.cullMode == MGS_CULL_AT_DIST) ? 1 : 0;
   uint32_t offset = 0, block = 0;
   for(int k = 0; k < F.nInstances; ++k)
   {
@@ -844,6 +978,7 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
     C.cov6    = d.cov6;
     C.rgba    = d.rgba;
     C.sh      = d.sh;
+    C.partBox = d.partBox;
     std::memcpy(C.model, I.M, sizeof(C.model));
     mat4Mul(p->view, I.M, C.modelView);  // mul(desc.transform, viewMatrix), mesh.slang:175
     float inv[16], cam[4] = {p->camera_pos[0], p->camera_pos[1], p->camera_pos[2], 1.0f}, cm[4];
@@ -852,6 +987,28 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
     C.camModel[0]  = cm[0];
     C.camModel[1]  = cm[1];
     C.camModel[2]  = cm[2];
+    {  // largest singular value of the 3x3: power iteration on A^T A (tiny, per frame, per instance)
+      float AtA[9];
+      for(int a = 0; a < 3; ++a)
+        for(int b = 0; b < 3; ++b)
+          AtA[3 * a + b] = I.M[4 * a] * I.M[4 * b] + I.M[4 * a + 1] * I.M[4 * b + 1] + I.M[4 * a + 2] * I.M[4 * b + 2];
+      float v[3] = {0.577f, 0.577f, 0.577f}, lam = 0.f;
+      for(int it = 0; it < 32; ++it)
+      {
+        float w[3];
+        for(int a = 0; a < 3; ++a)
+          w[a] = AtA[3 * a] * v[0] + AtA[3 * a + 1] * v[1] + AtA[3 * a + 2] * v[2];
+        lam = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        if(!(lam > 0.f))
+          break;
+        for(int a = 0; a < 3; ++a)
+          v[a] = w[a] / lam;
+      }
+      const float fro = std::sqrt(AtA[0] + AtA[4] + AtA[8]);
+      C.modelScale    = std::min(fro, std::sqrt(lam) * 1.02f + 1e-6f);  // never above the Frobenius bound
+      if(!(C.modelScale > 0.f))
+        C.modelScale = fro;
+    }
     C.count        = d.count;
     C.globalOffset = offset;
     C.blockBegin   = block;
@@ -871,9 +1028,14 @@ static int pairSortBits(int nTiles)
   return ((bits + 7) / 8) * 8;
 }
 
-static void keySort(MgsScene s, hipStream_t st)
+static void keySort(MgsScene s, hipStream_t st, bool fuseRectGather)
 {
   SortLaunch L{};
+  if(fuseRectGather)
+  {
+    L.gatherSrc = s->rect.p;
+    L.gatherDst = s->sortedRect.p;
+  }
   L.keys0 = s->keysSlot.p;
   L.vals0 = s->idsSlot.p;
   L.keysX = s->keysA.p;
@@ -1002,25 +1164,32 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
   const bool cpuMode = (p->sort_mode == MGS_SORT_CPU_ASYNC);
   if(cpuMode)  // rejected splats must look empty to the binning stage: rect with x0 > x1
     hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, st, s->rect.p, 1u, s->totalSplats);
+  if(F.partitionCull)
+    launchPartitionCull(st, A, s->partSkip.p);
   launchProject(st, A, true, s->shFormat, s->rgbaFormat, ctr, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p,
-                s->rect.p);
+                s->rect.p, F.partitionCull ? s->partSkip.p : nullptr);
   if(timed) HIPCHK(hipEventRecord(fev[1], st));
+  static const bool kFuseRect = [] { const char* e = std::getenv("MGS_FUSE_RECT"); return e ? std::atoi(e) != 0 : false; }();
   if(!cpuMode)
-    keySort(s, st);
+    keySort(s, st, kFuseRect);
   else
   {
     rc = cpuSortStep(s, p, p->cpu_sort_blocking != 0);
     if(rc != MGS_OK)
       return rc;
     if(s->cpuHaveIndices && s->cpuIndices.size() == s->totalSplats)
-      HIPCHK(hipMemcpyAsync(s->idsA.p, s->cpuIndices.data(), (size_t)s->totalSplats * 4, hipMemcpyHostToDevice, st));
+    {
+      s->cpuStorageIds = s->cpuIndices;  // the sorter works in the caller's id space
+      mapIdsToStorage(s, s->cpuStorageIds.data(), s->cpuStorageIds.size());
+      HIPCHK(hipMemcpyAsync(s->idsA.p, s->cpuStorageIds.data(), (size_t)s->totalSplats * 4, hipMemcpyHostToDevice, st));
+    }
     else  // no result yet: the reference draws with whatever the index buffer holds; we use identity order
       hipLaunchKernelGGL(k_iota_u32, dim3(1024), dim3(256), 0, st, s->idsA.p, s->totalSplats);
     hipLaunchKernelGGL(k_set_plan_n, dim3(1), dim3(1), 0, st, planK, ctr, s->totalSplats);
   }
   if(timed) HIPCHK(hipEventRecord(fev[2], st));
   launchBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, s->blockCount.p, (s->totalSplats + kPart - 1) / kPart, ctr,
-                s->sortedRect.p, s->splatOffset.p, s->chunkStart.p, s->pairKey0.p, s->pairVal0.p, s->pairCapacity, F.binsX);
+                s->sortedRect.p, s->splatOffset.p, s->chunkStart.p, s->pairKey0.p, s->pairVal0.p, s->pairCapacity, F.binsX, cpuMode || !kFuseRect);
   if(timed) HIPCHK(hipEventRecord(fev[3], st));
   {
     SortLaunch L{};
@@ -1225,9 +1394,12 @@ int mgs_sort_keys(MgsScene s, const MgsFrameParams* p, MgsSortOut* out)
   if((rc = s->ranges.ensure(1))) return rc;
   HIPCHK(hipEventRecord(s->ev[0], st));
   launchFrameInit(st, s->ctr.p, &s->plans.p[0], &s->plans.p[1], s->ranges.p, 0);
-  launchProject(st, A, false, 0, 0, s->ctr.p, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p, s->rect.p);
+  if(A.f.partitionCull)
+    launchPartitionCull(st, A, s->partSkip.p);
+  launchProject(st, A, false, 0, 0, s->ctr.p, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p, s->rect.p,
+                A.f.partitionCull ? s->partSkip.p : nullptr);
   HIPCHK(hipEventRecord(s->ev[1], st));
-  keySort(s, st);
+  keySort(s, st, false);
   HIPCHK(hipEventRecord(s->ev[2], st));
   HIPCHK(hipMemcpyAsync(s->hCtr, s->ctr.p, sizeof(FrameCounters), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(s->hPlans, s->plans.p, 2 * sizeof(SortPlan), hipMemcpyDeviceToHost, st));
@@ -1287,6 +1459,7 @@ int mgs_sort_download(MgsScene s, uint32_t* keys, uint32_t* ids, uint32_t capaci
     if(keys)
       HIPCHK(hipMemcpy(keys, y ? s->keysB.p : s->keysA.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(ids, y ? s->idsB.p : s->idsA.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    mapIdsToCaller(s, ids, n);  // the pipeline works on storage ids
   }
   return MGS_OK;
 }

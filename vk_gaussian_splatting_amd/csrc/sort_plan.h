@@ -14,7 +14,8 @@ struct SortPlan
   uint32_t finalSel;       // result lives in X (0) or Y (1)
   uint32_t passesRun;
   uint32_t n;
-  uint32_t pad[5];
+  uint32_t lastPass;       // index of the last pass that actually runs
+  uint32_t pad[4];
 };
 
 struct SortLaunch
@@ -33,6 +34,8 @@ struct SortLaunch
   uint32_t        pStride;
   uint32_t        maxElems;      // host-side upper bound of the element count (sizes the grids)
   int             beginBit, endBit;
+  const uint32_t* gatherSrc = nullptr;  // optional fused gather on the last executed pass:
+  uint32_t*       gatherDst = nullptr;  //   gatherDst[sortedPos] = gatherSrc[value]
 };
 
 void launchSortClearPlan(hipStream_t stream, SortPlan* plan);
