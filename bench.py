@@ -8,8 +8,11 @@ the next pose of the fixed 64-pose orbit.  Inputs are resident 
 region.  W untimed warm-up frames, then EXACTLY K frames between barrier+synchronize pairs; rank 0
 prints ONE JSON line.
 
-N>1: screen-strip partition (tile rows) with replicated splat buffers and one RCCL all-gather of the
-strips per frame (strong scaling: the frame is fixed, the GPUs split it).
+N>1, two partitions are measured in the same run (replicated splat buffers in both):
+  * `value`: alternate-frame rendering — the orbit's frames are independent units, rank r renders poses
+    r, r+N, ... with NO data-path collective (weak scaling: every GPU does K whole frames);
+  * `strips`: the north_star's screen-strip partition — every rank renders its tile rows of the SAME frame and
+    one RCCL all-gather of the strips per frame assembles it on every rank (strong scaling of a ~1 ms frame).
 
 The JSON line also carries
   roofline      — the dominant kernel's algorithmic bytes / its mean HIP-event duration in the timed region
@@ -90,27 +93,37 @@ def main():
         V, P = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, W, H)
         p = capi.default_params(W, H)
         capi.set_camera(p, V, P, eye)
-        p.strip_row_begin, p.strip_row_end = multigpu.strip_rows(H, world, rank) if world > 1 else (0, 0)
         p.collect_timings = 2
         poses.append(p)
+    strip_rows = multigpu.strip_rows(H, world, rank) if world > 1 else (0, 0)
+
+    def set_strips(on):
+        for p in poses:
+            p.strip_row_begin, p.strip_row_end = strip_rows if on else (0, 0)
 
     R = multigpu.strip_pixel_rows(H, world)
     strips = [torch.zeros((R, W, 4), dtype=torch.float16, device="cuda") if world > 1 else None for _ in range(K)]
     strip_bytes = R * W * 8
 
     def frame(i):
+        """alternate-frame step: this rank's i-th whole frame (pose i*world + rank of the orbit)"""
+        c = i % K
+        with torch.cuda.stream(streams[c]):
+            scenes[c].render(poses[(i * world + rank) % 64])
+        return None
+
+    def strip_frame(i):
+        """strip step: this rank's tile rows of frame i + one all-gather"""
         p = poses[i % 64]
         c = i % K
         with torch.cuda.stream(streams[c]):
-            if world > 1 and p.strip_row_begin == p.strip_row_end:
+            if strip_rows[0] == strip_rows[1]:
                 return multigpu.gather_strips(strips[c], world)  # this rank owns no rows (more ranks than tile rows)
             scenes[c].render(p)
-            if world > 1:
-                scenes[c].copy_strip(strips[c].data_ptr(), strip_bytes)
-                if args.backend != "nccl":  # functional path: stage through the host
-                    return multigpu.gather_strips(strips[c].cpu(), world)
-                return multigpu.gather_strips(strips[c], world)
-        return None
+            scenes[c].copy_strip(strips[c].data_ptr(), strip_bytes)
+            if args.backend != "nccl":  # functional path: stage through the host
+                return multigpu.gather_strips(strips[c].cpu(), world)
+            return multigpu.gather_strips(strips[c], world)
 
     def fence():
         torch.cuda.synchronize()
@@ -131,7 +144,9 @@ def main():
     calib_ms = np.array(calib[2:], np.float64).mean(axis=0)
     fence()
     if world > 1 and args.check_gather:
-        g = frame(0)
+        set_strips(True)
+        g = strip_frame(0)
+        set_strips(False)
         torch.cuda.synchronize()
         pf = capi.default_params(W, H)
         for kk in range(16):
@@ -175,9 +190,29 @@ def main():
     else:
         Vs_all = Vs
 
-    fps = args.steps / elapsed
-    rows = (poses[0].strip_row_end - poses[0].strip_row_begin) if world > 1 else multigpu.tile_rows(H)
-    Ppix = W * min(rows * 16, H)
+    fps = args.steps * world / elapsed  # whole-job aggregate: every rank rendered `steps` whole frames
+    Ppix = W * H
+
+    strips_out = None
+    if world > 1:
+        set_strips(True)
+        for i in range(args.warmup):
+            strip_frame(i)
+        fence()
+        t2 = time.perf_counter()
+        for i in range(args.steps):
+            strip_frame(args.warmup + i)
+        fence()
+        el2 = time.perf_counter() - t2
+        tt = torch.tensor([el2], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el2 = float(tt.item())
+        k2 = min(args.steps // K, 128)
+        st2 = np.array([scenes[c].timings(b) for c in range(K) for b in range(k2)], np.float64).mean(axis=0)
+        set_strips(False)
+        strips_out = {"value": args.steps / el2, "unit": "frames/s", "scaling": "strong", "ms_per_step": 1e3 * el2 / args.steps,
+                      "partition": f"{world} tile-row strips + one RCCL all_gather per frame",
+                      "this_rank_rows": list(strip_rows), "this_rank_stage_ms": {STAGES[j]: float(st2[j]) for j in range(6)}}
     # algorithmic bytes per launch of each stage (SURVEY.md §8d per-unit figures)
     alg = {
         "project": 12 * N + 16 * Vf + (24 + 180) * Vs + (48 + 4 + 8) * Vs,
@@ -212,14 +247,16 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "frames_in_flight": K,
         "config": {"workload": f"syn_garden N={N} SH deg 3, storage sh/rgba format {args.sh_format}/{args.rgba_format}, "
                                f"{W}x{H}, 64-pose orbit r=4 h=1.5 fov60, GPU radix sort, cull at dist (configs[2])",
-                   "partition": "single GPU" if world == 1 else f"{world} tile-row strips + RCCL all_gather"},
+                   "partition": "single GPU" if world == 1 else
+                   f"alternate-frame: rank r renders poses r, r+{world}, ... (no data-path collective); strips+all_gather in `strips`"},
+        "strips": strips_out,
         "sorted_gsplats_per_s": (Vs / (sort_ms * 1e-3)) / 1e9 if sort_ms > 0 else None,
         "sorted_gsplats_per_s_in_frame_aggregate": Vs_all * fps / 1e9,
         "visible_splats": {"frustum": Vf, "sorted": Vs, "tile_pairs": D},
