@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--splats", type=int, default=5_830_000, help="scene size (default: garden-sized, configs[2])")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--instances", type=int, default=1, help="instances of the scene on a 2 x ceil(k/2) grid, spacing 12 "
+                    "(configs[4]: 8 -> ~46.6 M splats under one unified depth sort)")
     ap.add_argument("--sh-format", type=int, default=0, help="0 fp32 (benchmark setting), 1 fp16, 2 uint8")
     ap.add_argument("--rgba-format", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -78,7 +80,15 @@ def main():
     scenes, streams = [], []
     for _ in range(K):
         sc_k = mgs.Scene(local)
-        sc_k.add_instance(ss)
+        for q in range(args.instances):
+            if args.instances == 1:
+                sc_k.add_instance(ss)
+            else:
+                cols = (args.instances + 1) // 2
+                M = np.eye(4, dtype=np.float32)
+                M[0, 3] = ((q % cols) - (cols - 1) / 2.0) * 12.0
+                M[2, 3] = ((q // cols) - 0.5) * 12.0
+                sc_k.add_instance(ss, M)
         sc_k.commit(args.sh_format, args.rgba_format)
         st_k = torch.cuda.Stream()        # a real (non-null) stream shared by this context's renderer and RCCL
         sc_k.set_stream(st_k.cuda_stream)
@@ -214,6 +224,7 @@ def main():
                       "partition": f"{world} tile-row strips + one RCCL all_gather per frame",
                       "this_rank_rows": list(strip_rows), "this_rank_stage_ms": {STAGES[j]: float(st2[j]) for j in range(6)}}
     # algorithmic bytes per launch of each stage (SURVEY.md §8d per-unit figures)
+    N = N * args.instances  # total global splats from here on
     alg = {
         "project": 12 * N + 16 * Vf + (24 + 180) * Vs + (48 + 4 + 8) * Vs,
         "sort": 68 * Vs,
@@ -252,7 +263,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "frames_in_flight": K,
-        "config": {"workload": f"syn_garden N={N} SH deg 3, storage sh/rgba format {args.sh_format}/{args.rgba_format}, "
+        "config": {"workload": f"syn_garden N={N} x {args.instances} instance(s) SH deg 3, storage sh/rgba format {args.sh_format}/{args.rgba_format}, "
                                f"{W}x{H}, 64-pose orbit r=4 h=1.5 fov60, GPU radix sort, cull at dist (configs[2])",
                    "partition": "single GPU" if world == 1 else
                    f"alternate-frame: rank r renders poses r, r+{world}, ... (no data-path collective); strips+all_gather in `strips`"},

@@ -48,6 +48,9 @@ enum { MGS_SORT_GPU_RADIX = 0, MGS_SORT_CPU_ASYNC = 1 };
 enum { MGS_CULL_NONE = 0, MGS_CULL_AT_DIST = 1, MGS_CULL_AT_RASTER = 2 };
 /* colour target — src/gaussian_splatting.h:338-340 (RGBA16F default, RGBA32F optional) */
 enum { MGS_TARGET_RGBA16F = 0, MGS_TARGET_RGBA32F = 1 };
+/* visualisation modes: POINT_CLOUD_MODE (threedgs.h.slang:108-110), SHOW_SH_ONLY (mesh.slang:205-207),
+ * DISABLE_OPACITY_GAUSSIAN (frag.slang:248-255) */
+enum { MGS_DEBUG_POINT_CLOUD = 1, MGS_DEBUG_SH_ONLY = 2, MGS_DEBUG_OPACITY_GAUSSIAN_DISABLED = 4 };
 /* alpha channel meaning: the reference's default back-to-front pipeline accumulates
  * A = sum(alpha) (src/gaussian_splatting.cpp:2083-2084); its FTB pipeline yields 1-T (:2071-2076). */
 enum { MGS_ALPHA_COVERAGE = 0 /* 1-T */, MGS_ALPHA_SUM = 1 /* sum(alpha); disables early termination */ };
@@ -133,7 +136,8 @@ typedef struct MgsFrameParams {
   int32_t collect_timings;      /* 1: bracket each stage with hipEvents on the render stream and wait for them;
                                    2: record the events but do not wait (query later with mgs_timings_query) */
   int32_t cpu_sort_blocking;    /* CPU_ASYNC only: 1 = wait for the sorter (deterministic tests) */
-  int32_t reserved[6];
+  int32_t debug_flags;          /* MGS_DEBUG_* bits: the reference's visualisation modes (parameters.h:86-201) */
+  int32_t reserved[5];
 } MgsFrameParams;
 
 void mgs_frame_params_default(MgsFrameParams* p); /* fills the defaults cited above */

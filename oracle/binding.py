@@ -16,7 +16,8 @@ class OrcFrame(C.Structure):
     _fields_ = [("view", C.c_float * 16), ("proj", C.c_float * 16), ("camera_pos", C.c_float * 3),
                 ("width", C.c_int), ("height", C.c_int), ("splat_scale", C.c_float), ("frustum_dilation", C.c_float),
                 ("alpha_cull_threshold", C.c_float), ("sh_degree", C.c_int), ("front_to_back", C.c_int),
-                ("frustum_culling", C.c_int), ("target_fp16", C.c_int), ("ms_antialiasing", C.c_int)]
+                ("frustum_culling", C.c_int), ("target_fp16", C.c_int), ("ms_antialiasing", C.c_int),
+                ("debug_flags", C.c_int)]
 
 
 class OrcInstance(C.Structure):
@@ -27,7 +28,7 @@ class OrcInstance(C.Structure):
 
 class OrcProjected(C.Structure):
     _fields_ = [("valid", C.c_int), ("center_px", C.c_float * 2), ("ndc_z", C.c_float), ("basis1", C.c_float * 2),
-                ("basis2", C.c_float * 2), ("rgba", C.c_float * 4)]
+                ("basis2", C.c_float * 2), ("rgba", C.c_float * 4), ("opacity_disabled", C.c_int)]
 
 
 class OrcSortInstance(C.Structure):
@@ -152,7 +153,7 @@ def make_instances(prepared_and_transforms):
 
 def make_frame(view, proj, camera_pos, width, height, splat_scale=1.0, frustum_dilation=0.2,
                alpha_cull=1.0 / 255.0, sh_degree=3, front_to_back=0, frustum_culling=1, target_fp16=0,
-               ms_antialiasing=0):
+               ms_antialiasing=0, debug_flags=0):
     f = OrcFrame()
     v = f32(view).T.reshape(-1)
     p = f32(proj).T.reshape(-1)
@@ -164,7 +165,7 @@ def make_frame(view, proj, camera_pos, width, height, splat_scale=1.0, frustum_d
     f.width, f.height = width, height
     f.splat_scale, f.frustum_dilation, f.alpha_cull_threshold = splat_scale, frustum_dilation, alpha_cull
     f.sh_degree, f.front_to_back, f.frustum_culling = sh_degree, front_to_back, frustum_culling
-    f.target_fp16, f.ms_antialiasing = target_fp16, ms_antialiasing
+    f.target_fp16, f.ms_antialiasing, f.debug_flags = target_fp16, ms_antialiasing, debug_flags
     return f
 
 

@@ -478,6 +478,8 @@ void orc_project(const OrcFrame* f, const OrcInstance* Ip, uint32_t i, OrcProjec
   dir[0] /= dl;
   dir[1] /= dl;
   dir[2] /= dl;
+  if(f->debug_flags & 2)  // SHOW_SH_ONLY, mesh.slang:205-207
+    rgba[0] = rgba[1] = rgba[2] = 0.5f;
   float sh[3];
   sh_radiance(I, i, f->sh_degree, dir, sh);
   rgba[0] += sh[0];
@@ -521,9 +523,11 @@ void orc_project(const OrcFrame* f, const OrcInstance* Ip, uint32_t i, OrcProjec
   const float D          = a * d - b * b;
   const float traceOver2 = 0.5f * (a + d);
   const float term2      = std::sqrt(std::max(0.1f, traceOver2 * traceOver2 - D));
-  const float ev1 = traceOver2 + term2, ev2 = traceOver2 - term2;
+  float ev1 = traceOver2 + term2, ev2 = traceOver2 - term2;
   if(ev2 <= 0.0f)
     return;
+  if(f->debug_flags & 1)  // POINT_CLOUD_MODE, threedgs.h.slang:108-110
+    ev1 = ev2 = 0.2f;
   float       e1[2] = {(std::fabs(b) < 0.001f) ? 1.0f : b, ev1 - a};
   const float el    = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1]);
   e1[0] /= el;
@@ -547,7 +551,8 @@ void orc_project(const OrcFrame* f, const OrcInstance* Ip, uint32_t i, OrcProjec
   out->center_px[0] = (ndc[0] + 1.0f) * 0.5f * (float)f->width;  // viewport transform, origin (0,0)
   out->center_px[1] = (ndc[1] + 1.0f) * 0.5f * (float)f->height;
   std::memcpy(out->rgba, rgba, sizeof(rgba));
-  out->valid = 1;
+  out->opacity_disabled = (f->debug_flags & 4) ? 1 : 0;
+  out->valid            = 1;
 }
 
 // fragments + blending: shaders/threedgs_raster.frag.slang:223-309, src/gaussian_splatting.cpp:2066-2087
@@ -579,7 +584,7 @@ static uint64_t raster_one(const OrcFrame* f, const OrcProjected& P, float* img)
       const float A  = px * px + py * py;  // frag.slang:236
       if(A > 8.0f)                         // :242-245
         continue;
-      const float opacity = std::exp(-0.5f * A) * P.rgba[3];  // :254
+      const float opacity = P.opacity_disabled ? 1.0f : std::exp(-0.5f * A) * P.rgba[3];  // :248-254
       if(opacity <= 1.0f / 255.0f)                            // :258-262
         continue;
       float* dst = img + ((size_t)y * W + x) * 4;

@@ -58,6 +58,8 @@ typedef struct OrcFrame {
   int   frustum_culling;      /* 0 none, 1 at dist (default), 2 at raster (shaderio.h:84-86) */
   int   target_fp16;          /* 1: round the colour target to fp16 after every blend (RGBA16F) */
   int   ms_antialiasing;      /* MS_ANTIALIASING macro (threedgs.h.slang:63-76) */
+  int   debug_flags;          /* 1 POINT_CLOUD_MODE (threedgs.h.slang:108-110), 2 SHOW_SH_ONLY (mesh.slang:205-207),
+                                 4 DISABLE_OPACITY_GAUSSIAN (frag.slang:248-255) */
 } OrcFrame;
 
 typedef struct OrcInstance {
@@ -78,6 +80,7 @@ typedef struct OrcProjected {
   float ndc_z;
   float basis1[2], basis2[2]; /* pixels */
   float rgba[4];
+  int   opacity_disabled;
 } OrcProjected;
 
 void orc_mat4_inverse(const float m[16], float out[16]);  /* glm::inverse restated (cofactors) */

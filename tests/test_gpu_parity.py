@@ -166,6 +166,29 @@ def test_frame_matches_oracle(scene_small, ob, pose, W, H):
     assert np.abs(img[..., 3] - fimg[..., 3]).max() <= ABS_TOL
 
 
+@pytest.mark.parametrize("kw", [dict(ms_antialiasing=1), dict(debug_flags=1), dict(debug_flags=2), dict(debug_flags=4),
+                                dict(splat_scale=0.5), dict(sh_degree=1), dict(sh_degree=0), dict(alpha_cull_threshold=0.3)])
+def test_raster_knobs_match_oracle(scene_small, ob, kw):
+    """the VK3DGSR raster knobs (gaussian_splatting_ui.cpp:2557-2811): Mip-Splatting AA, point-cloud / SH-only /
+    opacity-gaussian-disabled modes, splat scale, max SH degree, alpha cull"""
+    scene, sc = scene_small
+    W, H = 400, 300
+    p, V, P, eye = camera(14, W, H)
+    okw = {}
+    for k, v in kw.items():
+        setattr(p, k, v)
+        okw[{"alpha_cull_threshold": "alpha_cull"}.get(k, k)] = v
+    scene.render(p)
+    img = scene.download_frame(p).astype(np.float32)
+    ps = ob.PreparedSet(sc)
+    inst = ob.make_instances([(ps, None)])
+    _, order = oracle_sorted_stream(ob, scene, sc, dict(view=V, proj=P, camera_pos=eye, width=W, height=H))
+    oimg, _ = ob.render(ob.make_frame(V, P, eye, W, H, target_fp16=1, **okw), inst, order=order)
+    assert ob.psnr_rgb(img, oimg) >= (45.0 if kw.get("debug_flags") == 4 else PSNR_MIN), kw   # alpha=1 edges: one flip = 1.0
+    base, _ = ob.render(ob.make_frame(V, P, eye, W, H, target_fp16=1), inst, order=order)
+    assert ob.psnr_rgb(oimg, base) < 60.0, "the knob must change the frame"
+
+
 def test_alpha_sum_mode_and_fp32_target(scene_small, ob):
     scene, sc = scene_small
     p, V, P, eye = camera(12, 320, 240)
@@ -244,6 +267,56 @@ def test_multi_instance_unified_sort_and_golden_frame(ob):
     scene.close()
 
 
+def test_eight_instances_trs_unified_sort_and_4k(ob):
+    """configs[4] shape (8 instances of one splat set, unified depth order) at a size the oracle renders in
+    seconds, and configs[3]'s 3840x2160 resolution (tile/bin coordinates near their 8-bit limit)."""
+    sc = synth.make_scene(12000, seed=77)
+    ss = mgs.SplatSet.from_arrays(**sc)
+    scene = mgs.Scene(0)
+    mats = []
+    for k in range(8):
+        M, _ = mgs.compute_transform([0.6 + 0.1 * k, 0.8, 1.0 + 0.05 * k], [10.0 * k, 25.0 * k, -5.0 * k],
+                                     [(k % 4) * 2.5 - 3.75, 0.0, (k // 4) * 3.0 - 1.5])
+        mats.append(M)
+        scene.add_instance(ss, M)
+    scene.commit()
+    assert scene.splat_count == 96000
+    W, H = 480, 270
+    eye = np.array([6.0, 3.0, 7.0], np.float32)
+    V, P = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, W, H)
+    p = capi.default_params(W, H)
+    capi.set_camera(p, V, P, eye)
+    fk = dict(view=V, proj=P, camera_pos=eye, width=W, height=H)
+    oks, ois = oracle_sorted_stream(ob, scene, sc, fk, transforms=tuple(mats))
+    so = scene.sort_keys(p)
+    gk, gi = scene.sort_download(so.count)
+    assert np.array_equal(gk, oks) and np.array_equal(gi, ois)     # one global order across all 8 instances
+    out = scene.render(p, want_stats=True)
+    img = scene.download_frame(p).astype(np.float32)
+    ps = ob.PreparedSet(sc)
+    inst = ob.make_instances([(ps, m) for m in mats])
+    oimg, st = ob.render(ob.make_frame(V, P, eye, W, H, target_fp16=1), inst, order=ois)
+    assert out.error_flags == 0 and out.frustum_count == st["visible"]
+    assert ob.psnr_rgb(img, oimg) >= PSNR_MIN
+    # 4K: properties only (the oracle would take minutes): finite, deterministic, strips == full
+    p4 = capi.default_params(3840, 2160)
+    V4, P4 = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, 3840, 2160)
+    capi.set_camera(p4, V4, P4, eye)
+    o4 = scene.render(p4, want_stats=True)
+    full = scene.download_frame(p4).view(np.uint16)
+    assert o4.error_flags == 0 and np.isfinite(full.view(np.float16).astype(np.float32)).all() and full.any()
+    p4.strip_row_begin, p4.strip_row_end = 100, 135          # bottom rows incl. the last tile row (2160 = 135*16)
+    scene.render(p4)
+    part = scene.download_frame(p4).view(np.uint16)
+    assert np.array_equal(part[1600:2160], full[1600:2160])
+    # low-resolution 4K consistency: the 4K frame box-filtered to 480x270 resembles the 480x270 frame
+    lo = full.view(np.float16).astype(np.float32).reshape(270, 8, 480, 8, 4).mean(axis=(1, 3))
+    assert ob.psnr_rgb(lo, img) >= 25.0
+    with pytest.raises(mgs.MgsError):
+        scene.add_instance(ss)     # a 9th instance: MGS_ERR_UNSUPPORTED in this build (kMaxInlineInstances)
+    scene.close()
+
+
 def test_strips_are_bit_identical_to_full_frame(scene_small):
     """multi-GPU oracle: a frame assembled from G strips == the 1-GPU frame, bit for bit"""
     from vk_gaussian_splatting_amd import multigpu
@@ -303,6 +376,28 @@ def test_cpu_async_sort_mode(scene_small, ob):
     inst = ob.make_instances([(ps, None)])
     oimg, _ = ob.render(ob.make_frame(V, P, eye, 320, 240, frustum_culling=2, target_fp16=1), inst, order=oidx)
     assert ob.psnr_rgb(img, oimg) >= 45.0   # std::sort is not stable: tie order may differ from the oracle's run
+
+
+def test_cpu_async_sort_nonblocking_protocol(scene_small):
+    """READY -> SORTING -> SORTED like SplatSorterAsync (splat_sorter_async.h:41-48): frames never wait for the
+    sorter; the first frames draw in identity order, later ones pick up the sorted indices (>= 1 frame lag)."""
+    import time
+    scene, _ = scene_small
+    p, *_ = camera(6, 320, 240)
+    p.sort_mode, p.cpu_sort_blocking = capi.SORT_CPU_ASYNC, 0
+    scene.render(p)
+    first = scene.download_frame(p).view(np.uint16).copy()
+    deadline = time.time() + 30
+    while time.time() < deadline:
+        time.sleep(0.05)
+        scene.render(p)
+        cur = scene.download_frame(p).view(np.uint16)
+        if not np.array_equal(cur, first):
+            break
+    p.cpu_sort_blocking = 1
+    scene.render(p)
+    ref = scene.download_frame(p).view(np.uint16)
+    assert np.array_equal(cur, ref)          # the asynchronous result converged to the blocking one
 
 
 def test_api_error_behaviour():

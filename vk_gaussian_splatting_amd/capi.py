@@ -12,6 +12,7 @@ SORT_GPU_RADIX, SORT_CPU_ASYNC = 0, 1
 CULL_NONE, CULL_AT_DIST, CULL_AT_RASTER = 0, 1, 2
 TARGET_RGBA16F, TARGET_RGBA32F = 0, 1
 ALPHA_COVERAGE, ALPHA_SUM = 0, 1
+DEBUG_POINT_CLOUD, DEBUG_SH_ONLY, DEBUG_OPACITY_GAUSSIAN_DISABLED = 1, 2, 4
 STAGE_NAMES = ["project", "sort", "bin", "pairsort", "composite", "total"]
 
 
@@ -35,7 +36,8 @@ class FrameParams(C.Structure):
                 ("sh_degree", C.c_int32), ("sort_mode", C.c_int32), ("frustum_culling", C.c_int32),
                 ("target_format", C.c_int32), ("alpha_mode", C.c_int32), ("ms_antialiasing", C.c_int32),
                 ("strip_row_begin", C.c_int32), ("strip_row_end", C.c_int32),
-                ("collect_timings", C.c_int32), ("cpu_sort_blocking", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("collect_timings", C.c_int32), ("cpu_sort_blocking", C.c_int32), ("debug_flags", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
 
 
 class FrameOut(C.Structure):

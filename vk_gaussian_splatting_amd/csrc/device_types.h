@@ -55,6 +55,7 @@ struct FrameConst
   uint32_t totalSplats;
   uint32_t totalPartitions;  // project-kernel partitions
   int32_t  partitionCull;    // 1: k_partition_cull fills the skip flags this frame
+  int32_t  debugFlags;       // MGS_DEBUG_* bits
 };
 
 struct FrameArgs

@@ -215,8 +215,10 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   const float D     = a * d - b * b;
   const float half  = 0.5f * (a + d);
   const float term2 = sqrtf(fmaxf(0.1f, half * half - D));
-  const float ev1 = half + term2, ev2 = half - term2;
-  ok              = ok && !(ev2 <= 0.0f);
+  float ev1 = half + term2, ev2 = half - term2;
+  ok        = ok && !(ev2 <= 0.0f);
+  if(F.debugFlags & 1)  // POINT_CLOUD_MODE, threedgs.h.slang:108-110
+    ev1 = ev2 = 0.2f;
   float       e1x = (fabsf(b) < 0.001f) ? 1.0f : b, e1y = ev1 - a;
   const float el  = rsqrtf(e1x * e1x + e1y * e1y);
   e1x *= el;
@@ -229,9 +231,10 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   const float b2x = e1y * l2, b2y = -e1x * l2;  // basisVector2 = (e1.y, -e1.x) * l2
 
   // a fragment survives iff q = (d.p1)^2+(d.p2)^2 <= 4 (A<=8) and a*exp(-q) > 1/255 (frag.slang:242-262)
-  const float a255 = col.w * 255.0f;
-  ok               = ok && (a255 > 1.0f);
-  const float qmax   = fminf(4.0f, __logf(fmaxf(a255, 1.0f)) + 1e-3f);
+  const bool  noGauss = (F.debugFlags & 4) != 0;  // DISABLE_OPACITY_GAUSSIAN: alpha == 1 inside the ellipse
+  const float a255    = col.w * 255.0f;
+  ok                  = ok && (noGauss || a255 > 1.0f);
+  const float qmax    = noGauss ? 4.0f : fminf(4.0f, __logf(fmaxf(a255, 1.0f)) + 1e-3f);
   const float shrink = sqrtf(qmax * 0.25f) * 1.0005f;
   const float ex = shrink * sqrtf(b1x * b1x + b2x * b2x) + 0.01f;
   const float ey = shrink * sqrtf(b1y * b1y + b2y * b2y) + 0.01f;
@@ -256,6 +259,8 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   dx *= dl;
   dy *= dl;
   dz *= dl;
+  if(F.debugFlags & 2)  // SHOW_SH_ONLY, mesh.slang:205-207
+    col.x = col.y = col.z = 0.5f;
   shRadiance<DEG>(sh, dx, dy, dz, col.x, col.y, col.z);
 
   const float n1 = 2.0f / (b1x * b1x + b1y * b1y), n2 = 2.0f / (b2x * b2x + b2y * b2y);

@@ -328,6 +328,7 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
   const float    bcx = (float)(tx * kTilePx) + 8.0f, bcy = (float)(ty * kTilePx) + 8.0f;
   const bool     inside = px < F.width && py < F.height;
   const bool     early  = (F.alphaMode == 0);
+  const bool     noGauss = (F.debugFlags & 4) != 0;
   const uint32_t* vals  = plan->finalSel ? valY : valX;
   const int      bin    = (ty >> F.binShiftY) * F.binsX + (tx >> F.binShiftX);
   const uint2    range  = ranges[bin];
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
           const float  s1 = dx1 * b1.x + dy1 * b1.y, u1 = dx1 * b1.z + dy1 * b1.w;
           const float  s2 = dx2 * b2.x + dy2 * b2.y, u2 = dx2 * b2.z + dy2 * b2.w;
           const float  q1 = s1 * s1 + u1 * u1, q2 = s2 * s2 + u2 * u2;  // == A/2 of frag.slang:236
-          const float  al1 = c1.w * __expf(-q1), al2 = c2.w * __expf(-q2);  // frag.slang:254
+          const float  al1 = noGauss ? 1.0f : c1.w * __expf(-q1), al2 = noGauss ? 1.0f : c2.w * __expf(-q2);  // frag.slang:248-254
           // frag.slang:242-245,258-262, predicated
           const float ah1 = (q1 <= 4.0f && al1 > (1.0f / 255.0f) && !done) ? al1 : 0.0f;
           const float w1  = ah1 * T;

@@ -962,6 +962,7 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
     F.cullMode = MGS_CULL_AT_RASTER;  // gaussian_splatting_ui.cpp:1469-1479
   F.msAA            = p->ms_antialiasing;
   F.alphaMode       = p->alpha_mode;
+  F.debugFlags      = p->debug_flags;
   F.targetFormat    = p->target_format;
   F.nInstances      = (int)s->instances.size();
   F.totalSplats     = s->totalSplats;
