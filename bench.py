@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--sh-format", type=int, default=0, help="0 fp32 (benchmark setting), 1 fp16, 2 uint8")
     ap.add_argument("--rgba-format", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=2, help="frames in flight per GPU (each on its own HIP stream with "
+    ap.add_argument("--inflight", type=int, default=3, help="frames in flight per GPU (each on its own HIP stream with "
                     "its own working buffers); >1 overlaps one frame's tails/launch gaps/all-gather with the next frame")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (functional check of the N>1 path "
                     "when all ranks share one GPU; strips are staged through host memory)")
