@@ -96,17 +96,27 @@ __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ 
         count = partitionCount(nullptr, n, p, part);
         src   = keys + (size_t)p * part;
       }
-      const uint32_t iters = (count + 255u) >> 8;
-      for(uint32_t it = 0; it < iters; ++it)
+      // 8 loads in flight per thread, then the LDS work (the loop was one dependent round trip per key)
+      for(uint32_t i0 = 0; i0 < count; i0 += 2048u)
       {
-        const uint32_t i   = it * 256u + t;
-        const bool     in  = i < count;
-        const uint32_t key = in ? src[i] : 0u;
-        histAddRuns(s_h, (key >> shift) & 255u, in);
-        if(FIRST)
+        uint32_t kk[8];
+#pragma unroll
+        for(int u = 0; u < 8; ++u)
         {
-          for(int q = 1; q < nPasses; ++q)
-            histAddRuns(s_g[q], (key >> (shift + 8 * q)) & 255u, in);
+          const uint32_t i = min(i0 + (uint32_t)u * 256u + (uint32_t)t, count - 1u);  // clamped, not predicated
+          kk[u]            = src[i];
+        }
+#pragma unroll
+        for(int u = 0; u < 8; ++u)
+        {
+          const bool     in  = i0 + (uint32_t)u * 256u + (uint32_t)t < count;
+          const uint32_t key = kk[u];
+          histAddRuns(s_h, (key >> shift) & 255u, in);
+          if(FIRST)
+          {
+            for(int q = 1; q < nPasses; ++q)
+              histAddRuns(s_g[q], (key >> (shift + 8 * q)) & 255u, in);
+          }
         }
       }
     }
