@@ -166,6 +166,30 @@ def test_frame_matches_oracle(scene_small, ob, pose, W, H):
     assert np.abs(img[..., 3] - fimg[..., 3]).max() <= ABS_TOL
 
 
+def test_frame_1080p_psnr_target(ob):
+    """the north_star bar at the benchmark resolution: >= 40 dB PSNR vs the oracle of VK3DGSR @1920x1080
+    (oracle cost bounds the splat count here; the full-size scene is covered by test_full_size_properties)"""
+    sc = synth.make_scene(250_000, seed=0xC0FFEE + 2)
+    ss = mgs.SplatSet.from_arrays(**sc)
+    scene = mgs.Scene(0)
+    scene.add_instance(ss)
+    scene.commit()
+    W, H = 1920, 1080
+    p, V, P, eye = camera(0, W, H)
+    out = scene.render(p, want_stats=True)
+    img = scene.download_frame(p).astype(np.float32)
+    ps = ob.PreparedSet(sc)
+    inst = ob.make_instances([(ps, None)])
+    _, order = oracle_sorted_stream(ob, scene, sc, dict(view=V, proj=P, camera_pos=eye, width=W, height=H))
+    oimg, st = ob.render(ob.make_frame(V, P, eye, W, H, target_fp16=1), inst, order=order)
+    psnr = ob.psnr_rgb(img, oimg)
+    print(f"1080p PSNR vs oracle: {psnr:.2f} dB, max abs {np.abs(img[..., :3] - oimg[..., :3]).max():.4f}")
+    assert out.error_flags == 0 and out.frustum_count == st["visible"]
+    assert psnr >= PSNR_MIN                      # bar: 40 dB; measured ~71 dB
+    assert np.abs(img[..., :3] - oimg[..., :3]).max() <= ABS_TOL
+    scene.close()
+
+
 @pytest.mark.parametrize("kw", [dict(ms_antialiasing=1), dict(debug_flags=1), dict(debug_flags=2), dict(debug_flags=4),
                                 dict(splat_scale=0.5), dict(sh_degree=1), dict(sh_degree=0), dict(alpha_cull_threshold=0.3)])
 def test_raster_knobs_match_oracle(scene_small, ob, kw):

@@ -730,6 +730,9 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
   if((rc = s->blockCount.ensure(std::max<uint64_t>((total + kPart - 1) / kPart, 1)))) return rc;
   HIPCHK(hipMemset(s->ctr.p, 0, sizeof(FrameCounters)));
   HIPCHK(hipMemset(s->plans.p, 0, 2 * sizeof(SortPlan)));
+  // hipMemset on device memory is asynchronous on the NULL stream, and the render stream is non-blocking:
+  // without this the memsets above can land in the middle of the first frame (caught by the test suite)
+  HIPCHK(hipDeviceSynchronize());
   s->committed = true;
   s->haveFrame = false;
   return MGS_OK;
