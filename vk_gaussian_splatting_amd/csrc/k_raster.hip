@@ -269,8 +269,8 @@ __global__ void k_tile_ranges(const uint32_t* __restrict__ keyX, const uint32_t*
 // (not in MGS_ALPHA_SUM mode, where the reference's additive alpha must see every fragment).
 constexpr int kCmpEntries = 4;                  // list entries per thread per stage-A round (4 gathers in flight per lane)
 constexpr int kCmpRound   = 256 * kCmpEntries;  // 1024 entries scanned per round
-constexpr int kCmpCap     = 512;                // LDS batch capacity (records): 24 KB -> 6 workgroups per CU
-constexpr int kCmpGo      = 192;                // blend as soon as this many records are staged (<= kCmpCap-256)
+constexpr int kCmpCap     = 384;                // LDS batch capacity (records): 18 KB -> 8 workgroups per CU (sweep: 384/512/768 -> 0.220/0.230/0.275 ms)
+constexpr int kCmpGo      = 128;                // blend as soon as this many records are staged (<= kCmpCap-256)
 
 template <bool HALF_OUT>
 __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uint2* __restrict__ ranges,
