@@ -71,7 +71,12 @@ __device__ __forceinline__ void loadShVectors(const void* base, uint32_t li, uin
   uint4         x[NV];
 #pragma unroll
   for(int v = 0; v < NV; ++v)
-    x[v] = p[(size_t)v * count];
+  {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    // streamed once per frame by exactly one lane: non-temporal, so it does not evict the records/keys from L2
+    const u32x4 r = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(&p[(size_t)v * count]));
+    x[v]          = make_uint4(r.x, r.y, r.z, r.w);
+  }
 #pragma unroll
   for(int v = 0; v < NV; ++v)
   {

@@ -135,18 +135,20 @@ __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ 
   }
 }
 
-// decides which passes run and where each pass reads from (pass 0 always runs: src0 -> X)
-__global__ __launch_bounds__(256) void k_sort_plan(SortPlan* __restrict__ plan, const uint32_t* __restrict__ nPtr, int nPasses)
+// decides which passes run and where each pass reads from (pass 0 always runs: src0 -> X).  Executed by
+// workgroup 0 of the pass-0 scan kernel (a separate 1-workgroup launch cost ~4.7 us per sort).  When the sort
+// has a single pass the sorted order is fully described by the digit histogram, so the caller's per-digit
+// ranges ([begin,end) of every bin of the pair sort) are written here and no separate range kernel runs.
+__device__ __forceinline__ void sortPlanCompute(SortPlan* __restrict__ plan, uint32_t n, int nPasses, uint2* __restrict__ ranges,
+                                                uint32_t* s_tmp /*>=8*/)
 {
-  __shared__ uint32_t s_skip[4];
-  const int      t = threadIdx.x;
-  const uint32_t n = *nPtr;
+  const int t = threadIdx.x;
   if(t < 4)
-    s_skip[t] = 0;
+    s_tmp[4 + t] = 0;
   __syncthreads();
   for(int q = 1; q < nPasses; ++q)
     if(n > 0 && plan->ghist[q][t] == n)
-      s_skip[q] = 1;  // every key has the same digit: the pass would be the identity permutation
+      s_tmp[4 + q] = 1;  // every key has the same digit: the pass would be the identity permutation
   __syncthreads();
   if(t == 0)
   {
@@ -156,9 +158,9 @@ __global__ __launch_bounds__(256) void k_sort_plan(SortPlan* __restrict__ plan, 
     plan->srcSel[0] = 0;
     for(int q = 1; q < nPasses; ++q)
     {
-      plan->skip[q]   = s_skip[q];
+      plan->skip[q]   = s_tmp[4 + q];
       plan->srcSel[q] = cur;
-      if(!s_skip[q])
+      if(!s_tmp[4 + q])
       {
         cur ^= 1u;
         ++run;
@@ -170,6 +172,13 @@ __global__ __launch_bounds__(256) void k_sort_plan(SortPlan* __restrict__ plan, 
     plan->lastPass  = last;
     plan->n         = n;
   }
+  if(ranges != nullptr && nPasses == 1)
+  {
+    uint32_t       total;
+    const uint32_t c  = plan->ghist[0][t];
+    const uint32_t ex = blockExclusiveScan256(c, s_tmp, &total);
+    ranges[t]         = make_uint2(ex, ex + c);
+  }
 }
 
 // (b) one workgroup per digit: exclusive scan of that digit's row of partition counts, offset by the
@@ -177,13 +186,16 @@ __global__ __launch_bounds__(256) void k_sort_plan(SortPlan* __restrict__ plan, 
 // the first key of partition p with digit d.  8 consecutive entries per thread per step.
 __global__ __launch_bounds__(256) void k_sort_scan(const uint32_t* __restrict__ nPtr, const uint32_t* __restrict__ slotCount,
                                                    uint32_t partsSlotted, SortPlan* __restrict__ plan,
-                                                   uint32_t* __restrict__ partHist, uint32_t pStride, int pass, uint32_t part)
+                                                   uint32_t* __restrict__ partHist, uint32_t pStride, int pass, uint32_t part,
+                                                   int nPasses, uint2* __restrict__ ranges)
 {
-  __shared__ uint32_t s_tmp[4];
+  __shared__ uint32_t s_tmp[8];
   const int t = threadIdx.x, d = blockIdx.x;
-  if(plan->skip[pass])
+  if(pass > 0 && plan->skip[pass])
     return;
   const uint32_t n       = *nPtr;
+  if(pass == 0 && d == 0)
+    sortPlanCompute(plan, n, nPasses, ranges, s_tmp);  // the plan is first read by kernels launched after this one
   const bool     slotted = (pass == 0) && (slotCount != nullptr);
   const uint32_t parts   = slotted ? (partsSlotted + part / kSlotPart - 1) / (part / kSlotPart)
                                    : (uint32_t)(((uint64_t)n + part - 1) / part);
@@ -449,7 +461,6 @@ void launchRadixSort(hipStream_t stream, const SortLaunch& s)
   const uint32_t fatGrid = p0 < 512u ? p0 : 512u;
   hipLaunchKernelGGL((k_sort_hist<true>), dim3(fatGrid), dim3(256), 0, stream, s.keysX, s.keysY, s.keys0, s.slotCount, s.nPtr,
                      s.partsSlotted, s.plan, s.partHist, s.pStride, 0, s.beginBit, nPasses, partOf(0));
-  hipLaunchKernelGGL(k_sort_plan, dim3(1), dim3(256), 0, stream, s.plan, s.nPtr, nPasses);
   for(int pass = 0; pass < nPasses; ++pass)
   {
     const uint32_t parts = partsOf(pass), pp = partOf(pass);
@@ -457,7 +468,7 @@ void launchRadixSort(hipStream_t stream, const SortLaunch& s)
       hipLaunchKernelGGL((k_sort_hist<false>), dim3(parts), dim3(256), 0, stream, s.keysX, s.keysY, s.keys0,
                          (const uint32_t*)nullptr, s.nPtr, 0u, s.plan, s.partHist, s.pStride, pass, s.beginBit, nPasses, pp);
     hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, stream, s.nPtr, pass == 0 ? s.slotCount : nullptr,
-                       s.partsSlotted, s.plan, s.partHist, s.pStride, pass, pp);
+                       s.partsSlotted, s.plan, s.partHist, s.pStride, pass, pp, nPasses, s.ranges);
 #define MGS_SCATTER(FIRSTV, TH, KP, SLOTS)                                                                                  \
   hipLaunchKernelGGL((k_sort_scatter<FIRSTV, TH, KP>), dim3(parts), dim3(TH), 0, stream, s.keys0, s.vals0, s.keysX, s.valsX, \
                      s.keysY, s.valsY, SLOTS, s.nPtr, s.partsSlotted, s.plan, s.partHist, s.pStride, pass, s.beginBit,      \

@@ -1150,7 +1150,7 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
   const size_t      pixB   = half ? 8 : 16;
   s->imageRowBytes         = (size_t)F.width * pixB;
   s->imageBytes            = s->imageRowBytes * (size_t)F.height;
-  if((rc = s->ranges.ensure(nTiles))) return rc;
+  if((rc = s->ranges.ensure(std::max<uint32_t>(nTiles, 256u)))) return rc;
   if(s->image.n < s->imageBytes)
   {
     if((rc = s->image.ensure(s->imageBytes))) return rc;
@@ -1211,9 +1211,12 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
     L.maxElems  = s->pairCapacity;
     L.beginBit  = 0;
     L.endBit    = pairSortBits((int)nTiles);
+    const bool onePass = L.endBit <= 8;  // <= 256 bins: the digit histogram IS the range table
+    L.ranges    = onePass ? s->ranges.p : nullptr;
     launchRadixSort(st, L);
+    if(!onePass)
+      launchTileRanges(st, s->pairKey1.p, s->pairKey0.p, planP, s->ranges.p);
   }
-  launchTileRanges(st, s->pairKey1.p, s->pairKey0.p, planP, s->ranges.p);
   if(timed) HIPCHK(hipEventRecord(fev[4], st));
   launchComposite(st, F, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half);
   if(timed) HIPCHK(hipEventRecord(fev[5], st));

@@ -36,6 +36,7 @@ struct SortLaunch
   int             beginBit, endBit;
   const uint32_t* gatherSrc = nullptr;  // optional fused gather on the last executed pass:
   uint32_t*       gatherDst = nullptr;  //   gatherDst[sortedPos] = gatherSrc[value]
+  uint2*          ranges    = nullptr;  // optional, single-pass sorts: ranges[digit] = [begin,end) in the sorted output
 };
 
 void launchSortClearPlan(hipStream_t stream, SortPlan* plan);
