@@ -336,8 +336,11 @@ def test_eight_instances_trs_unified_sort_and_4k(ob):
     # low-resolution 4K consistency: the 4K frame box-filtered to 480x270 resembles the 480x270 frame
     lo = full.view(np.float16).astype(np.float32).reshape(270, 8, 480, 8, 4).mean(axis=(1, 3))
     assert ob.psnr_rgb(lo, img) >= 25.0
-    with pytest.raises(mgs.MgsError):
-        scene.add_instance(ss)     # a 9th instance: MGS_ERR_UNSUPPORTED in this build (kMaxInlineInstances)
+    for _ in range(8):
+        scene.add_instance(ss)     # up to 16 instances travel in the kernel-argument block
+    with pytest.raises(mgs.MgsError) as e:
+        scene.add_instance(ss)     # a 17th: MGS_ERR_UNSUPPORTED in this build (kMaxInlineInstances)
+    assert e.value.code == -8
     scene.close()
 
 

@@ -4,7 +4,7 @@
 
 namespace mgs {
 
-constexpr int kMaxInlineInstances = 8;   // instances carried by value in the kernel argument block
+constexpr int kMaxInlineInstances = 16;  // instances carried by value in the kernel argument block (16 x 208 B + frame < 4 KB)
 constexpr int kTilePx             = 16;  // compositing tile edge in pixels (one workgroup; 8x8 pixels per wave)
 
 // error bits reported through MgsFrameOut.error_flags
