@@ -243,7 +243,7 @@ def main():
     # runs of this same command, corrected as MI355X_MICROARCH.md prescribes; see profiles/*.json)
     traffic = None
     try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r1_e_pmc_hbm_traffic.json")))
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r1_f_pmc_hbm_traffic.json")))
         if dom_name == "project" and "k_project" in pj["kernel"] and world == 1 and N == 5_830_000:
             traffic = pj["traffic_bytes_per_launch_corrected"]
     except Exception:
