@@ -137,7 +137,9 @@ typedef struct MgsFrameParams {
                                    2: record the events but do not wait (query later with mgs_timings_query) */
   int32_t cpu_sort_blocking;    /* CPU_ASYNC only: 1 = wait for the sorter (deterministic tests) */
   int32_t debug_flags;          /* MGS_DEBUG_* bits: the reference's visualisation modes (parameters.h:86-201) */
-  int32_t reserved[5];
+  int32_t size_culling;         /* 0/1, default 0 (parameters.h:185): drop splats whose projected extent is below ...  */
+  float   size_culling_min_pixels; /* ... this many pixels, default 1.0 (shaderio.h:266, dist.comp.slang:93-134)      */
+  int32_t reserved[3];
 } MgsFrameParams;
 
 void mgs_frame_params_default(MgsFrameParams* p); /* fills the defaults cited above */

@@ -17,11 +17,11 @@ class OrcFrame(C.Structure):
                 ("width", C.c_int), ("height", C.c_int), ("splat_scale", C.c_float), ("frustum_dilation", C.c_float),
                 ("alpha_cull_threshold", C.c_float), ("sh_degree", C.c_int), ("front_to_back", C.c_int),
                 ("frustum_culling", C.c_int), ("target_fp16", C.c_int), ("ms_antialiasing", C.c_int),
-                ("debug_flags", C.c_int)]
+                ("size_culling", C.c_int), ("size_culling_min_pixels", C.c_float), ("debug_flags", C.c_int)]
 
 
 class OrcInstance(C.Structure):
-    _fields_ = [("centers", F32P), ("cov6", F32P), ("rgba", F32P), ("sh", F32P), ("count", C.c_uint32),
+    _fields_ = [("centers", F32P), ("cov6", F32P), ("rgba", F32P), ("sh", F32P), ("scales", F32P), ("count", C.c_uint32),
                 ("sh_degree", C.c_int), ("sh_stride", C.c_int), ("transform", C.c_float * 16),
                 ("transform_inv", C.c_float * 16)]
 
@@ -113,6 +113,7 @@ class PreparedSet:
         n = self.positions.size // 3
         self.count = n
         scale, rot = f32(arrays["scale"]).reshape(-1), f32(arrays["rotation"]).reshape(-1)
+        self.scales = scale
         f_dc, op = f32(arrays["f_dc"]).reshape(-1), f32(arrays["opacity"]).reshape(-1)
         f_rest = f32(arrays["f_rest"]).reshape(-1) if arrays.get("f_rest") is not None else np.zeros(0, np.float32)
         self.cov6 = np.zeros(6 * n, np.float32)
@@ -142,6 +143,7 @@ def make_instances(prepared_and_transforms):
         L.orc_mat4_inverse(_p(col), _p(inv))
         I = arr[i]
         I.centers, I.cov6, I.rgba, I.sh = _p(ps.positions), _p(ps.cov6), _p(ps.rgba), _p(ps.sh)
+        I.scales = _p(ps.scales)
         I.count, I.sh_degree, I.sh_stride = ps.count, ps.sh_degree, ps.sh_stride
         for k in range(16):
             I.transform[k] = float(col[k])
@@ -153,7 +155,7 @@ def make_instances(prepared_and_transforms):
 
 def make_frame(view, proj, camera_pos, width, height, splat_scale=1.0, frustum_dilation=0.2,
                alpha_cull=1.0 / 255.0, sh_degree=3, front_to_back=0, frustum_culling=1, target_fp16=0,
-               ms_antialiasing=0, debug_flags=0):
+               ms_antialiasing=0, debug_flags=0, size_culling=0, size_culling_min_pixels=1.0):
     f = OrcFrame()
     v = f32(view).T.reshape(-1)
     p = f32(proj).T.reshape(-1)
@@ -166,6 +168,7 @@ def make_frame(view, proj, camera_pos, width, height, splat_scale=1.0, frustum_d
     f.splat_scale, f.frustum_dilation, f.alpha_cull_threshold = splat_scale, frustum_dilation, alpha_cull
     f.sh_degree, f.front_to_back, f.frustum_culling = sh_degree, front_to_back, frustum_culling
     f.target_fp16, f.ms_antialiasing, f.debug_flags = target_fp16, ms_antialiasing, debug_flags
+    f.size_culling, f.size_culling_min_pixels = size_culling, size_culling_min_pixels
     return f
 
 

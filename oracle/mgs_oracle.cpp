@@ -378,6 +378,28 @@ uint32_t orc_key_cull(const OrcFrame* f, const OrcInstance* inst, int n_inst, ui
           continue;
         // NaN compares false in every test above, exactly as in the shader: a NaN splat survives.
       }
+      if(f->size_culling && I.scales)
+      {  // dist.comp.slang:93-134
+        const float sx = std::exp(I.scales[3 * i + 0]) * f->splat_scale, sy = std::exp(I.scales[3 * i + 1]) * f->splat_scale,
+                    sz = std::exp(I.scales[3 * i + 2]) * f->splat_scale;
+        const float radius = std::max(sx, std::max(sy, sz));
+        const float sqrt8  = 2.8284271247f;
+        float       extent = radius * sqrt8 * 2.0f;
+        auto        len3   = [&](int c) {
+          const float* m = I.transform + 4 * c;  // shader row c of the row-major view == glm column c
+          return std::sqrt((m[0] * m[0] + m[1] * m[1]) + m[2] * m[2]);
+        };
+        extent *= std::max(len3(0), std::max(len3(1), len3(2)));
+        const float viewDist = std::fabs(view[2]);
+        if(viewDist > 0.0001f)
+        {
+          const float focal0   = f->proj[0] * 0.5f * (float)f->width, focal1 = f->proj[5] * 0.5f * (float)f->height;
+          const float maxFocal = std::max(std::fabs(focal0), std::fabs(focal1));
+          const float projectedPixels = (extent * maxFocal) / viewDist;
+          if(projectedPixels < f->size_culling_min_pixels)
+            continue;
+        }
+      }
       ids[v]  = offset + i;
       keys[v] = f->front_to_back ? orc_encode_key(depth) : orc_encode_key(-depth);  // :163-167
       ++v;

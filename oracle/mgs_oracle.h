@@ -58,6 +58,8 @@ typedef struct OrcFrame {
   int   frustum_culling;      /* 0 none, 1 at dist (default), 2 at raster (shaderio.h:84-86) */
   int   target_fp16;          /* 1: round the colour target to fp16 after every blend (RGBA16F) */
   int   ms_antialiasing;      /* MS_ANTIALIASING macro (threedgs.h.slang:63-76) */
+  int   size_culling;         /* SIZE_CULLING_MODE (dist.comp.slang:93-134), default off (parameters.h:185) */
+  float size_culling_min_pixels; /* shaderio.h:266 */
   int   debug_flags;          /* 1 POINT_CLOUD_MODE (threedgs.h.slang:108-110), 2 SHOW_SH_ONLY (mesh.slang:205-207),
                                  4 DISABLE_OPACITY_GAUSSIAN (frag.slang:248-255) */
 } OrcFrame;
@@ -67,6 +69,7 @@ typedef struct OrcInstance {
   const float* cov6;     /* [count*6] */
   const float* rgba;     /* [count*4], already dequantised */
   const float* sh;       /* [count*sh_stride] interleaved [coef][rgb], may be NULL */
+  const float* scales;   /* [count*3] log-space scales (scalesAddress), only read by size culling; may be NULL */
   uint32_t count;
   int      sh_degree;    /* of the splat set */
   int      sh_stride;    /* 0, 9, 24, 45 */

@@ -132,6 +132,33 @@ def test_depth_keys_cull_and_sort_bit_exact(scene_small, ob, pose, flip):
         i2[np.lexsort((i2, k2))], gi[np.lexsort((gi, gk))])
 
 
+def test_size_culling_bit_exact(scene_small, ob):
+    """SIZE_CULLING_MODE (dist.comp.slang:93-134): same survivors, same keys, bit for bit"""
+    scene, sc = scene_small
+    base = None
+    for min_px in (1.0, 6.0, 20.0):
+        p, V, P, eye = camera(11, 640, 480)
+        p.size_culling, p.size_culling_min_pixels = 1, min_px
+        oks, ois = oracle_sorted_stream(ob, scene, sc, dict(view=V, proj=P, camera_pos=eye, width=640, height=480,
+                                                            size_culling=1, size_culling_min_pixels=min_px))
+        so = scene.sort_keys(p)
+        gk, gi = scene.sort_download(so.count)
+        assert np.array_equal(gk, oks) and np.array_equal(gi, ois)
+        assert base is None or so.count < base     # a larger threshold culls more
+        base = so.count
+    # and through the renderer
+    p.size_culling_min_pixels = 6.0
+    scene.render(p)
+    img = scene.download_frame(p).astype(np.float32)
+    ps = ob.PreparedSet(sc)
+    inst = ob.make_instances([(ps, None)])
+    fk = dict(view=V, proj=P, camera_pos=eye, width=640, height=480, size_culling=1, size_culling_min_pixels=6.0)
+    _, order = oracle_sorted_stream(ob, scene, sc, fk)
+    oimg, _ = ob.render(ob.make_frame(V, P, eye, 640, 480, target_fp16=1, size_culling=1, size_culling_min_pixels=6.0), inst,
+                        order=order)
+    assert ob.psnr_rgb(img, oimg) >= PSNR_MIN
+
+
 def test_cull_modes_and_dilation(scene_small, ob):
     scene, sc = scene_small
     ps = ob.PreparedSet(sc)

@@ -178,3 +178,29 @@ def test_strip_partition_covers_all_rows():
                 cover += list(range(b, e))
             assert cover == list(range(rows))
             assert multigpu.strip_pixel_rows(h, ws) * ws >= h
+
+
+def test_import_cameras_inria(tmp_path):
+    """importCamerasINRIA (src/camera_set.h:219-270): RDF->RUB re-signing, up/at from the rotation columns"""
+    import json
+    from vk_gaussian_splatting_amd import cameras
+    th = 0.3
+    R = [[np.cos(th), 0.0, np.sin(th)], [0.0, 1.0, 0.0], [-np.sin(th), 0.0, np.cos(th)]]
+    items = [dict(id=0, img_name="a.jpg", width=1959, height=1090, position=[1.0, 2.0, 3.0], rotation=R, fy=1160.0, fx=1159.0),
+             dict(id=1, img_name="b.jpg", width=1959, height=1090, position=[0.0, -1.0, 4.0],
+                  rotation=[[1, 0, 0], [0, 1, 0], [0, 0, 1]], fy=1160.0, fx=1159.0)]
+    p = tmp_path / "cameras.json"
+    p.write_text(json.dumps(items))
+    cams = cameras.import_cameras_inria(str(p))
+    assert len(cams) == 2 and cams[0].name == "a.jpg" and cams[0].fov == 60.0
+    assert np.allclose(cams[0].eye, [1.0, -2.0, -3.0])
+    assert np.allclose(cams[0].up, [0.0, 1.0, 0.0], atol=1e-6)                       # column 1: (-R01, R11, R21)
+    assert np.allclose(cams[0].ctr - cams[0].eye, [np.sin(th), 0.0, -np.cos(th)], atol=1e-6)  # column 2: (R02, -R12, -R22)
+    assert np.allclose(cams[1].ctr - cams[1].eye, [0, 0, -1]) and np.allclose(cams[1].eye, [0, 1, -4])
+    V, P = cams[1].matrices(640, 480)
+    assert np.allclose(V @ np.array([0, 1, -5, 1], np.float32), [0, 0, -1, 1], atol=1e-6)   # a point 1 unit ahead
+    d = cameras.Camera()
+    assert np.allclose(d.eye, [1.7, 1.5, 1.7]) and d.fov == 60.0 and d.clip == (0.1, 2000.0)
+    (tmp_path / "bad.json").write_text("[{\"position\": [1,2], \"rotation\": [[1,0,0],[0,1,0],[0,0,1]]}]")
+    with pytest.raises(ValueError):
+        cameras.import_cameras_inria(str(tmp_path / "bad.json"))

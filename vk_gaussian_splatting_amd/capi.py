@@ -37,7 +37,7 @@ class FrameParams(C.Structure):
                 ("target_format", C.c_int32), ("alpha_mode", C.c_int32), ("ms_antialiasing", C.c_int32),
                 ("strip_row_begin", C.c_int32), ("strip_row_end", C.c_int32),
                 ("collect_timings", C.c_int32), ("cpu_sort_blocking", C.c_int32), ("debug_flags", C.c_int32),
-                ("reserved", C.c_int32 * 5)]
+                ("size_culling", C.c_int32), ("size_culling_min_pixels", C.c_float), ("reserved", C.c_int32 * 3)]
 
 
 class FrameOut(C.Structure):

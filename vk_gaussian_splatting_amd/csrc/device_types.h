@@ -20,11 +20,13 @@ struct InstanceConst
   const float* centers;  // [count*3]
   const float* cov6;     // planar: float4 covA[count] = (S00,S01,S02,S11) then float2 covB[count] = (S12,S22)
   const void*  rgba;     // [count*4] fp32 | fp16 | u8
+  const float* maxScale; // [count] max(exp(scale)) per splat, host-computed (only read by size culling)
   const float* partBox;  // per 2048-splat partition: min xyz, max xyz (model space), rmax (sqrt(8*trace(Sigma))), pad
   const void*  sh;       // vector-planar: plane v holds 16 bytes of every splat's [coef][rgb] record: [planes][count][16 B]
   float        model[16];      // M   (glm column-major)
   float        modelView[16];  // V*M (host-computed with the same unfused fp32 products the shader does per thread)
   float        camModel[3];    // M^-1 * cameraPosition
+  float        modelAxisMax;   // max length of the model matrix columns (size culling, dist.comp.slang:110-115)
   float        modelScale;     // largest singular value of the model 3x3 (upper bound of any length stretch)
   uint32_t     count;
   uint32_t     globalOffset;   // first global splat id of this instance
@@ -56,6 +58,9 @@ struct FrameConst
   uint32_t totalPartitions;  // project-kernel partitions
   int32_t  partitionCull;    // 1: k_partition_cull fills the skip flags this frame
   int32_t  debugFlags;       // MGS_DEBUG_* bits
+  int32_t  sizeCulling;      // dist.comp.slang:93-134
+  float    sizeCullingMinPixels;
+  float    maxFocal;         // max(|focal.x|, |focal.y|)
 };
 
 struct FrameArgs

@@ -364,6 +364,9 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, Fram
       if(fabsf(nx) > c || fabsf(ny) > c || nz < 0.f - A.f.frustumDilation || nz > 1.0f)
         v = false;
     }
+    if(A.f.sizeCulling && v)  // dist.comp.slang:93-134 (after the frustum test, like the shader)
+      v = !sizeCulled(I.maxScale[min(li, I.count - 1u)], A.f.splatScale, I.modelAxisMax, vp[2], A.f.maxFocal,
+                      A.f.sizeCullingMinPixels);
     vis[it] = v;
     key[it] = A.f.frontToBack ? encodeKey(nz) : encodeKey(-nz);  // :163-167
     bal[it] = __ballot(v);

@@ -88,6 +88,23 @@ __device__ __forceinline__ void mulMat4Exact(const float* m, float x, float y, f
   }
 }
 
+// size culling of dist.comp.slang:93-134 with the oracle's exact unfused operation order
+__device__ __forceinline__ bool sizeCulled(float maxExpScale, float splatScale, float axisMax, float viewZ, float maxFocal,
+                                           float minPixels)
+{
+#pragma clang fp contract(off)
+  const float radius = maxExpScale * splatScale;
+  float       extent = radius * 2.8284271247f * 2.0f;
+  extent             = extent * axisMax;
+  const float viewDist = fabsf(viewZ);
+  if(viewDist > 0.0001f)
+  {
+    const float projectedPixels = (extent * maxFocal) / viewDist;
+    return projectedPixels < minPixels;
+  }
+  return false;
+}
+
 // IEEE-correct fp32 division (hipcc default: -fhip-fp32-correctly-rounded-divide-sqrt)
 __device__ __forceinline__ float divExact(float a, float b)
 {

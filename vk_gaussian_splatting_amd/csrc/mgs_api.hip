@@ -75,6 +75,7 @@ struct DeviceSet
   int      shDegree = 0, shStride = 0;  // logical elements per splat (0/9/24/45)
   int      shPitch = 0;                  // stored elements per splat: shStride padded to a 16-byte multiple
   int      shFormat = -1, rgbaFormat = -1;
+  float*   maxScale = nullptr;             // [count] max(exp(scale)), storage order
   float*   partBox = nullptr;              // [ceil(count/2048)][8]: AABB of the centres + footprint radius bound
   std::vector<uint32_t> newToOld, oldToNew;  // storage order (Morton) <-> caller's order
 };
@@ -411,7 +412,8 @@ static void freeSet(DeviceSet& d)
   if(d.rgba) (void)hipFree(d.rgba);
   if(d.sh) (void)hipFree(d.sh);
   if(d.partBox) (void)hipFree(d.partBox);
-  d.centers = d.cov6 = d.partBox = nullptr;
+  if(d.maxScale) (void)hipFree(d.maxScale);
+  d.centers = d.cov6 = d.partBox = d.maxScale = nullptr;
   d.rgba = d.sh = nullptr;
 }
 
@@ -641,6 +643,15 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
       });
       HIPCHK(hipMalloc((void**)&d.partBox, np * 8 * sizeof(float)));
       HIPCHK(hipMemcpy(d.partBox, box.data(), np * 8 * sizeof(float), hipMemcpyHostToDevice));
+    }
+    {  // size culling (dist.comp.slang:93-134) needs max(exp(scale)): 4 B/splat, exp() on the host like the oracle
+      std::vector<float> ms(n);
+      parallelBatches(n, [&](size_t i) {
+        const float* sc = &h.scale[3 * (size_t)perm[i]];
+        ms[i]           = std::max(std::exp(sc[0]), std::max(std::exp(sc[1]), std::exp(sc[2])));
+      });
+      HIPCHK(hipMalloc((void**)&d.maxScale, n * sizeof(float)));
+      HIPCHK(hipMemcpy(d.maxScale, ms.data(), n * sizeof(float), hipMemcpyHostToDevice));
     }
     {
       std::vector<float> planar(n * 6);
@@ -875,6 +886,7 @@ void mgs_frame_params_default(MgsFrameParams* p)
   p->frustum_culling      = MGS_CULL_AT_DIST;
   p->target_format        = MGS_TARGET_RGBA16F;
   p->alpha_mode           = MGS_ALPHA_COVERAGE;
+  p->size_culling_min_pixels = 1.0f;
 }
 
 // storage global id <-> caller global id.  Instances are concatenated in creation order in both spaces;
@@ -966,6 +978,9 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
   F.msAA            = p->ms_antialiasing;
   F.alphaMode       = p->alpha_mode;
   F.debugFlags      = p->debug_flags;
+  F.sizeCulling     = p->size_culling;
+  F.sizeCullingMinPixels = p->size_culling_min_pixels;
+  F.maxFocal        = std::max(std::fabs(F.focal[0]), std::fabs(F.focal[1]));
   F.targetFormat    = p->target_format;
   F.nInstances      = (int)s->instances.size();
   F.totalSplats     = s->totalSplats;
@@ -983,6 +998,11 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
     C.rgba    = d.rgba;
     C.sh      = d.sh;
     C.partBox = d.partBox;
+    C.maxScale = d.maxScale;
+    {
+      auto len3 = [&](int c) { return std::sqrt((I.M[4 * c] * I.M[4 * c] + I.M[4 * c + 1] * I.M[4 * c + 1]) + I.M[4 * c + 2] * I.M[4 * c + 2]); };
+      C.modelAxisMax = std::max(len3(0), std::max(len3(1), len3(2)));
+    }
     std::memcpy(C.model, I.M, sizeof(C.model));
     mat4Mul(p->view, I.M, C.modelView);  // mul(desc.transform, viewMatrix), mesh.slang:175
     float inv[16], cam[4] = {p->camera_pos[0], p->camera_pos[1], p->camera_pos[2], 1.0f}, cm[4];
