@@ -277,6 +277,8 @@ def main():
         "visible_splats": {"frustum": Vf, "sorted": Vs, "tile_pairs": D},
         "stage_ms": {STAGES[j]: float(stage_ms[j]) for j in range(6)},
         "stage_ms_single_stream": {STAGES[j]: float(calib_ms[j]) for j in range(6)},
+        "frame_span_ms_percentiles": {"p50": float(np.percentile(st[:, 5], 50)), "p95": float(np.percentile(st[:, 5], 95)),
+                                      "min": float(st[:, 5].min()), "max": float(st[:, 5].max())},
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg[dom_name], "launch_ms": float(dom_ms),

@@ -454,6 +454,50 @@ def test_cpu_async_sort_nonblocking_protocol(scene_small):
     assert np.array_equal(cur, ref)          # the asynchronous result converged to the blocking one
 
 
+def test_adversarial_splats_follow_the_shader_semantics(ob):
+    """non-finite / degenerate inputs: NaN and inf centres (NaN survives the dist-stage cull because every comparison is
+    false, dist.comp.slang:71-73, and is dropped by the clipper), zero quaternion ([glm] normalize -> identity),
+    huge / tiny scales (2048-px clamp, eigenvalue floor), saturated opacity logits, extreme SH"""
+    sc = synth.make_scene(20000, seed=99)
+    sc = {k: v.copy() for k, v in sc.items()}
+    sc["positions"][10] = [np.nan, 0.0, 0.0]
+    sc["positions"][11] = [np.inf, 1.0, -1.0]
+    sc["positions"][12] = [0.0, -np.inf, 0.0]
+    sc["rotation"][20] = 0.0                       # zero-length quaternion
+    sc["rotation"][21] = [1e-30, 0, 0, 0]
+    sc["scale"][30] = 8.0                          # exp(8) ~ 3000 units: clamps at 2048 px, covers the screen
+    sc["scale"][31] = [-30.0, -30.0, 2.0]          # needle
+    sc["scale"][32] = -40.0                        # sub-denormal covariance: +0.3 blur keeps it a ~3 px dot
+    sc["opacity"][40] = 1e30                       # sigmoid -> 1
+    sc["opacity"][41] = -1e30                      # sigmoid -> 0: alpha-culled
+    sc["f_dc"][50] = [1e6, -1e6, 0.0]              # clamp(0.5 + C0*f_dc) in [0,1]
+    sc["f_rest"][51] = 50.0                        # SH is not clamped afterwards (mesh.slang:243)
+    ss = mgs.SplatSet.from_arrays(**sc)
+    scene = mgs.Scene(0)
+    scene.add_instance(ss)
+    scene.commit()
+    W, H = 400, 300
+    p, V, P, eye = camera(8, W, H)
+    fk = dict(view=V, proj=P, camera_pos=eye, width=W, height=H)
+    oks, ois = oracle_sorted_stream(ob, scene, sc, fk)
+    so = scene.sort_keys(p)
+    gk, gi = scene.sort_download(so.count)
+    assert np.array_equal(gk, oks) and np.array_equal(gi, ois)
+    assert 10 in gi                                 # the NaN centre is "visible" to the dist stage, like in the shader
+    out = scene.render(p, want_stats=True)
+    img = scene.download_frame(p).astype(np.float32)
+    ps = ob.PreparedSet(sc)
+    inst = ob.make_instances([(ps, None)])
+    oimg, st = ob.render(ob.make_frame(V, P, eye, W, H, target_fp16=1), inst, order=ois)
+    assert out.error_flags == 0 and out.frustum_count == st["visible"]
+    assert np.isfinite(img).all() == np.isfinite(oimg).all()
+    fin = np.isfinite(img).all(axis=-1) & np.isfinite(oimg).all(axis=-1)
+    a, b = np.where(fin[..., None], img, 0), np.where(fin[..., None], oimg, 0)
+    big = max(1.0, float(np.abs(b[..., :3]).max()))
+    assert ob.psnr_rgb(a / big, b / big) >= PSNR_MIN     # SH-boosted colours exceed 1: compare relative to the frame's range
+    scene.close()
+
+
 def test_api_error_behaviour():
     scene = mgs.Scene(0)
     p = capi.default_params(64, 64)
