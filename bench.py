@@ -179,8 +179,11 @@ def main():
         elapsed = float(tt.item())
 
     # ---- per-stage HIP-event times of the timed frames (ring of 128) + counters per pose --------
-    k = min(args.steps // K, 128)
-    st = np.array([scenes[c].timings(b) for c in range(K) for b in range(k)], np.float64)  # [K*k, 6] ms
+    # context c rendered frames c, c+K, ... of the timed region (and possibly more during warm-up/calibration)
+    per_ctx = [len(range(c, args.steps, K)) for c in range(K)]
+    st = np.array([scenes[c].timings(b) for c in range(K) for b in range(min(per_ctx[c], 128))], np.float64)  # [*, 6] ms
+    if st.size == 0:
+        st = calib_ms[None, :]
     stage_ms = st.mean(axis=0)
     counts = []
     for i in range(min(64, args.steps)):
@@ -217,8 +220,8 @@ def main():
         tt = torch.tensor([el2], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el2 = float(tt.item())
-        k2 = min(args.steps // K, 128)
-        st2 = np.array([scenes[c].timings(b) for c in range(K) for b in range(k2)], np.float64).mean(axis=0)
+        st2 = np.array([scenes[c].timings(b) for c in range(K) for b in range(min(per_ctx[c], 128))], np.float64)
+        st2 = st2.mean(axis=0) if st2.size else calib_ms
         set_strips(False)
         strips_out = {"value": args.steps / el2, "unit": "frames/s", "scaling": "strong", "ms_per_step": 1e3 * el2 / args.steps,
                       "partition": f"{world} tile-row strips + one RCCL all_gather per frame",
