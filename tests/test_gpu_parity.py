@@ -498,6 +498,38 @@ def test_adversarial_splats_follow_the_shader_semantics(ob):
     scene.close()
 
 
+def test_vkgs_project_drives_the_renderer(tmp_path, ob):
+    """a .vkgs project (the reference's scene description) -> scene + frame params -> frame == oracle"""
+    import json
+    from vk_gaussian_splatting_amd import project
+    sc = synth.make_scene(8000, seed=5)
+    synth.write_ply(str(tmp_path / "set.ply"), sc)
+    doc = {"version": 5, "renderer": {"maxShDegree": 3, "frustumCulling": 1, "sortingMethod": 0},
+           "camera": {"eye": [3.0, 1.5, 2.5], "ctr": [0, 0, 0], "up": [0, 1, 0], "fov": 50.0, "clip": [0.1, 1000.0]},
+           "splatsGlobals": {"shFormat": 0, "rgbaFormat": 0},
+           "splatSets": [{"id": 0, "path": "set.ply"}],
+           "splats": [{"splatSetId": 0, "name": "a", "position": [0, 0, 0], "rotation": [0, 0, 0], "scale": [1, 1, 1]},
+                      {"splatSetId": 0, "name": "b", "position": [1.5, 0.2, -1.0], "rotation": [15, 40, -10], "scale": [0.5, 0.7, 0.6]}]}
+    (tmp_path / "p.vkgs").write_text(json.dumps(doc))
+    pr = project.load_project(str(tmp_path / "p.vkgs"))
+    scene = pr.build_scene(0)
+    W, H = 320, 240
+    p = pr.frame_params(W, H)
+    scene.render(p)
+    img = scene.download_frame(p).astype(np.float32)
+    V, P = pr.camera.matrices(W, H)
+    M1, _ = mgs.compute_transform([0.5, 0.7, 0.6], [15, 40, -10], [1.5, 0.2, -1.0])
+    loaded = mgs.SplatSet.load(str(tmp_path / "set.ply")).arrays()
+    scl = {k: loaded[k].reshape(sc[k].shape) for k in sc}
+    _, order = oracle_sorted_stream(ob, scene, scl, dict(view=V, proj=P, camera_pos=pr.camera.eye, width=W, height=H),
+                                    transforms=(None, M1))
+    ps = ob.PreparedSet(scl)
+    oimg, _ = ob.render(ob.make_frame(V, P, pr.camera.eye, W, H, target_fp16=1), ob.make_instances([(ps, None), (ps, M1)]),
+                        order=order)
+    assert ob.psnr_rgb(img, oimg) >= PSNR_MIN
+    scene.close()
+
+
 def test_api_error_behaviour():
     scene = mgs.Scene(0)
     p = capi.default_params(64, 64)

@@ -204,3 +204,44 @@ def test_import_cameras_inria(tmp_path):
     (tmp_path / "bad.json").write_text("[{\"position\": [1,2], \"rotation\": [[1,0,0],[0,1,0],[0,0,1]]}]")
     with pytest.raises(ValueError):
         cameras.import_cameras_inria(str(tmp_path / "bad.json"))
+
+
+def test_vkgs_project_roundtrip(tmp_path):
+    """.vkgs (vkgs_project_writer.cpp:75-330 / vkgs_project_reader.cpp): sections the raster path consumes"""
+    import json
+    from vk_gaussian_splatting_amd import project, cameras
+    sc = synth.make_scene(64, seed=8)
+    synth.write_ply(str(tmp_path / "a.ply"), sc)
+    doc = {"version": 5,
+           "renderer": {"maxShDegree": 2, "frustumCulling": 2, "sizeCulling": 1, "sizeCullingMinPixels": 3.5,
+                        "sortingMethod": 0, "pointCloudModeEnabled": True, "showShOnly": False, "pipeline": 1},
+           "camera": {"model": 0, "eye": [2, 1, 2], "ctr": [0, 0.5, 0], "up": [0, 1, 0], "fov": 45.0, "clip": [0.05, 500.0]},
+           "cameras": [{"eye": [1, 1, 1], "ctr": [0, 0, 0], "up": [0, 1, 0], "fov": 60.0, "clip": [0.1, 2000.0]}],
+           "splatsGlobals": {"shFormat": 2, "rgbaFormat": 1},
+           "splatSets": [{"id": 7, "path": "a.ply", "storage": 0, "shFormat": 2, "rgbaFormat": 1}],
+           "splats": [{"splatSetId": 7, "name": "one", "position": [1, 2, 3], "rotation": [0, 90, 0], "scale": [2, 2, 2]},
+                      {"splatSetId": 7, "name": "two"},
+                      {"splatSetId": 99, "name": "dangling"}],
+           "lights": {"assets": [], "instances": []}}
+    (tmp_path / "scene.vkgs").write_text(json.dumps(doc))
+    pr = project.load_project(str(tmp_path / "scene.vkgs"))
+    assert pr.version == 5 and pr.sh_format == 2 and pr.rgba_format == 1
+    assert pr.splat_sets == {7: str(tmp_path / "a.ply")}
+    assert [i.name for i in pr.instances] == ["one", "two", "dangling"]
+    assert pr.instances[0].rotation == (0, 90, 0) and pr.instances[1].scale == (1.0, 1.0, 1.0)
+    assert pr.camera.fov == 45.0 and pr.camera.clip == (0.05, 500.0) and len(pr.cameras) == 1
+    p = pr.frame_params(640, 480)
+    assert (p.sh_degree, p.frustum_culling, p.size_culling, p.debug_flags) == (2, 2, 1, 1)
+    assert abs(p.size_culling_min_pixels - 3.5) < 1e-6 and tuple(p.camera_pos) == (2.0, 1.0, 2.0)
+    project.save_project(pr, str(tmp_path / "out" if False else tmp_path / "copy.vkgs"))
+    pr2 = project.load_project(str(tmp_path / "copy.vkgs"))
+    assert pr2.splat_sets == pr.splat_sets and pr2.renderer == pr.renderer and "lights" in pr2.extra
+    assert [(i.splat_set_id, i.position, i.rotation, i.scale) for i in pr2.instances] == \
+           [(i.splat_set_id, tuple(i.position), tuple(i.rotation), tuple(i.scale)) for i in pr.instances]
+    (tmp_path / "new.vkgs").write_text(json.dumps({"version": 99}))
+    with pytest.raises(ValueError):
+        project.load_project(str(tmp_path / "new.vkgs"))
+    legacy = {"splats": [{"path": "a.ply", "name": "old", "position": [0, 0, 0], "rotation": [0, 0, 0], "scale": [1, 1, 1]}]}
+    (tmp_path / "legacy.vkgs").write_text(json.dumps(legacy))
+    pl = project.load_project(str(tmp_path / "legacy.vkgs"))
+    assert pl.version == 0 and pl.splat_sets == {0: str(tmp_path / "a.ply")} and pl.instances[0].name == "old"
