@@ -530,6 +530,33 @@ def test_vkgs_project_drives_the_renderer(tmp_path, ob):
     scene.close()
 
 
+def test_binning_paths_bit_identical():
+    """the record-free direct binning (default, <= 256 bins), the record + pair-sort path it replaced and other bin
+    sizes (one- and two-pass pair sorts) must all produce the same frame, bit for bit: every one of them hands the
+    compositor the same depth-ordered list restricted to a bin"""
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_child_render.py")
+
+    def run(extra):
+        env = dict(os.environ)
+        env.update(extra)
+        out = subprocess.run([sys.executable, child, "60000", "1280", "720"], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return [l for l in out.stdout.splitlines() if l.startswith("FRAMES_SHA1")][0]
+
+    ref = run({})
+    assert run({"MGS_DIRECT_BIN": "0"}) == ref
+    for shift in ("1,1", "2,3", "4,4"):
+        a = run({"MGS_BIN_SHIFT": shift})
+        b = run({"MGS_BIN_SHIFT": shift, "MGS_DIRECT_BIN": "0"})
+        assert a == b, shift
+        # pair counts differ with the bin size, frames must not
+    base = run({"MGS_BIN_SHIFT": "3,3"})
+    for shift in ("1,1", "2,3", "4,4"):
+        assert run({"MGS_BIN_SHIFT": shift}) == base, shift
+
+
 def test_api_error_behaviour():
     scene = mgs.Scene(0)
     p = capi.default_params(64, 64)

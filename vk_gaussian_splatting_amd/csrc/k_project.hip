@@ -311,14 +311,20 @@ template <bool FULL, int SHF, int RGBAF>
 __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, FrameCounters* __restrict__ ctr,
                                                          uint32_t* __restrict__ keysSlot, uint32_t* __restrict__ idsSlot,
                                                          uint32_t* __restrict__ slotCount, SplatRec* __restrict__ rec,
-                                                         uint32_t* __restrict__ rect, const uint32_t* __restrict__ partSkip)
+                                                         uint32_t* __restrict__ rect, const uint32_t* __restrict__ partSkip,
+                                                         uint32_t* __restrict__ slotHist, uint32_t histStride)
 {
+  // slotHist[d * histStride + partition] = survivors of this partition whose low key byte is d: the radix
+  // sort's pass-0 partition histogram, produced here while the keys are still on chip.
   if(partSkip != nullptr && partSkip[blockIdx.x] != 0u)
   {  // k_partition_cull proved that no splat of this partition can survive the cull / reach the strip
     if(threadIdx.x == 0)
       slotCount[blockIdx.x] = 0u;
+    slotHist[(size_t)threadIdx.x * histStride + blockIdx.x] = 0u;
     return;
   }
+  __shared__ uint32_t s_hist[256];
+  s_hist[threadIdx.x] = 0u;  // ordered before its first use by the barriers of phase 1
   __shared__ uint16_t s_li[kPrjPart];   // bit 15: survived phase 2
   __shared__ uint32_t s_key[kPrjPart];
   __shared__ uint32_t s_cnt[32];
@@ -394,6 +400,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, Fram
     {
       keysSlot[slotBase + j] = s_key[j];
       idsSlot[slotBase + j]  = I.globalOffset + local0 + s_li[j];
+      atomicAdd(&s_hist[s_key[j] & 255u], 1u);
     }
     if(t == 0)
     {
@@ -401,6 +408,8 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, Fram
       if(M)
         atomicAdd(&ctr->sortedCount, M);
     }
+    __syncthreads();
+    slotHist[(size_t)t * histStride + part] = s_hist[t];
     return;
   }
   else
@@ -454,6 +463,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, Fram
         const uint32_t pos       = s_base[r * 4 + w] + lanesBelow(bal[r]);
         keysSlot[slotBase + pos] = s_key[j];
         idsSlot[slotBase + pos]  = I.globalOffset + local0 + (s_li[j] & 0x7FFFu);
+        atomicAdd(&s_hist[s_key[j] & 255u], 1u);
       }
     if(t == 0)
     {
@@ -461,6 +471,8 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, Fram
       if(outCount)
         atomicAdd(&ctr->sortedCount, outCount);
     }
+    __syncthreads();
+    slotHist[(size_t)t * histStride + part] = s_hist[t];
   }
 }
 
@@ -550,13 +562,14 @@ void launchPartitionCull(hipStream_t stream, const FrameArgs& args, uint32_t* pa
 // host-callable launcher
 void launchProject(hipStream_t stream, const FrameArgs& args, bool full, int shFormat, int rgbaFormat, FrameCounters* ctr,
                    uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, SplatRec* rec, uint32_t* rect,
-                   const uint32_t* partSkip)
+                   const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride)
 {
   const dim3 grid(args.f.totalPartitions), block(kPrjThreads);
   if(args.f.totalPartitions == 0)
     return;
 #define MGS_LAUNCH(FULLV, S, R)                                                                                          \
-  hipLaunchKernelGGL((k_project<FULLV, S, R>), grid, block, 0, stream, args, ctr, keysSlot, idsSlot, slotCount, rec, rect, partSkip)
+  hipLaunchKernelGGL((k_project<FULLV, S, R>), grid, block, 0, stream, args, ctr, keysSlot, idsSlot, slotCount, rec, rect, partSkip, \
+                     slotHist, histStride)
   if(!full)
   {
     MGS_LAUNCH(false, 0, 0);

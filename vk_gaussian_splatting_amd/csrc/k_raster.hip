@@ -215,6 +215,309 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_expand(const uint32_t* __re
   }
 }
 
+// ---- direct binning (<= 256 bins, <= 32 bin columns and <= 32 bin rows) ----------------------------
+// With coarse bins the (bin, splat) records never need to exist as sortable pairs: splitting the
+// depth-sorted splat list into per-bin lists is ONE stable multi-split, done reduce-then-scan like a
+// radix pass whose "digit" is a set (every bin of the splat's rect):
+//   k_dbin_count : per chunk of 1024 sorted splats, how many of them touch each bin -> binHist[bin][chunk]
+//                  (also re-lays the rects out in sorted order: the only random gather of the stage)
+//   k_dbin_scan  : one workgroup per bin: exclusive scan of its row, row total
+//   k_dbin_emit  : per chunk, append the ids to every bin list at binBase + rowOffset, in sorted order
+// Both per-chunk kernels work on bit matrices: per round of 64 splats, column mask c[bx] = lanes whose rect
+// spans column bx (one ballot), row mask r[by] likewise; the lanes hitting bin (bx,by) are c[bx] & r[by].
+// Counting is a popcount per bin (lane = bin), emission walks the set bits (lane = bin, appending to its own
+// list), so the cost per splat does not depend on how many bins it covers — a splat covering the whole
+// screen is one more bit in every mask (per-lane loops over the rect were tried: every round of 64
+// depth-neighbours contains some large splat, and the wave pays its trip count).  Gone with the records:
+// their 8-byte round trips, the output-partitioned expansion and the whole pair sort.
+constexpr int kDbRounds = 4;                 // rounds of 64 splats per wave
+constexpr int kDbChunk  = 256 * kDbRounds;   // sorted splats per workgroup
+constexpr int kDbStage  = 4096;              // list entries staged in LDS per chunk so that the appends are coalesced
+constexpr int kDbMaxDim = 32;
+
+// column / row hit masks of one round of 64 rects -> wave-private LDS (the ballots are wave-uniform)
+__device__ __forceinline__ void rectMasks(uint32_t r, bool valid, int binsX, int binsY, uint64_t* s_col, uint64_t* s_row)
+{
+  const int lane = laneId();
+  if(!valid)
+    r = 1u;  // x0 = 1 > x1 = 0: no bins
+  const uint32_t x0 = r & 255u, y0 = (r >> 8) & 255u, dx = ((r >> 16) & 255u) - x0, dy = (r >> 24) - y0;
+  const bool     ok = (int)dx >= 0 && (int)dy >= 0;
+  const uint32_t ux = ok ? dx : 0u, nx0 = ok ? x0 : 0xFFFFu;  // rejected: b - nx0 wraps far above ux
+  for(int b = 0; b < binsX; ++b)
+  {
+    const uint64_t m = __ballot((uint32_t)b - nx0 <= ux);
+    if(lane == 0)
+      s_col[b] = m;
+  }
+  for(int b = 0; b < binsY; ++b)
+  {
+    const uint64_t m = __ballot((uint32_t)b - y0 <= dy);
+    if(lane == 0)
+      s_row[b] = m;
+  }
+}
+
+// the (up to 4) bins lane `lane` is responsible for: b = lane + 64 j
+struct LaneBins
+{
+  int  bx[4], by[4];
+  bool on[4];
+};
+__device__ __forceinline__ LaneBins laneBins(int binsX, int nb)
+{
+  LaneBins L;
+#pragma unroll
+  for(int j = 0; j < 4; ++j)
+  {
+    const int b = laneId() + 64 * j;
+    L.on[j]     = b < nb;
+    L.bx[j]     = L.on[j] ? b % binsX : 0;
+    L.by[j]     = L.on[j] ? b / binsX : 0;
+  }
+  return L;
+}
+
+__global__ __launch_bounds__(256) void k_dbin_count(const uint32_t* __restrict__ idsX, const uint32_t* __restrict__ idsY,
+                                                    const SortPlan* __restrict__ plan, const uint32_t* __restrict__ rect,
+                                                    uint32_t* __restrict__ sortedRect, uint32_t* __restrict__ binHist,
+                                                    uint32_t pStride, int binsX, int binsY, int gather)
+{
+  __shared__ uint64_t s_col[4][kDbMaxDim], s_row[4][kDbMaxDim];
+  __shared__ uint32_t s_cnt[4][256];
+  const uint32_t n      = plan->n;
+  const uint32_t chunks = (n + kDbChunk - 1) / kDbChunk;
+  if(blockIdx.x >= chunks)
+    return;
+  const int       t = threadIdx.x, lane = laneId(), w = t >> 6;
+  const uint32_t* ids = plan->finalSel ? idsY : idsX;
+  const uint32_t  e0  = blockIdx.x * (uint32_t)kDbChunk + (uint32_t)w * (kDbRounds * 64) + (uint32_t)lane;
+  uint32_t        r[kDbRounds];
+  if(gather)
+  {
+    uint32_t id[kDbRounds];
+#pragma unroll
+    for(int i = 0; i < kDbRounds; ++i)
+      id[i] = ids[min(e0 + i * 64u, n - 1u)];  // clamped, not predicated: all loads in flight
+#pragma unroll
+    for(int i = 0; i < kDbRounds; ++i)
+      r[i] = rect[id[i]];
+#pragma unroll
+    for(int i = 0; i < kDbRounds; ++i)
+      if(e0 + i * 64u < n)
+        sortedRect[e0 + i * 64u] = r[i];
+  }
+  else
+  {
+#pragma unroll
+    for(int i = 0; i < kDbRounds; ++i)
+      r[i] = sortedRect[min(e0 + i * 64u, n - 1u)];
+  }
+  const int      nb = binsX * binsY;
+  const LaneBins L  = laneBins(binsX, nb);
+  uint32_t       cnt[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for(int i = 0; i < kDbRounds; ++i)
+  {
+    rectMasks(r[i], e0 + i * 64u < n, binsX, binsY, s_col[w], s_row[w]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for(int j = 0; j < 4; ++j)
+      if(j * 64 < nb)
+      {
+        const uint64_t m = L.on[j] ? (s_col[w][L.bx[j]] & s_row[w][L.by[j]]) : 0ull;
+        cnt[j] += (uint32_t)__popcll(m);
+      }
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for(int j = 0; j < 4; ++j)
+    s_cnt[w][lane + 64 * j] = cnt[j];
+  __syncthreads();
+  if(t < nb)
+    binHist[(size_t)t * pStride + blockIdx.x] = s_cnt[0][t] + s_cnt[1][t] + s_cnt[2][t] + s_cnt[3][t];
+}
+
+__global__ __launch_bounds__(256) void k_dbin_scan(const SortPlan* __restrict__ plan, uint32_t* __restrict__ binHist,
+                                                   uint32_t pStride, uint32_t* __restrict__ binTotal)
+{
+  __shared__ uint32_t s_tmp[4];
+  const int      t      = threadIdx.x;
+  const uint32_t n      = plan->n;
+  const uint32_t chunks = (n + kDbChunk - 1) / kDbChunk;
+  uint32_t*      row    = binHist + (size_t)blockIdx.x * pStride;
+  uint32_t       carry  = 0;
+  for(uint32_t base = 0; base < chunks; base += 2048)
+  {
+    const uint32_t p0 = base + t * 8;
+    uint32_t       v[8], sum = 0;
+#pragma unroll
+    for(int i = 0; i < 8; ++i)
+    {
+      v[i] = (p0 + i < chunks) ? row[p0 + i] : 0u;
+      sum += v[i];
+    }
+    uint32_t chunk;
+    uint32_t run = carry + blockExclusiveScan256(sum, s_tmp, &chunk);
+#pragma unroll
+    for(int i = 0; i < 8; ++i)
+    {
+      if(p0 + i < chunks)
+        row[p0 + i] = run;
+      run += v[i];
+    }
+    carry += chunk;
+  }
+  if(t == 0)
+    binTotal[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ idsX, const uint32_t* __restrict__ idsY,
+                                                   const SortPlan* __restrict__ plan, const uint32_t* __restrict__ sortedRect,
+                                                   const uint32_t* __restrict__ binHist, uint32_t pStride,
+                                                   const uint32_t* __restrict__ binTotal, uint32_t* __restrict__ binList,
+                                                   uint2* __restrict__ ranges, FrameCounters* __restrict__ ctr,
+                                                   uint32_t capacity, int binsX, int binsY)
+{
+  __shared__ uint64_t s_col[4][kDbRounds][kDbMaxDim], s_row[4][kDbRounds][kDbMaxDim];  // masks of every round
+  __shared__ uint32_t s_cnt[4][256];  // per-wave counts, then per-wave write cursors
+  __shared__ uint32_t s_ids[kDbChunk];
+  __shared__ uint32_t s_stage[kDbStage];  // (bin << 16) | position inside the chunk
+  __shared__ uint32_t s_gdst[256], s_loc[256];
+  __shared__ uint32_t s_tmp[4];
+  const uint32_t n      = plan->n;
+  const uint32_t chunks = (n + kDbChunk - 1) / kDbChunk;
+  if(blockIdx.x >= chunks)
+    return;
+  // nearest splats (the end of the list) are the largest: start their chunks first
+  const uint32_t  chunk = chunks - 1u - blockIdx.x;
+  const int       t = threadIdx.x, lane = laneId(), w = t >> 6;
+  const uint32_t* ids = plan->finalSel ? idsY : idsX;
+  const uint32_t  wbase = (uint32_t)w * (kDbRounds * 64);
+  const uint32_t  e0    = chunk * (uint32_t)kDbChunk + wbase + (uint32_t)lane;
+  const int       nb    = binsX * binsY;
+  const LaneBins  L     = laneBins(binsX, nb);
+  uint32_t        cnt[4] = {0u, 0u, 0u, 0u};
+  {
+    uint32_t r[kDbRounds];
+#pragma unroll
+    for(int i = 0; i < kDbRounds; ++i)
+    {
+      const uint32_t e              = min(e0 + i * 64u, n - 1u);
+      r[i]                          = sortedRect[e];
+      s_ids[wbase + i * 64 + lane] = ids[e];
+    }
+#pragma unroll
+    for(int i = 0; i < kDbRounds; ++i)
+      rectMasks(r[i], e0 + i * 64u < n, binsX, binsY, s_col[w][i], s_row[w][i]);
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for(int i = 0; i < kDbRounds; ++i)
+#pragma unroll
+    for(int j = 0; j < 4; ++j)
+      if(j * 64 < nb)
+      {
+        const uint64_t m = L.on[j] ? (s_col[w][i][L.bx[j]] & s_row[w][i][L.by[j]]) : 0ull;
+        cnt[j] += (uint32_t)__popcll(m);
+      }
+#pragma unroll
+  for(int j = 0; j < 4; ++j)
+    s_cnt[w][lane + 64 * j] = cnt[j];
+  __syncthreads();
+
+  // thread t == bin t: where this chunk's run starts in the bin's list, and in the LDS stage
+  const uint32_t c0 = s_cnt[0][t], c1 = s_cnt[1][t], c2 = s_cnt[2][t], c3 = s_cnt[3][t];
+  const uint32_t tot   = (t < nb) ? c0 + c1 + c2 + c3 : 0u;
+  const uint32_t btot  = (t < nb) ? binTotal[t] : 0u;
+  uint32_t       D32, P;
+  const uint32_t binBase = blockExclusiveScan256(btot, s_tmp, &D32);
+  const uint32_t local   = blockExclusiveScan256(tot, s_tmp, &P);
+  // 64-bit total without 64-bit shuffles: sum the halves separately
+  uint32_t       dLo, dHi;
+  (void)blockExclusiveScan256(btot & 0xFFFFu, s_tmp, &dLo);
+  (void)blockExclusiveScan256(btot >> 16, s_tmp, &dHi);
+  const uint64_t D64     = ((uint64_t)dHi << 16) + dLo;
+  const bool     wrapped = D64 > 0xFFFFFFFFull;  // bin bases are meaningless: emit nothing, report the overflow
+  const bool     staged  = P <= (uint32_t)kDbStage;
+  const uint32_t gdst    = binBase + ((t < nb) ? binHist[(size_t)t * pStride + chunk] : 0u);
+  s_gdst[t] = gdst;
+  s_loc[t]  = local;
+  {
+    const uint32_t start = staged ? local : gdst;
+    s_cnt[0][t] = start;
+    s_cnt[1][t] = start + c0;
+    s_cnt[2][t] = start + c0 + c1;
+    s_cnt[3][t] = start + c0 + c1 + c2;
+  }
+  if(chunk == 0)
+  {
+    if(t < nb)
+      ranges[t] = wrapped ? make_uint2(0u, 0u)
+                          : make_uint2(min(binBase, capacity), (uint32_t)min((uint64_t)binBase + btot, (uint64_t)capacity));
+    if(t == 0)
+    {
+      ctr->pairCount = (uint32_t)min(D64, (uint64_t)capacity);
+      if(D64 > capacity)
+        atomicOr(&ctr->errorFlags, kErrPairOverflow);
+    }
+  }
+  __syncthreads();
+  if(wrapped)
+    return;
+
+  // lane == bin: walk the set bits of its mask (low word, then high word), appending to its own list
+#pragma unroll
+  for(int j = 0; j < 4; ++j)
+    if(j * 64 < nb)
+    {
+      uint32_t       run  = s_cnt[w][lane + 64 * j];
+      const uint32_t btag = (uint32_t)(lane + 64 * j) << 16;
+      for(int i = 0; i < kDbRounds; ++i)
+      {
+        const uint64_t m = L.on[j] ? (s_col[w][i][L.bx[j]] & s_row[w][i][L.by[j]]) : 0ull;
+#pragma unroll
+        for(int h = 0; h < 2; ++h)
+        {
+          uint32_t       mh  = h ? (uint32_t)(m >> 32) : (uint32_t)m;
+          const uint32_t pos0 = wbase + (uint32_t)i * 64u + (uint32_t)h * 32u;
+          if(staged)
+          {  // no memory read in the loop: the entry is (bin, position), the id is looked up at copy-out
+            while(__ballot(mh != 0u) != 0ull)
+              if(mh != 0u)
+              {
+                s_stage[run++] = btag | (pos0 + (uint32_t)__builtin_ctz(mh));
+                mh &= mh - 1u;
+              }
+          }
+          else
+          {
+            while(__ballot(mh != 0u) != 0ull)
+              if(mh != 0u)
+              {
+                const uint32_t id = s_ids[pos0 + (uint32_t)__builtin_ctz(mh)];
+                mh &= mh - 1u;
+                if(run < capacity)
+                  binList[run] = id;
+                ++run;
+              }
+          }
+        }
+      }
+    }
+  if(!staged)
+    return;
+  __syncthreads();
+  for(uint32_t i = t; i < P; i += 256)
+  {
+    const uint32_t v   = s_stage[i];
+    const uint32_t b   = v >> 16;
+    const uint32_t dst = s_gdst[b] + (i - s_loc[b]);
+    if(dst < capacity)
+      binList[dst] = s_ids[v & 0xFFFFu];
+  }
+}
+
 // ---- tile ranges over the tile-sorted pair list ------------------------------------------------
 // 4 keys per thread (one 16-byte load) + the two neighbours.
 __global__ void k_tile_ranges(const uint32_t* __restrict__ keyX, const uint32_t* __restrict__ keyY,
@@ -526,6 +829,26 @@ void launchBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* ids
                      splatOffset, chunkStart, chunks + 1);
   hipLaunchKernelGGL(k_bin_expand, dim3(chunks), dim3(kBinThreads), 0, stream, idsX, idsY, planKeys, ctr, sortedRect,
                      splatOffset, chunkStart, pairKey, pairVal, binsX);
+}
+
+bool directBinningSupported(int binsX, int binsY)
+{
+  return binsX <= kDbMaxDim && binsY <= kDbMaxDim && binsX * binsY <= 256;
+}
+
+void launchDirectBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
+                         const uint32_t* rect, uint32_t* sortedRect, uint32_t maxSplats, uint32_t* binHist, uint32_t pStride,
+                         uint32_t* binTotal, uint32_t* binList, uint2* ranges, FrameCounters* ctr, uint32_t capacity,
+                         int binsX, int binsY, bool gatherRects)
+{
+  const uint32_t maxChunks = (maxSplats + kDbChunk - 1) / kDbChunk;
+  if(maxChunks == 0)
+    return;
+  hipLaunchKernelGGL(k_dbin_count, dim3(maxChunks), dim3(256), 0, stream, idsX, idsY, planKeys, rect, sortedRect, binHist,
+                     pStride, binsX, binsY, gatherRects ? 1 : 0);
+  hipLaunchKernelGGL(k_dbin_scan, dim3(binsX * binsY), dim3(256), 0, stream, planKeys, binHist, pStride, binTotal);
+  hipLaunchKernelGGL(k_dbin_emit, dim3(maxChunks), dim3(256), 0, stream, idsX, idsY, planKeys, sortedRect, binHist, pStride,
+                     binTotal, binList, ranges, ctr, capacity, binsX, binsY);
 }
 
 void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* keyY, const SortPlan* planPairs,

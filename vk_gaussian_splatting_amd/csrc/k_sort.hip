@@ -11,9 +11,14 @@
 //   * ranking inside a partition uses 64-lane ballots (8 per key) to find the lanes holding the same
 //     digit, one LDS counter row per wave, then an LDS re-order so the global scatter is coalesced.
 //   * pass 0 can read "slotted" input (the project kernel's per-partition survivor lists), which
-//     fuses the stream compaction into the sort.
+//     fuses the stream compaction into the sort; the producer also hands over the pass-0 digit
+//     histogram of every slot, so the in-frame sort starts directly with a scan.
+//   * no global atomics anywhere: the scan kernel leaves each digit row's total in the plan and the
+//     scatter workgroups turn the 256 totals into digit bases themselves (a 256-wide scan is noise
+//     next to ranking 8192 keys).
 //   * a pass whose digit is identical for every key (the top byte of a depth key, typically) is
-//     skipped on the device; the ping-pong selection lives in a device-side plan.
+//     detected by its scan kernel and its scatter exits; the ping-pong selection is derived from the
+//     skip flags on the device.
 #include <cstdlib>
 
 #include "kernels_common.h"
@@ -49,161 +54,65 @@ __device__ __forceinline__ void histAddRuns(uint32_t* hist, uint32_t digit, bool
   }
 }
 
-// (a) per-partition digit histogram.  FIRST additionally accumulates the global histogram of every
-// pass (order independent), flushed once per workgroup.
-template <bool FIRST>
+// where pass `pass` (> 0) reads from: 0 = X, 1 = Y.  Pass 0 writes X; every executed pass flips.
+__device__ __forceinline__ uint32_t planSrcSel(const SortPlan* __restrict__ plan, int pass)
+{
+  uint32_t cur = 0;
+  for(int q = 1; q < pass; ++q)
+    cur ^= plan->skip[q] ? 0u : 1u;
+  return cur;
+}
+
+// (a) per-partition digit histogram of one pass (pass 0 of a slotted sort gets it from the producer instead)
 __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ keysX, const uint32_t* __restrict__ keysY,
-                                                   const uint32_t* __restrict__ keys0, const uint32_t* __restrict__ slotCount,
-                                                   const uint32_t* __restrict__ nPtr, uint32_t partsSlotted,
-                                                   SortPlan* __restrict__ plan, uint32_t* __restrict__ partHist,
-                                                   uint32_t pStride, int pass, int beginBit, int nPasses, uint32_t part)
+                                                   const uint32_t* __restrict__ keys0, const uint32_t* __restrict__ nPtr,
+                                                   const SortPlan* __restrict__ plan, uint32_t* __restrict__ partHist,
+                                                   uint32_t pStride, int pass, int beginBit, uint32_t part)
 {
   __shared__ uint32_t s_h[256];
-  __shared__ uint32_t s_g[4][256];
-  const int      t       = threadIdx.x;
-  const bool     slotted = FIRST && (slotCount != nullptr);
-  const uint32_t n       = *nPtr;
-  if(!FIRST && plan->skip[pass])
-    return;
-  const uint32_t* keys  = FIRST ? keys0 : (plan->srcSel[pass] ? keysY : keysX);
-  const uint32_t  parts = slotted ? (partsSlotted + part / kSlotPart - 1) / (part / kSlotPart)
-                                  : (uint32_t)(((uint64_t)n + part - 1) / part);
+  const int       t     = threadIdx.x;
+  const uint32_t  n     = *nPtr;
+  const uint32_t* keys  = (pass == 0) ? keys0 : (planSrcSel(plan, pass) ? keysY : keysX);
+  const uint32_t  parts = (uint32_t)(((uint64_t)n + part - 1) / part);
   const int       shift = beginBit + 8 * pass;
-  if(FIRST)
-  {
-#pragma unroll
-    for(int q = 0; q < 4; ++q)
-      s_g[q][t] = 0;
-  }
-  const uint32_t spp = part / kSlotPart;  // slots per slotted partition
   for(uint32_t p = blockIdx.x; p < parts; p += gridDim.x)
   {
     s_h[t] = 0;
     __syncthreads();
-    const uint32_t nseg = slotted ? spp : 1u;
-    for(uint32_t sg = 0; sg < nseg; ++sg)
+    const uint32_t  count = partitionCount(nullptr, n, p, part);
+    const uint32_t* src   = keys + (size_t)p * part;
+    // 8 loads in flight per thread, then the LDS work (the loop was one dependent round trip per key)
+    for(uint32_t i0 = 0; i0 < count; i0 += 2048u)
     {
-      uint32_t        count;
-      const uint32_t* src;
-      if(slotted)
-      {
-        const uint32_t slot = p * spp + sg;
-        count               = slot < partsSlotted ? slotCount[slot] : 0u;
-        src                 = keys + (size_t)slot * kSlotPart;
-      }
-      else
-      {
-        count = partitionCount(nullptr, n, p, part);
-        src   = keys + (size_t)p * part;
-      }
-      // 8 loads in flight per thread, then the LDS work (the loop was one dependent round trip per key)
-      for(uint32_t i0 = 0; i0 < count; i0 += 2048u)
-      {
-        uint32_t kk[8];
+      uint32_t kk[8];
 #pragma unroll
-        for(int u = 0; u < 8; ++u)
-        {
-          const uint32_t i = min(i0 + (uint32_t)u * 256u + (uint32_t)t, count - 1u);  // clamped, not predicated
-          kk[u]            = src[i];
-        }
-#pragma unroll
-        for(int u = 0; u < 8; ++u)
-        {
-          const bool     in  = i0 + (uint32_t)u * 256u + (uint32_t)t < count;
-          const uint32_t key = kk[u];
-          histAddRuns(s_h, (key >> shift) & 255u, in);
-          if(FIRST)
-          {
-            for(int q = 1; q < nPasses; ++q)
-              histAddRuns(s_g[q], (key >> (shift + 8 * q)) & 255u, in);
-          }
-        }
+      for(int u = 0; u < 8; ++u)
+      {
+        const uint32_t i = min(i0 + (uint32_t)u * 256u + (uint32_t)t, count - 1u);  // clamped, not predicated
+        kk[u]            = src[i];
       }
+#pragma unroll
+      for(int u = 0; u < 8; ++u)
+        histAddRuns(s_h, (kk[u] >> shift) & 255u, i0 + (uint32_t)u * 256u + (uint32_t)t < count);
     }
     __syncthreads();
-    const uint32_t c                  = s_h[t];
-    partHist[(size_t)t * pStride + p] = c;
-    if(FIRST)
-      s_g[0][t] += c;
+    partHist[(size_t)t * pStride + p] = s_h[t];
     __syncthreads();
-  }
-  if(FIRST)
-  {
-    for(int q = 0; q < nPasses; ++q)
-      if(s_g[q][t])
-        atomicAdd(&plan->ghist[q][t], s_g[q][t]);
   }
 }
 
-// decides which passes run and where each pass reads from (pass 0 always runs: src0 -> X).  Executed by
-// workgroup 0 of the pass-0 scan kernel (a separate 1-workgroup launch cost ~4.7 us per sort).  When the sort
-// has a single pass the sorted order is fully described by the digit histogram, so the caller's per-digit
-// ranges ([begin,end) of every bin of the pair sort) are written here and no separate range kernel runs.
-__device__ __forceinline__ void sortPlanCompute(SortPlan* __restrict__ plan, uint32_t n, int nPasses, uint2* __restrict__ ranges,
-                                                uint32_t* s_tmp /*>=8*/)
+// (b) one workgroup per digit: exclusive scan of that digit's row of partition counts, in place.  The row
+// total goes to plan->ghist[pass][d]; a row that holds every key marks the pass as skippable.
+__global__ __launch_bounds__(256) void k_sort_scan(const uint32_t* __restrict__ nPtr, uint32_t partsSlotted,
+                                                   SortPlan* __restrict__ plan, uint32_t* __restrict__ partHist,
+                                                   uint32_t pStride, int pass, uint32_t part)
 {
-  const int t = threadIdx.x;
-  if(t < 4)
-    s_tmp[4 + t] = 0;
-  __syncthreads();
-  for(int q = 1; q < nPasses; ++q)
-    if(n > 0 && plan->ghist[q][t] == n)
-      s_tmp[4 + q] = 1;  // every key has the same digit: the pass would be the identity permutation
-  __syncthreads();
-  if(t == 0)
-  {
-    uint32_t cur = 0;  // after pass 0 the data is in X (sel 0)
-    uint32_t run = 1, last = 0;
-    plan->skip[0]   = 0;
-    plan->srcSel[0] = 0;
-    for(int q = 1; q < nPasses; ++q)
-    {
-      plan->skip[q]   = s_tmp[4 + q];
-      plan->srcSel[q] = cur;
-      if(!s_tmp[4 + q])
-      {
-        cur ^= 1u;
-        ++run;
-        last = (uint32_t)q;
-      }
-    }
-    plan->finalSel  = cur;
-    plan->passesRun = run;
-    plan->lastPass  = last;
-    plan->n         = n;
-  }
-  if(ranges != nullptr && nPasses == 1)
-  {
-    uint32_t       total;
-    const uint32_t c  = plan->ghist[0][t];
-    const uint32_t ex = blockExclusiveScan256(c, s_tmp, &total);
-    ranges[t]         = make_uint2(ex, ex + c);
-  }
-}
-
-// (b) one workgroup per digit: exclusive scan of that digit's row of partition counts, offset by the
-// number of keys with a smaller digit.  In place: partHist[d][p] becomes the global destination of
-// the first key of partition p with digit d.  8 consecutive entries per thread per step.
-__global__ __launch_bounds__(256) void k_sort_scan(const uint32_t* __restrict__ nPtr, const uint32_t* __restrict__ slotCount,
-                                                   uint32_t partsSlotted, SortPlan* __restrict__ plan,
-                                                   uint32_t* __restrict__ partHist, uint32_t pStride, int pass, uint32_t part,
-                                                   int nPasses, uint2* __restrict__ ranges)
-{
-  __shared__ uint32_t s_tmp[8];
-  const int t = threadIdx.x, d = blockIdx.x;
-  if(pass > 0 && plan->skip[pass])
-    return;
-  const uint32_t n       = *nPtr;
-  if(pass == 0 && d == 0)
-    sortPlanCompute(plan, n, nPasses, ranges, s_tmp);  // the plan is first read by kernels launched after this one
-  const bool     slotted = (pass == 0) && (slotCount != nullptr);
-  const uint32_t parts   = slotted ? (partsSlotted + part / kSlotPart - 1) / (part / kSlotPart)
-                                   : (uint32_t)(((uint64_t)n + part - 1) / part);
-  uint32_t       total;
-  const uint32_t below = (t < d) ? plan->ghist[pass][t] : 0u;
-  (void)blockExclusiveScan256(below, s_tmp, &total);
-  uint32_t  carry = total;  // keys with a smaller digit
-  uint32_t* row   = partHist + (size_t)d * pStride;
+  __shared__ uint32_t s_tmp[4];
+  const int      t = threadIdx.x, d = blockIdx.x;
+  const uint32_t n     = *nPtr;
+  const uint32_t parts = partsSlotted ? partsSlotted : (uint32_t)(((uint64_t)n + part - 1) / part);
+  uint32_t       carry = 0;
+  uint32_t*      row   = partHist + (size_t)d * pStride;
   for(uint32_t base = 0; base < parts; base += 2048)
   {
     const uint32_t p0 = base + t * 8;
@@ -225,6 +134,12 @@ __global__ __launch_bounds__(256) void k_sort_scan(const uint32_t* __restrict__ 
     }
     carry += chunk;
   }
+  if(t == 0)
+  {
+    plan->ghist[pass][d] = carry;
+    if(pass > 0 && n > 0 && carry == n)
+      plan->skip[pass] = 1u;  // every key has this digit: the pass would be the identity permutation
+  }
 }
 
 // exclusive scan over the first 256 threads of a THREADS-wide block (one value per digit)
@@ -244,16 +159,17 @@ __device__ __forceinline__ uint32_t digitExclusiveScan(uint32_t v, uint32_t* s_t
   return base + inc - v;  // meaningful for threads < 256 only
 }
 
-// (c) ranked scatter of one partition of THREADS*KPT keys.
+// (c) ranked scatter of one partition of THREADS*KPT keys.  Workgroup 0 of the last pass also publishes the
+// outcome (which buffer holds the result, how many passes ran); on a single-pass sort the digit histogram IS the
+// sorted layout, so the caller's per-digit ranges are written there too.
 template <bool FIRST, int THREADS, int KPT>
 __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __restrict__ keys0, const uint32_t* __restrict__ vals0,
                                                           uint32_t* __restrict__ keysX, uint32_t* __restrict__ valsX,
                                                           uint32_t* __restrict__ keysY, uint32_t* __restrict__ valsY,
                                                           const uint32_t* __restrict__ slotCount, const uint32_t* __restrict__ nPtr,
-                                                          uint32_t partsSlotted, const SortPlan* __restrict__ plan,
+                                                          uint32_t partsSlotted, SortPlan* __restrict__ plan,
                                                           const uint32_t* __restrict__ partHist, uint32_t pStride, int pass,
-                                                          int beginBit, const uint32_t* __restrict__ gatherSrc,
-                                                          uint32_t* __restrict__ gatherDst)
+                                                          int beginBit, int nPasses, uint2* __restrict__ ranges)
 {
   constexpr int PART  = THREADS * KPT;
   constexpr int SPP   = PART / kSlotPart;  // slots per slotted partition
@@ -266,10 +182,20 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
   __shared__ uint32_t s_tmp[WAVES];
 
   const int t = threadIdx.x, lane = laneId(), w = t >> 6;
-  if(!FIRST && plan->skip[pass])
-    return;
+  const bool     skipped = !FIRST && plan->skip[pass] != 0u;
   const bool     slotted = FIRST && (slotCount != nullptr);
   const uint32_t n       = *nPtr;
+  if(blockIdx.x == 0 && t == 0 && pass == nPasses - 1)
+  {
+    uint32_t run = 1;
+    for(int q = 1; q < nPasses; ++q)
+      run += plan->skip[q] ? 0u : 1u;
+    plan->finalSel  = planSrcSel(plan, nPasses);
+    plan->passesRun = run;
+    plan->n         = n;
+  }
+  if(skipped)
+    return;
   const uint32_t parts   = slotted ? (partsSlotted + SPP - 1) / SPP : (uint32_t)(((uint64_t)n + PART - 1) / PART);
   const uint32_t p       = blockIdx.x;
   if(p >= parts)
@@ -296,7 +222,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
     kout = keysX;
     vout = valsX;
   }
-  else if(plan->srcSel[pass])
+  else if(planSrcSel(plan, pass))
   {
     kin  = keysY;
     vin  = valsY;
@@ -382,11 +308,15 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
     }
     tot = acc;
   }
-  const uint32_t loff = digitExclusiveScan<THREADS>(tot, s_tmp);
+  const uint32_t loff  = digitExclusiveScan<THREADS>(tot, s_tmp);
+  const uint32_t gtot  = (t < 256) ? plan->ghist[pass][t] : 0u;
+  const uint32_t below = digitExclusiveScan<THREADS>(gtot, s_tmp);  // keys with a smaller digit
   if(t < 256)
   {
     s_loff[t]  = loff;
-    s_gbase[t] = partHist[(size_t)t * pStride + p] - loff;  // wraps are fine: only base+idx is used
+    s_gbase[t] = below + partHist[(size_t)t * pStride + p] - loff;  // wraps are fine: only base+idx is used
+    if(ranges != nullptr && nPasses == 1 && p == 0)
+      ranges[t] = make_uint2(below, below + gtot);
   }
   __syncthreads();
 
@@ -401,11 +331,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
   }
   __syncthreads();
 
-  // coalesced scatter: consecutive threads write consecutive addresses inside each digit run.
-  // On the LAST executed pass the caller may ask for a fused gather: gatherDst[dst] = gatherSrc[value]
-  // (the binning stage needs the splat's bin rect in sorted order; doing the random 4-byte gather here
-  // overlaps it with the scatter instead of paying a separate latency-bound kernel).
-  const bool fuse = gatherSrc != nullptr && (uint32_t)pass == plan->lastPass;
+  // coalesced scatter: consecutive threads write consecutive addresses inside each digit run
 #pragma unroll
   for(int i = 0; i < KPT; ++i)
   {
@@ -418,8 +344,6 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
       const uint32_t dst = s_gbase[d] + idx;
       kout[dst]          = k;
       vout[dst]          = v;
-      if(fuse)
-        gatherDst[dst] = gatherSrc[v];
     }
   }
 }
@@ -444,35 +368,28 @@ void launchRadixSort(hipStream_t stream, const SortLaunch& s)
   const int nPasses = (s.endBit - s.beginBit + 7) / 8;
   if(nPasses <= 0 || s.maxElems == 0)
     return;
-  const bool     slotted = s.slotCount != nullptr;
+  const bool     slotted = s.slotCount != nullptr;  // pass 0: 2048-key slots + the producer's slot histograms
   // big sorts use 8192-key partitions (digit runs of ~32 keys = 128-byte scatter segments, 4x shorter
-  // partition tables); small ones keep 2048 so that 256 CUs still see enough workgroups.  A slotted pass 0
-  // takes part/2048 of the project kernel's slots per partition.
+  // partition tables); small ones keep 2048 so that 256 CUs still see enough workgroups.
   const uint32_t part    = (s.maxElems >= (2u << 20)) ? 8192u : 2048u;
-  static const uint32_t kSlotPartOverride = [] { const char* e = std::getenv("MGS_SLOT_PART"); return e ? (uint32_t)std::atoi(e) : 0u; }();
-  auto partOf  = [&](int pass) { return (pass == 0 && slotted && kSlotPartOverride) ? kSlotPartOverride : part; };
+  auto partOf  = [&](int pass) { return (pass == 0 && slotted) ? 2048u : part; };
   auto partsOf = [&](int pass) {
-    const uint32_t pp = partOf(pass);
-    return (pass == 0 && slotted) ? (s.partsSlotted + pp / 2048u - 1) / (pp / 2048u)
-                                  : (uint32_t)(((uint64_t)s.maxElems + pp - 1) / pp);
+    return (pass == 0 && slotted) ? s.partsSlotted : (uint32_t)(((uint64_t)s.maxElems + partOf(pass) - 1) / partOf(pass));
   };
-  const uint32_t p0      = partsOf(0);
-  // few, fat workgroups: each flushes up to nPasses*256 global atomics once (profiles/r1_b: 2048 groups cost 39 us)
-  const uint32_t fatGrid = p0 < 512u ? p0 : 512u;
-  hipLaunchKernelGGL((k_sort_hist<true>), dim3(fatGrid), dim3(256), 0, stream, s.keysX, s.keysY, s.keys0, s.slotCount, s.nPtr,
-                     s.partsSlotted, s.plan, s.partHist, s.pStride, 0, s.beginBit, nPasses, partOf(0));
   for(int pass = 0; pass < nPasses; ++pass)
   {
     const uint32_t parts = partsOf(pass), pp = partOf(pass);
-    if(pass > 0)
-      hipLaunchKernelGGL((k_sort_hist<false>), dim3(parts), dim3(256), 0, stream, s.keysX, s.keysY, s.keys0,
-                         (const uint32_t*)nullptr, s.nPtr, 0u, s.plan, s.partHist, s.pStride, pass, s.beginBit, nPasses, pp);
-    hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, stream, s.nPtr, pass == 0 ? s.slotCount : nullptr,
-                       s.partsSlotted, s.plan, s.partHist, s.pStride, pass, pp, nPasses, s.ranges);
+    if(parts == 0)
+      continue;
+    if(!(pass == 0 && slotted))
+      hipLaunchKernelGGL(k_sort_hist, dim3(parts), dim3(256), 0, stream, s.keysX, s.keysY, s.keys0, s.nPtr, s.plan, s.partHist,
+                         s.pStride, pass, s.beginBit, pp);
+    hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, stream, s.nPtr, (pass == 0 && slotted) ? s.partsSlotted : 0u, s.plan,
+                       s.partHist, s.pStride, pass, pp);
 #define MGS_SCATTER(FIRSTV, TH, KP, SLOTS)                                                                                  \
   hipLaunchKernelGGL((k_sort_scatter<FIRSTV, TH, KP>), dim3(parts), dim3(TH), 0, stream, s.keys0, s.vals0, s.keysX, s.valsX, \
-                     s.keysY, s.valsY, SLOTS, s.nPtr, s.partsSlotted, s.plan, s.partHist, s.pStride, pass, s.beginBit,      \
-                     s.gatherSrc, s.gatherDst)
+                     s.keysY, s.valsY, SLOTS, s.nPtr, s.partsSlotted, s.plan, s.partHist, s.pStride, pass, s.beginBit, nPasses, \
+                     s.ranges)
     if(pass == 0)
     {
       if(pp == 2048u)

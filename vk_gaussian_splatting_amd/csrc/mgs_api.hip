@@ -29,7 +29,7 @@ namespace mgs {
 // kernels_*.hip
 void launchProject(hipStream_t stream, const FrameArgs& args, bool full, int shFormat, int rgbaFormat, FrameCounters* ctr,
                    uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, SplatRec* rec, uint32_t* rect,
-                   const uint32_t* partSkip);
+                   const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride);
 void launchPartitionCull(hipStream_t stream, const FrameArgs& args, uint32_t* partSkip);
 void launchFrameInit(hipStream_t stream, FrameCounters* ctr, SortPlan* planKeys, SortPlan* planPairs, uint2* ranges,
                      uint32_t nTiles);
@@ -37,6 +37,11 @@ void launchBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* ids
                    const uint32_t* rect, uint32_t* blockCount, uint32_t maxBlocks, FrameCounters* ctr, uint32_t* sortedRect,
                    uint32_t* splatOffset, uint32_t* chunkStart, uint32_t* pairKey, uint32_t* pairVal, uint32_t capacity,
                    int binsX, bool gatherRects);
+bool directBinningSupported(int binsX, int binsY);
+void launchDirectBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
+                         const uint32_t* rect, uint32_t* sortedRect, uint32_t maxSplats, uint32_t* binHist, uint32_t pStride,
+                         uint32_t* binTotal, uint32_t* binList, uint2* ranges, FrameCounters* ctr, uint32_t capacity,
+                         int binsX, int binsY, bool gatherRects);
 void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* keyY, const SortPlan* planPairs,
                       uint2* ranges);
 void launchComposite(hipStream_t stream, const FrameConst& F, const uint2* ranges, const uint32_t* valX,
@@ -735,7 +740,7 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
   if((rc = s->pairKey1.ensure(cap))) return rc;
   if((rc = s->pairVal1.ensure(cap))) return rc;
   if((rc = s->chunkStart.ensure(cap / kPart + 4))) return rc;
-  const uint64_t maxParts = std::max<uint64_t>((cap + kPart - 1) / kPart, parts);
+  const uint64_t maxParts = std::max<uint64_t>((cap + kPart - 1) / kPart, std::max<uint64_t>(parts, (total + 1023) / 1024 + 1));  // direct binning scans rows of 1024-splat chunks
   s->pStride              = (uint32_t)maxParts;
   if((rc = s->partHist.ensure(256ull * maxParts))) return rc;
   if((rc = s->blockCount.ensure(std::max<uint64_t>((total + kPart - 1) / kPart, 1)))) return rc;
@@ -961,6 +966,18 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
   int bsx = 3, bsy = 3;
   if(const char* e = std::getenv("MGS_BIN_SHIFT"))
     std::sscanf(e, "%d,%d", &bsx, &bsy);
+  else
+  {  // keep the frame at <= 256 bins so that the direct (record-free) binning applies: 4K -> 256x128 px bins
+    while(((F.tilesX + (1 << bsx) - 1) >> bsx) * ((F.tilesY + (1 << bsy) - 1) >> bsy) > 256 && (bsx < 4 || bsy < 4))
+    {
+      if(bsx <= bsy && bsx < 4)
+        ++bsx;
+      else if(bsy < 4)
+        ++bsy;
+      else
+        ++bsx;
+    }
+  }
   bsx         = std::min(std::max(bsx, 0), 4);
   bsy         = std::min(std::max(bsy, 0), 4);
   F.binShiftX = bsx;
@@ -1052,14 +1069,9 @@ static int pairSortBits(int nTiles)
   return ((bits + 7) / 8) * 8;
 }
 
-static void keySort(MgsScene s, hipStream_t st, bool fuseRectGather)
+static void keySort(MgsScene s, hipStream_t st)
 {
   SortLaunch L{};
-  if(fuseRectGather)
-  {
-    L.gatherSrc = s->rect.p;
-    L.gatherDst = s->sortedRect.p;
-  }
   L.keys0 = s->keysSlot.p;
   L.vals0 = s->idsSlot.p;
   L.keysX = s->keysA.p;
@@ -1191,11 +1203,10 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
   if(F.partitionCull)
     launchPartitionCull(st, A, s->partSkip.p);
   launchProject(st, A, true, s->shFormat, s->rgbaFormat, ctr, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p,
-                s->rect.p, F.partitionCull ? s->partSkip.p : nullptr);
+                s->rect.p, F.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride);
   if(timed) HIPCHK(hipEventRecord(fev[1], st));
-  static const bool kFuseRect = [] { const char* e = std::getenv("MGS_FUSE_RECT"); return e ? std::atoi(e) != 0 : false; }();
   if(!cpuMode)
-    keySort(s, st, kFuseRect);
+    keySort(s, st);
   else
   {
     rc = cpuSortStep(s, p, p->cpu_sort_blocking != 0);
@@ -1212,30 +1223,43 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
     hipLaunchKernelGGL(k_set_plan_n, dim3(1), dim3(1), 0, st, planK, ctr, s->totalSplats);
   }
   if(timed) HIPCHK(hipEventRecord(fev[2], st));
-  launchBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, s->blockCount.p, (s->totalSplats + kPart - 1) / kPart, ctr,
-                s->sortedRect.p, s->splatOffset.p, s->chunkStart.p, s->pairKey0.p, s->pairVal0.p, s->pairCapacity, F.binsX, cpuMode || !kFuseRect);
-  if(timed) HIPCHK(hipEventRecord(fev[3], st));
+  // coarse bins (the default): stable multi-split straight into the per-bin lists, no records, no pair sort
+  static const bool kDirectBin = [] { const char* e = std::getenv("MGS_DIRECT_BIN"); return e ? std::atoi(e) != 0 : true; }();
+  const bool direct = kDirectBin && directBinningSupported(F.binsX, F.binsY);
+  if(direct)
   {
-    SortLaunch L{};
-    L.keys0 = s->pairKey0.p;
-    L.vals0 = s->pairVal0.p;
-    L.keysX = s->pairKey1.p;
-    L.valsX = s->pairVal1.p;
-    L.keysY = s->pairKey0.p;
-    L.valsY = s->pairVal0.p;
-    L.slotCount = nullptr;
-    L.nPtr      = &ctr->pairCount;
-    L.plan      = planP;
-    L.partHist  = s->partHist.p;
-    L.pStride   = s->pStride;
-    L.maxElems  = s->pairCapacity;
-    L.beginBit  = 0;
-    L.endBit    = pairSortBits((int)nTiles);
-    const bool onePass = L.endBit <= 8;  // <= 256 bins: the digit histogram IS the range table
-    L.ranges    = onePass ? s->ranges.p : nullptr;
-    launchRadixSort(st, L);
-    if(!onePass)
-      launchTileRanges(st, s->pairKey1.p, s->pairKey0.p, planP, s->ranges.p);
+    launchDirectBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, s->sortedRect.p, s->totalSplats,
+                        s->partHist.p, s->pStride, &planP->ghist[0][0], s->pairVal1.p, s->ranges.p, ctr, s->pairCapacity,
+                        F.binsX, F.binsY, true);
+    if(timed) HIPCHK(hipEventRecord(fev[3], st));
+  }
+  else
+  {
+    launchBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, s->blockCount.p, (s->totalSplats + kPart - 1) / kPart, ctr,
+                  s->sortedRect.p, s->splatOffset.p, s->chunkStart.p, s->pairKey0.p, s->pairVal0.p, s->pairCapacity, F.binsX, true);
+    if(timed) HIPCHK(hipEventRecord(fev[3], st));
+    {
+      SortLaunch L{};
+      L.keys0 = s->pairKey0.p;
+      L.vals0 = s->pairVal0.p;
+      L.keysX = s->pairKey1.p;
+      L.valsX = s->pairVal1.p;
+      L.keysY = s->pairKey0.p;
+      L.valsY = s->pairVal0.p;
+      L.slotCount = nullptr;
+      L.nPtr      = &ctr->pairCount;
+      L.plan      = planP;
+      L.partHist  = s->partHist.p;
+      L.pStride   = s->pStride;
+      L.maxElems  = s->pairCapacity;
+      L.beginBit  = 0;
+      L.endBit    = pairSortBits((int)nTiles);
+      const bool onePass = L.endBit <= 8;  // <= 256 bins: the digit histogram IS the range table
+      L.ranges    = onePass ? s->ranges.p : nullptr;
+      launchRadixSort(st, L);
+      if(!onePass)
+        launchTileRanges(st, s->pairKey1.p, s->pairKey0.p, planP, s->ranges.p);
+    }
   }
   if(timed) HIPCHK(hipEventRecord(fev[4], st));
   launchComposite(st, F, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half);
@@ -1424,9 +1448,9 @@ int mgs_sort_keys(MgsScene s, const MgsFrameParams* p, MgsSortOut* out)
   if(A.f.partitionCull)
     launchPartitionCull(st, A, s->partSkip.p);
   launchProject(st, A, false, 0, 0, s->ctr.p, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p, s->rect.p,
-                A.f.partitionCull ? s->partSkip.p : nullptr);
+                A.f.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride);
   HIPCHK(hipEventRecord(s->ev[1], st));
-  keySort(s, st, false);
+  keySort(s, st);
   HIPCHK(hipEventRecord(s->ev[2], st));
   HIPCHK(hipMemcpyAsync(s->hCtr, s->ctr.p, sizeof(FrameCounters), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(s->hPlans, s->plans.p, 2 * sizeof(SortPlan), hipMemcpyDeviceToHost, st));

@@ -8,14 +8,13 @@ namespace mgs {
 
 struct SortPlan
 {
-  uint32_t ghist[4][256];  // global digit histograms of every pass (order independent)
-  uint32_t skip[4];        // pass is the identity permutation (single occupied digit) -> skipped
-  uint32_t srcSel[4];      // pass reads from X (0) or Y (1); pass 0 always reads src0 and writes X
-  uint32_t finalSel;       // result lives in X (0) or Y (1)
+  uint32_t ghist[4][256];  // digit totals of every pass, written by that pass's scan kernel
+  uint32_t skip[4];        // pass is the identity permutation (single occupied digit) -> its scatter exits
+  uint32_t reserved[4];
+  uint32_t finalSel;       // result lives in X (0) or Y (1); written by the last pass
   uint32_t passesRun;
   uint32_t n;
-  uint32_t lastPass;       // index of the last pass that actually runs
-  uint32_t pad[4];
+  uint32_t pad[5];
 };
 
 struct SortLaunch
@@ -26,7 +25,8 @@ struct SortLaunch
   uint32_t*       valsX;
   uint32_t*       keysY;
   uint32_t*       valsY;
-  const uint32_t* slotCount;     // non-null: pass 0 reads slotted partitions (stride 2048) with these counts
+  const uint32_t* slotCount;     // non-null: pass 0 reads slotted partitions (stride 2048) with these counts, and the
+                                 // producer has already written their pass-0 digit histograms into partHist
   uint32_t        partsSlotted;  // number of slotted partitions
   const uint32_t* nPtr;          // device-side element count (uniform partitions)
   SortPlan*       plan;          // must be zeroed before the launch (launchSortClearPlan / frame init)
@@ -34,8 +34,6 @@ struct SortLaunch
   uint32_t        pStride;
   uint32_t        maxElems;      // host-side upper bound of the element count (sizes the grids)
   int             beginBit, endBit;
-  const uint32_t* gatherSrc = nullptr;  // optional fused gather on the last executed pass:
-  uint32_t*       gatherDst = nullptr;  //   gatherDst[sortedPos] = gatherSrc[value]
   uint2*          ranges    = nullptr;  // optional, single-pass sorts: ranges[digit] = [begin,end) in the sorted output
 };
 
