@@ -558,22 +558,26 @@ __global__ void k_tile_ranges(const uint32_t* __restrict__ keyX, const uint32_t*
 }
 
 // ---- compositing ------------------------------------------------------------------------------
-// One workgroup per 16x16 tile, one wave per 8x8 quadrant (lane = pixel).  Lists exist per BIN (a
-// block of tiles, e.g. 64x64 px), not per tile: duplicating every splat into every 16x16 tile it
-// touches costs ~13 records per splat and made the (tile,id) sort the most expensive stage
+// One workgroup per 32x16-pixel region (two 16x16 tiles side by side), one wave per 16x8 quarter, TWO
+// pixels per lane (x and x+8): the per-fragment arithmetic then runs on gfx950's packed-fp32 pipe
+// (v_pk_fma_f32 & co, two pixels per instruction) with the splat's parameters broadcast through op_sel.
+// Lists exist per BIN (a block of tiles, e.g. 256x128 px), not per tile: duplicating every splat into every
+// 16x16 tile it touches costs ~13 records per splat and made the (tile,id) sort the most expensive stage
 // (profiles/r1_a/b).  Instead each workgroup walks its bin's depth-ordered list nearest-first and does
 // the fine culling on chip:
 //   stage A  every thread fetches 4 list entries (id -> first 16 bytes of the record: centre + extent),
-//            tests the footprint against the workgroup's 16x16 tile, and the survivors are compacted
+//            tests the footprint against the workgroup's region, and the survivors are compacted
 //            IN ORDER (ballot + mbcnt) into an LDS batch together with the rest of their record;
-//   stage B  each wave walks the batch, skips splats that miss its quadrant, and blends front-to-back:
+//   stage B  each wave walks the batch, skips splats that miss its quarter, and blends front-to-back:
 //            q=(d.p1)^2+(d.p2)^2 (== A/2, frag.slang:236), discard q>4, alpha=a*exp(-q), discard <=1/255.
-// A wave retires when all 64 pixels have T < 1e-4; the workgroup stops fetching when all 4 have
+//            (p1, p2 are pre-scaled by sqrt(log2 e) when staged, so the exponential is a bare v_exp_f32.)
+// A wave retires when all 128 pixels have T < 1e-4; the workgroup stops fetching when all 4 have
 // (not in MGS_ALPHA_SUM mode, where the reference's additive alpha must see every fragment).
 constexpr int kCmpEntries = 4;                  // list entries per thread per stage-A round (4 gathers in flight per lane)
 constexpr int kCmpRound   = 256 * kCmpEntries;  // 1024 entries scanned per round
 constexpr int kCmpCap     = 384;                // LDS batch capacity (records): 18 KB -> 8 workgroups per CU (sweep: 384/512/768 -> 0.220/0.230/0.275 ms)
 constexpr int kCmpGo      = 128;                // blend as soon as this many records are staged (<= kCmpCap-256)
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <bool HALF_OUT>
 __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uint2* __restrict__ ranges,
@@ -582,63 +586,71 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
                                                    void* __restrict__ outImage)
 {
   __shared__ float4   s_a[kCmpCap];  // cx, cy, ex, ey
-  __shared__ float4   s_b[kCmpCap];  // p1, p2
+  __shared__ float4   s_b[kCmpCap];  // p1, p2 (scaled by sqrt(log2 e))
   __shared__ float4   s_c[kCmpCap];  // r, g, b, a
   __shared__ uint32_t s_wc[2][kCmpEntries][4];
-  __shared__ uint8_t  s_m[kCmpCap];  // which of the 4 quadrants (waves) the record's footprint touches
+  __shared__ uint8_t  s_m[kCmpCap];  // which of the 4 quarters (waves) the record's footprint touches
 
   const int t = threadIdx.x, lane = laneId(), w = t >> 6;
-  const int stripTiles = F.tilesX * (F.stripRow1 - F.stripRow0);
-  // XCD-aware tile mapping: workgroup b lands on XCD b%8 (observed dispatch rule); give each XCD a
-  // contiguous run of tiles so the tiles of one bin — which read the same list — share an L2.
-  const int per  = (stripTiles + 7) >> 3;
+  // regions are enumerated in 32-px columns ("tile pairs"); binShiftX >= 1, so a pair never straddles two bins
+  const int colsX      = (F.tilesX + 1) >> 1;
+  const int stripCols  = colsX * (F.stripRow1 - F.stripRow0);
+  // XCD-aware mapping: workgroup b lands on XCD b%8 (observed dispatch rule); give each XCD a contiguous
+  // run of regions so the regions of one bin — which read the same list — share an L2.
+  const int per  = (stripCols + 7) >> 3;
   const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if(tile >= stripTiles || (int)(blockIdx.x >> 3) >= per)
+  if(tile >= stripCols || (int)(blockIdx.x >> 3) >= per)
     return;
-  // walk tiles bin by bin inside the strip so that consecutive workgroups share a list
-  const int bw = 1 << F.binShiftX, bh = 1 << F.binShiftY;
+  // walk regions bin by bin inside the strip so that consecutive workgroups share a list
+  const int bw = 1 << (F.binShiftX - 1), bh = 1 << F.binShiftY;  // bin size in regions
   const int rowsInStrip = F.stripRow1 - F.stripRow0;
-  int       tx, ty;
+  int       cx2, ty;
   {
-    // tiles are enumerated per bin-row band: band = group of bh tile rows
-    const int bandTiles = F.tilesX * bh;
+    // regions are enumerated per bin-row band: band = group of bh tile rows
+    const int bandTiles = colsX * bh;
     const int band      = tile / bandTiles;
     const int inBand    = tile - band * bandTiles;
     const int bandRow0  = band * bh;
     const int bandRows  = min(bh, rowsInStrip - bandRow0);
     const int binCol    = inBand / (bw * bandRows);
     const int inBin     = inBand - binCol * (bw * bandRows);
-    const int colsHere  = min(bw, F.tilesX - binCol * bw);
+    const int colsHere  = min(bw, colsX - binCol * bw);
     if(colsHere <= 0)
       return;
     // the last bin column may be narrower: re-derive with its true width
-    const int full = (F.tilesX / bw) * (bw * bandRows);
-    if(inBand < full || (F.tilesX % bw) == 0)
+    const int full = (colsX / bw) * (bw * bandRows);
+    if(inBand < full || (colsX % bw) == 0)
     {
-      tx = binCol * bw + inBin % bw;
-      ty = F.stripRow0 + bandRow0 + inBin / bw;
+      cx2 = binCol * bw + inBin % bw;
+      ty  = F.stripRow0 + bandRow0 + inBin / bw;
     }
     else
     {
-      const int rem = inBand - full, wlast = F.tilesX % bw;
-      tx            = (F.tilesX / bw) * bw + rem % wlast;
+      const int rem = inBand - full, wlast = colsX % bw;
+      cx2           = (colsX / bw) * bw + rem % wlast;
       ty            = F.stripRow0 + bandRow0 + rem / wlast;
     }
   }
-  const int      qx0 = tx * kTilePx + (w & 1) * 8, qy0 = ty * kTilePx + (w >> 1) * 8;
-  const int      px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
-  const float    pcx = (float)px + 0.5f, pcy = (float)py + 0.5f;
-  const float    bcx = (float)(tx * kTilePx) + 8.0f, bcy = (float)(ty * kTilePx) + 8.0f;
-  const bool     inside = px < F.width && py < F.height;
-  const bool     early  = (F.alphaMode == 0);
+  const int      tx  = cx2 * 2;  // left 16-px tile of the region
+  const int      qx0 = tx * kTilePx + (w & 1) * 16, qy0 = ty * kTilePx + (w >> 1) * 8;
+  const int      px = qx0 + (lane & 7), py = qy0 + (lane >> 3);  // second pixel: px + 8
+  const v2f      pcx = {(float)px + 0.5f, (float)px + 8.5f};
+  const float    pcy = (float)py + 0.5f;
+  const float    bcx = (float)(tx * kTilePx) + 16.0f, bcy = (float)(ty * kTilePx) + 8.0f;  // region centre
+  const bool     in0 = px < F.width && py < F.height, in1 = px + 8 < F.width && py < F.height;
+  const bool     early   = (F.alphaMode == 0);
   const bool     noGauss = (F.debugFlags & 4) != 0;
-  const uint32_t* vals  = plan->finalSel ? valY : valX;
-  const int      bin    = (ty >> F.binShiftY) * F.binsX + (tx >> F.binShiftX);
-  const uint2    range  = ranges[bin];
+  // a saturated pixel (T < 1e-4) takes no further fragments: the result must not depend on WHEN its wave
+  // notices (batch boundaries differ between a strip and the full frame, the frames must not)
+  const float    tMin    = early ? 1.0e-4f : -1.0f;
+  const uint32_t* vals   = plan->finalSel ? valY : valX;
+  const int      bin     = (ty >> F.binShiftY) * F.binsX + (tx >> F.binShiftX);
+  const uint2    range   = ranges[bin];
+  constexpr float kSqrtLog2e = 1.2011224087864498f;   // sqrt(log2 e): exp(-q) == exp2(-(q * log2 e))
+  constexpr float kQMax      = 4.0f * 1.4426950408889634f;
 
-  float T = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, asum = 0.f;
-  bool  done     = !inside;
-  bool  waveDone = (__ballot(!done) == 0ull);
+  v2f  T = {1.0f, 1.0f}, cr = {0.f, 0.f}, cg = {0.f, 0.f}, cb = {0.f, 0.f}, asum = {0.f, 0.f};
+  bool waveDone = (__ballot(in0 || in1) == 0ull);
 
   uint32_t hi   = range.y;
   uint32_t fill = 0;  // records currently in the LDS batch
@@ -686,7 +698,8 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
 #pragma unroll
       for(int k = 0; k < kCmpEntries; ++k)
       {
-        ok[k]  = ok[k] && fabsf(a[k].x - bcx) <= a[k].z + 7.5f && fabsf(a[k].y - bcy) <= a[k].w + 7.5f;
+        // pixel centres of the region span bcx +- 15.5, bcy +- 7.5
+        ok[k]  = ok[k] && fabsf(a[k].x - bcx) <= a[k].z + 15.5f && fabsf(a[k].y - bcy) <= a[k].w + 7.5f;
         bal[k] = __ballot(ok[k]);
         if(lane == 0)
           s_wc[rnd & 1][k][w] = (uint32_t)__popcll(bal[k]);
@@ -710,10 +723,11 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
           {
             const uint32_t pos = base + wb + lanesBelow(bal[k]);
             const float4*  r   = reinterpret_cast<const float4*>(rec + g[k]);
+            const float4   pb  = r[1];
             s_a[pos]           = a[k];
-            s_b[pos]           = r[1];
+            s_b[pos]           = make_float4(pb.x * kSqrtLog2e, pb.y * kSqrtLog2e, pb.z * kSqrtLog2e, pb.w * kSqrtLog2e);
             s_c[pos]           = r[2];
-            // quadrant q covers pixel centres [x0+8(q&1)+0.5, +7.5]: centre bcx -4 / +4, half width 3.5
+            // quarter (qx,qy): pixel centres x in [bcx-15.5,bcx-0.5] / [bcx+0.5,bcx+15.5], y in [bcy-7.5,bcy-0.5] / [bcy+0.5,bcy+7.5]
             const bool xl = a[k].x - a[k].z <= bcx - 0.5f, xr = a[k].x + a[k].z >= bcx + 0.5f;
             const bool yt = a[k].y - a[k].w <= bcy - 0.5f, yb = a[k].y + a[k].w >= bcy + 0.5f;
             s_m[pos] = (uint8_t)((xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u));
@@ -731,9 +745,8 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
     }
     __syncthreads();
     // ---- stage B: blend the batch ------------------------------------------------------------------------
-    // 64 records at a time: a ballot over the quadrant masks gives this wave's hit set; the hits are walked
-    // with scalar bit tricks (no per-record branch), the next record is fetched from LDS while the current
-    // one is blended, and the per-pixel discards are predicated instead of branched.
+    // 64 records at a time: a ballot over the quarter masks gives this wave's hit set; the hits are walked
+    // with scalar bit tricks (no per-record branch) and the per-pixel discards are predicated.
     if(!waveDone)
     {
       for(uint32_t j0 = 0; j0 < fill; j0 += 64)
@@ -741,42 +754,29 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
         const uint32_t jl   = j0 + (uint32_t)lane;
         const bool     mine = jl < fill && ((s_m[jl] >> w) & 1u);
         uint64_t       hits = __ballot(mine);
-        if(hits == 0ull)
-          continue;
-        // two hits per iteration: their alpha evaluations are independent (ILP), the blend is sequential
         while(hits != 0ull)
         {
-          const uint32_t j1 = j0 + (uint32_t)__builtin_ctzll(hits);
+          const uint32_t j = j0 + (uint32_t)__builtin_ctzll(hits);
           hits &= hits - 1ull;
-          const bool     two = hits != 0ull;
-          const uint32_t j2  = two ? j0 + (uint32_t)__builtin_ctzll(hits) : j1;
-          hits &= hits - 1ull;  // no-op on 0
-          const float4 a1 = s_a[j1], b1 = s_b[j1], c1 = s_c[j1];
-          const float4 a2 = s_a[j2], b2 = s_b[j2], c2 = s_c[j2];
-          const float  dx1 = pcx - a1.x, dy1 = pcy - a1.y, dx2 = pcx - a2.x, dy2 = pcy - a2.y;
-          const float  s1 = dx1 * b1.x + dy1 * b1.y, u1 = dx1 * b1.z + dy1 * b1.w;
-          const float  s2 = dx2 * b2.x + dy2 * b2.y, u2 = dx2 * b2.z + dy2 * b2.w;
-          const float  q1 = s1 * s1 + u1 * u1, q2 = s2 * s2 + u2 * u2;  // == A/2 of frag.slang:236
-          const float  al1 = noGauss ? 1.0f : c1.w * __expf(-q1), al2 = noGauss ? 1.0f : c2.w * __expf(-q2);  // frag.slang:248-254
-          // frag.slang:242-245,258-262, predicated
-          const float ah1 = (q1 <= 4.0f && al1 > (1.0f / 255.0f) && !done) ? al1 : 0.0f;
-          const float w1  = ah1 * T;
-          cr += w1 * c1.x;
-          cg += w1 * c1.y;
-          cb += w1 * c1.z;
-          asum += ah1;
-          T -= w1;
-          done = done || (early && T < 1.0e-4f);
-          const float ah2 = (two && q2 <= 4.0f && al2 > (1.0f / 255.0f) && !done) ? al2 : 0.0f;
-          const float w2  = ah2 * T;
-          cr += w2 * c2.x;
-          cg += w2 * c2.y;
-          cb += w2 * c2.z;
-          asum += ah2;
-          T -= w2;
-          done = done || (early && T < 1.0e-4f);
+          const float4 a1 = s_a[j], b1 = s_b[j], c1 = s_c[j];
+          const v2f    dx = pcx - a1.x;
+          const float  dy = pcy - a1.y;
+          const v2f    s1 = dx * b1.x + dy * b1.y, u1 = dx * b1.z + dy * b1.w;
+          const v2f    q  = s1 * s1 + u1 * u1;  // == (A/2) * log2 e of frag.slang:236
+          v2f          al;
+          al.x = noGauss ? 1.0f : c1.w * __builtin_amdgcn_exp2f(-q.x);  // frag.slang:248-254
+          al.y = noGauss ? 1.0f : c1.w * __builtin_amdgcn_exp2f(-q.y);
+          v2f ah;  // frag.slang:242-245,258-262, predicated
+          ah.x = (q.x <= kQMax && al.x > (1.0f / 255.0f) && T.x >= tMin) ? al.x : 0.0f;
+          ah.y = (q.y <= kQMax && al.y > (1.0f / 255.0f) && T.y >= tMin) ? al.y : 0.0f;
+          const v2f wgt = ah * T;
+          cr += wgt * c1.x;
+          cg += wgt * c1.y;
+          cb += wgt * c1.z;
+          asum += ah;
+          T -= wgt;
         }
-        if(early && __ballot(!done) == 0ull)
+        if(early && __ballot((in0 && T.x >= 1.0e-4f) || (in1 && T.y >= 1.0e-4f)) == 0ull)
         {
           waveDone = true;
           break;
@@ -789,20 +789,25 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
       break;
   }
 
-  if(inside)
+  const v2f aout = early ? (v2f){1.0f - T.x, 1.0f - T.y} : asum;
+#pragma unroll
+  for(int h = 0; h < 2; ++h)
   {
-    const float  aout = early ? (1.0f - T) : asum;
-    const size_t o    = (size_t)py * (size_t)F.width + (size_t)px;
-    if(HALF_OUT)
+    if(h ? in1 : in0)
     {
-      const __half2 lo = __floats2half2_rn(cr, cg), hi2 = __floats2half2_rn(cb, aout);
-      uint2         pk;
-      pk.x = *reinterpret_cast<const uint32_t*>(&lo);
-      pk.y = *reinterpret_cast<const uint32_t*>(&hi2);
-      reinterpret_cast<uint2*>(outImage)[o] = pk;
+      const float  r = h ? cr.y : cr.x, g = h ? cg.y : cg.x, b = h ? cb.y : cb.x, ao = h ? aout.y : aout.x;
+      const size_t o = (size_t)py * (size_t)F.width + (size_t)(px + 8 * h);
+      if(HALF_OUT)
+      {
+        const __half2 lo = __floats2half2_rn(r, g), hi2 = __floats2half2_rn(b, ao);
+        uint2         pk;
+        pk.x = *reinterpret_cast<const uint32_t*>(&lo);
+        pk.y = *reinterpret_cast<const uint32_t*>(&hi2);
+        reinterpret_cast<uint2*>(outImage)[o] = pk;
+      }
+      else
+        reinterpret_cast<float4*>(outImage)[o] = make_float4(r, g, b, ao);
     }
-    else
-      reinterpret_cast<float4*>(outImage)[o] = make_float4(cr, cg, cb, aout);
   }
 }
 
@@ -860,10 +865,10 @@ void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* 
 void launchComposite(hipStream_t stream, const FrameConst& F, const uint2* ranges, const uint32_t* valX,
                      const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, bool halfOut)
 {
-  const int stripTiles = F.tilesX * (F.stripRow1 - F.stripRow0);
-  if(stripTiles <= 0)
+  const int stripCols = ((F.tilesX + 1) >> 1) * (F.stripRow1 - F.stripRow0);  // 32x16-px regions
+  if(stripCols <= 0)
     return;
-  const int per = (stripTiles + 7) >> 3;
+  const int per = (stripCols + 7) >> 3;
   if(halfOut)
     hipLaunchKernelGGL((k_composite<true>), dim3(per * 8), dim3(256), 0, stream, F, ranges, valX, valY, planPairs, rec, image);
   else

@@ -963,7 +963,7 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
   F.stripRow1       = r1;
   // bins: lists are built per (16<<shift)-pixel bin; the compositor culls per 16x16 tile on chip.
   // Default 128x128 px (MGS_BIN_SHIFT="x,y" overrides, 0..4 each; measured sweep in DESIGN.md §3.3).
-  int bsx = 3, bsy = 3;
+  int bsx = 4, bsy = 3;  // 256x128 px
   if(const char* e = std::getenv("MGS_BIN_SHIFT"))
     std::sscanf(e, "%d,%d", &bsx, &bsy);
   else
@@ -978,7 +978,7 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
         ++bsx;
     }
   }
-  bsx         = std::min(std::max(bsx, 0), 4);
+  bsx         = std::min(std::max(bsx, 1), 4);  // the compositor's 32x16-px regions must not straddle bins
   bsy         = std::min(std::max(bsy, 0), 4);
   F.binShiftX = bsx;
   F.binShiftY = bsy;
