@@ -579,7 +579,7 @@ constexpr int kCmpCap     = 384;                // LDS batch capacity (records):
 constexpr int kCmpGo      = 128;                // blend as soon as this many records are staged (<= kCmpCap-256)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <bool HALF_OUT>
+template <bool HALF_OUT, int MODE>  // MODE bit 0: additive alpha (no early-out), bit 1: DISABLE_OPACITY_GAUSSIAN
 __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ valX, const uint32_t* __restrict__ valY,
                                                    const SortPlan* __restrict__ plan, const SplatRec* __restrict__ rec,
@@ -592,45 +592,24 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
   __shared__ uint8_t  s_m[kCmpCap];  // which of the 4 quarters (waves) the record's footprint touches
 
   const int t = threadIdx.x, lane = laneId(), w = t >> 6;
-  // regions are enumerated in 32-px columns ("tile pairs"); binShiftX >= 1, so a pair never straddles two bins
-  const int colsX      = (F.tilesX + 1) >> 1;
-  const int stripCols  = colsX * (F.stripRow1 - F.stripRow0);
-  // XCD-aware mapping: workgroup b lands on XCD b%8 (observed dispatch rule); give each XCD a contiguous
-  // run of regions so the regions of one bin — which read the same list — share an L2.
-  const int per  = (stripCols + 7) >> 3;
-  const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if(tile >= stripCols || (int)(blockIdx.x >> 3) >= per)
+  // regions are 32-px columns x 16-px rows ("tile pairs"); binShiftX >= 1, so a pair never straddles two bins.
+  // XCD-aware mapping: workgroup b lands on XCD b%8 (observed dispatch rule).  All regions of a bin — which
+  // read the same list — go to one XCD (shared L2), and consecutive bins go to different XCDs so that the dense
+  // part of the image is spread over all eight (contiguous screen bands per XCD left most of them idle).
+  const int colsX    = (F.tilesX + 1) >> 1;
+  const int bw       = 1 << (F.binShiftX - 1), bh = 1 << F.binShiftY;  // bin size in regions
+  const int binRow0  = F.stripRow0 >> F.binShiftY;
+  const int binRows  = ((F.stripRow1 - 1) >> F.binShiftY) - binRow0 + 1;
+  const int perBin   = bw * bh;
+  const int seq      = (int)(blockIdx.x >> 3);
+  const int ord      = (seq / perBin) * 8 + (int)(blockIdx.x & 7);  // bin ordinal inside the strip
+  const int inBin    = seq % perBin;
+  if(ord >= binRows * F.binsX)
     return;
-  // walk regions bin by bin inside the strip so that consecutive workgroups share a list
-  const int bw = 1 << (F.binShiftX - 1), bh = 1 << F.binShiftY;  // bin size in regions
-  const int rowsInStrip = F.stripRow1 - F.stripRow0;
-  int       cx2, ty;
-  {
-    // regions are enumerated per bin-row band: band = group of bh tile rows
-    const int bandTiles = colsX * bh;
-    const int band      = tile / bandTiles;
-    const int inBand    = tile - band * bandTiles;
-    const int bandRow0  = band * bh;
-    const int bandRows  = min(bh, rowsInStrip - bandRow0);
-    const int binCol    = inBand / (bw * bandRows);
-    const int inBin     = inBand - binCol * (bw * bandRows);
-    const int colsHere  = min(bw, colsX - binCol * bw);
-    if(colsHere <= 0)
-      return;
-    // the last bin column may be narrower: re-derive with its true width
-    const int full = (colsX / bw) * (bw * bandRows);
-    if(inBand < full || (colsX % bw) == 0)
-    {
-      cx2 = binCol * bw + inBin % bw;
-      ty  = F.stripRow0 + bandRow0 + inBin / bw;
-    }
-    else
-    {
-      const int rem = inBand - full, wlast = colsX % bw;
-      cx2           = (colsX / bw) * bw + rem % wlast;
-      ty            = F.stripRow0 + bandRow0 + rem / wlast;
-    }
-  }
+  const int cx2 = (ord % F.binsX) * bw + inBin % bw;
+  const int ty  = (binRow0 + ord / F.binsX) * bh + inBin / bw;
+  if(cx2 >= colsX || ty < F.stripRow0 || ty >= F.stripRow1)
+    return;
   const int      tx  = cx2 * 2;  // left 16-px tile of the region
   const int      qx0 = tx * kTilePx + (w & 1) * 16, qy0 = ty * kTilePx + (w >> 1) * 8;
   const int      px = qx0 + (lane & 7), py = qy0 + (lane >> 3);  // second pixel: px + 8
@@ -638,8 +617,8 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
   const float    pcy = (float)py + 0.5f;
   const float    bcx = (float)(tx * kTilePx) + 16.0f, bcy = (float)(ty * kTilePx) + 8.0f;  // region centre
   const bool     in0 = px < F.width && py < F.height, in1 = px + 8 < F.width && py < F.height;
-  const bool     early   = (F.alphaMode == 0);
-  const bool     noGauss = (F.debugFlags & 4) != 0;
+  constexpr bool early   = (MODE & 1) == 0;
+  constexpr bool noGauss = (MODE & 2) != 0;
   // a saturated pixel (T < 1e-4) takes no further fragments: the result must not depend on WHEN its wave
   // notices (batch boundaries differ between a strip and the full frame, the frames must not)
   const float    tMin    = early ? 1.0e-4f : -1.0f;
@@ -763,9 +742,12 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
           const float  dy = pcy - a1.y;
           const v2f    s1 = dx * b1.x + dy * b1.y, u1 = dx * b1.z + dy * b1.w;
           const v2f    q  = s1 * s1 + u1 * u1;  // == (A/2) * log2 e of frag.slang:236
-          v2f          al;
-          al.x = noGauss ? 1.0f : c1.w * __builtin_amdgcn_exp2f(-q.x);  // frag.slang:248-254
-          al.y = noGauss ? 1.0f : c1.w * __builtin_amdgcn_exp2f(-q.y);
+          v2f          al = {1.0f, 1.0f};
+          if(!noGauss)  // frag.slang:248-254
+          {
+            const v2f e = {__builtin_amdgcn_exp2f(-q.x), __builtin_amdgcn_exp2f(-q.y)};
+            al          = e * c1.w;
+          }
           v2f ah;  // frag.slang:242-245,258-262, predicated
           ah.x = (q.x <= kQMax && al.x > (1.0f / 255.0f) && T.x >= tMin) ? al.x : 0.0f;
           ah.y = (q.y <= kQMax && al.y > (1.0f / 255.0f) && T.y >= tMin) ? al.y : 0.0f;
@@ -773,7 +755,8 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
           cr += wgt * c1.x;
           cg += wgt * c1.y;
           cb += wgt * c1.z;
-          asum += ah;
+          if(!early)
+            asum += ah;
           T -= wgt;
         }
         if(early && __ballot((in0 && T.x >= 1.0e-4f) || (in1 && T.y >= 1.0e-4f)) == 0ull)
@@ -865,14 +848,25 @@ void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* 
 void launchComposite(hipStream_t stream, const FrameConst& F, const uint2* ranges, const uint32_t* valX,
                      const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, bool halfOut)
 {
-  const int stripCols = ((F.tilesX + 1) >> 1) * (F.stripRow1 - F.stripRow0);  // 32x16-px regions
-  if(stripCols <= 0)
+  if(F.stripRow1 <= F.stripRow0)
     return;
-  const int per = (stripCols + 7) >> 3;
-  if(halfOut)
-    hipLaunchKernelGGL((k_composite<true>), dim3(per * 8), dim3(256), 0, stream, F, ranges, valX, valY, planPairs, rec, image);
-  else
-    hipLaunchKernelGGL((k_composite<false>), dim3(per * 8), dim3(256), 0, stream, F, ranges, valX, valY, planPairs, rec, image);
+  const int binRows = ((F.stripRow1 - 1) >> F.binShiftY) - (F.stripRow0 >> F.binShiftY) + 1;
+  const int nBins   = binRows * F.binsX;
+  const int per     = ((nBins + 7) / 8) * (1 << (F.binShiftX - 1 + F.binShiftY));  // workgroups per XCD
+  const int mode = (F.alphaMode != 0 ? 1 : 0) | ((F.debugFlags & 4) ? 2 : 0);
+#define MGS_CMP(H, M) hipLaunchKernelGGL((k_composite<H, M>), dim3(per * 8), dim3(256), 0, stream, F, ranges, valX, valY, planPairs, rec, image)
+  switch(mode + (halfOut ? 4 : 0))
+  {
+    case 0: MGS_CMP(false, 0); break;
+    case 1: MGS_CMP(false, 1); break;
+    case 2: MGS_CMP(false, 2); break;
+    case 3: MGS_CMP(false, 3); break;
+    case 4: MGS_CMP(true, 0); break;
+    case 5: MGS_CMP(true, 1); break;
+    case 6: MGS_CMP(true, 2); break;
+    default: MGS_CMP(true, 3); break;
+  }
+#undef MGS_CMP
 }
 
 }  // namespace mgs
