@@ -22,7 +22,7 @@ struct InstanceConst
   const void*  rgba;     // [count*4] fp32 | fp16 | u8
   const float* maxScale; // [count] max(exp(scale)) per splat, host-computed (only read by size culling)
   const float* partBox;  // per 2048-splat partition: min xyz, max xyz (model space), rmax (sqrt(8*trace(Sigma))), pad
-  const void*  sh;       // vector-planar: plane v holds 16 bytes of every splat's [coef][rgb] record: [planes][count][16 B]
+  const void*  sh;       // [count] records of 48 elements, [coef][rgb] + padding (192 B fp32 / 96 B fp16 / 48 B uint8)
   float        model[16];      // M   (glm column-major)
   float        modelView[16];  // V*M (host-computed with the same unfused fp32 products the shader does per thread)
   float        camModel[3];    // M^-1 * cameraPosition
@@ -69,14 +69,16 @@ struct FrameArgs
   InstanceConst inst[kMaxInlineInstances];
 };
 
-// projected splat record consumed by the compositor (48 B, 16-B aligned)
+// projected splat record consumed by the compositor (64 B = one sector, 16-B aligned)
 struct alignas(16) SplatRec
 {
   float cx, cy;    // centre in pixels
   float ex, ey;    // tight half extents of the visible footprint in pixels   -- first 16 B: all a cull test needs
   float p1x, p1y;  // 2*b1/|b1|^2 : (d.p1)^2 + (d.p2)^2 == A/2 of threedgs_raster.frag.slang:236
   float p2x, p2y;
-  float r, g, b, a;
+  float r, g, b, a;  // base colour (before the SH sum) and opacity
+  float dx, dy, dz;  // unit direction camera -> splat in model space (mesh.slang:240-241): input of the deferred SH sum
+  int   inst;        // instance the splat belongs to
 };
 
 // device-resident counters of one frame

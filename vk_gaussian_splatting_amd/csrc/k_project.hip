@@ -15,8 +15,6 @@
 //     is no global atomic append and no inter-workgroup chain.
 //   * splats that can never produce a fragment (alpha cull, lambda2<=0, clipped by z, footprint
 //     outside the strip) are dropped BEFORE the sort.
-#include <type_traits>
-
 #include "kernels_common.h"
 
 namespace mgs {
@@ -53,119 +51,19 @@ __device__ __forceinline__ float4 loadRgba(const void* base, uint32_t i)
   }
 }
 
-// SH storage is VECTOR-PLANAR: the [coef][rgb] record of a splat (padded to 48 elements) is cut into
-// 16-byte vectors and vector v of all splats forms one contiguous plane: sh[v][splat] (12 planes fp32,
-// 6 fp16, 3 uint8).  Lanes process (mostly) consecutive splats, so every load instruction of a wave
-// covers one contiguous ~1 KB run of full cache lines.  With per-splat 192-byte records each
-// instruction touched 64 different lines and the 16 KB-per-wave footprint thrashed the 32 KB L1
-// (k_project 0.43 ms, profiles/r1_b); the reference's AoS layout (threedgs_particle_buffers.h.slang:112-207)
-// is kept only as the logical order inside a record.
-// NV = number of 16-byte vectors to fetch (compile time: the loads must be straight-line code — a
-// run-time guard per vector turns each load into its own branch + s_waitcnt vmcnt(0), i.e. 12
-// serialized round trips; that was the real cost of this kernel in profiles/r1_a..b).
-template <int FMT, int NV>
-__device__ __forceinline__ void loadShVectors(const void* base, uint32_t li, uint32_t count, float (&s)[48])
-{
-  constexpr int PER = FMT == 0 ? 4 : (FMT == 1 ? 8 : 16);
-  const uint4*  p   = reinterpret_cast<const uint4*>(base) + li;
-  uint4         x[NV];
-#pragma unroll
-  for(int v = 0; v < NV; ++v)
-  {
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    // streamed once per frame by exactly one lane: non-temporal, so it does not evict the records/keys from L2
-    const u32x4 r = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(&p[(size_t)v * count]));
-    x[v]          = make_uint4(r.x, r.y, r.z, r.w);
-  }
-#pragma unroll
-  for(int v = 0; v < NV; ++v)
-  {
-    const uint32_t w[4] = {x[v].x, x[v].y, x[v].z, x[v].w};
-    if constexpr(FMT == 0)
-    {
-#pragma unroll
-      for(int q = 0; q < 4; ++q)
-        s[PER * v + q] = __uint_as_float(w[q]);
-    }
-    else if constexpr(FMT == 1)
-    {
-#pragma unroll
-      for(int q = 0; q < 4; ++q)
-      {
-        const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&w[q]));
-        s[PER * v + 2 * q]     = f.x;
-        s[PER * v + 2 * q + 1] = f.y;
-      }
-    }
-    else
-    {
-#pragma unroll
-      for(int q = 0; q < 4; ++q)
-#pragma unroll
-        for(int k = 0; k < 4; ++k)  // threedgs_particle_buffers.h.slang:128-131: v/255*2-1
-          s[PER * v + 4 * q + k] = (float)((w[q] >> (8 * k)) & 255u) / 255.0f * 2.0f - 1.0f;
-    }
-  }
-}
-
-// SH degrees 1..3 (constants and term order of threedgs_particle_storage.h.slang:48-52,121-155) from an
-// already-fetched record
-template <int degree>
-__device__ __forceinline__ void shRadiance(const float (&s)[48], float x, float y, float z, float& r, float& g, float& b)
-{
-  if constexpr(degree < 1)
-    return;
-  const float C1 = 0.4886025119029199f;
-  float       acc[3];
-#pragma unroll
-  for(int c = 0; c < 3; ++c)
-    acc[c] = C1 * (-s[0 + c] * y + s[3 + c] * z - s[6 + c] * x);
-  if constexpr(degree >= 2)
-  {
-    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-    const float k0 = 1.0925484f * xy, k1 = -1.0925484f * yz, k2 = 0.3153916f * (2.0f * zz - xx - yy),
-                k3 = -1.0925484f * xz, k4 = 0.5462742f * (xx - yy);
-#pragma unroll
-    for(int c = 0; c < 3; ++c)
-      acc[c] += k0 * s[9 + c] + k1 * s[12 + c] + k2 * s[15 + c] + k3 * s[18 + c] + k4 * s[21 + c];
-    if constexpr(degree >= 3)
-    {
-      const float m0 = -0.5900435899266435f * (3.0f * xx - yy) * y, m1 = 2.890611442640554f * xy * z,
-                  m2 = -0.4570457994644658f * (4.0f * zz - xx - yy) * y,
-                  m3 = 0.3731763325901154f * z * (2.0f * zz - 3.0f * xx - 3.0f * yy),
-                  m4 = -0.4570457994644658f * x * (4.0f * zz - xx - yy), m5 = 1.445305721320277f * (xx - yy) * z,
-                  m6 = -0.5900435899266435f * x * (xx - 3.0f * yy);
-#pragma unroll
-      for(int c = 0; c < 3; ++c)
-        acc[c] += m0 * s[24 + c] + m1 * s[27 + c] + m2 * s[30 + c] + m3 * s[33 + c] + m4 * s[36 + c] + m5 * s[39 + c]
-                  + m6 * s[42 + c];
-    }
-  }
-  r += acc[0];
-  g += acc[1];
-  b += acc[2];
-}
-
 // The per-splat raster front end.  Returns false when the splat cannot produce a fragment.
 // Written BRANCH-FREE with every load issued first: rocprof showed the waves of this kernel waiting on
 // memory 70 % of their cycles when the fetches were staged behind the early-outs (rgba -> centre -> cov
 // -> SH, four dependent round trips).  ~96 % of the frustum survivors pass every test, so the
 // speculative SH fetch of the rest costs ~4 % extra traffic and buys one round trip instead of four.
-template <int SHF, int RGBAF, int DEG>
-__device__ __forceinline__ bool projectSplat(const FrameConst& F, const InstanceConst& I, uint32_t li, Projected& out)
+template <int RGBAF>
+__device__ __forceinline__ bool projectSplat(const FrameConst& F, const InstanceConst& I, int instIdx, uint32_t li, Projected& out)
 {
   // ---- all fetches --------------------------------------------------------------------------------------
   float4       col = loadRgba<RGBAF>(I.rgba, li);
   const float  px = I.centers[3 * (size_t)li + 0], py = I.centers[3 * (size_t)li + 1], pz = I.centers[3 * (size_t)li + 2];
   const float4 cA = reinterpret_cast<const float4*>(I.cov6)[li];                       // planar: 16 B per lane
   const float2 cB = reinterpret_cast<const float2*>(I.cov6 + 4 * (size_t)I.count)[li];  //          8 B per lane
-  float        sh[48];
-  if constexpr(DEG >= 1)
-  {
-    constexpr int PER = SHF == 0 ? 4 : (SHF == 1 ? 8 : 16);
-    constexpr int NEL = DEG == 1 ? 9 : (DEG == 2 ? 24 : 45);
-    loadShVectors<SHF, (NEL + PER - 1) / PER>(I.sh, li, I.count, sh);
-  }
 
   // ---- mesh.slang:164-190 ---------------------------------------------------------------------------------
   bool         ok = !(col.w < F.alphaCull);
@@ -266,7 +164,8 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   dz *= dl;
   if(F.debugFlags & 2)  // SHOW_SH_ONLY, mesh.slang:205-207
     col.x = col.y = col.z = 0.5f;
-  shRadiance<DEG>(sh, dx, dy, dz, col.x, col.y, col.z);
+  // the SH sum itself (mesh.slang:243) is added by the compositor when the splat is staged: rec carries the
+  // base colour, the direction and the instance the record belongs to
 
   const float n1 = 2.0f / (b1x * b1x + b1y * b1y), n2 = 2.0f / (b2x * b2x + b2y * b2y);
   out.rec.cx  = pcx;
@@ -281,6 +180,10 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   out.rec.a   = col.w;
   out.rec.ex  = ex;
   out.rec.ey  = ey;
+  out.rec.dx  = dx;
+  out.rec.dy  = dy;
+  out.rec.dz  = dz;
+  out.rec.inst = instIdx;
   return true;
 }
 
@@ -307,7 +210,7 @@ __device__ __forceinline__ uint32_t scanRoundWaveCounts(uint32_t* s_cnt /*32*/, 
 // Output: survivors of partition p, ascending id, in keysSlot/idsSlot[p*2048 ...], count in slotCount[p].
 // No barrier sits inside a loop that waits on memory: all 8 centre loads of a thread are issued up front,
 // and the heavy per-survivor loop runs barrier-free (waves drift apart and overlap each other's loads).
-template <bool FULL, int SHF, int RGBAF>
+template <bool FULL, int RGBAF>
 __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, FrameCounters* __restrict__ ctr,
                                                          uint32_t* __restrict__ keysSlot, uint32_t* __restrict__ idsSlot,
                                                          uint32_t* __restrict__ slotCount, SplatRec* __restrict__ rec,
@@ -415,34 +318,22 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, Fram
   else
   {
     // ---- phase 2: dense raster front end over the survivors (no barriers inside) ------------------------
-    // SH degree is uniform per instance: dispatch once so that the record fetch is straight-line code
-    const int degree = (I.sh == nullptr) ? 0 : min(I.shDegree, A.f.shDegree);
-    auto      body   = [&](auto degTag) {
-      constexpr int DEG = decltype(degTag)::value;
-      for(uint32_t j = t; j < M; j += kPrjThreads)
+    for(uint32_t j = t; j < M; j += kPrjThreads)
+    {
+      const uint32_t li = local0 + s_li[j];
+      Projected      pr;
+      if(projectSplat<RGBAF>(A.f, I, k, li, pr))
       {
-        const uint32_t li = local0 + s_li[j];
-        Projected      pr;
-        if(projectSplat<SHF, RGBAF, DEG>(A.f, I, li, pr))
-        {
-          const uint32_t gid = I.globalOffset + li;
-          float4*        dst = reinterpret_cast<float4*>(rec + gid);
-          dst[0]             = make_float4(pr.rec.cx, pr.rec.cy, pr.rec.ex, pr.rec.ey);
-          dst[1]             = make_float4(pr.rec.p1x, pr.rec.p1y, pr.rec.p2x, pr.rec.p2y);
-          dst[2]             = make_float4(pr.rec.r, pr.rec.g, pr.rec.b, pr.rec.a);
-          rect[gid]          = pr.rect;
-          s_li[j] |= 0x8000u;  // own entry only: no race
-        }
+        const uint32_t gid = I.globalOffset + li;
+        float4*        dst = reinterpret_cast<float4*>(rec + gid);
+        dst[0]             = make_float4(pr.rec.cx, pr.rec.cy, pr.rec.ex, pr.rec.ey);
+        dst[1]             = make_float4(pr.rec.p1x, pr.rec.p1y, pr.rec.p2x, pr.rec.p2y);
+        dst[2]             = make_float4(pr.rec.r, pr.rec.g, pr.rec.b, pr.rec.a);
+        dst[3]             = make_float4(pr.rec.dx, pr.rec.dy, pr.rec.dz, __int_as_float(pr.rec.inst));
+        rect[gid]          = pr.rect;
+        s_li[j] |= 0x8000u;  // own entry only: no race
       }
-    };
-    if(degree >= 3)
-      body(std::integral_constant<int, 3>{});
-    else if(degree == 2)
-      body(std::integral_constant<int, 2>{});
-    else if(degree == 1)
-      body(std::integral_constant<int, 1>{});
-    else
-      body(std::integral_constant<int, 0>{});
+    }
     // ---- second ordered compaction straight into the partition's slot region ---------------------------
     __syncthreads();
 #pragma unroll
@@ -567,25 +458,19 @@ void launchProject(hipStream_t stream, const FrameArgs& args, bool full, int shF
   const dim3 grid(args.f.totalPartitions), block(kPrjThreads);
   if(args.f.totalPartitions == 0)
     return;
-#define MGS_LAUNCH(FULLV, S, R)                                                                                          \
-  hipLaunchKernelGGL((k_project<FULLV, S, R>), grid, block, 0, stream, args, ctr, keysSlot, idsSlot, slotCount, rec, rect, partSkip, \
+#define MGS_LAUNCH(FULLV, R)                                                                                             \
+  hipLaunchKernelGGL((k_project<FULLV, R>), grid, block, 0, stream, args, ctr, keysSlot, idsSlot, slotCount, rec, rect, partSkip, \
                      slotHist, histStride)
   if(!full)
   {
-    MGS_LAUNCH(false, 0, 0);
+    MGS_LAUNCH(false, 0);
     return;
   }
-  switch(shFormat * 3 + rgbaFormat)
+  switch(rgbaFormat)
   {
-    case 0: MGS_LAUNCH(true, 0, 0); break;
-    case 1: MGS_LAUNCH(true, 0, 1); break;
-    case 2: MGS_LAUNCH(true, 0, 2); break;
-    case 3: MGS_LAUNCH(true, 1, 0); break;
-    case 4: MGS_LAUNCH(true, 1, 1); break;
-    case 5: MGS_LAUNCH(true, 1, 2); break;
-    case 6: MGS_LAUNCH(true, 2, 0); break;
-    case 7: MGS_LAUNCH(true, 2, 1); break;
-    default: MGS_LAUNCH(true, 2, 2); break;
+    case 0: MGS_LAUNCH(true, 0); break;
+    case 1: MGS_LAUNCH(true, 1); break;
+    default: MGS_LAUNCH(true, 2); break;
   }
 #undef MGS_LAUNCH
 }

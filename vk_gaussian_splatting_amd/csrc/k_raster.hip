@@ -9,6 +9,7 @@
 // accumulate front-to-back with transmittance, which is the same sum in exact arithmetic:
 //   C = sum_i c_i a_i prod_{j nearer than i} (1 - a_j).
 #include "kernels_common.h"
+#include "sh_eval.h"
 #include "sort_plan.h"
 
 namespace mgs {
@@ -580,14 +581,16 @@ constexpr int kCmpGo      = 128;                // blend as soon as this many re
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <bool HALF_OUT, int MODE>  // MODE bit 0: additive alpha (no early-out), bit 1: DISABLE_OPACITY_GAUSSIAN
-__global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uint2* __restrict__ ranges,
+__global__ __launch_bounds__(256) void k_composite(const FrameArgs A, const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ valX, const uint32_t* __restrict__ valY,
                                                    const SortPlan* __restrict__ plan, const SplatRec* __restrict__ rec,
-                                                   void* __restrict__ outImage)
+                                                   void* __restrict__ outImage, int shFormat)
 {
+  const FrameConst& F = A.f;
   __shared__ float4   s_a[kCmpCap];  // cx, cy, ex, ey
   __shared__ float4   s_b[kCmpCap];  // p1, p2 (scaled by sqrt(log2 e))
   __shared__ float4   s_c[kCmpCap];  // r, g, b, a
+  __shared__ float4   s_d[kCmpCap];  // direction (model space), global id: what the deferred SH sum needs
   __shared__ uint32_t s_wc[2][kCmpEntries][4];
   __shared__ uint8_t  s_m[kCmpCap];  // which of the 4 quarters (waves) the record's footprint touches
 
@@ -706,6 +709,8 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
             s_a[pos]           = a[k];
             s_b[pos]           = make_float4(pb.x * kSqrtLog2e, pb.y * kSqrtLog2e, pb.z * kSqrtLog2e, pb.w * kSqrtLog2e);
             s_c[pos]           = r[2];
+            const float4 rd    = r[3];
+            s_d[pos]           = make_float4(rd.x, rd.y, rd.z, __uint_as_float(g[k]));
             // quarter (qx,qy): pixel centres x in [bcx-15.5,bcx-0.5] / [bcx+0.5,bcx+15.5], y in [bcy-7.5,bcy-0.5] / [bcy+0.5,bcy+7.5]
             const bool xl = a[k].x - a[k].z <= bcx - 0.5f, xr = a[k].x + a[k].z >= bcx + 0.5f;
             const bool yt = a[k].y - a[k].w <= bcy - 0.5f, yb = a[k].y + a[k].w >= bcy + 0.5f;
@@ -721,6 +726,33 @@ __global__ __launch_bounds__(256) void k_composite(const FrameConst F, const uin
       hi -= consumed;
       if(used < kCmpEntries)
         break;  // batch full: blend, then rescan the unconsumed sub-groups
+    }
+    __syncthreads();
+    // ---- shading: the SH sum of the staged splats (mesh.slang:243), one thread per record ---------------------
+    // Deferred from the projection: only splats that reach an unsaturated region are ever shaded (a quarter of
+    // the frustum survivors on the garden-sized bench), and their 192-byte SH records are the bulk of a splat.
+    for(uint32_t j = t; j < fill; j += 256)
+    {
+      const float4   dd  = s_d[j];
+      const uint32_t gid = __float_as_uint(dd.w);
+      int            ki  = 0;
+      for(int i = 1; i < F.nInstances; ++i)
+        if(gid >= A.inst[i].globalOffset)
+          ki = i;
+      const InstanceConst& I   = A.inst[ki];
+      const int            deg = (I.sh == nullptr) ? 0 : min(I.shDegree, F.shDegree);
+      if(deg > 0)
+      {
+        const uint32_t li = gid - I.globalOffset;
+        float4         c  = s_c[j];
+        if(shFormat == 0)
+          addShRadiance<0>(I.sh, li, deg, dd.x, dd.y, dd.z, c.x, c.y, c.z);
+        else if(shFormat == 1)
+          addShRadiance<1>(I.sh, li, deg, dd.x, dd.y, dd.z, c.x, c.y, c.z);
+        else
+          addShRadiance<2>(I.sh, li, deg, dd.x, dd.y, dd.z, c.x, c.y, c.z);
+        s_c[j] = c;
+      }
     }
     __syncthreads();
     // ---- stage B: blend the batch ------------------------------------------------------------------------
@@ -845,16 +877,18 @@ void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* 
   hipLaunchKernelGGL(k_tile_ranges, dim3(4096), dim3(256), 0, stream, keyX, keyY, planPairs, ranges);
 }
 
-void launchComposite(hipStream_t stream, const FrameConst& F, const uint2* ranges, const uint32_t* valX,
-                     const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, bool halfOut)
+void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
+                     const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, bool halfOut,
+                     int shFormat)
 {
+  const FrameConst& F = A.f;
   if(F.stripRow1 <= F.stripRow0)
     return;
   const int binRows = ((F.stripRow1 - 1) >> F.binShiftY) - (F.stripRow0 >> F.binShiftY) + 1;
   const int nBins   = binRows * F.binsX;
   const int per     = ((nBins + 7) / 8) * (1 << (F.binShiftX - 1 + F.binShiftY));  // workgroups per XCD
   const int mode = (F.alphaMode != 0 ? 1 : 0) | ((F.debugFlags & 4) ? 2 : 0);
-#define MGS_CMP(H, M) hipLaunchKernelGGL((k_composite<H, M>), dim3(per * 8), dim3(256), 0, stream, F, ranges, valX, valY, planPairs, rec, image)
+#define MGS_CMP(H, M) hipLaunchKernelGGL((k_composite<H, M>), dim3(per * 8), dim3(256), 0, stream, A, ranges, valX, valY, planPairs, rec, image, shFormat)
   switch(mode + (halfOut ? 4 : 0))
   {
     case 0: MGS_CMP(false, 0); break;

@@ -44,8 +44,9 @@ void launchDirectBinning(hipStream_t stream, const uint32_t* idsX, const uint32_
                          int binsX, int binsY, bool gatherRects);
 void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* keyY, const SortPlan* planPairs,
                       uint2* ranges);
-void launchComposite(hipStream_t stream, const FrameConst& F, const uint2* ranges, const uint32_t* valX,
-                     const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, bool halfOut);
+void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
+                     const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, bool halfOut,
+                     int shFormat);
 constexpr uint32_t kPart = 2048;  // == kPrjPart == kSortPart == kBinPart
 }  // namespace mgs
 
@@ -680,15 +681,13 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
     {
       std::vector<float> sh, padded;
       buildShInterleaved(h, sh);
-      const int per = shFormat == MGS_FORMAT_FLOAT32 ? 4 : shFormat == MGS_FORMAT_FLOAT16 ? 8 : 16;
-      d.shPitch     = (d.shStride + per - 1) / per * per;
-      // vector-planar: element k of (storage) splat i lives in plane k/per at [plane][i][k%per]
+      // one 48-element record per (storage) splat, [coef][rgb] like the reference, zero padded: the compositor
+      // fetches whole records of the splats it stages (192 B fp32 = three 64-byte sectors)
+      d.shPitch = 48;
       padded.assign(n * (size_t)d.shPitch, 0.f);
       const int stride = d.shStride;
       parallelBatches(n, [&](size_t i) {
-        const float* src = &sh[(size_t)perm[i] * (size_t)stride];
-        for(int k = 0; k < stride; ++k)
-          padded[((size_t)(k / per) * n + i) * per + (k % per)] = src[k];
+        std::memcpy(&padded[i * (size_t)d.shPitch], &sh[(size_t)perm[i] * (size_t)stride], sizeof(float) * stride);
       });
       int rc = uploadFormatted(padded, shFormat, true, &d.sh);
       if(rc != MGS_OK)
@@ -823,16 +822,15 @@ int mgs_scene_download_set(MgsScene s, int instance, int which, float* dst, size
     return MGS_OK;
   }
   if(isSh)
-  {  // vector-planar with a padded pitch: fetch, dequantise, restore [splat][coef][rgb] in the caller's order
+  {  // padded records in storage order: fetch, dequantise, restore [splat][coef][rgb] in the caller's order
     const size_t         tot = (size_t)d.shPitch * n;
     const size_t         esz = fmt == MGS_FORMAT_FLOAT32 ? 4 : fmt == MGS_FORMAT_FLOAT16 ? 2 : 1;
-    const int            per = (int)(16 / esz);
     std::vector<uint8_t> raw(tot * esz);
     HIPCHK(hipMemcpy(raw.data(), src, raw.size(), hipMemcpyDeviceToHost));
     for(size_t i = 0; i < n; ++i)
       for(int k = 0; k < d.shStride; ++k)
       {
-        const size_t j = ((size_t)(k / per) * n + i) * per + (k % per);
+        const size_t j = i * (size_t)d.shPitch + (size_t)k;
         float        v;
         if(fmt == MGS_FORMAT_FLOAT32)
           std::memcpy(&v, raw.data() + 4 * j, 4);
@@ -1262,7 +1260,7 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
     }
   }
   if(timed) HIPCHK(hipEventRecord(fev[4], st));
-  launchComposite(st, F, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half);
+  launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat);
   if(timed) HIPCHK(hipEventRecord(fev[5], st));
   HIPCHK(hipMemcpyAsync(s->hCtr, ctr, sizeof(FrameCounters), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(s->hPlans, s->plans.p, 2 * sizeof(SortPlan), hipMemcpyDeviceToHost, st));
