@@ -580,11 +580,12 @@ constexpr int kCmpCap     = 384;                // LDS batch capacity (records):
 constexpr int kCmpGo      = 128;                // blend as soon as this many records are staged (<= kCmpCap-256)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <bool HALF_OUT, int MODE>  // MODE bit 0: additive alpha (no early-out), bit 1: DISABLE_OPACITY_GAUSSIAN
+// MODE bit 0: additive alpha (no early-out), bit 1: DISABLE_OPACITY_GAUSSIAN; SHF: SH storage format
+template <int MODE, int SHF>
 __global__ __launch_bounds__(256) void k_composite(const FrameArgs A, const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ valX, const uint32_t* __restrict__ valY,
                                                    const SortPlan* __restrict__ plan, const SplatRec* __restrict__ rec,
-                                                   void* __restrict__ outImage, int shFormat)
+                                                   void* __restrict__ outImage, int halfOut)
 {
   const FrameConst& F = A.f;
   __shared__ float4   s_a[kCmpCap];  // cx, cy, ex, ey
@@ -631,7 +632,8 @@ __global__ __launch_bounds__(256) void k_composite(const FrameArgs A, const uint
   constexpr float kSqrtLog2e = 1.2011224087864498f;   // sqrt(log2 e): exp(-q) == exp2(-(q * log2 e))
   constexpr float kQMax      = 4.0f * 1.4426950408889634f;
 
-  v2f  T = {1.0f, 1.0f}, cr = {0.f, 0.f}, cg = {0.f, 0.f}, cb = {0.f, 0.f}, asum = {0.f, 0.f};
+  // pixels outside the image start saturated (they are never stored), so "any T >= tMin" is the wave's liveness
+  v2f  T = {in0 ? 1.0f : 0.0f, in1 ? 1.0f : 0.0f}, cr = {0.f, 0.f}, cg = {0.f, 0.f}, cb = {0.f, 0.f}, asum = {0.f, 0.f};
   bool waveDone = (__ballot(in0 || in1) == 0ull);
 
   uint32_t hi   = range.y;
@@ -706,15 +708,33 @@ __global__ __launch_bounds__(256) void k_composite(const FrameArgs A, const uint
             const uint32_t pos = base + wb + lanesBelow(bal[k]);
             const float4*  r   = reinterpret_cast<const float4*>(rec + g[k]);
             const float4   pb  = r[1];
+            const float4   sb  = make_float4(pb.x * kSqrtLog2e, pb.y * kSqrtLog2e, pb.z * kSqrtLog2e, pb.w * kSqrtLog2e);
             s_a[pos]           = a[k];
-            s_b[pos]           = make_float4(pb.x * kSqrtLog2e, pb.y * kSqrtLog2e, pb.z * kSqrtLog2e, pb.w * kSqrtLog2e);
+            s_b[pos]           = sb;
             s_c[pos]           = r[2];
             const float4 rd    = r[3];
             s_d[pos]           = make_float4(rd.x, rd.y, rd.z, __uint_as_float(g[k]));
-            // quarter (qx,qy): pixel centres x in [bcx-15.5,bcx-0.5] / [bcx+0.5,bcx+15.5], y in [bcy-7.5,bcy-0.5] / [bcy+0.5,bcy+7.5]
-            const bool xl = a[k].x - a[k].z <= bcx - 0.5f, xr = a[k].x + a[k].z >= bcx + 0.5f;
-            const bool yt = a[k].y - a[k].w <= bcy - 0.5f, yb = a[k].y + a[k].w >= bcy + 0.5f;
-            s_m[pos] = (uint8_t)((xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u));
+            // quarter (qx,qy): pixel centres x in [bcx-15.5,bcx-0.5] / [bcx+0.5,bcx+15.5], y in [bcy-7.5,bcy-0.5] / [bcy+0.5,bcy+7.5].
+            // Footprint box first, then a bound in the ellipse's own frame: over the quarter (centre m, half
+            // extents 7.5 x 3.5) s = d.p1 stays within |s_m| -+ (7.5|p1x| + 3.5|p1y|), likewise u = d.p2, so
+            // q >= max(0,|s_m|-rs)^2 + max(0,|u_m|-ru)^2; a quarter whose bound exceeds what the alpha
+            // threshold lets through (a 2^-q > 1/255) cannot receive a fragment.  43 % of the wave-level
+            // evaluations were empty before this test (corner overlaps of slanted ellipses).
+            const bool  xl = a[k].x - a[k].z <= bcx - 0.5f, xr = a[k].x + a[k].z >= bcx + 0.5f;
+            const bool  yt = a[k].y - a[k].w <= bcy - 0.5f, yb = a[k].y + a[k].w >= bcy + 0.5f;
+            const float rc = r[2].w;
+            const float qLim = noGauss ? kQMax : fminf(kQMax, __log2f(fmaxf(rc * 255.0f, 1.0f))) * 1.001f + 1e-3f;
+            const float rs = 7.5f * fabsf(sb.x) + 3.5f * fabsf(sb.y), ru = 7.5f * fabsf(sb.z) + 3.5f * fabsf(sb.w);
+            uint32_t    qm = 0;
+#pragma unroll
+            for(int qd = 0; qd < 4; ++qd)
+            {
+              const float mx = bcx + ((qd & 1) ? 8.0f : -8.0f) - a[k].x, my = bcy + ((qd & 2) ? 4.0f : -4.0f) - a[k].y;
+              const float ds = fmaxf(fabsf(mx * sb.x + my * sb.y) - rs, 0.0f), du = fmaxf(fabsf(mx * sb.z + my * sb.w) - ru, 0.0f);
+              const bool  box = ((qd & 1) ? xr : xl) && ((qd & 2) ? yb : yt);
+              qm |= (box && (ds * ds + du * du <= qLim || (F.debugFlags & 256))) ? (1u << qd) : 0u;
+            }
+            s_m[pos] = (uint8_t)qm;
           }
           base += m;
           used = k + 1;
@@ -745,12 +765,7 @@ __global__ __launch_bounds__(256) void k_composite(const FrameArgs A, const uint
       {
         const uint32_t li = gid - I.globalOffset;
         float4         c  = s_c[j];
-        if(shFormat == 0)
-          addShRadiance<0>(I.sh, li, deg, dd.x, dd.y, dd.z, c.x, c.y, c.z);
-        else if(shFormat == 1)
-          addShRadiance<1>(I.sh, li, deg, dd.x, dd.y, dd.z, c.x, c.y, c.z);
-        else
-          addShRadiance<2>(I.sh, li, deg, dd.x, dd.y, dd.z, c.x, c.y, c.z);
+        addShRadiance<SHF>(I.sh, li, deg, dd.x, dd.y, dd.z, c.x, c.y, c.z);
         s_c[j] = c;
       }
     }
@@ -790,12 +805,16 @@ __global__ __launch_bounds__(256) void k_composite(const FrameArgs A, const uint
           if(!early)
             asum += ah;
           T -= wgt;
+          // checked per record (the compares are the predicate's): a 64-record chunk used to run to its end
+          // after the last pixel had saturated
+          if(early && __ballot(T.x >= tMin || T.y >= tMin) == 0ull)
+          {
+            waveDone = true;
+            break;
+          }
         }
-        if(early && __ballot((in0 && T.x >= 1.0e-4f) || (in1 && T.y >= 1.0e-4f)) == 0ull)
-        {
-          waveDone = true;
+        if(waveDone)
           break;
-        }
       }
     }
     fill = 0;
@@ -812,7 +831,7 @@ __global__ __launch_bounds__(256) void k_composite(const FrameArgs A, const uint
     {
       const float  r = h ? cr.y : cr.x, g = h ? cg.y : cg.x, b = h ? cb.y : cb.x, ao = h ? aout.y : aout.x;
       const size_t o = (size_t)py * (size_t)F.width + (size_t)(px + 8 * h);
-      if(HALF_OUT)
+      if(halfOut)
       {
         const __half2 lo = __floats2half2_rn(r, g), hi2 = __floats2half2_rn(b, ao);
         uint2         pk;
@@ -888,18 +907,24 @@ void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges
   const int nBins   = binRows * F.binsX;
   const int per     = ((nBins + 7) / 8) * (1 << (F.binShiftX - 1 + F.binShiftY));  // workgroups per XCD
   const int mode = (F.alphaMode != 0 ? 1 : 0) | ((F.debugFlags & 4) ? 2 : 0);
-#define MGS_CMP(H, M) hipLaunchKernelGGL((k_composite<H, M>), dim3(per * 8), dim3(256), 0, stream, A, ranges, valX, valY, planPairs, rec, image, shFormat)
-  switch(mode + (halfOut ? 4 : 0))
-  {
-    case 0: MGS_CMP(false, 0); break;
-    case 1: MGS_CMP(false, 1); break;
-    case 2: MGS_CMP(false, 2); break;
-    case 3: MGS_CMP(false, 3); break;
-    case 4: MGS_CMP(true, 0); break;
-    case 5: MGS_CMP(true, 1); break;
-    case 6: MGS_CMP(true, 2); break;
-    default: MGS_CMP(true, 3); break;
+#define MGS_CMP(M, S)                                                                                                  \
+  hipLaunchKernelGGL((k_composite<M, S>), dim3(per * 8), dim3(256), 0, stream, A, ranges, valX, valY, planPairs, rec, image, \
+                     halfOut ? 1 : 0)
+#define MGS_CMP_FMT(M)                                                                                                 \
+  switch(shFormat)                                                                                                     \
+  {                                                                                                                    \
+    case 0: MGS_CMP(M, 0); break;                                                                                      \
+    case 1: MGS_CMP(M, 1); break;                                                                                      \
+    default: MGS_CMP(M, 2); break;                                                                                     \
   }
+  switch(mode)
+  {
+    case 0: MGS_CMP_FMT(0); break;
+    case 1: MGS_CMP_FMT(1); break;
+    case 2: MGS_CMP_FMT(2); break;
+    default: MGS_CMP_FMT(3); break;
+  }
+#undef MGS_CMP_FMT
 #undef MGS_CMP
 }
 

@@ -993,6 +993,7 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
   F.msAA            = p->ms_antialiasing;
   F.alphaMode       = p->alpha_mode;
   F.debugFlags      = p->debug_flags;
+  if(std::getenv("MGS_LOOSE_MASK")) F.debugFlags |= 256;  // A/B knob: footprint-box quarter masks only
   F.sizeCulling     = p->size_culling;
   F.sizeCullingMinPixels = p->size_culling_min_pixels;
   F.maxFocal        = std::max(std::fabs(F.focal[0]), std::fabs(F.focal[1]));

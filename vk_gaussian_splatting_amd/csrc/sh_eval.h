@@ -77,7 +77,10 @@ __device__ __forceinline__ void addShRadiance(const void* sh, uint32_t li, int d
   shBasis(dx, dy, dz, bs);
   const int nEl = degree >= 3 ? 45 : (degree == 2 ? 24 : (degree == 1 ? 9 : 0));
   float     acc[3] = {0.f, 0.f, 0.f};
-  constexpr int GROUP = FMT == 0 ? 4 : (FMT == 1 ? 2 : 1);  // 16 elements per group
+#ifndef MGS_SH_GROUP
+#define MGS_SH_GROUP 6
+#endif
+  constexpr int GROUP = FMT == 0 ? MGS_SH_GROUP : (FMT == 1 ? 6 : 3);  // fp32: two groups of 96 B, fp16 / uint8: the whole record
 #pragma unroll
   for(int v0 = 0; v0 < REC; v0 += GROUP)
   {
