@@ -30,6 +30,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PMC_FILE = "r1_h_pmc_hbm_traffic.json"  # written by tools/pmc_traffic.py from rocprofv3 --pmc passes of this command
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 STAGES = ["project", "sort", "bin", "pairsort", "composite", "total"]
 
@@ -229,11 +230,15 @@ def main():
     # algorithmic bytes per launch of each stage (SURVEY.md §8d per-unit figures)
     N = N * args.instances  # total global splats from here on
     alg = {
-        "project": 12 * N + 16 * Vf + (24 + 180) * Vs + (48 + 4 + 8) * Vs,
+        # centres of every splat; rgba + covariance of the frustum survivors; 64-B record + rect + (key, id) of the sorted ones
+        # (the 180-B SH records are no longer streamed here: shading is deferred to the compositor)
+        "project": 12 * N + (16 + 24) * Vf + (64 + 4 + 8) * Vs,
         "sort": 68 * Vs,
-        "bin": 2 * 8 * Vs + 8 * D,
-        "pairsort": (4 + 2 * 16) * D,
-        "composite": 48 * Vs + 4 * D + 8 * Ppix,
+        # direct binning: ids + rect gather + sorted rect (count), sorted rect + ids + list append (emit)
+        "bin": 20 * Vs + 4 * D,
+        "pairsort": 0,
+        # upper bound (every sorted splat staged once): list walk + record + SH record + RGBA16F frame
+        "composite": 4 * D + (64 + 192) * Vs + 8 * Ppix,
     }
     dom = max(range(5), key=lambda j: calib_ms[j])  # dominant stage of an un-overlapped frame
     dom_name = STAGES[dom]
@@ -250,9 +255,9 @@ def main():
     # runs of this same command, corrected as MI355X_MICROARCH.md prescribes; see profiles/*.json)
     traffic = None
     try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r1_f_pmc_hbm_traffic.json")))
-        if dom_name == "project" and "k_project" in pj["kernel"] and world == 1 and N == 5_830_000:
-            traffic = pj["traffic_bytes_per_launch_corrected"]
+        pj = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+        if dom_name in pj["kernels"] and world == 1 and N == 5_830_000 and args.instances == 1:
+            traffic = pj["kernels"][dom_name]["traffic_bytes_per_launch_corrected"]
     except Exception:
         pass
 
