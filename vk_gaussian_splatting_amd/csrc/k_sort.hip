@@ -110,7 +110,10 @@ __global__ __launch_bounds__(256) void k_sort_scan(const uint32_t* __restrict__ 
   __shared__ uint32_t s_tmp[4];
   const int      t = threadIdx.x, d = blockIdx.x;
   const uint32_t n     = *nPtr;
-  const uint32_t parts = partsSlotted ? partsSlotted : (uint32_t)(((uint64_t)n + part - 1) / part);
+  // slotted pass 0: the producer wrote one histogram per 2048-key slot; a partition takes spp = part/2048 slots.
+  // In place is safe: slot index >= partition index, and the block scan's barriers sit between reads and writes.
+  const uint32_t spp   = partsSlotted ? part / kSlotPart : 1u;
+  const uint32_t parts = partsSlotted ? (partsSlotted + spp - 1) / spp : (uint32_t)(((uint64_t)n + part - 1) / part);
   uint32_t       carry = 0;
   uint32_t*      row   = partHist + (size_t)d * pStride;
   for(uint32_t base = 0; base < parts; base += 2048)
@@ -120,7 +123,15 @@ __global__ __launch_bounds__(256) void k_sort_scan(const uint32_t* __restrict__ 
 #pragma unroll
     for(int i = 0; i < 8; ++i)
     {
-      v[i] = (p0 + i < parts) ? row[p0 + i] : 0u;
+      v[i] = 0u;
+      if(p0 + i < parts)
+      {
+        if(spp == 1u)
+          v[i] = row[p0 + i];
+        else
+          for(uint32_t q = 0; q < spp; ++q)
+            v[i] += ((p0 + i) * spp + q < partsSlotted) ? row[(p0 + i) * spp + q] : 0u;
+      }
       sum += v[i];
     }
     uint32_t chunk;
@@ -372,9 +383,11 @@ void launchRadixSort(hipStream_t stream, const SortLaunch& s)
   // big sorts use 8192-key partitions (digit runs of ~32 keys = 128-byte scatter segments, 4x shorter
   // partition tables); small ones keep 2048 so that 256 CUs still see enough workgroups.
   const uint32_t part    = (s.maxElems >= (2u << 20)) ? 8192u : 2048u;
-  auto partOf  = [&](int pass) { return (pass == 0 && slotted) ? 2048u : part; };
+  static const uint32_t kSlotPartOverride = [] { const char* e = std::getenv("MGS_SLOT_PART"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+  auto partOf  = [&](int pass) { return (pass == 0 && slotted && kSlotPartOverride) ? kSlotPartOverride : part; };
   auto partsOf = [&](int pass) {
-    return (pass == 0 && slotted) ? s.partsSlotted : (uint32_t)(((uint64_t)s.maxElems + partOf(pass) - 1) / partOf(pass));
+    const uint32_t pp = partOf(pass);
+    return (pass == 0 && slotted) ? (s.partsSlotted + pp / 2048u - 1) / (pp / 2048u) : (uint32_t)(((uint64_t)s.maxElems + pp - 1) / pp);
   };
   for(int pass = 0; pass < nPasses; ++pass)
   {
