@@ -30,9 +30,29 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PMC_SQ_FILE = "r1_h_pmc_sq_composite.json"  # {"k_composite": {"SQ_INSTS_VALU": per-launch mean, ...}}
 PMC_FILE = "r1_h_pmc_hbm_traffic.json"  # written by tools/pmc_traffic.py from rocprofv3 --pmc passes of this command
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 STAGES = ["project", "sort", "bin", "pairsort", "composite", "total"]
+
+
+def composite_roofline(ms, alg_bytes, world, N, args):
+    """k_composite against the fp32 VALU issue rate: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles per SIMD
+    at the 2.4 GHz peak engine clock = 614 G wave-instructions/s.  SQ_INSTS_VALU per launch comes from the committed
+    rocprofv3 --pmc pass of this command (profiles/); its HBM side is reported next to it."""
+    out = {"bound": "valu", "peak": 614.4, "unit": "G wave-instr/s", "launch_ms": float(ms), "achieved": None, "frac": None,
+           "hbm_algorithmic_bytes_per_launch": float(alg_bytes),
+           "hbm_achieved_GBps": (alg_bytes / (ms * 1e-3)) / 1e9 if ms > 0 else None}
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", PMC_SQ_FILE)))
+        if world == 1 and N == 5_830_000 and args.instances == 1 and ms > 0:
+            insts = pj["k_composite"]["SQ_INSTS_VALU"]
+            out["valu_insts_per_launch"] = insts
+            out["achieved"] = insts / (ms * 1e-3) / 1e9
+            out["frac"] = out["achieved"] / out["peak"]
+    except Exception:
+        pass
+    return out
 
 
 def main():
@@ -192,10 +212,11 @@ def main():
         # counters are per pose; re-render untimed to read them back (outside the timed region)
         pp.collect_timings = 0
         o = scene.render(pp, want_stats=True)
-        counts.append((o.frustum_count, o.sorted_count, o.tile_pairs, o.error_flags))
+        counts.append((o.frustum_count, o.sorted_count, o.tile_pairs, o.error_flags, o.shaded_count, o.scanned_entries))
         pp.collect_timings = 2
     counts = np.array(counts, np.float64)
     Vf, Vs, D = counts[:, 0].mean(), counts[:, 1].mean(), counts[:, 2].mean()
+    shaded, scanned = counts[:, 4].mean(), counts[:, 5].mean()
     err = int(counts[:, 3].max())
     if world > 1:
         agg = torch.tensor([Vs, D, Vf], dtype=torch.float64, device="cuda")
@@ -237,11 +258,15 @@ def main():
         # direct binning: ids + rect gather + sorted rect (count), sorted rect + ids + list append (emit)
         "bin": 20 * Vs + 4 * D,
         "pairsort": 0,
-        # upper bound (every sorted splat staged once): list walk + record + SH record + RGBA16F frame
-        "composite": 4 * D + (64 + 192) * Vs + 8 * Ppix,
+        # list entries actually walked + first 16 B of their record; 48 B more + the 192-B SH record of the staged ones; RGBA16F frame
+        "composite": (4 + 16) * scanned + (48 + 192) * shaded + 8 * Ppix,
     }
-    dom = max(range(5), key=lambda j: calib_ms[j])  # dominant stage of an un-overlapped frame
+    # `roofline` describes the dominant HBM-bound stage.  The compositor can be the longest stage, but it is bound by
+    # fp32 VALU issue (exp + blend per pixel-splat pair; no matrix contraction, so neither "hbm" nor "mfma" describes
+    # it): it gets its own `roofline_composite` object with its VALU utilisation instead of a made-up HBM fraction.
+    dom = max((0, 1, 2, 3), key=lambda j: calib_ms[j])
     dom_name = STAGES[dom]
+    longest = STAGES[max(range(5), key=lambda j: calib_ms[j])]
     # kernel duration: HIP events around the stage on an otherwise idle GPU (the untimed calibration frames).  With
     # several frames in flight the event span of a stage also contains queueing behind the other streams' kernels —
     # rocprofv3's per-kernel duration of this same command agrees with the calibration value, not with the span.
@@ -282,7 +307,7 @@ def main():
         "strips": strips_out,
         "sorted_gsplats_per_s": (Vs / (sort_ms * 1e-3)) / 1e9 if sort_ms > 0 else None,
         "sorted_gsplats_per_s_in_frame_aggregate": Vs_all * fps / 1e9,
-        "visible_splats": {"frustum": Vf, "sorted": Vs, "tile_pairs": D},
+        "visible_splats": {"frustum": Vf, "sorted": Vs, "tile_pairs": D, "shaded": shaded, "list_entries_scanned": scanned},
         "stage_ms": {STAGES[j]: float(stage_ms[j]) for j in range(6)},
         "stage_ms_single_stream": {STAGES[j]: float(calib_ms[j]) for j in range(6)},
         "frame_span_ms_percentiles": {"p50": float(np.percentile(st[:, 5], 50)), "p95": float(np.percentile(st[:, 5], 95)),
@@ -291,8 +316,9 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg[dom_name], "launch_ms": float(dom_ms),
                      "stage_span_ms_in_timed_region": float(stage_ms[dom]),
-                     "note": "composite is fp32-VALU bound (exp + blend per pixel-splat pair), not HBM bound; see DESIGN.md"
-                     if dom_name == "composite" else ""},
+                     "note": f"dominant HBM-bound stage; the longest stage of the frame is `{longest}`"
+                             + (" (fp32-VALU bound, see roofline_composite)" if longest == "composite" else "")},
+        "roofline_composite": composite_roofline(calib_ms[4] if K > 1 else stage_ms[4], alg["composite"], world, N, args),
         "roofline_sort": {"bound": "hbm", "achieved": (68 * Vs / (sort_ms * 1e-3)) / 1e9 if sort_ms > 0 else None,
                           "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                           "frac": (68 * Vs / (sort_ms * 1e-3)) / HBM_PEAK if sort_ms > 0 else None},

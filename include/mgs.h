@@ -154,7 +154,8 @@ typedef struct MgsFrameOut {
   uint32_t sorted_count;    /* elements actually sorted (after alpha/extent/off-screen rejection) */
   uint64_t tile_pairs;      /* (tile, splat) records built by the binning stage */
   uint32_t error_flags;     /* device-side diagnostics, 0 = clean */
-  uint32_t reserved;
+  uint32_t shaded_count;    /* (splat, screen region) pairs staged and shaded by the compositor (deferred SH evaluation) */
+  uint64_t scanned_entries; /* bin-list entries the compositor looked at before its regions saturated */
   float    stage_ms[MGS_STAGE_COUNT]; /* valid when collect_timings; HIP-event times on the render stream */
 } MgsFrameOut;
 

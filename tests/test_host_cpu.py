@@ -32,7 +32,7 @@ def test_struct_layouts_match_header_sizes():
 
     import ctypes
     assert ctypes.sizeof(capi.FrameParams) == 224
-    assert ctypes.sizeof(capi.FrameOut) == 8 + 8 + 4 + 4 + 8 + 4 + 4 + 32
+    assert ctypes.sizeof(capi.FrameOut) == 8 + 8 + 4 + 4 + 8 + 4 + 4 + 8 + 32
     assert ctypes.sizeof(capi.SortOut) == 32
     assert ctypes.sizeof(capi.SplatSetView) == 6 * 8 + 8 + 4 + 4
 

@@ -43,7 +43,8 @@ class FrameParams(C.Structure):
 class FrameOut(C.Structure):
     _fields_ = [("rgba_device", C.c_void_p), ("rgba_bytes", C.c_uint64),
                 ("frustum_count", C.c_uint32), ("sorted_count", C.c_uint32), ("tile_pairs", C.c_uint64),
-                ("error_flags", C.c_uint32), ("reserved", C.c_uint32), ("stage_ms", C.c_float * 8)]
+                ("error_flags", C.c_uint32), ("shaded_count", C.c_uint32), ("scanned_entries", C.c_uint64),
+                ("stage_ms", C.c_float * 8)]
 
 
 class SortOut(C.Structure):

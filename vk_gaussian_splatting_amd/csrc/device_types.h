@@ -88,13 +88,9 @@ struct FrameCounters
   uint32_t sortedCount;    // V: elements handed to the radix sort
   uint32_t pairCount;      // D: (tile, splat) records
   uint32_t errorFlags;
-  uint32_t ticketProject;
-  uint32_t ticketBin;
-  uint32_t ticketSort[8];  // one per radix pass (4 key passes + up to 4 pair passes)
-  uint32_t sortSelect;     // which ping-pong buffer holds the current keys (0/1)
-  uint32_t pairSelect;
-  uint32_t passesRun;
-  uint32_t pad[13];
+  uint32_t stagedSlots[8];   // compositor statistics, spread over 8 words (one per XCD-ish) to keep the atomics apart
+  uint32_t scannedSlots[8];
+  uint32_t pad[11];
 };
 
 }  // namespace mgs

@@ -585,9 +585,10 @@ template <int MODE, int SHF>
 __global__ __launch_bounds__(256) void k_composite(const FrameArgs A, const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ valX, const uint32_t* __restrict__ valY,
                                                    const SortPlan* __restrict__ plan, const SplatRec* __restrict__ rec,
-                                                   void* __restrict__ outImage, int halfOut)
+                                                   void* __restrict__ outImage, int halfOut, FrameCounters* __restrict__ ctr)
 {
   const FrameConst& F = A.f;
+  uint32_t statStaged = 0, statScanned = 0;
   __shared__ float4   s_a[kCmpCap];  // cx, cy, ex, ey
   __shared__ float4   s_b[kCmpCap];  // p1, p2 (scaled by sqrt(log2 e))
   __shared__ float4   s_c[kCmpCap];  // r, g, b, a
@@ -740,8 +741,10 @@ __global__ __launch_bounds__(256) void k_composite(const FrameArgs A, const uint
           used = k + 1;
         }
       }
+      statStaged += base - fill;
       fill                    = base;
       const uint32_t consumed = min(avail, (uint32_t)used * 256u);
+      statScanned += consumed;
       prefValid               = (used == kCmpEntries);
       hi -= consumed;
       if(used < kCmpEntries)
@@ -823,6 +826,11 @@ __global__ __launch_bounds__(256) void k_composite(const FrameArgs A, const uint
       break;
   }
 
+  if(t == 0)
+  {  // frame statistics (mgs_frame_stats): two fire-and-forget adds per workgroup
+    atomicAdd(&ctr->stagedSlots[blockIdx.x & 7], statStaged);
+    atomicAdd(&ctr->scannedSlots[blockIdx.x & 7], statScanned);
+  }
   const v2f aout = early ? (v2f){1.0f - T.x, 1.0f - T.y} : asum;
 #pragma unroll
   for(int h = 0; h < 2; ++h)
@@ -898,7 +906,7 @@ void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* 
 
 void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
                      const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, bool halfOut,
-                     int shFormat)
+                     int shFormat, FrameCounters* ctr)
 {
   const FrameConst& F = A.f;
   if(F.stripRow1 <= F.stripRow0)
@@ -909,7 +917,7 @@ void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges
   const int mode = (F.alphaMode != 0 ? 1 : 0) | ((F.debugFlags & 4) ? 2 : 0);
 #define MGS_CMP(M, S)                                                                                                  \
   hipLaunchKernelGGL((k_composite<M, S>), dim3(per * 8), dim3(256), 0, stream, A, ranges, valX, valY, planPairs, rec, image, \
-                     halfOut ? 1 : 0)
+                     halfOut ? 1 : 0, ctr)
 #define MGS_CMP_FMT(M)                                                                                                 \
   switch(shFormat)                                                                                                     \
   {                                                                                                                    \

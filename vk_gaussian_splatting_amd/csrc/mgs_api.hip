@@ -46,7 +46,7 @@ void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* 
                       uint2* ranges);
 void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
                      const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, bool halfOut,
-                     int shFormat);
+                     int shFormat, FrameCounters* ctr);
 constexpr uint32_t kPart = 2048;  // == kPrjPart == kSortPart == kBinPart
 }  // namespace mgs
 
@@ -1262,7 +1262,7 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
     }
   }
   if(timed) HIPCHK(hipEventRecord(fev[4], st));
-  launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat);
+  launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat, ctr);
   if(timed) HIPCHK(hipEventRecord(fev[5], st));
   HIPCHK(hipMemcpyAsync(s->hCtr, ctr, sizeof(FrameCounters), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(s->hPlans, s->plans.p, 2 * sizeof(SortPlan), hipMemcpyDeviceToHost, st));
@@ -1334,6 +1334,13 @@ int mgs_frame_stats(MgsScene s, MgsFrameOut* out)
   out->sorted_count  = s->hCtr->sortedCount;
   out->tile_pairs    = s->hCtr->pairCount;
   out->error_flags   = s->hCtr->errorFlags;
+  out->shaded_count  = 0;
+  out->scanned_entries = 0;
+  for(int i = 0; i < 8; ++i)
+  {
+    out->shaded_count += s->hCtr->stagedSlots[i];
+    out->scanned_entries += s->hCtr->scannedSlots[i];
+  }
   if(s->lastTimed && !s->lastWasSortOnly)
   {
     int rc = mgs_timings_query(s, 0, out->stage_ms);
