@@ -322,9 +322,11 @@ def main():
         "roofline_sort": {"bound": "hbm", "achieved": (68 * Vs / (sort_ms * 1e-3)) / 1e9 if sort_ms > 0 else None,
                           "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                           "frac": (68 * Vs / (sort_ms * 1e-3)) / HBM_PEAK if sort_ms > 0 else None},
-        "roofline_frame": {"bound": "hbm", "achieved": (b_frame / (frame_gpu_ms * 1e-3)) / 1e9 if frame_gpu_ms > 0 else None,
-                           "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                           "frac": (b_frame / (frame_gpu_ms * 1e-3)) / HBM_PEAK if frame_gpu_ms > 0 else None,
+        # throughput form: bytes SURVEY.md 8d says a frame must move x frames/s per GPU (== the latency form when one
+        # frame is in flight); `frac_single_frame` is the same bytes over the GPU time of one frame in the timed region
+        "roofline_frame": {"bound": "hbm", "achieved": b_frame * fps / world / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                           "frac": b_frame * fps / world / HBM_PEAK,
+                           "frac_single_frame": (b_frame / (frame_gpu_ms * 1e-3)) / HBM_PEAK if frame_gpu_ms > 0 else None,
                            "algorithmic_bytes_per_frame": b_frame},
         "error_flags": err,
         "setup_s": setup_s,

@@ -581,8 +581,11 @@ constexpr int kCmpGo      = 128;                // blend as soon as this many re
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // MODE bit 0: additive alpha (no early-out), bit 1: DISABLE_OPACITY_GAUSSIAN; SHF: SH storage format
+#ifndef MGS_CMP_WAVES
+#define MGS_CMP_WAVES 5
+#endif
 template <int MODE, int SHF>
-__global__ __launch_bounds__(256) void k_composite(const FrameArgs A, const uint2* __restrict__ ranges,
+__global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const FrameArgs A, const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ valX, const uint32_t* __restrict__ valY,
                                                    const SortPlan* __restrict__ plan, const SplatRec* __restrict__ rec,
                                                    void* __restrict__ outImage, int halfOut, FrameCounters* __restrict__ ctr)
