@@ -281,8 +281,8 @@ __device__ __forceinline__ LaneBins laneBins(int binsX, int nb)
 
 __global__ __launch_bounds__(256) void k_dbin_count(const uint32_t* __restrict__ idsX, const uint32_t* __restrict__ idsY,
                                                     const SortPlan* __restrict__ plan, const uint32_t* __restrict__ rect,
-                                                    uint32_t* __restrict__ sortedRect, uint32_t* __restrict__ binHist,
-                                                    uint32_t pStride, int binsX, int binsY, int gather)
+                                                    uint64_t* __restrict__ maskBuf, uint32_t* __restrict__ binHist,
+                                                    uint32_t pStride, int binsX, int binsY)
 {
   __shared__ uint64_t s_col[4][kDbMaxDim], s_row[4][kDbMaxDim];
   __shared__ uint32_t s_cnt[4][256];
@@ -294,7 +294,6 @@ __global__ __launch_bounds__(256) void k_dbin_count(const uint32_t* __restrict__
   const uint32_t* ids = plan->finalSel ? idsY : idsX;
   const uint32_t  e0  = blockIdx.x * (uint32_t)kDbChunk + (uint32_t)w * (kDbRounds * 64) + (uint32_t)lane;
   uint32_t        r[kDbRounds];
-  if(gather)
   {
     uint32_t id[kDbRounds];
 #pragma unroll
@@ -302,26 +301,21 @@ __global__ __launch_bounds__(256) void k_dbin_count(const uint32_t* __restrict__
       id[i] = ids[min(e0 + i * 64u, n - 1u)];  // clamped, not predicated: all loads in flight
 #pragma unroll
     for(int i = 0; i < kDbRounds; ++i)
-      r[i] = rect[id[i]];
-#pragma unroll
-    for(int i = 0; i < kDbRounds; ++i)
-      if(e0 + i * 64u < n)
-        sortedRect[e0 + i * 64u] = r[i];
+      r[i] = rect[id[i]];  // the stage's one random gather
   }
-  else
-  {
-#pragma unroll
-    for(int i = 0; i < kDbRounds; ++i)
-      r[i] = sortedRect[min(e0 + i * 64u, n - 1u)];
-  }
-  const int      nb = binsX * binsY;
+  const int      nb = binsX * binsY, S = binsX + binsY;
   const LaneBins L  = laneBins(binsX, nb);
   uint32_t       cnt[4] = {0u, 0u, 0u, 0u};
+  // the masks of every round are kept for k_dbin_emit (17 x 8 B per round instead of re-reading 64 rects and
+  // redoing the ballots): maskBuf[((chunk*4 + wave)*rounds + round)*S + {column masks, row masks}]
+  uint64_t* mOut = maskBuf + ((size_t)blockIdx.x * 4 + w) * kDbRounds * S;
 #pragma unroll
   for(int i = 0; i < kDbRounds; ++i)
   {
     rectMasks(r[i], e0 + i * 64u < n, binsX, binsY, s_col[w], s_row[w]);
     __builtin_amdgcn_wave_barrier();
+    if(lane < S)
+      mOut[i * S + lane] = (lane < binsX) ? s_col[w][lane] : s_row[w][lane - binsX];
 #pragma unroll
     for(int j = 0; j < 4; ++j)
       if(j * 64 < nb)
@@ -374,7 +368,7 @@ __global__ __launch_bounds__(256) void k_dbin_scan(const SortPlan* __restrict__ 
 }
 
 __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ idsX, const uint32_t* __restrict__ idsY,
-                                                   const SortPlan* __restrict__ plan, const uint32_t* __restrict__ sortedRect,
+                                                   const SortPlan* __restrict__ plan, const uint64_t* __restrict__ maskBuf,
                                                    const uint32_t* __restrict__ binHist, uint32_t pStride,
                                                    const uint32_t* __restrict__ binTotal, uint32_t* __restrict__ binList,
                                                    uint2* __restrict__ ranges, FrameCounters* __restrict__ ctr,
@@ -400,17 +394,24 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
   const LaneBins  L     = laneBins(binsX, nb);
   uint32_t        cnt[4] = {0u, 0u, 0u, 0u};
   {
-    uint32_t r[kDbRounds];
+    const int       S   = binsX + binsY;
+    const uint64_t* mIn = maskBuf + ((size_t)chunk * 4 + w) * kDbRounds * S;
+    uint64_t        mk[kDbRounds];
 #pragma unroll
     for(int i = 0; i < kDbRounds; ++i)
     {
-      const uint32_t e              = min(e0 + i * 64u, n - 1u);
-      r[i]                          = sortedRect[e];
-      s_ids[wbase + i * 64 + lane] = ids[e];
+      s_ids[wbase + i * 64 + lane] = ids[min(e0 + i * 64u, n - 1u)];
+      mk[i]                        = (lane < S) ? mIn[i * S + lane] : 0ull;
     }
 #pragma unroll
     for(int i = 0; i < kDbRounds; ++i)
-      rectMasks(r[i], e0 + i * 64u < n, binsX, binsY, s_col[w][i], s_row[w][i]);
+      if(lane < S)
+      {
+        if(lane < binsX)
+          s_col[w][i][lane] = mk[i];
+        else
+          s_row[w][i][lane - binsX] = mk[i];
+      }
   }
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -576,8 +577,14 @@ __global__ void k_tile_ranges(const uint32_t* __restrict__ keyX, const uint32_t*
 // (not in MGS_ALPHA_SUM mode, where the reference's additive alpha must see every fragment).
 constexpr int kCmpEntries = 4;                  // list entries per thread per stage-A round (4 gathers in flight per lane)
 constexpr int kCmpRound   = 256 * kCmpEntries;  // 1024 entries scanned per round
-constexpr int kCmpCap     = 384;                // LDS batch capacity (records): 18 KB -> 8 workgroups per CU (sweep: 384/512/768 -> 0.220/0.230/0.275 ms)
-constexpr int kCmpGo      = 128;                // blend as soon as this many records are staged (<= kCmpCap-256)
+#ifndef MGS_CMP_CAP
+#define MGS_CMP_CAP 320
+#endif
+#ifndef MGS_CMP_GO
+#define MGS_CMP_GO 64
+#endif
+constexpr int kCmpCap     = MGS_CMP_CAP;                // LDS batch capacity (records): 18 KB -> 8 workgroups per CU (sweep: 384/512/768 -> 0.220/0.230/0.275 ms)
+constexpr int kCmpGo      = MGS_CMP_GO;                // blend as soon as this many records are staged (<= kCmpCap-256)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // MODE bit 0: additive alpha (no early-out), bit 1: DISABLE_OPACITY_GAUSSIAN; SHF: SH storage format
@@ -887,17 +894,17 @@ bool directBinningSupported(int binsX, int binsY)
 }
 
 void launchDirectBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
-                         const uint32_t* rect, uint32_t* sortedRect, uint32_t maxSplats, uint32_t* binHist, uint32_t pStride,
+                         const uint32_t* rect, uint64_t* maskBuf, uint32_t maxSplats, uint32_t* binHist, uint32_t pStride,
                          uint32_t* binTotal, uint32_t* binList, uint2* ranges, FrameCounters* ctr, uint32_t capacity,
-                         int binsX, int binsY, bool gatherRects)
+                         int binsX, int binsY)
 {
   const uint32_t maxChunks = (maxSplats + kDbChunk - 1) / kDbChunk;
   if(maxChunks == 0)
     return;
-  hipLaunchKernelGGL(k_dbin_count, dim3(maxChunks), dim3(256), 0, stream, idsX, idsY, planKeys, rect, sortedRect, binHist,
-                     pStride, binsX, binsY, gatherRects ? 1 : 0);
+  hipLaunchKernelGGL(k_dbin_count, dim3(maxChunks), dim3(256), 0, stream, idsX, idsY, planKeys, rect, maskBuf, binHist,
+                     pStride, binsX, binsY);
   hipLaunchKernelGGL(k_dbin_scan, dim3(binsX * binsY), dim3(256), 0, stream, planKeys, binHist, pStride, binTotal);
-  hipLaunchKernelGGL(k_dbin_emit, dim3(maxChunks), dim3(256), 0, stream, idsX, idsY, planKeys, sortedRect, binHist, pStride,
+  hipLaunchKernelGGL(k_dbin_emit, dim3(maxChunks), dim3(256), 0, stream, idsX, idsY, planKeys, maskBuf, binHist, pStride,
                      binTotal, binList, ranges, ctr, capacity, binsX, binsY);
 }
 

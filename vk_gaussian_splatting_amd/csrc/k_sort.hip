@@ -382,7 +382,8 @@ void launchRadixSort(hipStream_t stream, const SortLaunch& s)
   const bool     slotted = s.slotCount != nullptr;  // pass 0: 2048-key slots + the producer's slot histograms
   // big sorts use 8192-key partitions (digit runs of ~32 keys = 128-byte scatter segments, 4x shorter
   // partition tables); small ones keep 2048 so that 256 CUs still see enough workgroups.
-  const uint32_t part    = (s.maxElems >= (2u << 20)) ? 8192u : 2048u;
+  static const uint32_t kPartOverride = [] { const char* e = std::getenv("MGS_SORT_PART"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+  const uint32_t part    = kPartOverride ? kPartOverride : ((s.maxElems >= (2u << 20)) ? 8192u : 2048u);
   static const uint32_t kSlotPartOverride = [] { const char* e = std::getenv("MGS_SLOT_PART"); return e ? (uint32_t)std::atoi(e) : 0u; }();
   auto partOf  = [&](int pass) { return (pass == 0 && slotted && kSlotPartOverride) ? kSlotPartOverride : part; };
   auto partsOf = [&](int pass) {
@@ -407,6 +408,8 @@ void launchRadixSort(hipStream_t stream, const SortLaunch& s)
     {
       if(pp == 2048u)
         MGS_SCATTER(true, 256, 8, s.slotCount);
+      else if(pp == 4096u)
+        MGS_SCATTER(true, 256, 16, s.slotCount);
       else
         MGS_SCATTER(true, 512, 16, s.slotCount);
     }
@@ -414,6 +417,8 @@ void launchRadixSort(hipStream_t stream, const SortLaunch& s)
     {
       if(pp == 2048u)
         MGS_SCATTER(false, 256, 8, (const uint32_t*)nullptr);
+      else if(pp == 4096u)
+        MGS_SCATTER(false, 256, 16, (const uint32_t*)nullptr);
       else
         MGS_SCATTER(false, 512, 16, (const uint32_t*)nullptr);
     }

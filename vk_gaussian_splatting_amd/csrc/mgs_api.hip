@@ -39,9 +39,9 @@ void launchBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* ids
                    int binsX, bool gatherRects);
 bool directBinningSupported(int binsX, int binsY);
 void launchDirectBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
-                         const uint32_t* rect, uint32_t* sortedRect, uint32_t maxSplats, uint32_t* binHist, uint32_t pStride,
+                         const uint32_t* rect, uint64_t* maskBuf, uint32_t maxSplats, uint32_t* binHist, uint32_t pStride,
                          uint32_t* binTotal, uint32_t* binList, uint2* ranges, FrameCounters* ctr, uint32_t capacity,
-                         int binsX, int binsY, bool gatherRects);
+                         int binsX, int binsY);
 void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* keyY, const SortPlan* planPairs,
                       uint2* ranges);
 void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
@@ -1228,9 +1228,10 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
   const bool direct = kDirectBin && directBinningSupported(F.binsX, F.binsY);
   if(direct)
   {
-    launchDirectBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, s->sortedRect.p, s->totalSplats,
+    // the (idle) record buffer of the fallback path holds the bit masks: 64 x 8 B per 256 sorted splats at most
+    launchDirectBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, reinterpret_cast<uint64_t*>(s->pairKey0.p), s->totalSplats,
                         s->partHist.p, s->pStride, &planP->ghist[0][0], s->pairVal1.p, s->ranges.p, ctr, s->pairCapacity,
-                        F.binsX, F.binsY, true);
+                        F.binsX, F.binsY);
     if(timed) HIPCHK(hipEventRecord(fev[3], st));
   }
   else
