@@ -56,14 +56,33 @@ __device__ __forceinline__ float4 loadRgba(const void* base, uint32_t i)
 // memory 70 % of their cycles when the fetches were staged behind the early-outs (rgba -> centre -> cov
 // -> SH, four dependent round trips).  ~96 % of the frustum survivors pass every test, so the
 // speculative SH fetch of the rest costs ~4 % extra traffic and buys one round trip instead of four.
-template <int RGBAF>
-__device__ __forceinline__ bool projectSplat(const FrameConst& F, const InstanceConst& I, int instIdx, uint32_t li, Projected& out)
+struct SplatFetch
 {
-  // ---- all fetches --------------------------------------------------------------------------------------
-  float4       col = loadRgba<RGBAF>(I.rgba, li);
-  const float  px = I.centers[3 * (size_t)li + 0], py = I.centers[3 * (size_t)li + 1], pz = I.centers[3 * (size_t)li + 2];
-  const float4 cA = reinterpret_cast<const float4*>(I.cov6)[li];                       // planar: 16 B per lane
-  const float2 cB = reinterpret_cast<const float2*>(I.cov6 + 4 * (size_t)I.count)[li];  //          8 B per lane
+  float4 col;
+  float  px, py, pz;
+  float4 cA;
+  float2 cB;
+};
+template <int RGBAF>
+__device__ __forceinline__ SplatFetch fetchSplat(const InstanceConst& I, uint32_t li)
+{
+  SplatFetch f;
+  f.col = loadRgba<RGBAF>(I.rgba, li);
+  f.px  = I.centers[3 * (size_t)li + 0];
+  f.py  = I.centers[3 * (size_t)li + 1];
+  f.pz  = I.centers[3 * (size_t)li + 2];
+  f.cA  = reinterpret_cast<const float4*>(I.cov6)[li];                        // planar: 16 B per lane
+  f.cB  = reinterpret_cast<const float2*>(I.cov6 + 4 * (size_t)I.count)[li];  //          8 B per lane
+  return f;
+}
+
+__device__ __forceinline__ bool projectSplat(const FrameConst& F, const InstanceConst& I, int instIdx, const SplatFetch& in,
+                                             Projected& out)
+{
+  float4       col = in.col;
+  const float  px = in.px, py = in.py, pz = in.pz;
+  const float4 cA = in.cA;
+  const float2 cB = in.cB;
 
   // ---- mesh.slang:164-190 ---------------------------------------------------------------------------------
   bool         ok = !(col.w < F.alphaCull);
@@ -324,15 +343,30 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, Fram
     // lanes per record, so a store instruction covers whole 64-byte sectors (16 records = 1 KB contiguous when the
     // survivors are).  Written lane-per-record, each instruction put 16 bytes into 64 different sectors and
     // the kernel spent half its time on those partial-sector writes (0.20 ms -> 0.11 ms with the stores removed).
+    // The fetches of the NEXT batch of 256 survivors are issued before this batch is computed (13 registers):
+    // otherwise every batch starts with a full memory round trip and the kernel spent half its wave cycles parked.
+    SplatFetch cur;
+    uint32_t   liCur = 0;
+    if(t < M)
+    {
+      liCur = local0 + s_li[t];
+      cur   = fetchSplat<RGBAF>(I, liCur);
+    }
     for(uint32_t j0 = 0; j0 < M; j0 += kPrjThreads)
     {
       const uint32_t j     = j0 + t;
       uint32_t       gidOk = 0xFFFFFFFFu;
+      SplatFetch     nxt;
+      uint32_t       liNxt = 0;
+      const bool     haveNxt = j + kPrjThreads < M;
+      liNxt = local0 + s_li[haveNxt ? j + kPrjThreads : 0u];
+      liNxt = min(liNxt, I.count - 1u);
+      nxt   = fetchSplat<RGBAF>(I, liNxt);  // clamped, not predicated: straight-line loads
       if(j < M)
       {
-        const uint32_t li = local0 + s_li[j];
+        const uint32_t li = liCur;
         Projected      pr;
-        if(projectSplat<RGBAF>(A.f, I, k, li, pr))
+        if(projectSplat(A.f, I, k, cur, pr))
         {
           gidOk       = I.globalOffset + li;
           float4* dst = &s_rec[w][lane * 5];  // 80-byte pitch: conflict-free 16-byte accesses
@@ -355,6 +389,8 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, Fram
           reinterpret_cast<float4*>(rec + g)[part] = s_rec[w][rr * 5 + part];
       }
       __builtin_amdgcn_wave_barrier();
+      cur   = nxt;
+      liCur = liNxt;
     }
     // ---- second ordered compaction straight into the partition's slot region ---------------------------
     __syncthreads();
