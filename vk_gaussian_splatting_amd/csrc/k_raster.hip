@@ -281,8 +281,8 @@ __device__ __forceinline__ LaneBins laneBins(int binsX, int nb)
 
 __global__ __launch_bounds__(256) void k_dbin_count(const uint32_t* __restrict__ idsX, const uint32_t* __restrict__ idsY,
                                                     const SortPlan* __restrict__ plan, const uint32_t* __restrict__ rect,
-                                                    uint64_t* __restrict__ maskBuf, uint32_t* __restrict__ binHist,
-                                                    uint32_t pStride, int binsX, int binsY)
+                                                    const uint32_t* __restrict__ sortedRect, uint64_t* __restrict__ maskBuf,
+                                                    uint32_t* __restrict__ binHist, uint32_t pStride, int binsX, int binsY)
 {
   __shared__ uint64_t s_col[4][kDbMaxDim], s_row[4][kDbMaxDim];
   __shared__ uint32_t s_cnt[4][256];
@@ -294,6 +294,13 @@ __global__ __launch_bounds__(256) void k_dbin_count(const uint32_t* __restrict__
   const uint32_t* ids = plan->finalSel ? idsY : idsX;
   const uint32_t  e0  = blockIdx.x * (uint32_t)kDbChunk + (uint32_t)w * (kDbRounds * 64) + (uint32_t)lane;
   uint32_t        r[kDbRounds];
+  if(plan->reserved[0])
+  {  // the key sort's last pass already laid the rects out in sorted order (fused gather)
+#pragma unroll
+    for(int i = 0; i < kDbRounds; ++i)
+      r[i] = sortedRect[min(e0 + i * 64u, n - 1u)];
+  }
+  else
   {
     uint32_t id[kDbRounds];
 #pragma unroll
@@ -894,15 +901,15 @@ bool directBinningSupported(int binsX, int binsY)
 }
 
 void launchDirectBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
-                         const uint32_t* rect, uint64_t* maskBuf, uint32_t maxSplats, uint32_t* binHist, uint32_t pStride,
+                         const uint32_t* rect, const uint32_t* sortedRect, uint64_t* maskBuf, uint32_t maxSplats, uint32_t* binHist, uint32_t pStride,
                          uint32_t* binTotal, uint32_t* binList, uint2* ranges, FrameCounters* ctr, uint32_t capacity,
                          int binsX, int binsY)
 {
   const uint32_t maxChunks = (maxSplats + kDbChunk - 1) / kDbChunk;
   if(maxChunks == 0)
     return;
-  hipLaunchKernelGGL(k_dbin_count, dim3(maxChunks), dim3(256), 0, stream, idsX, idsY, planKeys, rect, maskBuf, binHist,
-                     pStride, binsX, binsY);
+  hipLaunchKernelGGL(k_dbin_count, dim3(maxChunks), dim3(256), 0, stream, idsX, idsY, planKeys, rect, sortedRect, maskBuf,
+                     binHist, pStride, binsX, binsY);
   hipLaunchKernelGGL(k_dbin_scan, dim3(binsX * binsY), dim3(256), 0, stream, planKeys, binHist, pStride, binTotal);
   hipLaunchKernelGGL(k_dbin_emit, dim3(maxChunks), dim3(256), 0, stream, idsX, idsY, planKeys, maskBuf, binHist, pStride,
                      binTotal, binList, ranges, ctr, capacity, binsX, binsY);

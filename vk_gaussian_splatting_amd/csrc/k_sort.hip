@@ -173,15 +173,20 @@ __device__ __forceinline__ uint32_t digitExclusiveScan(uint32_t v, uint32_t* s_t
 // (c) ranked scatter of one partition of THREADS*KPT keys.  Workgroup 0 of the last pass also publishes the
 // outcome (which buffer holds the result, how many passes ran); on a single-pass sort the digit histogram IS the
 // sorted layout, so the caller's per-digit ranges are written there too.
-template <bool FIRST, int THREADS, int KPT>
+template <bool FIRST, int THREADS, int KPT, bool GATHER = false>
 __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __restrict__ keys0, const uint32_t* __restrict__ vals0,
                                                           uint32_t* __restrict__ keysX, uint32_t* __restrict__ valsX,
                                                           uint32_t* __restrict__ keysY, uint32_t* __restrict__ valsY,
                                                           const uint32_t* __restrict__ slotCount, const uint32_t* __restrict__ nPtr,
                                                           uint32_t partsSlotted, SortPlan* __restrict__ plan,
                                                           const uint32_t* __restrict__ partHist, uint32_t pStride, int pass,
-                                                          int beginBit, int nPasses, uint2* __restrict__ ranges)
+                                                          int beginBit, int nPasses, uint2* __restrict__ ranges,
+                                                          const uint32_t* __restrict__ gatherSrc, uint32_t* __restrict__ gatherDst)
 {
+  // GATHER (last pass of the in-frame key sort only): the keys are dead after this pass, so the workgroup writes
+  // gatherDst[sortedPos] = gatherSrc[value] in their place (the splat's bin rect, which the binning stage needs in
+  // sorted order).  The random 4-byte gathers are issued as soon as the values are loaded and land while the keys are
+  // being ranked, instead of being the exposed dependent trip of their own kernel.
   constexpr int PART  = THREADS * KPT;
   constexpr int SPP   = PART / kSlotPart;  // slots per slotted partition
   constexpr int WAVES = THREADS / 64;
@@ -191,6 +196,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
   __shared__ uint32_t s_loff[256];
   __shared__ uint32_t s_gbase[256];
   __shared__ uint32_t s_tmp[WAVES];
+  __shared__ uint8_t  s_dig[GATHER ? PART : 1];
 
   const int t = threadIdx.x, lane = laneId(), w = t >> 6;
   const bool     skipped = !FIRST && plan->skip[pass] != 0u;
@@ -204,6 +210,8 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
     plan->finalSel  = planSrcSel(plan, nPasses);
     plan->passesRun = run;
     plan->n         = n;
+    if(GATHER)
+      plan->reserved[0] = skipped ? 0u : 1u;  // gatherDst is valid: consumers need not gather themselves
   }
   if(skipped)
     return;
@@ -277,6 +285,13 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
     key[i] = in ? kin[src] : 0xFFFFFFFFu;
     val[i] = in ? vin[src] : 0u;
   }
+  uint32_t gat[GATHER ? KPT : 1];
+  if constexpr(GATHER)
+  {
+#pragma unroll
+    for(int i = 0; i < KPT; ++i)
+      gat[i] = (wofs + i * 64 + lane < count) ? gatherSrc[val[i]] : 0u;
+  }
   __syncthreads();
 
   // per-wave multi-split: rank of each key among the keys of its wave with the same digit
@@ -337,8 +352,14 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
   {
     const uint32_t d   = (key[i] >> shift) & 255u;
     const uint32_t pos = s_loff[d] + s_whist[w][d] + rank[i];
-    s_k[pos]           = key[i];
     s_v[pos]           = val[i];
+    if constexpr(GATHER)
+    {
+      s_k[pos]   = gat[i];
+      s_dig[pos] = (uint8_t)d;
+    }
+    else
+      s_k[pos] = key[i];
   }
   __syncthreads();
 
@@ -351,10 +372,13 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
     {
       const uint32_t k   = s_k[idx];
       const uint32_t v   = s_v[idx];
-      const uint32_t d   = (k >> shift) & 255u;
+      const uint32_t d   = GATHER ? (uint32_t)s_dig[idx] : ((k >> shift) & 255u);
       const uint32_t dst = s_gbase[d] + idx;
-      kout[dst]          = k;
-      vout[dst]          = v;
+      if constexpr(GATHER)
+        gatherDst[dst] = k;
+      else
+        kout[dst] = k;
+      vout[dst] = v;
     }
   }
 }
@@ -403,7 +427,11 @@ void launchRadixSort(hipStream_t stream, const SortLaunch& s)
 #define MGS_SCATTER(FIRSTV, TH, KP, SLOTS)                                                                                  \
   hipLaunchKernelGGL((k_sort_scatter<FIRSTV, TH, KP>), dim3(parts), dim3(TH), 0, stream, s.keys0, s.vals0, s.keysX, s.valsX, \
                      s.keysY, s.valsY, SLOTS, s.nPtr, s.partsSlotted, s.plan, s.partHist, s.pStride, pass, s.beginBit, nPasses, \
-                     s.ranges)
+                     s.ranges, s.gatherSrc, s.gatherDst)
+#define MGS_SCATTER_G(TH, KP)                                                                                               \
+  hipLaunchKernelGGL((k_sort_scatter<false, TH, KP, true>), dim3(parts), dim3(TH), 0, stream, s.keys0, s.vals0, s.keysX,     \
+                     s.valsX, s.keysY, s.valsY, (const uint32_t*)nullptr, s.nPtr, s.partsSlotted, s.plan, s.partHist,        \
+                     s.pStride, pass, s.beginBit, nPasses, s.ranges, s.gatherSrc, s.gatherDst)
     if(pass == 0)
     {
       if(pp == 2048u)
@@ -412,6 +440,13 @@ void launchRadixSort(hipStream_t stream, const SortLaunch& s)
         MGS_SCATTER(true, 256, 16, s.slotCount);
       else
         MGS_SCATTER(true, 512, 16, s.slotCount);
+    }
+    else if(s.gatherSrc != nullptr && pass == nPasses - 1 && pp != 4096u)
+    {
+      if(pp == 2048u)
+        MGS_SCATTER_G(256, 8);
+      else
+        MGS_SCATTER_G(512, 16);
     }
     else
     {
@@ -422,6 +457,7 @@ void launchRadixSort(hipStream_t stream, const SortLaunch& s)
       else
         MGS_SCATTER(false, 512, 16, (const uint32_t*)nullptr);
     }
+#undef MGS_SCATTER_G
 #undef MGS_SCATTER
   }
 }

@@ -10,7 +10,7 @@ struct SortPlan
 {
   uint32_t ghist[4][256];  // digit totals of every pass, written by that pass's scan kernel
   uint32_t skip[4];        // pass is the identity permutation (single occupied digit) -> its scatter exits
-  uint32_t reserved[4];
+  uint32_t reserved[4];    // [0]: the last pass left gatherDst filled (fused gather)
   uint32_t finalSel;       // result lives in X (0) or Y (1); written by the last pass
   uint32_t passesRun;
   uint32_t n;
@@ -35,6 +35,8 @@ struct SortLaunch
   uint32_t        maxElems;      // host-side upper bound of the element count (sizes the grids)
   int             beginBit, endBit;
   uint2*          ranges    = nullptr;  // optional, single-pass sorts: ranges[digit] = [begin,end) in the sorted output
+  const uint32_t* gatherSrc = nullptr;  // optional (multi-pass sorts): the LAST pass writes gatherDst[pos] = gatherSrc[value]
+  uint32_t*       gatherDst = nullptr;  //   instead of the keys, and sets plan->reserved[0] when it ran (not skipped)
 };
 
 void launchSortClearPlan(hipStream_t stream, SortPlan* plan);
