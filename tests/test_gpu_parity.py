@@ -547,6 +547,9 @@ def test_binning_paths_bit_identical():
 
     ref = run({})
     assert run({"MGS_DIRECT_BIN": "0"}) == ref
+    # optional fusions / culling refinements must not change a bit either
+    assert run({"MGS_FUSE_RECT": "1"}) == ref      # rect gather fused into the last key-sort pass
+    assert run({"MGS_LOOSE_MASK": "1"}) == ref     # compositor quarter masks from the footprint box only
     for shift in ("1,1", "2,3", "4,4"):
         a = run({"MGS_BIN_SHIFT": shift})
         b = run({"MGS_BIN_SHIFT": shift, "MGS_DIRECT_BIN": "0"})
@@ -555,6 +558,23 @@ def test_binning_paths_bit_identical():
     base = run({"MGS_BIN_SHIFT": "3,3"})
     for shift in ("1,1", "2,3", "4,4"):
         assert run({"MGS_BIN_SHIFT": shift}) == base, shift
+
+
+def test_frame_statistics_are_consistent(scene_small):
+    """mgs_frame_stats: the compositor's counters (deferred shading) are plausible and deterministic"""
+    scene, sc = scene_small
+    W, H = 640, 360
+    eye = synth.orbit_pose(5)
+    V, P = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, W, H)
+    p = capi.default_params(W, H)
+    capi.set_camera(p, V, P, eye)
+    a = scene.render(p, want_stats=True)
+    b = scene.render(p, want_stats=True)
+    assert a.error_flags == 0
+    assert (a.shaded_count, a.scanned_entries, a.tile_pairs) == (b.shaded_count, b.scanned_entries, b.tile_pairs)
+    assert 0 < a.shaded_count and a.scanned_entries >= a.shaded_count
+    # every list entry is scanned by at most all regions of its bin; every region scans at most its whole list
+    assert a.scanned_entries <= a.tile_pairs * 64 * 4
 
 
 def test_api_error_behaviour():
