@@ -20,6 +20,7 @@ The JSON line also carries
                   timed on this box's host cores (rank 0, N=1 only); a baseline, not a target.
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -83,9 +84,9 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=300))
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=datetime.timedelta(seconds=300))
     ndev = torch.cuda.device_count()
     local = local % max(ndev, 1)   # gloo functional check: several ranks may share one GPU
     torch.cuda.set_device(local)
@@ -230,24 +231,30 @@ def main():
 
     strips_out = None
     if world > 1:
-        set_strips(True)
-        for i in range(args.warmup):
-            strip_frame(i)
-        fence()
-        t2 = time.perf_counter()
-        for i in range(args.steps):
-            strip_frame(args.warmup + i)
-        fence()
-        el2 = time.perf_counter() - t2
-        tt = torch.tensor([el2], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el2 = float(tt.item())
-        st2 = np.array([scenes[c].timings(b) for c in range(K) for b in range(min(per_ctx[c], 128))], np.float64)
-        st2 = st2.mean(axis=0) if st2.size else calib_ms
-        set_strips(False)
-        strips_out = {"value": args.steps / el2, "unit": "frames/s", "scaling": "strong", "ms_per_step": 1e3 * el2 / args.steps,
-                      "partition": f"{world} tile-row strips + one RCCL all_gather per frame",
-                      "this_rank_rows": list(strip_rows), "this_rank_stage_ms": {STAGES[j]: float(st2[j]) for j in range(6)}}
+        # the strip partition is the secondary measurement of an N>1 run: a failure here (a collective that times out,
+        # an allocation) must not take the headline line with it
+        try:
+            set_strips(True)
+            for i in range(args.warmup):
+                strip_frame(i)
+            fence()
+            t2 = time.perf_counter()
+            for i in range(args.steps):
+                strip_frame(args.warmup + i)
+            fence()
+            el2 = time.perf_counter() - t2
+            tt = torch.tensor([el2], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el2 = float(tt.item())
+            st2 = np.array([scenes[c].timings(b) for c in range(K) for b in range(min(per_ctx[c], 128))], np.float64)
+            st2 = st2.mean(axis=0) if st2.size else calib_ms
+            strips_out = {"value": args.steps / el2, "unit": "frames/s", "scaling": "strong", "ms_per_step": 1e3 * el2 / args.steps,
+                          "partition": f"{world} tile-row strips + one RCCL all_gather per frame",
+                          "this_rank_rows": list(strip_rows), "this_rank_stage_ms": {STAGES[j]: float(st2[j]) for j in range(6)}}
+        except Exception as e:  # noqa: BLE001
+            strips_out = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            set_strips(False)
     # algorithmic bytes per launch of each stage (SURVEY.md §8d per-unit figures)
     N = N * args.instances  # total global splats from here on
     alg = {
