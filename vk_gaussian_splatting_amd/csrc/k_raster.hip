@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
                                                    const uint32_t* __restrict__ binHist, uint32_t pStride,
                                                    const uint32_t* __restrict__ binTotal, uint32_t* __restrict__ binList,
                                                    uint2* __restrict__ ranges, FrameCounters* __restrict__ ctr,
-                                                   uint32_t capacity, int binsX, int binsY)
+                                                   uint32_t capacity, int binsX, int binsY, uint32_t* __restrict__ binOrder)
 {
   __shared__ uint64_t s_col[4][kDbRounds][kDbMaxDim], s_row[4][kDbRounds][kDbMaxDim];  // masks of every round
   __shared__ uint32_t s_cnt[4][256];  // per-wave counts, then per-wave write cursors
@@ -461,6 +461,20 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
   }
   if(chunk == 0)
   {
+    // longest list first: the compositor hands its workgroups out in this bin order, so the regions with the most
+    // to blend start early instead of forming the kernel's tail (binOrder[rank] = bin; ties by bin index)
+    __shared__ uint32_t s_tot[256];
+    s_tot[t] = btot;
+    __syncthreads();
+    if(t < nb)
+    {
+      uint32_t rank = 0;
+      for(int u = 0; u < nb; ++u)
+        rank += (s_tot[u] > btot || (s_tot[u] == btot && u < t)) ? 1u : 0u;
+      binOrder[rank] = (uint32_t)t;
+    }
+    if(t == 0)
+      binOrder[256] = 1u;  // valid
     if(t < nb)
       ranges[t] = wrapped ? make_uint2(0u, 0u)
                           : make_uint2(min(binBase, capacity), (uint32_t)min((uint64_t)binBase + btot, (uint64_t)capacity));
@@ -582,7 +596,10 @@ __global__ void k_tile_ranges(const uint32_t* __restrict__ keyX, const uint32_t*
 //            (p1, p2 are pre-scaled by sqrt(log2 e) when staged, so the exponential is a bare v_exp_f32.)
 // A wave retires when all 128 pixels have T < 1e-4; the workgroup stops fetching when all 4 have
 // (not in MGS_ALPHA_SUM mode, where the reference's additive alpha must see every fragment).
-constexpr int kCmpEntries = 4;                  // list entries per thread per stage-A round (4 gathers in flight per lane)
+#ifndef MGS_CMP_ENTRIES
+#define MGS_CMP_ENTRIES 4
+#endif
+constexpr int kCmpEntries = MGS_CMP_ENTRIES;                  // list entries per thread per stage-A round (4 gathers in flight per lane)
 constexpr int kCmpRound   = 256 * kCmpEntries;  // 1024 entries scanned per round
 #ifndef MGS_CMP_CAP
 #define MGS_CMP_CAP 320
@@ -624,12 +641,25 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const FrameArg
   const int binRows  = ((F.stripRow1 - 1) >> F.binShiftY) - binRow0 + 1;
   const int perBin   = bw * bh;
   const int seq      = (int)(blockIdx.x >> 3);
-  const int ord      = (seq / perBin) * 8 + (int)(blockIdx.x & 7);  // bin ordinal inside the strip
+  int       ord      = (seq / perBin) * 8 + (int)(blockIdx.x & 7);  // bin ordinal
   const int inBin    = seq % perBin;
-  if(ord >= binRows * F.binsX)
-    return;
-  const int cx2 = (ord % F.binsX) * bw + inBin % bw;
-  const int ty  = (binRow0 + ord / F.binsX) * bh + inBin / bw;
+  const bool ordered = plan->ghist[2][0] != 0u;  // the binning stage ranked the bins by list length (all bins of the frame)
+  int cx2, ty;
+  if(ordered)
+  {
+    if(ord >= F.binsX * F.binsY)
+      return;
+    const int b = (int)plan->ghist[1][ord];
+    cx2         = (b % F.binsX) * bw + inBin % bw;
+    ty          = (b / F.binsX) * bh + inBin / bw;
+  }
+  else
+  {
+    if(ord >= binRows * F.binsX)
+      return;
+    cx2 = (ord % F.binsX) * bw + inBin % bw;
+    ty  = (binRow0 + ord / F.binsX) * bh + inBin / bw;
+  }
   if(cx2 >= colsX || ty < F.stripRow0 || ty >= F.stripRow1)
     return;
   const int      tx  = cx2 * 2;  // left 16-px tile of the region
@@ -912,7 +942,7 @@ void launchDirectBinning(hipStream_t stream, const uint32_t* idsX, const uint32_
                      binHist, pStride, binsX, binsY);
   hipLaunchKernelGGL(k_dbin_scan, dim3(binsX * binsY), dim3(256), 0, stream, planKeys, binHist, pStride, binTotal);
   hipLaunchKernelGGL(k_dbin_emit, dim3(maxChunks), dim3(256), 0, stream, idsX, idsY, planKeys, maskBuf, binHist, pStride,
-                     binTotal, binList, ranges, ctr, capacity, binsX, binsY);
+                     binTotal, binList, ranges, ctr, capacity, binsX, binsY, binTotal + 256);
 }
 
 void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* keyY, const SortPlan* planPairs,
@@ -928,8 +958,9 @@ void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges
   const FrameConst& F = A.f;
   if(F.stripRow1 <= F.stripRow0)
     return;
-  const int binRows = ((F.stripRow1 - 1) >> F.binShiftY) - (F.stripRow0 >> F.binShiftY) + 1;
-  const int nBins   = binRows * F.binsX;
+  // all bins of the frame are enumerated (the bin order of the binning stage is over the whole frame; bins outside
+  // a strip have empty regions that exit at once)
+  const int nBins   = F.binsX * F.binsY;
   const int per     = ((nBins + 7) / 8) * (1 << (F.binShiftX - 1 + F.binShiftY));  // workgroups per XCD
   const int mode = (F.alphaMode != 0 ? 1 : 0) | ((F.debugFlags & 4) ? 2 : 0);
 #define MGS_CMP(M, S)                                                                                                  \
