@@ -994,7 +994,6 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
   F.alphaMode       = p->alpha_mode;
   F.debugFlags      = p->debug_flags;
   if(std::getenv("MGS_LOOSE_MASK")) F.debugFlags |= 256;
-  if(std::getenv("MGS_DBGP")) F.debugFlags |= std::atoi(std::getenv("MGS_DBGP"));  // A/B knob: footprint-box quarter masks only
   F.sizeCulling     = p->size_culling;
   F.sizeCullingMinPixels = p->size_culling_min_pixels;
   F.maxFocal        = std::max(std::fabs(F.focal[0]), std::fabs(F.focal[1]));
