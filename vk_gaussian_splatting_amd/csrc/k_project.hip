@@ -3,18 +3,20 @@
 // Replaces, in ONE pass over the splats in storage (id) order:
 //   shaders/dist.comp.slang:40-171          depth key, frustum cull, survivor append
 //   shaders/threedgs_raster.mesh.slang:111-291  per-splat raster front end (colour fetch, alpha cull,
-//                                            SH -> RGB, covariance projection, extent basis)
+//                                            covariance projection, extent basis) — except the SH sum
+//                                            (:243), which the compositor evaluates for the splats it stages
 //   shaders/threedgs.h.slang:26-121         threedgsCovarianceProjection / threedgsProjectedExtentBasis
-//   shaders/threedgs_particle_storage.h.slang:103-159  fetchViewDependentRadiance
-// MI355X-first differences (DESIGN.md §Kernels):
+// MI355X-first differences (DESIGN.md §3.1):
 //   * the reference runs dist in id order and the mesh shader in SORTED order, so its 232 B/splat
 //     attribute gather is uncoalesced; here the gather happens before the sort, in id order, and the
-//     sort only moves 8-byte (key,id) pairs.  The 48-byte projected record is indexed by global id.
+//     sort only moves 8-byte (key,id) pairs.  The 64-byte projected record is indexed by global id.
 //   * survivors are compacted per 2048-splat partition into a fixed slot region (ascending id, so
 //     the order is deterministic); the radix sort's first pass consumes the slots directly — there
-//     is no global atomic append and no inter-workgroup chain.
+//     is no global atomic append and no inter-workgroup chain — together with the partition's
+//     low-byte histogram, which is built here while the keys are on chip.
 //   * splats that can never produce a fragment (alpha cull, lambda2<=0, clipped by z, footprint
 //     outside the strip) are dropped BEFORE the sort.
+//   * the 180-byte SH record (62 % of a splat's bytes) is not read here: shading is deferred.
 #include "kernels_common.h"
 
 namespace mgs {

@@ -42,10 +42,10 @@ __global__ void k_frame_init(FrameCounters* ctr, SortPlan* planKeys, SortPlan* p
     ranges[i] = make_uint2(0u, 0u);
 }
 
-// ---- binning -------------------------------------------------------------------------------------
-// Contract: per 16x16 tile, the splats whose footprint box overlaps it, in global depth order.
-// Records (tile id, global id) are emitted in sorted-splat order; a STABLE sort by tile id then keeps
-// every tile's list depth-ordered.  The expansion is partitioned by OUTPUT range, not by splat: the
+// ---- binning, record path (frames with more than 256 bins; the default is the direct multi-split below) ----
+// Contract: per bin, the splats whose footprint box overlaps it, in global depth order.
+// Records (bin id, global id) are emitted in sorted-splat order; a STABLE sort by bin id then keeps
+// every bin's list depth-ordered.  The expansion is partitioned by OUTPUT range, not by splat: the
 // nearest splats are the largest on screen and sit together at the end of the sorted list, so a
 // splat-partitioned expansion leaves a ~1 ms tail on a handful of workgroups (profiles/r1_a).
 //   k_bin_count   : tile count of every sorted splat (+ its rect, re-laid out in sorted order) -> block sums
