@@ -139,7 +139,11 @@ typedef struct MgsFrameParams {
   int32_t debug_flags;          /* MGS_DEBUG_* bits: the reference's visualisation modes (parameters.h:86-201) */
   int32_t size_culling;         /* 0/1, default 0 (parameters.h:185): drop splats whose projected extent is below ...  */
   float   size_culling_min_pixels; /* ... this many pixels, default 1.0 (shaderio.h:266, dist.comp.slang:93-134)      */
-  int32_t reserved[3];
+  int32_t surface_outputs;      /* 0/1, default 0: also produce the FTB side outputs of NEED_SURFACE_INFO
+                                   (threedgs_raster.frag.slang:320-349): picked depth + the splat that set it */
+  float   depth_iso_threshold;  /* default 0.7 (parameters.h:200): depth = ndc z of the first fragment after which
+                                   the pixel's transmittance is below this */
+  int32_t reserved[1];
 } MgsFrameParams;
 
 void mgs_frame_params_default(MgsFrameParams* p); /* fills the defaults cited above */
@@ -169,6 +173,10 @@ int mgs_frame_stats(MgsScene scene, MgsFrameOut* out);
 /* per-stage HIP-event times of the timed frame rendered `frames_back` frames ago (0 = latest;
  * a ring of 128 timed frames is kept).  Waits only for that frame's last event. */
 int mgs_timings_query(MgsScene scene, uint32_t frames_back, float stage_ms[MGS_STAGE_COUNT]);
+/* side outputs of the last frame rendered with surface_outputs = 1, [height][width], row 0 = NDC y -1:
+ * which 0: picked depth, float32 (0 where the transmittance never fell below the threshold);
+ * which 1: global id (caller's order) of the splat that set it, uint32 (0xFFFFFFFF where none) */
+int mgs_frame_download_surface(MgsScene scene, int which, void* host_dst, size_t bytes);
 /* copy the last frame to the host (screenshot path, gaussian_splatting_ui.cpp:508-540, no tonemap) */
 int mgs_frame_download(MgsScene scene, void* host_dst, size_t bytes);
 /* copy this device's strip of the last frame into a caller-owned device buffer (all-gather staging) */

@@ -204,6 +204,19 @@ def render(frame, inst, order=None):
     return img, dict(fragments=int(frags), visible=int(stats[0]), quads=int(stats[1]))
 
 
+def render_surface(frame, inst, order_front_to_back, depth_iso_threshold=0.7):
+    """FTB side outputs: (depth[H,W] float32, splat_id[H,W] uint32) — picked depth and the splat that set it"""
+    o = np.ascontiguousarray(order_front_to_back, np.uint32)
+    depth = np.zeros((frame.height, frame.width), np.float32)
+    ids = np.zeros((frame.height, frame.width), np.uint32)
+    fn = lib().orc_render_surface
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p]
+    fn(C.cast(C.byref(frame), C.c_void_p), C.cast(inst, C.c_void_p), len(inst), o.ctypes.data, o.size, float(depth_iso_threshold),
+       depth.ctypes.data, ids.ctypes.data)
+    return depth, ids
+
+
 def psnr_rgb(a, b):
     a, b = f32(a), f32(b)
     return float(lib().orc_psnr_rgb(_p(a), _p(b), a.shape[1], a.shape[0]))

@@ -664,6 +664,67 @@ uint64_t orc_render_order(const OrcFrame* f, const OrcInstance* inst, int n_inst
   return frags;
 }
 
+// NEED_SURFACE_INFO + FRONT_TO_BACK side output of the fragment shader (threedgs_raster.frag.slang:320-349):
+// depthTransmittanceBuffer starts at (depth 0, transmittance 1); every fragment that passes the discards does
+//   transmittance *= (1 - opacity);  if(depth == 0 && transmittance < depthIsoThreshold) depth = fragCoord.z;
+// `ids` is the FRONT-TO-BACK draw order.  id_out receives the global id of the splat that set the depth
+// (0xFFFFFFFF where none did) — the build's reading of "splat id" for a picked depth.
+void orc_render_surface(const OrcFrame* f, const OrcInstance* inst, int n_inst, const uint32_t* ids, uint32_t v,
+                        float depth_iso_threshold, float* depth_out, uint32_t* id_out)
+{
+  const int          W = f->width, H = f->height;
+  const size_t       np = (size_t)W * H;
+  std::vector<float> trans(np, 1.0f);
+  std::fill(depth_out, depth_out + np, 0.0f);
+  std::fill(id_out, id_out + np, 0xFFFFFFFFu);
+  std::vector<uint32_t> offsets(n_inst + 1, 0);
+  for(int k = 0; k < n_inst; ++k)
+    offsets[k + 1] = offsets[k] + inst[k].count;
+  for(uint32_t s = 0; s < v; ++s)
+  {
+    const uint32_t g = ids[s];
+    int            k = 0;
+    while(k + 1 < n_inst && g >= offsets[k + 1])
+      ++k;
+    OrcProjected P;
+    orc_project(f, &inst[k], g - offsets[k], &P);
+    if(!P.valid)
+      continue;
+    const float ex = std::fabs(P.basis1[0]) + std::fabs(P.basis2[0]);
+    const float ey = std::fabs(P.basis1[1]) + std::fabs(P.basis2[1]);
+    const float fx0 = P.center_px[0] - ex - 0.5f, fx1 = P.center_px[0] + ex - 0.5f;
+    const float fy0 = P.center_px[1] - ey - 0.5f, fy1 = P.center_px[1] + ey - 0.5f;
+    if(!(fx1 >= 0.f && fy1 >= 0.f && fx0 <= (float)(W - 1) && fy0 <= (float)(H - 1)))
+      continue;
+    const int   x0 = (int)std::max(0.0f, std::floor(fx0)), x1 = (int)std::min((float)(W - 1), std::ceil(fx1));
+    const int   y0 = (int)std::max(0.0f, std::floor(fy0)), y1 = (int)std::min((float)(H - 1), std::ceil(fy1));
+    const float n1 = P.basis1[0] * P.basis1[0] + P.basis1[1] * P.basis1[1];
+    const float n2 = P.basis2[0] * P.basis2[0] + P.basis2[1] * P.basis2[1];
+    for(int y = y0; y <= y1; ++y)
+      for(int x = x0; x <= x1; ++x)
+      {
+        const float dx = ((float)x + 0.5f) - P.center_px[0];
+        const float dy = ((float)y + 0.5f) - P.center_px[1];
+        const float u  = (dx * P.basis1[0] + dy * P.basis1[1]) / n1;
+        const float vv = (dx * P.basis2[0] + dy * P.basis2[1]) / n2;
+        const float px = u * kSqrt8, py = vv * kSqrt8;
+        const float A  = px * px + py * py;
+        if(A > 8.0f)
+          continue;
+        const float opacity = P.opacity_disabled ? 1.0f : std::exp(-0.5f * A) * P.rgba[3];
+        if(opacity <= 1.0f / 255.0f)
+          continue;
+        const size_t i = (size_t)y * W + x;
+        trans[i] *= (1.0f - opacity);
+        if(depth_out[i] == 0.0f && trans[i] < depth_iso_threshold)
+        {
+          depth_out[i] = P.ndc_z;
+          id_out[i]    = g;
+        }
+      }
+  }
+}
+
 uint64_t orc_render(const OrcFrame* f, const OrcInstance* inst, int n_inst, float* rgba_out, uint64_t* stats)
 {
   size_t total = 0;

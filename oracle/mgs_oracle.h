@@ -105,6 +105,10 @@ uint64_t orc_render(const OrcFrame* f, const OrcInstance* inst, int n_inst,
 uint64_t orc_render_order(const OrcFrame* f, const OrcInstance* inst, int n_inst,
                           const uint32_t* ids, uint32_t v, float* rgba_out, uint64_t* stats);
 
+/* FTB surface side outputs (picked depth + the splat that set it), threedgs_raster.frag.slang:320-349; `ids` front-to-back */
+void orc_render_surface(const OrcFrame* f, const OrcInstance* inst, int n_inst, const uint32_t* ids, uint32_t v,
+                        float depth_iso_threshold, float* depth_out, uint32_t* id_out);
+
 /* PSNR as the reference defines it: MSE over RGB / (W*H*3), 10*log10(1/MSE), cap 99.99
  * image_compare_metric.comp.slang:116-130, image_compare.cpp:869-893 */
 double orc_psnr_rgb(const float* a, const float* b, int width, int height);

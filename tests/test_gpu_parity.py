@@ -560,6 +560,42 @@ def test_binning_paths_bit_identical():
         assert run({"MGS_BIN_SHIFT": shift}) == base, shift
 
 
+def test_surface_side_outputs_match_oracle(scene_small, ob):
+    """FTB side outputs of NEED_SURFACE_INFO (threedgs_raster.frag.slang:320-349): picked depth and the splat that set
+    it.  The pick is a threshold test on the transmittance, so a pixel whose T lands within rounding of the threshold
+    may pick the neighbouring fragment: >= 99.5 % of the pixels must pick the same splat (its depth within 1e-6 relative),
+    and the frame itself must be unchanged by the side outputs."""
+    scene, sc = scene_small
+    W, H = 640, 360
+    p, V, P, eye = camera(11, W, H)
+    scene.render(p)
+    plain = scene.download_frame(p).copy()
+    p.surface_outputs = 1
+    p.depth_iso_threshold = 0.7
+    out = scene.render(p, want_stats=True)
+    assert out.error_flags == 0
+    assert np.array_equal(scene.download_frame(p).view(np.uint16), plain.view(np.uint16))
+    depth, ids = scene.download_surface(p)
+    _, order = oracle_sorted_stream(ob, scene, sc, dict(view=V, proj=P, camera_pos=eye, width=W, height=H))
+    inst = ob.make_instances([(ob.PreparedSet(sc), None)])
+    odepth, oids = ob.render_surface(ob.make_frame(V, P, eye, W, H), inst, order[::-1].copy(), 0.7)
+    same = (ids == oids)
+    assert same.mean() >= 0.995, same.mean()
+    # fragCoord.z comes from the raster front end's clip.z * (1/clip.w) (fused MV products), the oracle divides: 1-2 ulp
+    assert np.allclose(depth[same], odepth[same], rtol=1e-6, atol=1e-7)
+    assert (ids != 0xFFFFFFFF).any() and ((depth == 0) == (ids == 0xFFFFFFFF)).all()
+    # a different threshold picks earlier / later fragments
+    p.depth_iso_threshold = 0.2
+    scene.render(p)
+    depth2, ids2 = scene.download_surface(p)
+    odepth2, oids2 = ob.render_surface(ob.make_frame(V, P, eye, W, H), inst, order[::-1].copy(), 0.2)
+    assert (ids2 == oids2).mean() >= 0.995
+    p.surface_outputs = 0
+    scene.render(p)
+    with pytest.raises(mgs.MgsError):
+        scene.download_surface(p)
+
+
 def test_frame_statistics_are_consistent(scene_small):
     """mgs_frame_stats: the compositor's counters (deferred shading) are plausible and deterministic"""
     scene, sc = scene_small

@@ -4,10 +4,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import vk_gaussian_splatting_amd as mgs
 from vk_gaussian_splatting_amd import capi, synth, multigpu
-N, W, H = 5_830_000, 1920, 1080
+import sys
+N = 5_830_000
+W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
 sc = synth.make_scene(N, seed=0xC0FFEE + 2)
 ss = mgs.SplatSet.from_arrays(**sc); scene = mgs.Scene(0); scene.add_instance(ss); scene.commit()
-G = 8
+G = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 for r in range(G):
     b, e = multigpu.strip_rows(H, G, r)
     eye = synth.orbit_pose(3)

@@ -37,7 +37,8 @@ class FrameParams(C.Structure):
                 ("target_format", C.c_int32), ("alpha_mode", C.c_int32), ("ms_antialiasing", C.c_int32),
                 ("strip_row_begin", C.c_int32), ("strip_row_end", C.c_int32),
                 ("collect_timings", C.c_int32), ("cpu_sort_blocking", C.c_int32), ("debug_flags", C.c_int32),
-                ("size_culling", C.c_int32), ("size_culling_min_pixels", C.c_float), ("reserved", C.c_int32 * 3)]
+                ("size_culling", C.c_int32), ("size_culling_min_pixels", C.c_float),
+                ("surface_outputs", C.c_int32), ("depth_iso_threshold", C.c_float), ("reserved", C.c_int32 * 1)]
 
 
 class FrameOut(C.Structure):
@@ -98,6 +99,7 @@ def load_library():
         "mgs_frame_stats": (C.c_int, [vp, P(FrameOut)]),
         "mgs_timings_query": (C.c_int, [vp, C.c_uint32, P(F)]),
         "mgs_frame_download": (C.c_int, [vp, vp, C.c_size_t]),
+        "mgs_frame_download_surface": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
         "mgs_frame_copy_strip": (C.c_int, [vp, vp, C.c_size_t]),
         "mgs_sync": (C.c_int, [vp]),
         "mgs_sort_keys": (C.c_int, [vp, P(FrameParams), P(SortOut)]),
@@ -119,7 +121,7 @@ EXPORTED_SYMBOLS = [
     "mgs_last_error", "mgs_version", "mgs_splatset_load", "mgs_splatset_from_arrays", "mgs_splatset_view",
     "mgs_splatset_destroy", "mgs_scene_create", "mgs_scene_destroy", "mgs_scene_set_stream", "mgs_instance_add",
     "mgs_instance_set_transform", "mgs_scene_commit", "mgs_scene_splat_count", "mgs_scene_storage_order", "mgs_scene_download_set",
-    "mgs_frame_params_default", "mgs_render", "mgs_frame_stats", "mgs_timings_query", "mgs_frame_download", "mgs_frame_copy_strip",
+    "mgs_frame_params_default", "mgs_render", "mgs_frame_stats", "mgs_timings_query", "mgs_frame_download", "mgs_frame_download_surface", "mgs_frame_copy_strip",
     "mgs_sync", "mgs_sort_keys", "mgs_sort_download", "mgs_radix_sort_u32", "mgs_radix_sort_host",
     "mgs_camera_lookat_perspective", "mgs_compute_transform"]
 
@@ -300,6 +302,15 @@ class Scene:
             img = np.zeros((params.height, params.width, 4), np.float32)
         _check(self._lib.mgs_frame_download(self._h, img.ctypes.data_as(C.c_void_p), img.nbytes))
         return img
+
+    def download_surface(self, params):
+        """FTB side outputs of a frame rendered with params.surface_outputs = 1: (picked depth float32[H,W],
+        splat id uint32[H,W] in the caller's id space, 0xFFFFFFFF = none)"""
+        depth = np.zeros((params.height, params.width), np.float32)
+        ids = np.zeros((params.height, params.width), np.uint32)
+        _check(self._lib.mgs_frame_download_surface(self._h, 0, depth.ctypes.data_as(C.c_void_p), depth.nbytes))
+        _check(self._lib.mgs_frame_download_surface(self._h, 1, ids.ctypes.data_as(C.c_void_p), ids.nbytes))
+        return depth, ids
 
     def copy_strip(self, device_ptr, nbytes):
         _check(self._lib.mgs_frame_copy_strip(self._h, C.c_void_p(device_ptr), nbytes))

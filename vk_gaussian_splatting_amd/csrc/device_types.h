@@ -61,6 +61,8 @@ struct FrameConst
   int32_t  sizeCulling;      // dist.comp.slang:93-134
   float    sizeCullingMinPixels;
   float    maxFocal;         // max(|focal.x|, |focal.y|)
+  int32_t  surfaceOutputs;   // picked depth + splat id side outputs (frag.slang:320-349)
+  float    depthIsoThreshold;
 };
 
 struct FrameArgs
@@ -78,7 +80,7 @@ struct alignas(16) SplatRec
   float p2x, p2y;
   float r, g, b, a;  // base colour (before the SH sum) and opacity
   float dx, dy, dz;  // unit direction camera -> splat in model space (mesh.slang:240-241): input of the deferred SH sum
-  int   inst;        // instance the splat belongs to
+  float ndcZ;        // fragCoord.z of the splat's quad (the picked-depth side output)
 };
 
 // device-resident counters of one frame

@@ -204,7 +204,7 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   out.rec.dx  = dx;
   out.rec.dy  = dy;
   out.rec.dz  = dz;
-  out.rec.inst = instIdx;
+  out.rec.ndcZ = ndcz;
   return true;
 }
 
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, Fram
           dst[0]      = make_float4(pr.rec.cx, pr.rec.cy, pr.rec.ex, pr.rec.ey);
           dst[1]      = make_float4(pr.rec.p1x, pr.rec.p1y, pr.rec.p2x, pr.rec.p2y);
           dst[2]      = make_float4(pr.rec.r, pr.rec.g, pr.rec.b, pr.rec.a);
-          dst[3]      = make_float4(pr.rec.dx, pr.rec.dy, pr.rec.dz, __int_as_float(pr.rec.inst));
+          dst[3]      = make_float4(pr.rec.dx, pr.rec.dy, pr.rec.dz, pr.rec.ndcZ);
           rect[gidOk] = pr.rect;
           s_li[j] |= 0x8000u;  // own entry only: no race
         }

@@ -611,7 +611,8 @@ constexpr int kCmpCap     = MGS_CMP_CAP;                // LDS batch capacity (r
 constexpr int kCmpGo      = MGS_CMP_GO;                // blend as soon as this many records are staged (<= kCmpCap-256)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// MODE bit 0: additive alpha (no early-out), bit 1: DISABLE_OPACITY_GAUSSIAN; SHF: SH storage format
+// MODE bit 0: additive alpha (no early-out), bit 1: DISABLE_OPACITY_GAUSSIAN, bit 2: surface side outputs; SHF: SH storage format
+constexpr bool surf_lds(int mode) { return (mode & 4) != 0; }
 #ifndef MGS_CMP_WAVES
 #define MGS_CMP_WAVES 5
 #endif
@@ -619,7 +620,8 @@ template <int MODE, int SHF>
 __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const FrameArgs A, const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ valX, const uint32_t* __restrict__ valY,
                                                    const SortPlan* __restrict__ plan, const SplatRec* __restrict__ rec,
-                                                   void* __restrict__ outImage, int halfOut, FrameCounters* __restrict__ ctr)
+                                                   void* __restrict__ outImage, int halfOut, FrameCounters* __restrict__ ctr,
+                                                   float* __restrict__ outDepth, uint32_t* __restrict__ outSplatId)
 {
   const FrameConst& F = A.f;
   uint32_t statStaged = 0, statScanned = 0;
@@ -627,6 +629,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const FrameArg
   __shared__ float4   s_b[kCmpCap];  // p1, p2 (scaled by sqrt(log2 e))
   __shared__ float4   s_c[kCmpCap];  // r, g, b, a
   __shared__ float4   s_d[kCmpCap];  // direction (model space), global id: what the deferred SH sum needs
+  __shared__ float    s_z[surf_lds(MODE) ? kCmpCap : 1];  // fragCoord.z of the record (surface outputs only)
   __shared__ uint32_t s_wc[2][kCmpEntries][4];
   __shared__ uint8_t  s_m[kCmpCap];  // which of the 4 quarters (waves) the record's footprint touches
 
@@ -671,6 +674,9 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const FrameArg
   const bool     in0 = px < F.width && py < F.height, in1 = px + 8 < F.width && py < F.height;
   constexpr bool early   = (MODE & 1) == 0;
   constexpr bool noGauss = (MODE & 2) != 0;
+  constexpr bool surf    = (MODE & 4) != 0;  // FTB side outputs: picked depth + the splat that set it (frag.slang:320-349)
+  v2f            pickZ   = {0.0f, 0.0f};
+  uint32_t       pickId0 = 0xFFFFFFFFu, pickId1 = 0xFFFFFFFFu;
   // a saturated pixel (T < 1e-4) takes no further fragments: the result must not depend on WHEN its wave
   // notices (batch boundaries differ between a strip and the full frame, the frames must not)
   const float    tMin    = early ? 1.0e-4f : -1.0f;
@@ -762,6 +768,8 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const FrameArg
             s_c[pos]           = r[2];
             const float4 rd    = r[3];
             s_d[pos]           = make_float4(rd.x, rd.y, rd.z, __uint_as_float(g[k]));
+            if constexpr(surf)
+              s_z[pos] = rd.w;
             // quarter (qx,qy): pixel centres x in [bcx-15.5,bcx-0.5] / [bcx+0.5,bcx+15.5], y in [bcy-7.5,bcy-0.5] / [bcy+0.5,bcy+7.5].
             // Footprint box first, then a bound in the ellipse's own frame: over the quarter (centre m, half
             // extents 7.5 x 3.5) s = d.p1 stays within |s_m| -+ (7.5|p1x| + 3.5|p1y|), likewise u = d.p2, so
@@ -855,6 +863,21 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const FrameArg
           if(!early)
             asum += ah;
           T -= wgt;
+          if constexpr(surf)
+          {  // transmittance *= (1 - opacity); if(depth == 0 && transmittance < threshold) depth = fragCoord.z
+            const float    zr  = s_z[j];
+            const uint32_t gid = __float_as_uint(s_d[j].w);
+            if(ah.x > 0.0f && pickZ.x == 0.0f && T.x < F.depthIsoThreshold)
+            {
+              pickZ.x = zr;
+              pickId0 = gid;
+            }
+            if(ah.y > 0.0f && pickZ.y == 0.0f && T.y < F.depthIsoThreshold)
+            {
+              pickZ.y = zr;
+              pickId1 = gid;
+            }
+          }
           // checked per record (the compares are the predicate's): a 64-record chunk used to run to its end
           // after the last pixel had saturated
           if(early && __ballot(T.x >= tMin || T.y >= tMin) == 0ull)
@@ -896,6 +919,11 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const FrameArg
       }
       else
         reinterpret_cast<float4*>(outImage)[o] = make_float4(r, g, b, ao);
+      if constexpr(surf)
+      {
+        outDepth[o]   = h ? pickZ.y : pickZ.x;
+        outSplatId[o] = h ? pickId1 : pickId0;
+      }
     }
   }
 }
@@ -953,7 +981,7 @@ void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* 
 
 void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
                      const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, bool halfOut,
-                     int shFormat, FrameCounters* ctr)
+                     int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId)
 {
   const FrameConst& F = A.f;
   if(F.stripRow1 <= F.stripRow0)
@@ -962,10 +990,10 @@ void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges
   // a strip have empty regions that exit at once)
   const int nBins   = F.binsX * F.binsY;
   const int per     = ((nBins + 7) / 8) * (1 << (F.binShiftX - 1 + F.binShiftY));  // workgroups per XCD
-  const int mode = (F.alphaMode != 0 ? 1 : 0) | ((F.debugFlags & 4) ? 2 : 0);
+  const int mode = (F.alphaMode != 0 ? 1 : 0) | ((F.debugFlags & 4) ? 2 : 0) | (F.surfaceOutputs ? 4 : 0);
 #define MGS_CMP(M, S)                                                                                                  \
   hipLaunchKernelGGL((k_composite<M, S>), dim3(per * 8), dim3(256), 0, stream, A, ranges, valX, valY, planPairs, rec, image, \
-                     halfOut ? 1 : 0, ctr)
+                     halfOut ? 1 : 0, ctr, outDepth, outSplatId)
 #define MGS_CMP_FMT(M)                                                                                                 \
   switch(shFormat)                                                                                                     \
   {                                                                                                                    \
@@ -978,7 +1006,11 @@ void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges
     case 0: MGS_CMP_FMT(0); break;
     case 1: MGS_CMP_FMT(1); break;
     case 2: MGS_CMP_FMT(2); break;
-    default: MGS_CMP_FMT(3); break;
+    case 3: MGS_CMP_FMT(3); break;
+    case 4: MGS_CMP_FMT(4); break;
+    case 5: MGS_CMP_FMT(5); break;
+    case 6: MGS_CMP_FMT(6); break;
+    default: MGS_CMP_FMT(7); break;
   }
 #undef MGS_CMP_FMT
 #undef MGS_CMP

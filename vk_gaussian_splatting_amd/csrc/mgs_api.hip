@@ -46,7 +46,7 @@ void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* 
                       uint2* ranges);
 void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
                      const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, bool halfOut,
-                     int shFormat, FrameCounters* ctr);
+                     int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId);
 constexpr uint32_t kPart = 2048;  // == kPrjPart == kSortPart == kBinPart
 }  // namespace mgs
 
@@ -234,6 +234,9 @@ struct MgsScene_t
   // frame buffers
   DevBuf<uint32_t>      keysSlot, idsSlot, slotCount, keysA, idsA, keysB, idsB, rect, partHist, blockCount;
   DevBuf<uint32_t>      sortedRect, splatOffset, chunkStart, partSkip;
+  DevBuf<float>         surfDepth;   // FTB side outputs of the last frame rendered with surface_outputs
+  DevBuf<uint32_t>      surfId;
+  bool                  haveSurface = false;
   DevBuf<SplatRec>      rec;
   DevBuf<uint32_t>      pairKey0, pairVal0, pairKey1, pairVal1;
   DevBuf<uint2>         ranges;
@@ -436,6 +439,7 @@ void mgs_scene_destroy(MgsScene s)
   s->keysB.release(); s->idsB.release(); s->rect.release(); s->partHist.release(); s->blockCount.release();
   s->rec.release(); s->pairKey0.release(); s->pairVal0.release(); s->pairKey1.release(); s->pairVal1.release();
   s->sortedRect.release(); s->splatOffset.release(); s->chunkStart.release(); s->partSkip.release();
+  s->surfDepth.release(); s->surfId.release();
   s->ranges.release(); s->image.release(); s->ctr.release(); s->plans.release(); s->cpuDistDev.release();
   if(s->hCtr) (void)hipHostFree(s->hCtr);
   if(s->hPlans) (void)hipHostFree(s->hPlans);
@@ -890,6 +894,8 @@ void mgs_frame_params_default(MgsFrameParams* p)
   p->target_format        = MGS_TARGET_RGBA16F;
   p->alpha_mode           = MGS_ALPHA_COVERAGE;
   p->size_culling_min_pixels = 1.0f;
+  p->surface_outputs         = 0;
+  p->depth_iso_threshold     = 0.7f;  // parameters.h:200
 }
 
 // storage global id <-> caller global id.  Instances are concatenated in creation order in both spaces;
@@ -996,6 +1002,8 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
   if(std::getenv("MGS_LOOSE_MASK")) F.debugFlags |= 256;
   F.sizeCulling     = p->size_culling;
   F.sizeCullingMinPixels = p->size_culling_min_pixels;
+  F.surfaceOutputs  = p->surface_outputs ? 1 : 0;
+  F.depthIsoThreshold = p->depth_iso_threshold;
   F.maxFocal        = std::max(std::fabs(F.focal[0]), std::fabs(F.focal[1]));
   F.targetFormat    = p->target_format;
   F.nInstances      = (int)s->instances.size();
@@ -1192,6 +1200,12 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
     if((rc = s->image.ensure(s->imageBytes))) return rc;
     HIPCHK(hipMemsetAsync(s->image.p, 0, s->imageBytes, s->stream));
   }
+  if(F.surfaceOutputs)
+  {
+    if((rc = s->surfDepth.ensure((size_t)F.width * F.height))) return rc;
+    if((rc = s->surfId.ensure((size_t)F.width * F.height))) return rc;
+  }
+  s->haveSurface    = F.surfaceOutputs != 0;
   hipStream_t st    = s->stream;
   const bool  timed = p->collect_timings != 0;
   FrameCounters* ctr = s->ctr.p;
@@ -1269,7 +1283,8 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
     }
   }
   if(timed) HIPCHK(hipEventRecord(fev[4], st));
-  launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat, ctr);
+  launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat, ctr,
+                  F.surfaceOutputs ? s->surfDepth.p : nullptr, F.surfaceOutputs ? s->surfId.p : nullptr);
   if(timed) HIPCHK(hipEventRecord(fev[5], st));
   HIPCHK(hipMemcpyAsync(s->hCtr, ctr, sizeof(FrameCounters), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(s->hPlans, s->plans.p, 2 * sizeof(SortPlan), hipMemcpyDeviceToHost, st));
@@ -1358,6 +1373,45 @@ int mgs_frame_stats(MgsScene s, MgsFrameOut* out)
   {
     setError("frame: tile-pair capacity exceeded (raise MGS_PAIR_CAPACITY); frame is incomplete");
     return MGS_ERR_OVERFLOW;
+  }
+  return MGS_OK;
+}
+
+int mgs_frame_download_surface(MgsScene s, int which, void* dst, size_t bytes)
+{
+  if(!s || !dst || (which != 0 && which != 1))
+  {
+    setError("mgs_frame_download_surface: bad argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(!s->haveFrame || !s->haveSurface || s->lastWasSortOnly)
+  {
+    setError("mgs_frame_download_surface: the last frame was not rendered with surface_outputs = 1");
+    return MGS_ERR_STATE;
+  }
+  const size_t n = (size_t)s->lastParams.width * (size_t)s->lastParams.height;
+  if(bytes < n * 4)
+  {
+    setError("mgs_frame_download_surface: destination too small");
+    return MGS_ERR_INVALID_ARG;
+  }
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  HIPCHK(hipMemcpy(dst, which == 0 ? (const void*)s->surfDepth.p : (const void*)s->surfId.p, n * 4, hipMemcpyDeviceToHost));
+  if(which == 1)
+  {  // the pipeline works on storage ids: hand out the caller's
+    uint32_t*             ids = static_cast<uint32_t*>(dst);
+    std::vector<uint32_t> hit;
+    std::vector<size_t>   where;
+    for(size_t i = 0; i < n; ++i)
+      if(ids[i] != 0xFFFFFFFFu)
+      {
+        hit.push_back(ids[i]);
+        where.push_back(i);
+      }
+    mapIdsToCaller(s, hit.data(), hit.size());
+    for(size_t i = 0; i < hit.size(); ++i)
+      ids[where[i]] = hit[i];
   }
   return MGS_OK;
 }
