@@ -1286,8 +1286,8 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
   launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat, ctr,
                   F.surfaceOutputs ? s->surfDepth.p : nullptr, F.surfaceOutputs ? s->surfId.p : nullptr);
   if(timed) HIPCHK(hipEventRecord(fev[5], st));
-  HIPCHK(hipMemcpyAsync(s->hCtr, ctr, sizeof(FrameCounters), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(s->hPlans, s->plans.p, 2 * sizeof(SortPlan), hipMemcpyDeviceToHost, st));
+  // the counters stay on the device; mgs_frame_stats fetches them when somebody asks (two API calls per frame less
+  // on the submitting thread, which spends ~6 us per call)
   HIPCHK(hipGetLastError());
   s->lastParams      = *p;
   s->lastParams.strip_row_begin = F.stripRow0;
@@ -1348,6 +1348,11 @@ int mgs_frame_stats(MgsScene s, MgsFrameOut* out)
     return MGS_ERR_STATE;
   }
   HIPCHK(hipSetDevice(s->device));
+  if(!s->lastWasSortOnly)
+  {
+    HIPCHK(hipMemcpyAsync(s->hCtr, s->ctr.p, sizeof(FrameCounters), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(s->hPlans, s->plans.p, 2 * sizeof(SortPlan), hipMemcpyDeviceToHost, s->stream));
+  }
   HIPCHK(hipStreamSynchronize(s->stream));
   std::memset(out->stage_ms, 0, sizeof(out->stage_ms));
   out->rgba_device   = s->image.p;
@@ -1564,6 +1569,11 @@ int mgs_sort_download(MgsScene s, uint32_t* keys, uint32_t* ids, uint32_t capaci
       for(size_t i = 0; i < n; ++i)
         std::memcpy(&keys[i], &s->cpu.distances[s->cpuIndices[i]], 4);
     return MGS_OK;
+  }
+  if(!s->lastWasSortOnly)
+  {  // after a full frame the counters are still on the device
+    HIPCHK(hipMemcpyAsync(s->hCtr, s->ctr.p, sizeof(FrameCounters), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(s->hPlans, s->plans.p, 2 * sizeof(SortPlan), hipMemcpyDeviceToHost, s->stream));
   }
   HIPCHK(hipStreamSynchronize(s->stream));
   const uint32_t n = s->hCtr->sortedCount;
