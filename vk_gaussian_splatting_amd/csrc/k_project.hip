@@ -436,9 +436,19 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, Fram
 // partition is skipped only if every splat in it would certainly be culled.  For strips the footprint
 // of a splat of the partition is bounded by R = s*(k*fmax*S*rmax/zmin + 3.2) + 1 px (derivation in
 // DESIGN.md §3.1), and the partition is skipped when [ymin-R, ymax+R] misses the strip's pixel rows.
-__global__ __launch_bounds__(256) void k_partition_cull(const FrameArgs A, uint32_t* __restrict__ partSkip)
+// It is also the frame's first kernel, so it zeroes the per-frame device state (counters, both sort plans, the bin
+// ranges): one launch less than a separate init kernel.
+__global__ __launch_bounds__(256) void k_partition_cull(const FrameArgs A, uint32_t* __restrict__ partSkip,
+                                                        uint32_t* __restrict__ zero0, uint32_t n0, uint32_t* __restrict__ zero1,
+                                                        uint32_t n1, uint32_t* __restrict__ zero2, uint32_t n2)
 {
   const uint32_t part = blockIdx.x * blockDim.x + threadIdx.x;
+  for(uint32_t i = part; i < n0; i += gridDim.x * blockDim.x)
+    zero0[i] = 0u;
+  for(uint32_t i = part; i < n1; i += gridDim.x * blockDim.x)
+    zero1[i] = 0u;
+  for(uint32_t i = part; i < n2; i += gridDim.x * blockDim.x)
+    zero2[i] = 0u;
   if(part >= A.f.totalPartitions)
     return;
   int k = 0;
@@ -502,11 +512,13 @@ __global__ __launch_bounds__(256) void k_partition_cull(const FrameArgs A, uint3
   partSkip[part] = skip;
 }
 
-void launchPartitionCull(hipStream_t stream, const FrameArgs& args, uint32_t* partSkip)
+void launchPartitionCull(hipStream_t stream, const FrameArgs& args, uint32_t* partSkip, uint32_t* zero0, uint32_t n0,
+                         uint32_t* zero1, uint32_t n1, uint32_t* zero2, uint32_t n2)
 {
   if(args.f.totalPartitions == 0)
     return;
-  hipLaunchKernelGGL(k_partition_cull, dim3((args.f.totalPartitions + 255) / 256), dim3(256), 0, stream, args, partSkip);
+  hipLaunchKernelGGL(k_partition_cull, dim3((args.f.totalPartitions + 255) / 256), dim3(256), 0, stream, args, partSkip, zero0,
+                     n0, zero1, n1, zero2, n2);
 }
 
 // ---------------------------------------------------------------------------------------------

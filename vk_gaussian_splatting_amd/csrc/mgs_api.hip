@@ -30,7 +30,8 @@ namespace mgs {
 void launchProject(hipStream_t stream, const FrameArgs& args, bool full, int shFormat, int rgbaFormat, FrameCounters* ctr,
                    uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, SplatRec* rec, uint32_t* rect,
                    const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride);
-void launchPartitionCull(hipStream_t stream, const FrameArgs& args, uint32_t* partSkip);
+void launchPartitionCull(hipStream_t stream, const FrameArgs& args, uint32_t* partSkip, uint32_t* zero0, uint32_t n0,
+                         uint32_t* zero1, uint32_t n1, uint32_t* zero2, uint32_t n2);
 void launchFrameInit(hipStream_t stream, FrameCounters* ctr, SortPlan* planKeys, SortPlan* planPairs, uint2* ranges,
                      uint32_t nTiles);
 void launchBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
@@ -1214,12 +1215,18 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
 
   hipEvent_t* fev = s->evRing[s->frameIndex % MgsScene_t::kRing];
   if(timed) HIPCHK(hipEventRecord(fev[0], st));
-  launchFrameInit(st, ctr, planK, planP, s->ranges.p, nTiles);
+  // per-frame device state: counters, both sort plans (adjacent), bin ranges.  The partition cull, when it runs, is
+  // the frame's first kernel and zeroes them on the way.
+  static_assert(sizeof(SortPlan) % 4 == 0 && sizeof(FrameCounters) % 4 == 0, "word-sized state");
+  if(F.partitionCull && s->totalParts > 0)
+    launchPartitionCull(st, A, s->partSkip.p, reinterpret_cast<uint32_t*>(ctr), (uint32_t)(sizeof(FrameCounters) / 4),
+                        reinterpret_cast<uint32_t*>(planK), (uint32_t)(2 * sizeof(SortPlan) / 4),
+                        reinterpret_cast<uint32_t*>(s->ranges.p), 2u * nTiles);
+  else
+    launchFrameInit(st, ctr, planK, planP, s->ranges.p, nTiles);
   const bool cpuMode = (p->sort_mode == MGS_SORT_CPU_ASYNC);
   if(cpuMode)  // rejected splats must look empty to the binning stage: rect with x0 > x1
     hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, st, s->rect.p, 1u, s->totalSplats);
-  if(F.partitionCull)
-    launchPartitionCull(st, A, s->partSkip.p);
   launchProject(st, A, true, s->shFormat, s->rgbaFormat, ctr, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p,
                 s->rect.p, F.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride);
   if(timed) HIPCHK(hipEventRecord(fev[1], st));
@@ -1517,9 +1524,11 @@ int mgs_sort_keys(MgsScene s, const MgsFrameParams* p, MgsSortOut* out)
   hipStream_t st = s->stream;
   if((rc = s->ranges.ensure(1))) return rc;
   HIPCHK(hipEventRecord(s->ev[0], st));
-  launchFrameInit(st, s->ctr.p, &s->plans.p[0], &s->plans.p[1], s->ranges.p, 0);
-  if(A.f.partitionCull)
-    launchPartitionCull(st, A, s->partSkip.p);
+  if(A.f.partitionCull && s->totalParts > 0)
+    launchPartitionCull(st, A, s->partSkip.p, reinterpret_cast<uint32_t*>(s->ctr.p), (uint32_t)(sizeof(FrameCounters) / 4),
+                        reinterpret_cast<uint32_t*>(s->plans.p), (uint32_t)(2 * sizeof(SortPlan) / 4), nullptr, 0u);
+  else
+    launchFrameInit(st, s->ctr.p, &s->plans.p[0], &s->plans.p[1], s->ranges.p, 0);
   launchProject(st, A, false, 0, 0, s->ctr.p, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p, s->rect.p,
                 A.f.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride);
   HIPCHK(hipEventRecord(s->ev[1], st));
