@@ -232,12 +232,13 @@ __device__ __forceinline__ uint32_t scanRoundWaveCounts(uint32_t* s_cnt /*32*/, 
 // No barrier sits inside a loop that waits on memory: all 8 centre loads of a thread are issued up front,
 // and the heavy per-survivor loop runs barrier-free (waves drift apart and overlap each other's loads).
 template <bool FULL, int RGBAF>
-__global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, FrameCounters* __restrict__ ctr,
+__global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __restrict__ Ap, FrameCounters* __restrict__ ctr,
                                                          uint32_t* __restrict__ keysSlot, uint32_t* __restrict__ idsSlot,
                                                          uint32_t* __restrict__ slotCount, SplatRec* __restrict__ rec,
                                                          uint32_t* __restrict__ rect, const uint32_t* __restrict__ partSkip,
                                                          uint32_t* __restrict__ slotHist, uint32_t histStride)
 {
+  const FrameArgs& A = *Ap;  // frame constants live in device memory (same pointer every frame: graph-replayable)
   // slotHist[d * histStride + partition] = survivors of this partition whose low key byte is d: the radix
   // sort's pass-0 partition histogram, produced here while the keys are still on chip.
   if(partSkip != nullptr && partSkip[blockIdx.x] != 0u)
@@ -438,10 +439,11 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs A, Fram
 // DESIGN.md §3.1), and the partition is skipped when [ymin-R, ymax+R] misses the strip's pixel rows.
 // It is also the frame's first kernel, so it zeroes the per-frame device state (counters, both sort plans, the bin
 // ranges): one launch less than a separate init kernel.
-__global__ __launch_bounds__(256) void k_partition_cull(const FrameArgs A, uint32_t* __restrict__ partSkip,
+__global__ __launch_bounds__(256) void k_partition_cull(const FrameArgs* __restrict__ Ap, uint32_t* __restrict__ partSkip,
                                                         uint32_t* __restrict__ zero0, uint32_t n0, uint32_t* __restrict__ zero1,
                                                         uint32_t n1, uint32_t* __restrict__ zero2, uint32_t n2)
 {
+  const FrameArgs& A = *Ap;
   const uint32_t part = blockIdx.x * blockDim.x + threadIdx.x;
   for(uint32_t i = part; i < n0; i += gridDim.x * blockDim.x)
     zero0[i] = 0u;
@@ -512,18 +514,19 @@ __global__ __launch_bounds__(256) void k_partition_cull(const FrameArgs A, uint3
   partSkip[part] = skip;
 }
 
-void launchPartitionCull(hipStream_t stream, const FrameArgs& args, uint32_t* partSkip, uint32_t* zero0, uint32_t n0,
-                         uint32_t* zero1, uint32_t n1, uint32_t* zero2, uint32_t n2)
+void launchPartitionCull(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, uint32_t* partSkip, uint32_t* zero0,
+                         uint32_t n0, uint32_t* zero1, uint32_t n1, uint32_t* zero2, uint32_t n2)
 {
   if(args.f.totalPartitions == 0)
     return;
-  hipLaunchKernelGGL(k_partition_cull, dim3((args.f.totalPartitions + 255) / 256), dim3(256), 0, stream, args, partSkip, zero0,
+  hipLaunchKernelGGL(k_partition_cull, dim3((args.f.totalPartitions + 255) / 256), dim3(256), 0, stream, dArgs, partSkip, zero0,
                      n0, zero1, n1, zero2, n2);
 }
 
 // ---------------------------------------------------------------------------------------------
 // host-callable launcher
-void launchProject(hipStream_t stream, const FrameArgs& args, bool full, int shFormat, int rgbaFormat, FrameCounters* ctr,
+void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full, int shFormat, int rgbaFormat,
+                   FrameCounters* ctr,
                    uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, SplatRec* rec, uint32_t* rect,
                    const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride)
 {
@@ -531,7 +534,7 @@ void launchProject(hipStream_t stream, const FrameArgs& args, bool full, int shF
   if(args.f.totalPartitions == 0)
     return;
 #define MGS_LAUNCH(FULLV, R)                                                                                             \
-  hipLaunchKernelGGL((k_project<FULLV, R>), grid, block, 0, stream, args, ctr, keysSlot, idsSlot, slotCount, rec, rect, partSkip, \
+  hipLaunchKernelGGL((k_project<FULLV, R>), grid, block, 0, stream, dArgs, ctr, keysSlot, idsSlot, slotCount, rec, rect, partSkip, \
                      slotHist, histStride)
   if(!full)
   {

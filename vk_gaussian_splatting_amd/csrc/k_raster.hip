@@ -617,12 +617,13 @@ constexpr bool surf_lds(int mode) { return (mode & 4) != 0; }
 #define MGS_CMP_WAVES 5
 #endif
 template <int MODE, int SHF>
-__global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const FrameArgs A, const uint2* __restrict__ ranges,
+__global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const FrameArgs* __restrict__ Ap, const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ valX, const uint32_t* __restrict__ valY,
                                                    const SortPlan* __restrict__ plan, const SplatRec* __restrict__ rec,
                                                    void* __restrict__ outImage, int halfOut, FrameCounters* __restrict__ ctr,
                                                    float* __restrict__ outDepth, uint32_t* __restrict__ outSplatId)
 {
+  const FrameArgs&  A = *Ap;  // frame constants live in device memory (same pointer every frame: graph-replayable)
   const FrameConst& F = A.f;
   uint32_t statStaged = 0, statScanned = 0;
   __shared__ float4   s_a[kCmpCap];  // cx, cy, ex, ey
@@ -979,7 +980,7 @@ void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* 
   hipLaunchKernelGGL(k_tile_ranges, dim3(4096), dim3(256), 0, stream, keyX, keyY, planPairs, ranges);
 }
 
-void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
+void launchComposite(hipStream_t stream, const FrameArgs& A, const FrameArgs* dArgs, const uint2* ranges, const uint32_t* valX,
                      const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, bool halfOut,
                      int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId)
 {
@@ -992,7 +993,7 @@ void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges
   const int per     = ((nBins + 7) / 8) * (1 << (F.binShiftX - 1 + F.binShiftY));  // workgroups per XCD
   const int mode = (F.alphaMode != 0 ? 1 : 0) | ((F.debugFlags & 4) ? 2 : 0) | (F.surfaceOutputs ? 4 : 0);
 #define MGS_CMP(M, S)                                                                                                  \
-  hipLaunchKernelGGL((k_composite<M, S>), dim3(per * 8), dim3(256), 0, stream, A, ranges, valX, valY, planPairs, rec, image, \
+  hipLaunchKernelGGL((k_composite<M, S>), dim3(per * 8), dim3(256), 0, stream, dArgs, ranges, valX, valY, planPairs, rec, image, \
                      halfOut ? 1 : 0, ctr, outDepth, outSplatId)
 #define MGS_CMP_FMT(M)                                                                                                 \
   switch(shFormat)                                                                                                     \

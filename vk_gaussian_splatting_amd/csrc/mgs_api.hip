@@ -18,6 +18,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <map>
 #include <vector>
 
 #include "../../include/mgs.h"
@@ -27,11 +28,12 @@
 
 namespace mgs {
 // kernels_*.hip
-void launchProject(hipStream_t stream, const FrameArgs& args, bool full, int shFormat, int rgbaFormat, FrameCounters* ctr,
+void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full, int shFormat, int rgbaFormat,
+                   FrameCounters* ctr,
                    uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, SplatRec* rec, uint32_t* rect,
                    const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride);
-void launchPartitionCull(hipStream_t stream, const FrameArgs& args, uint32_t* partSkip, uint32_t* zero0, uint32_t n0,
-                         uint32_t* zero1, uint32_t n1, uint32_t* zero2, uint32_t n2);
+void launchPartitionCull(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, uint32_t* partSkip, uint32_t* zero0,
+                         uint32_t n0, uint32_t* zero1, uint32_t n1, uint32_t* zero2, uint32_t n2);
 void launchFrameInit(hipStream_t stream, FrameCounters* ctr, SortPlan* planKeys, SortPlan* planPairs, uint2* ranges,
                      uint32_t nTiles);
 void launchBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
@@ -45,7 +47,7 @@ void launchDirectBinning(hipStream_t stream, const uint32_t* idsX, const uint32_
                          int binsX, int binsY);
 void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* keyY, const SortPlan* planPairs,
                       uint2* ranges);
-void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
+void launchComposite(hipStream_t stream, const FrameArgs& A, const FrameArgs* dArgs, const uint2* ranges, const uint32_t* valX,
                      const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, bool halfOut,
                      int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId);
 constexpr uint32_t kPart = 2048;  // == kPrjPart == kSortPart == kBinPart
@@ -235,6 +237,16 @@ struct MgsScene_t
   // frame buffers
   DevBuf<uint32_t>      keysSlot, idsSlot, slotCount, keysA, idsA, keysB, idsB, rect, partHist, blockCount;
   DevBuf<uint32_t>      sortedRect, splatOffset, chunkStart, partSkip;
+  DevBuf<FrameArgs>     dArgs;       // this frame's constants (view/proj, instances, knobs): the kernels read them through
+                                     // this pointer, so a captured frame graph replays with nothing but a 5 KB upload
+  struct GraphKey
+  {
+    int32_t v[12];
+    const void* p[2];
+    bool operator<(const GraphKey& o) const { return std::memcmp(this, &o, sizeof(*this)) < 0; }
+  };
+  std::map<GraphKey, hipGraphExec_t> graphs;  // captured frames, one per (resolution, strip, mode); cleared at commit
+  bool                  graphOk = true;
   DevBuf<float>         surfDepth;   // FTB side outputs of the last frame rendered with surface_outputs
   DevBuf<uint32_t>      surfId;
   bool                  haveSurface = false;
@@ -440,7 +452,9 @@ void mgs_scene_destroy(MgsScene s)
   s->keysB.release(); s->idsB.release(); s->rect.release(); s->partHist.release(); s->blockCount.release();
   s->rec.release(); s->pairKey0.release(); s->pairVal0.release(); s->pairKey1.release(); s->pairVal1.release();
   s->sortedRect.release(); s->splatOffset.release(); s->chunkStart.release(); s->partSkip.release();
-  s->surfDepth.release(); s->surfId.release();
+  s->surfDepth.release(); s->surfId.release(); s->dArgs.release();
+  for(auto& g : s->graphs) (void)hipGraphExecDestroy(g.second);
+  s->graphs.clear();
   s->ranges.release(); s->image.release(); s->ctr.release(); s->plans.release(); s->cpuDistDev.release();
   if(s->hCtr) (void)hipHostFree(s->hCtr);
   if(s->hPlans) (void)hipHostFree(s->hPlans);
@@ -584,6 +598,9 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
   }
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamSynchronize(s->stream));
+  for(auto& g : s->graphs)  // captured frames hold the old buffers and grid sizes
+    (void)hipGraphExecDestroy(g.second);
+  s->graphs.clear();
   for(auto& d : s->sets)
   {
     if(d.centers && d.shFormat == shFormat && d.rgbaFormat == rgbaFormat)
@@ -1214,85 +1231,142 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
   SortPlan*      planP = &s->plans.p[1];
 
   hipEvent_t* fev = s->evRing[s->frameIndex % MgsScene_t::kRing];
-  if(timed) HIPCHK(hipEventRecord(fev[0], st));
-  // per-frame device state: counters, both sort plans (adjacent), bin ranges.  The partition cull, when it runs, is
-  // the frame's first kernel and zeroes them on the way.
-  static_assert(sizeof(SortPlan) % 4 == 0 && sizeof(FrameCounters) % 4 == 0, "word-sized state");
-  if(F.partitionCull && s->totalParts > 0)
-    launchPartitionCull(st, A, s->partSkip.p, reinterpret_cast<uint32_t*>(ctr), (uint32_t)(sizeof(FrameCounters) / 4),
-                        reinterpret_cast<uint32_t*>(planK), (uint32_t)(2 * sizeof(SortPlan) / 4),
-                        reinterpret_cast<uint32_t*>(s->ranges.p), 2u * nTiles);
-  else
-    launchFrameInit(st, ctr, planK, planP, s->ranges.p, nTiles);
-  const bool cpuMode = (p->sort_mode == MGS_SORT_CPU_ASYNC);
-  if(cpuMode)  // rejected splats must look empty to the binning stage: rect with x0 > x1
-    hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, st, s->rect.p, 1u, s->totalSplats);
-  launchProject(st, A, true, s->shFormat, s->rgbaFormat, ctr, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p,
-                s->rect.p, F.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride);
-  if(timed) HIPCHK(hipEventRecord(fev[1], st));
-  static const bool kFuseRect = [] { const char* e = std::getenv("MGS_FUSE_RECT"); return e ? std::atoi(e) != 0 : false; }();  // measured: +43 us in the scatter for -17 us in the count kernel
-  const bool direct0 = directBinningSupported(F.binsX, F.binsY);
-  if(!cpuMode)
-    keySort(s, st, kFuseRect && direct0);
-  else
+  const bool  cpuModeOuter = (p->sort_mode == MGS_SORT_CPU_ASYNC);
+  // this frame's constants: a 5 KB upload (pageable source: staged by the runtime before the call returns)
+  if((rc = s->dArgs.ensure(1))) return rc;
+  HIPCHK(hipMemcpyAsync(s->dArgs.p, &A, sizeof(FrameArgs), hipMemcpyHostToDevice, st));
+  auto issue = [&](bool withEvents) -> int {
+    if(withEvents) HIPCHK(hipEventRecord(fev[0], st));
+    // per-frame device state: counters, both sort plans (adjacent), bin ranges.  The partition cull, when it runs, is
+    // the frame's first kernel and zeroes them on the way.
+    static_assert(sizeof(SortPlan) % 4 == 0 && sizeof(FrameCounters) % 4 == 0, "word-sized state");
+    if(F.partitionCull && s->totalParts > 0)
+      launchPartitionCull(st, A, s->dArgs.p, s->partSkip.p, reinterpret_cast<uint32_t*>(ctr), (uint32_t)(sizeof(FrameCounters) / 4),
+                          reinterpret_cast<uint32_t*>(planK), (uint32_t)(2 * sizeof(SortPlan) / 4),
+                          reinterpret_cast<uint32_t*>(s->ranges.p), 2u * nTiles);
+    else
+      launchFrameInit(st, ctr, planK, planP, s->ranges.p, nTiles);
+    const bool cpuMode = (p->sort_mode == MGS_SORT_CPU_ASYNC);
+    if(cpuMode)  // rejected splats must look empty to the binning stage: rect with x0 > x1
+      hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, st, s->rect.p, 1u, s->totalSplats);
+    launchProject(st, A, s->dArgs.p, true, s->shFormat, s->rgbaFormat, ctr, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p,
+                  s->rect.p, F.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride);
+    if(withEvents) HIPCHK(hipEventRecord(fev[1], st));
+    static const bool kFuseRect = [] { const char* e = std::getenv("MGS_FUSE_RECT"); return e ? std::atoi(e) != 0 : false; }();  // measured: +43 us in the scatter for -17 us in the count kernel
+    const bool direct0 = directBinningSupported(F.binsX, F.binsY);
+    if(!cpuMode)
+      keySort(s, st, kFuseRect && direct0);
+    else
+    {
+      rc = cpuSortStep(s, p, p->cpu_sort_blocking != 0);
+      if(rc != MGS_OK)
+        return rc;
+      if(s->cpuHaveIndices && s->cpuIndices.size() == s->totalSplats)
+      {
+        s->cpuStorageIds = s->cpuIndices;  // the sorter works in the caller's id space
+        mapIdsToStorage(s, s->cpuStorageIds.data(), s->cpuStorageIds.size());
+        HIPCHK(hipMemcpyAsync(s->idsA.p, s->cpuStorageIds.data(), (size_t)s->totalSplats * 4, hipMemcpyHostToDevice, st));
+      }
+      else  // no result yet: the reference draws with whatever the index buffer holds; we use identity order
+        hipLaunchKernelGGL(k_iota_u32, dim3(1024), dim3(256), 0, st, s->idsA.p, s->totalSplats);
+      hipLaunchKernelGGL(k_set_plan_n, dim3(1), dim3(1), 0, st, planK, ctr, s->totalSplats);
+    }
+    if(withEvents) HIPCHK(hipEventRecord(fev[2], st));
+    // coarse bins (the default): stable multi-split straight into the per-bin lists, no records, no pair sort
+    static const bool kDirectBin = [] { const char* e = std::getenv("MGS_DIRECT_BIN"); return e ? std::atoi(e) != 0 : true; }();
+    const bool direct = kDirectBin && directBinningSupported(F.binsX, F.binsY);
+    if(direct)
+    {
+      // the (idle) record buffer of the fallback path holds the bit masks: 64 x 8 B per 256 sorted splats at most
+      launchDirectBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, s->sortedRect.p, reinterpret_cast<uint64_t*>(s->pairKey0.p), s->totalSplats,
+                          s->partHist.p, s->pStride, &planP->ghist[0][0], s->pairVal1.p, s->ranges.p, ctr, s->pairCapacity,
+                          F.binsX, F.binsY);
+      if(withEvents) HIPCHK(hipEventRecord(fev[3], st));
+    }
+    else
+    {
+      launchBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, s->blockCount.p, (s->totalSplats + kPart - 1) / kPart, ctr,
+                    s->sortedRect.p, s->splatOffset.p, s->chunkStart.p, s->pairKey0.p, s->pairVal0.p, s->pairCapacity, F.binsX, true);
+      if(withEvents) HIPCHK(hipEventRecord(fev[3], st));
+      {
+        SortLaunch L{};
+        L.keys0 = s->pairKey0.p;
+        L.vals0 = s->pairVal0.p;
+        L.keysX = s->pairKey1.p;
+        L.valsX = s->pairVal1.p;
+        L.keysY = s->pairKey0.p;
+        L.valsY = s->pairVal0.p;
+        L.slotCount = nullptr;
+        L.nPtr      = &ctr->pairCount;
+        L.plan      = planP;
+        L.partHist  = s->partHist.p;
+        L.pStride   = s->pStride;
+        L.maxElems  = s->pairCapacity;
+        L.beginBit  = 0;
+        L.endBit    = pairSortBits((int)nTiles);
+        const bool onePass = L.endBit <= 8;  // <= 256 bins: the digit histogram IS the range table
+        L.ranges    = onePass ? s->ranges.p : nullptr;
+        launchRadixSort(st, L);
+        if(!onePass)
+          launchTileRanges(st, s->pairKey1.p, s->pairKey0.p, planP, s->ranges.p);
+      }
+    }
+    if(withEvents) HIPCHK(hipEventRecord(fev[4], st));
+    launchComposite(st, A, s->dArgs.p, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat, ctr,
+                    F.surfaceOutputs ? s->surfDepth.p : nullptr, F.surfaceOutputs ? s->surfId.p : nullptr);
+    if(withEvents) HIPCHK(hipEventRecord(fev[5], st));
+    return MGS_OK;
+  };
+  // The frame is 18 dependent launches; on the submitting thread that is ~0.15 ms of API calls.  A frame whose
+  // launch sequence does not depend on host-side data (GPU sort, no per-stage events) is captured ONCE per
+  // (resolution, strip, mode) into a hipGraph and replayed: the kernels read everything that changes from frame to
+  // frame through dArgs.  MGS_GRAPH=0 forces plain launches.
+  static const bool kUseGraph = [] { const char* e = std::getenv("MGS_GRAPH"); return e ? std::atoi(e) != 0 : true; }();
+  bool launched = false;
+  if(kUseGraph && s->graphOk && !timed && !cpuModeOuter)
   {
-    rc = cpuSortStep(s, p, p->cpu_sort_blocking != 0);
+    MgsScene_t::GraphKey key;
+    std::memset(&key, 0, sizeof(key));
+    const int32_t kv[12] = {F.width, F.height, F.stripRow0, F.stripRow1, F.binShiftX, F.binShiftY, F.partitionCull, F.alphaMode,
+                            F.debugFlags & 4, F.surfaceOutputs, half ? 1 : 0, F.nInstances};
+    std::memcpy(key.v, kv, sizeof(kv));
+    key.p[0] = s->image.p;
+    key.p[1] = s->surfDepth.p;
+    auto it = s->graphs.find(key);
+    if(it == s->graphs.end())
+    {
+      hipGraph_t     graph = nullptr;
+      hipGraphExec_t exec  = nullptr;
+      bool           ok    = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      if(ok)
+      {
+        const int rcI = issue(false);
+        ok            = (hipStreamEndCapture(st, &graph) == hipSuccess) && rcI == MGS_OK && graph != nullptr;
+      }
+      if(ok)
+        ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      if(graph)
+        (void)hipGraphDestroy(graph);
+      if(ok)
+        it = s->graphs.emplace(key, exec).first;
+      else
+      {
+        (void)hipGetLastError();
+        s->graphOk = false;  // this runtime cannot capture the frame: stay with plain launches
+      }
+    }
+    if(it != s->graphs.end())
+    {
+      HIPCHK(hipGraphLaunch(it->second, st));
+      launched = true;
+    }
+  }
+  if(!launched)
+  {
+    rc = issue(timed);
     if(rc != MGS_OK)
       return rc;
-    if(s->cpuHaveIndices && s->cpuIndices.size() == s->totalSplats)
-    {
-      s->cpuStorageIds = s->cpuIndices;  // the sorter works in the caller's id space
-      mapIdsToStorage(s, s->cpuStorageIds.data(), s->cpuStorageIds.size());
-      HIPCHK(hipMemcpyAsync(s->idsA.p, s->cpuStorageIds.data(), (size_t)s->totalSplats * 4, hipMemcpyHostToDevice, st));
-    }
-    else  // no result yet: the reference draws with whatever the index buffer holds; we use identity order
-      hipLaunchKernelGGL(k_iota_u32, dim3(1024), dim3(256), 0, st, s->idsA.p, s->totalSplats);
-    hipLaunchKernelGGL(k_set_plan_n, dim3(1), dim3(1), 0, st, planK, ctr, s->totalSplats);
   }
-  if(timed) HIPCHK(hipEventRecord(fev[2], st));
-  // coarse bins (the default): stable multi-split straight into the per-bin lists, no records, no pair sort
-  static const bool kDirectBin = [] { const char* e = std::getenv("MGS_DIRECT_BIN"); return e ? std::atoi(e) != 0 : true; }();
-  const bool direct = kDirectBin && directBinningSupported(F.binsX, F.binsY);
-  if(direct)
-  {
-    // the (idle) record buffer of the fallback path holds the bit masks: 64 x 8 B per 256 sorted splats at most
-    launchDirectBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, s->sortedRect.p, reinterpret_cast<uint64_t*>(s->pairKey0.p), s->totalSplats,
-                        s->partHist.p, s->pStride, &planP->ghist[0][0], s->pairVal1.p, s->ranges.p, ctr, s->pairCapacity,
-                        F.binsX, F.binsY);
-    if(timed) HIPCHK(hipEventRecord(fev[3], st));
-  }
-  else
-  {
-    launchBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, s->blockCount.p, (s->totalSplats + kPart - 1) / kPart, ctr,
-                  s->sortedRect.p, s->splatOffset.p, s->chunkStart.p, s->pairKey0.p, s->pairVal0.p, s->pairCapacity, F.binsX, true);
-    if(timed) HIPCHK(hipEventRecord(fev[3], st));
-    {
-      SortLaunch L{};
-      L.keys0 = s->pairKey0.p;
-      L.vals0 = s->pairVal0.p;
-      L.keysX = s->pairKey1.p;
-      L.valsX = s->pairVal1.p;
-      L.keysY = s->pairKey0.p;
-      L.valsY = s->pairVal0.p;
-      L.slotCount = nullptr;
-      L.nPtr      = &ctr->pairCount;
-      L.plan      = planP;
-      L.partHist  = s->partHist.p;
-      L.pStride   = s->pStride;
-      L.maxElems  = s->pairCapacity;
-      L.beginBit  = 0;
-      L.endBit    = pairSortBits((int)nTiles);
-      const bool onePass = L.endBit <= 8;  // <= 256 bins: the digit histogram IS the range table
-      L.ranges    = onePass ? s->ranges.p : nullptr;
-      launchRadixSort(st, L);
-      if(!onePass)
-        launchTileRanges(st, s->pairKey1.p, s->pairKey0.p, planP, s->ranges.p);
-    }
-  }
-  if(timed) HIPCHK(hipEventRecord(fev[4], st));
-  launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat, ctr,
-                  F.surfaceOutputs ? s->surfDepth.p : nullptr, F.surfaceOutputs ? s->surfId.p : nullptr);
-  if(timed) HIPCHK(hipEventRecord(fev[5], st));
   // the counters stay on the device; mgs_frame_stats fetches them when somebody asks (two API calls per frame less
   // on the submitting thread, which spends ~6 us per call)
   HIPCHK(hipGetLastError());
@@ -1523,13 +1597,16 @@ int mgs_sort_keys(MgsScene s, const MgsFrameParams* p, MgsSortOut* out)
     return rc;
   hipStream_t st = s->stream;
   if((rc = s->ranges.ensure(1))) return rc;
+  if((rc = s->dArgs.ensure(1))) return rc;
+  HIPCHK(hipMemcpyAsync(s->dArgs.p, &A, sizeof(FrameArgs), hipMemcpyHostToDevice, st));
   HIPCHK(hipEventRecord(s->ev[0], st));
   if(A.f.partitionCull && s->totalParts > 0)
-    launchPartitionCull(st, A, s->partSkip.p, reinterpret_cast<uint32_t*>(s->ctr.p), (uint32_t)(sizeof(FrameCounters) / 4),
-                        reinterpret_cast<uint32_t*>(s->plans.p), (uint32_t)(2 * sizeof(SortPlan) / 4), nullptr, 0u);
+    launchPartitionCull(st, A, s->dArgs.p, s->partSkip.p, reinterpret_cast<uint32_t*>(s->ctr.p),
+                        (uint32_t)(sizeof(FrameCounters) / 4), reinterpret_cast<uint32_t*>(s->plans.p),
+                        (uint32_t)(2 * sizeof(SortPlan) / 4), nullptr, 0u);
   else
     launchFrameInit(st, s->ctr.p, &s->plans.p[0], &s->plans.p[1], s->ranges.p, 0);
-  launchProject(st, A, false, 0, 0, s->ctr.p, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p, s->rect.p,
+  launchProject(st, A, s->dArgs.p, false, 0, 0, s->ctr.p, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p, s->rect.p,
                 A.f.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride);
   HIPCHK(hipEventRecord(s->ev[1], st));
   keySort(s, st, false);
