@@ -1212,6 +1212,7 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
   const size_t      pixB   = half ? 8 : 16;
   s->imageRowBytes         = (size_t)F.width * pixB;
   s->imageBytes            = s->imageRowBytes * (size_t)F.height;
+  const void* before[4] = {s->ranges.p, s->image.p, s->surfDepth.p, s->surfId.p};
   if((rc = s->ranges.ensure(std::max<uint32_t>(nTiles, 256u)))) return rc;
   if(s->image.n < s->imageBytes)
   {
@@ -1224,6 +1225,16 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
     if((rc = s->surfId.ensure((size_t)F.width * F.height))) return rc;
   }
   s->haveSurface    = F.surfaceOutputs != 0;
+  {
+    const void* after[4] = {s->ranges.p, s->image.p, s->surfDepth.p, s->surfId.p};
+    if(std::memcmp(before, after, sizeof(before)) != 0 && !s->graphs.empty())
+    {  // a buffer moved: captured frames point at the old one
+      HIPCHK(hipStreamSynchronize(s->stream));
+      for(auto& g : s->graphs)
+        (void)hipGraphExecDestroy(g.second);
+      s->graphs.clear();
+    }
+  }
   hipStream_t st    = s->stream;
   const bool  timed = p->collect_timings != 0;
   FrameCounters* ctr = s->ctr.p;
