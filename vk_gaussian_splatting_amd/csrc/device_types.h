@@ -71,6 +71,29 @@ struct FrameArgs
   InstanceConst inst[kMaxInlineInstances];
 };
 
+// What the compositor needs besides the lists: screen geometry, mode knobs and the SH table of the instances.  All of
+// it is constant for a captured frame graph (it is part of the graph's key, or scene state that a commit
+// invalidates), so it travels BY VALUE: kernel arguments are preloaded into SGPRs, while reading the same fields through
+// the per-frame FrameArgs pointer cost the compositor 10 us (an extra dependent scalar load at every workgroup start).
+struct CompositeArgs
+{
+  int32_t width, height;
+  int32_t tilesX;
+  int32_t binShiftX, binShiftY;
+  int32_t binsX, binsY;
+  int32_t stripRow0, stripRow1;
+  int32_t nInstances;
+  int32_t shDegree;
+  int32_t looseMask;          // A/B knob (MGS_LOOSE_MASK)
+  float   depthIsoThreshold;
+  struct Inst
+  {
+    const void* sh;
+    uint32_t    globalOffset;
+    int32_t     shDegree;
+  } inst[kMaxInlineInstances];
+};
+
 // projected splat record consumed by the compositor (64 B = one sector, 16-B aligned)
 struct alignas(16) SplatRec
 {

@@ -8,6 +8,8 @@
 // The reference blends back-to-front ("over"); we walk the same order from the other end and
 // accumulate front-to-back with transmittance, which is the same sum in exact arithmetic:
 //   C = sum_i c_i a_i prod_{j nearer than i} (1 - a_j).
+#include <cstring>
+
 #include "kernels_common.h"
 #include "sh_eval.h"
 #include "sort_plan.h"
@@ -617,14 +619,12 @@ constexpr bool surf_lds(int mode) { return (mode & 4) != 0; }
 #define MGS_CMP_WAVES 5
 #endif
 template <int MODE, int SHF>
-__global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const FrameArgs* __restrict__ Ap, const uint2* __restrict__ ranges,
+__global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const CompositeArgs F, const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ valX, const uint32_t* __restrict__ valY,
                                                    const SortPlan* __restrict__ plan, const SplatRec* __restrict__ rec,
                                                    void* __restrict__ outImage, int halfOut, FrameCounters* __restrict__ ctr,
                                                    float* __restrict__ outDepth, uint32_t* __restrict__ outSplatId)
 {
-  const FrameArgs&  A = *Ap;  // frame constants live in device memory (same pointer every frame: graph-replayable)
-  const FrameConst& F = A.f;
   uint32_t statStaged = 0, statScanned = 0;
   __shared__ float4   s_a[kCmpCap];  // cx, cy, ex, ey
   __shared__ float4   s_b[kCmpCap];  // p1, p2 (scaled by sqrt(log2 e))
@@ -789,7 +789,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const FrameArg
               const float mx = bcx + ((qd & 1) ? 8.0f : -8.0f) - a[k].x, my = bcy + ((qd & 2) ? 4.0f : -4.0f) - a[k].y;
               const float ds = fmaxf(fabsf(mx * sb.x + my * sb.y) - rs, 0.0f), du = fmaxf(fabsf(mx * sb.z + my * sb.w) - ru, 0.0f);
               const bool  box = ((qd & 1) ? xr : xl) && ((qd & 2) ? yb : yt);
-              qm |= (box && (ds * ds + du * du <= qLim || (F.debugFlags & 256))) ? (1u << qd) : 0u;
+              qm |= (box && (ds * ds + du * du <= qLim || F.looseMask)) ? (1u << qd) : 0u;
             }
             s_m[pos] = (uint8_t)qm;
           }
@@ -816,9 +816,9 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const FrameArg
       const uint32_t gid = __float_as_uint(dd.w);
       int            ki  = 0;
       for(int i = 1; i < F.nInstances; ++i)
-        if(gid >= A.inst[i].globalOffset)
+        if(gid >= F.inst[i].globalOffset)
           ki = i;
-      const InstanceConst& I   = A.inst[ki];
+      const CompositeArgs::Inst& I = F.inst[ki];
       const int            deg = (I.sh == nullptr) ? 0 : min(I.shDegree, F.shDegree);
       if(deg > 0)
       {
@@ -980,7 +980,7 @@ void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* 
   hipLaunchKernelGGL(k_tile_ranges, dim3(4096), dim3(256), 0, stream, keyX, keyY, planPairs, ranges);
 }
 
-void launchComposite(hipStream_t stream, const FrameArgs& A, const FrameArgs* dArgs, const uint2* ranges, const uint32_t* valX,
+void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
                      const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, bool halfOut,
                      int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId)
 {
@@ -992,8 +992,21 @@ void launchComposite(hipStream_t stream, const FrameArgs& A, const FrameArgs* dA
   const int nBins   = F.binsX * F.binsY;
   const int per     = ((nBins + 7) / 8) * (1 << (F.binShiftX - 1 + F.binShiftY));  // workgroups per XCD
   const int mode = (F.alphaMode != 0 ? 1 : 0) | ((F.debugFlags & 4) ? 2 : 0) | (F.surfaceOutputs ? 4 : 0);
+  CompositeArgs C;
+  std::memset(&C, 0, sizeof(C));
+  C.width = F.width; C.height = F.height; C.tilesX = F.tilesX;
+  C.binShiftX = F.binShiftX; C.binShiftY = F.binShiftY; C.binsX = F.binsX; C.binsY = F.binsY;
+  C.stripRow0 = F.stripRow0; C.stripRow1 = F.stripRow1;
+  C.nInstances = F.nInstances; C.shDegree = F.shDegree; C.looseMask = (F.debugFlags & 256) ? 1 : 0;
+  C.depthIsoThreshold = F.depthIsoThreshold;
+  for(int i = 0; i < F.nInstances && i < kMaxInlineInstances; ++i)
+  {
+    C.inst[i].sh           = A.inst[i].sh;
+    C.inst[i].globalOffset = A.inst[i].globalOffset;
+    C.inst[i].shDegree     = A.inst[i].shDegree;
+  }
 #define MGS_CMP(M, S)                                                                                                  \
-  hipLaunchKernelGGL((k_composite<M, S>), dim3(per * 8), dim3(256), 0, stream, dArgs, ranges, valX, valY, planPairs, rec, image, \
+  hipLaunchKernelGGL((k_composite<M, S>), dim3(per * 8), dim3(256), 0, stream, C, ranges, valX, valY, planPairs, rec, image, \
                      halfOut ? 1 : 0, ctr, outDepth, outSplatId)
 #define MGS_CMP_FMT(M)                                                                                                 \
   switch(shFormat)                                                                                                     \

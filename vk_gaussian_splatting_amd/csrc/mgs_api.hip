@@ -47,7 +47,7 @@ void launchDirectBinning(hipStream_t stream, const uint32_t* idsX, const uint32_
                          int binsX, int binsY);
 void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* keyY, const SortPlan* planPairs,
                       uint2* ranges);
-void launchComposite(hipStream_t stream, const FrameArgs& A, const FrameArgs* dArgs, const uint2* ranges, const uint32_t* valX,
+void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
                      const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, bool halfOut,
                      int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId);
 constexpr uint32_t kPart = 2048;  // == kPrjPart == kSortPart == kBinPart
@@ -241,7 +241,7 @@ struct MgsScene_t
                                      // this pointer, so a captured frame graph replays with nothing but a 5 KB upload
   struct GraphKey
   {
-    int32_t v[12];
+    int32_t v[16];
     const void* p[2];
     bool operator<(const GraphKey& o) const { return std::memcmp(this, &o, sizeof(*this)) < 0; }
   };
@@ -1323,7 +1323,7 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
       }
     }
     if(withEvents) HIPCHK(hipEventRecord(fev[4], st));
-    launchComposite(st, A, s->dArgs.p, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat, ctr,
+    launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat, ctr,
                     F.surfaceOutputs ? s->surfDepth.p : nullptr, F.surfaceOutputs ? s->surfId.p : nullptr);
     if(withEvents) HIPCHK(hipEventRecord(fev[5], st));
     return MGS_OK;
@@ -1338,8 +1338,11 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
   {
     MgsScene_t::GraphKey key;
     std::memset(&key, 0, sizeof(key));
-    const int32_t kv[12] = {F.width, F.height, F.stripRow0, F.stripRow1, F.binShiftX, F.binShiftY, F.partitionCull, F.alphaMode,
-                            F.debugFlags & 4, F.surfaceOutputs, half ? 1 : 0, F.nInstances};
+    int32_t isoBits;
+    std::memcpy(&isoBits, &F.depthIsoThreshold, 4);
+    // everything the compositor receives by value (CompositeArgs) must be part of the key
+    const int32_t kv[16] = {F.width, F.height, F.stripRow0, F.stripRow1, F.binShiftX, F.binShiftY, F.partitionCull, F.alphaMode,
+                            F.debugFlags & (4 | 256), F.surfaceOutputs, half ? 1 : 0, F.nInstances, F.shDegree, isoBits, 0, 0};
     std::memcpy(key.v, kv, sizeof(kv));
     key.p[0] = s->image.p;
     key.p[1] = s->surfDepth.p;
