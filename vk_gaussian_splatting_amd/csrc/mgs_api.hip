@@ -237,6 +237,7 @@ struct MgsScene_t
   // frame buffers
   DevBuf<uint32_t>      keysSlot, idsSlot, slotCount, keysA, idsA, keysB, idsB, rect, partHist, blockCount;
   DevBuf<uint32_t>      sortedRect, splatOffset, chunkStart, partSkip;
+  DevBuf<uint64_t>      dbinMasks;
   DevBuf<FrameArgs>     dArgs;       // this frame's constants (view/proj, instances, knobs): the kernels read them through
                                      // this pointer, so a captured frame graph replays with nothing but a 5 KB upload
   struct GraphKey
@@ -452,7 +453,7 @@ void mgs_scene_destroy(MgsScene s)
   s->keysB.release(); s->idsB.release(); s->rect.release(); s->partHist.release(); s->blockCount.release();
   s->rec.release(); s->pairKey0.release(); s->pairVal0.release(); s->pairKey1.release(); s->pairVal1.release();
   s->sortedRect.release(); s->splatOffset.release(); s->chunkStart.release(); s->partSkip.release();
-  s->surfDepth.release(); s->surfId.release(); s->dArgs.release();
+  s->surfDepth.release(); s->surfId.release(); s->dArgs.release(); s->dbinMasks.release();
   for(auto& g : s->graphs) (void)hipGraphExecDestroy(g.second);
   s->graphs.clear();
   s->ranges.release(); s->image.release(); s->ctr.release(); s->plans.release(); s->cpuDistDev.release();
@@ -747,7 +748,6 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
   if((rc = s->rect.ensure(total))) return rc;
   if((rc = s->rec.ensure(total))) return rc;
   if((rc = s->sortedRect.ensure(total))) return rc;
-  if((rc = s->splatOffset.ensure(total))) return rc;
   if((rc = s->ctr.ensure(1))) return rc;
   if((rc = s->plans.ensure(2))) return rc;
 
@@ -756,11 +756,10 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
     cap = std::strtoull(e, nullptr, 10);
   cap = std::min<uint64_t>(std::max<uint64_t>(cap, kPart), 0xFFFFF000ull);
   s->pairCapacity = (uint32_t)cap;
-  if((rc = s->pairKey0.ensure(cap))) return rc;
-  if((rc = s->pairVal0.ensure(cap))) return rc;
-  if((rc = s->pairKey1.ensure(cap))) return rc;
-  if((rc = s->pairVal1.ensure(cap))) return rc;
-  if((rc = s->chunkStart.ensure(cap / kPart + 4))) return rc;
+  if((rc = s->pairVal1.ensure(cap))) return rc;  // the per-bin lists
+  // bit masks handed from k_dbin_count to k_dbin_emit: <= 64 x 8 B per 64 sorted splats
+  if((rc = s->dbinMasks.ensure(((size_t)total / 1024 + 1) * 16 * 64))) return rc;
+  // the record path's buffers (16 B per record + per-splat offsets) are allocated when a frame first needs them
   const uint64_t maxParts = std::max<uint64_t>((cap + kPart - 1) / kPart, std::max<uint64_t>(parts, (total + 1023) / 1024 + 1));  // direct binning scans rows of 1024-splat chunks
   s->pStride              = (uint32_t)maxParts;
   if((rc = s->partHist.ensure(256ull * maxParts))) return rc;
@@ -1224,6 +1223,18 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
     if((rc = s->surfDepth.ensure((size_t)F.width * F.height))) return rc;
     if((rc = s->surfId.ensure((size_t)F.width * F.height))) return rc;
   }
+  {
+    static const bool kDirectBin0 = [] { const char* e = std::getenv("MGS_DIRECT_BIN"); return e ? std::atoi(e) != 0 : true; }();
+    if(!(kDirectBin0 && directBinningSupported(F.binsX, F.binsY)) && s->pairKey0.n < s->pairCapacity)
+    {  // first frame on the record + pair-sort path (> 256 bins, or forced): its buffers
+      const uint64_t cap = s->pairCapacity;
+      if((rc = s->pairKey0.ensure(cap))) return rc;
+      if((rc = s->pairVal0.ensure(cap))) return rc;
+      if((rc = s->pairKey1.ensure(cap))) return rc;
+      if((rc = s->chunkStart.ensure(cap / kPart + 4))) return rc;
+      if((rc = s->splatOffset.ensure(s->totalSplats))) return rc;
+    }
+  }
   s->haveSurface    = F.surfaceOutputs != 0;
   {
     const void* after[4] = {s->ranges.p, s->image.p, s->surfDepth.p, s->surfId.p};
@@ -1288,8 +1299,7 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
     const bool direct = kDirectBin && directBinningSupported(F.binsX, F.binsY);
     if(direct)
     {
-      // the (idle) record buffer of the fallback path holds the bit masks: 64 x 8 B per 256 sorted splats at most
-      launchDirectBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, s->sortedRect.p, reinterpret_cast<uint64_t*>(s->pairKey0.p), s->totalSplats,
+      launchDirectBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, s->sortedRect.p, s->dbinMasks.p, s->totalSplats,
                           s->partHist.p, s->pStride, &planP->ghist[0][0], s->pairVal1.p, s->ranges.p, ctr, s->pairCapacity,
                           F.binsX, F.binsY);
       if(withEvents) HIPCHK(hipEventRecord(fev[3], st));
