@@ -613,6 +613,31 @@ def test_frame_statistics_are_consistent(scene_small):
     assert a.scanned_entries <= a.tile_pairs * 64 * 4
 
 
+def test_bench_prints_one_strict_json_line_with_the_contract_keys():
+    """bench.py is the driver's measurement hook: one strict-JSON line carrying the contract's keys"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "2",
+                          "--splats", "300000"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0], parse_constant=lambda c: pytest.fail(f"non-strict JSON constant {c}"))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2 and d["value"] > 0 and d["higher_is_better"] is True
+    assert "workload" in d["config"] and d["vs_baseline"] is None and d["data"] == "synthetic"
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert d["roofline"]["bound"] in ("hbm", "mfma") and 0 < d["roofline"]["frac"] < 1
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert d["error_flags"] == 0
+
+
 def test_api_error_behaviour():
     scene = mgs.Scene(0)
     p = capi.default_params(64, 64)
