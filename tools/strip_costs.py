@@ -1,4 +1,5 @@
-"""scratch: per-strip counts"""
+"""per-strip counts and stage times of the tile-row strip partition, rendered one strip at a time on one GPU:
+python tools/strip_costs.py [W H [G]]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
