@@ -638,6 +638,40 @@ def test_bench_prints_one_strict_json_line_with_the_contract_keys():
     assert d["error_flags"] == 0
 
 
+def test_cpp_caller_renders_the_same_frame(tmp_path):
+    """examples/mgs_render (C++ against include/mgs.h, no Python in the call path) == the ctypes path, pixel for pixel"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "mgs_render")
+    if not os.path.exists(exe):
+        assert subprocess.run(["make", "-C", os.path.join(root, "examples")]).returncode == 0
+    sc = synth.make_scene(30000, seed=4)
+    ply = str(tmp_path / "s.ply")
+    synth.write_ply(ply, sc)
+    W, H = 320, 200
+    r = subprocess.run([exe, ply, str(tmp_path / "o.ppm"), str(W), str(H), "1.7", "1.5", "1.7", "2"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(tmp_path / "o.ppm", "rb").read()
+    head = f"P6\n{W} {H}\n255\n".encode()
+    assert raw.startswith(head) and len(raw) == len(head) + W * H * 3
+    ppm = np.frombuffer(raw[len(head):], np.uint8).reshape(H, W, 3)
+    ss = mgs.SplatSet.load(ply)
+    scene = mgs.Scene(0)
+    scene.add_instance(ss)
+    M, _ = mgs.compute_transform([1, 1, 1], [0, 0, 0], [3.0, 0, 0])
+    scene.add_instance(ss, M)
+    scene.commit(2, 2)
+    eye = [1.7, 1.5, 1.7]
+    V, P = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, W, H)
+    p = capi.default_params(W, H)
+    capi.set_camera(p, V, P, eye)
+    scene.render(p)
+    img = np.clip(scene.download_frame(p).astype(np.float32)[..., :3], 0, 1)
+    assert np.array_equal((img * 255.0 + 0.5).astype(np.uint8), ppm)
+    scene.close()
+
+
 def test_api_error_behaviour():
     scene = mgs.Scene(0)
     p = capi.default_params(64, 64)

@@ -245,3 +245,13 @@ def test_vkgs_project_roundtrip(tmp_path):
     (tmp_path / "legacy.vkgs").write_text(json.dumps(legacy))
     pl = project.load_project(str(tmp_path / "legacy.vkgs"))
     assert pl.version == 0 and pl.splat_sets == {0: str(tmp_path / "a.ply")} and pl.instances[0].name == "old"
+
+
+def test_cpp_caller_builds_against_the_header_and_prints_usage():
+    """examples/mgs_render.cpp: a plain C++ caller of include/mgs.h (what a maintainer of the C++ reference would write)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "examples")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([os.path.join(root, "examples", "mgs_render")], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage:" in r.stderr and "gfx950" in r.stderr
