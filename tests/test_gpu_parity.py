@@ -363,10 +363,42 @@ def test_eight_instances_trs_unified_sort_and_4k(ob):
     # low-resolution 4K consistency: the 4K frame box-filtered to 480x270 resembles the 480x270 frame
     lo = full.view(np.float16).astype(np.float32).reshape(270, 8, 480, 8, 4).mean(axis=(1, 3))
     assert ob.psnr_rgb(lo, img) >= 25.0
-    for _ in range(8):
-        scene.add_instance(ss)     # up to 16 instances travel in the kernel-argument block
+    scene.close()
+
+
+def test_forty_instances_beyond_the_inline_table(ob):
+    """more instances than the 16 the compositor carries by value: the projection walks the device-resident instance
+    table, the compositor binary-searches its SH table; the limit of this build is 256"""
+    sc = synth.make_scene(1500, seed=9)
+    ss = mgs.SplatSet.from_arrays(**sc)
+    scene = mgs.Scene(0)
+    mats = []
+    for k in range(40):
+        M, _ = mgs.compute_transform([0.5 + 0.01 * k] * 3, [7.0 * k, 13.0 * k, 0.0], [(k % 8) * 1.6 - 5.6, 0.3 * (k % 3), (k // 8) * 1.8 - 3.6])
+        mats.append(M)
+        scene.add_instance(ss, M)
+    scene.commit()
+    assert scene.splat_count == 60000
+    W, H = 480, 270
+    eye = np.array([7.0, 4.0, 8.0], np.float32)
+    V, P = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, W, H)
+    p = capi.default_params(W, H)
+    capi.set_camera(p, V, P, eye)
+    fk = dict(view=V, proj=P, camera_pos=eye, width=W, height=H)
+    oks, ois = oracle_sorted_stream(ob, scene, sc, fk, transforms=tuple(mats))
+    so = scene.sort_keys(p)
+    gk, gi = scene.sort_download(so.count)
+    assert np.array_equal(gk, oks) and np.array_equal(gi, ois)
+    out = scene.render(p, want_stats=True)
+    img = scene.download_frame(p).astype(np.float32)
+    ps = ob.PreparedSet(sc)
+    oimg, st = ob.render(ob.make_frame(V, P, eye, W, H, target_fp16=1), ob.make_instances([(ps, m) for m in mats]), order=ois)
+    assert out.error_flags == 0 and out.frustum_count == st["visible"]
+    assert ob.psnr_rgb(img, oimg) >= PSNR_MIN
+    for _ in range(256 - 40):
+        scene.add_instance(ss)
     with pytest.raises(mgs.MgsError) as e:
-        scene.add_instance(ss)     # a 17th: MGS_ERR_UNSUPPORTED in this build (kMaxInlineInstances)
+        scene.add_instance(ss)     # a 257th: MGS_ERR_UNSUPPORTED in this build (kMaxInstances)
     assert e.value.code == -8
     scene.close()
 

@@ -4,7 +4,8 @@
 
 namespace mgs {
 
-constexpr int kMaxInlineInstances = 16;  // instances carried by value in the kernel argument block (16 x 208 B + frame < 4 KB)
+constexpr int kMaxInstances       = 256;  // instances per scene: FrameArgs lives in device memory, only the used part is uploaded
+constexpr int kMaxInlineInstances = 16;   // SH-table entries the compositor carries by value; larger scenes read a device table
 constexpr int kTilePx             = 16;  // compositing tile edge in pixels (one workgroup; 8x8 pixels per wave)
 
 // error bits reported through MgsFrameOut.error_flags
@@ -68,7 +69,7 @@ struct FrameConst
 struct FrameArgs
 {
   FrameConst    f;
-  InstanceConst inst[kMaxInlineInstances];
+  InstanceConst inst[kMaxInstances];
 };
 
 // What the compositor needs besides the lists: screen geometry, mode knobs and the SH table of the instances.  All of
@@ -92,6 +93,7 @@ struct CompositeArgs
     uint32_t    globalOffset;
     int32_t     shDegree;
   } inst[kMaxInlineInstances];
+  const Inst* instTable;      // all instances (device memory, rebuilt at commit); used when nInstances > kMaxInlineInstances
 };
 
 // projected splat record consumed by the compositor (64 B = one sector, 16-B aligned)

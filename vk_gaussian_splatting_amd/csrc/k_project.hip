@@ -260,9 +260,8 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   const int      t = threadIdx.x, lane = laneId(), w = t >> 6;
   const uint32_t part = blockIdx.x;
   int            k    = 0;
-#pragma unroll
-  for(int i = 1; i < kMaxInlineInstances; ++i)
-    if(i < A.f.nInstances && part >= A.inst[i].blockBegin)
+  for(int i = 1; i < A.f.nInstances; ++i)  // instances own consecutive partition ranges
+    if(part >= A.inst[i].blockBegin)
       k = i;
   const InstanceConst& I      = A.inst[k];
   const uint32_t       local0 = (part - I.blockBegin) * kPrjPart;
@@ -454,9 +453,8 @@ __global__ __launch_bounds__(256) void k_partition_cull(const FrameArgs* __restr
   if(part >= A.f.totalPartitions)
     return;
   int k = 0;
-#pragma unroll
-  for(int i = 1; i < kMaxInlineInstances; ++i)
-    if(i < A.f.nInstances && part >= A.inst[i].blockBegin)
+  for(int i = 1; i < A.f.nInstances; ++i)
+    if(part >= A.inst[i].blockBegin)
       k = i;
   const InstanceConst& I  = A.inst[k];
   const float*         bx = I.partBox + 8 * (size_t)(part - I.blockBegin);

@@ -814,11 +814,26 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
     {
       const float4   dd  = s_d[j];
       const uint32_t gid = __float_as_uint(dd.w);
-      int            ki  = 0;
-      for(int i = 1; i < F.nInstances; ++i)
-        if(gid >= F.inst[i].globalOffset)
-          ki = i;
-      const CompositeArgs::Inst& I = F.inst[ki];
+      CompositeArgs::Inst I = F.inst[0];
+      if(F.nInstances <= kMaxInlineInstances)
+      {
+        for(int i = 1; i < F.nInstances; ++i)
+          if(gid >= F.inst[i].globalOffset)
+            I = F.inst[i];
+      }
+      else
+      {  // many instances: binary search in the device table (ascending global offsets)
+        int lo = 0, hi2 = F.nInstances;
+        while(hi2 - lo > 1)
+        {
+          const int mid = (lo + hi2) >> 1;
+          if(gid >= F.instTable[mid].globalOffset)
+            lo = mid;
+          else
+            hi2 = mid;
+        }
+        I = F.instTable[lo];
+      }
       const int            deg = (I.sh == nullptr) ? 0 : min(I.shDegree, F.shDegree);
       if(deg > 0)
       {
@@ -982,7 +997,7 @@ void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* 
 
 void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
                      const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, bool halfOut,
-                     int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId)
+                     int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId, const void* instTable)
 {
   const FrameConst& F = A.f;
   if(F.stripRow1 <= F.stripRow0)
@@ -1005,6 +1020,7 @@ void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges
     C.inst[i].globalOffset = A.inst[i].globalOffset;
     C.inst[i].shDegree     = A.inst[i].shDegree;
   }
+  C.instTable = static_cast<const CompositeArgs::Inst*>(instTable);
 #define MGS_CMP(M, S)                                                                                                  \
   hipLaunchKernelGGL((k_composite<M, S>), dim3(per * 8), dim3(256), 0, stream, C, ranges, valX, valY, planPairs, rec, image, \
                      halfOut ? 1 : 0, ctr, outDepth, outSplatId)

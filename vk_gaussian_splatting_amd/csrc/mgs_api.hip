@@ -9,6 +9,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -49,7 +50,7 @@ void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* 
                       uint2* ranges);
 void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
                      const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, bool halfOut,
-                     int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId);
+                     int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId, const void* instTable);
 constexpr uint32_t kPart = 2048;  // == kPrjPart == kSortPart == kBinPart
 }  // namespace mgs
 
@@ -238,6 +239,7 @@ struct MgsScene_t
   DevBuf<uint32_t>      keysSlot, idsSlot, slotCount, keysA, idsA, keysB, idsB, rect, partHist, blockCount;
   DevBuf<uint32_t>      sortedRect, splatOffset, chunkStart, partSkip;
   DevBuf<uint64_t>      dbinMasks;
+  DevBuf<CompositeArgs::Inst> compInst;  // SH table of all instances for the compositor (scenes with > 16 instances)
   DevBuf<FrameArgs>     dArgs;       // this frame's constants (view/proj, instances, knobs): the kernels read them through
                                      // this pointer, so a captured frame graph replays with nothing but a 5 KB upload
   struct GraphKey
@@ -453,7 +455,7 @@ void mgs_scene_destroy(MgsScene s)
   s->keysB.release(); s->idsB.release(); s->rect.release(); s->partHist.release(); s->blockCount.release();
   s->rec.release(); s->pairKey0.release(); s->pairVal0.release(); s->pairKey1.release(); s->pairVal1.release();
   s->sortedRect.release(); s->splatOffset.release(); s->chunkStart.release(); s->partSkip.release();
-  s->surfDepth.release(); s->surfId.release(); s->dArgs.release(); s->dbinMasks.release();
+  s->surfDepth.release(); s->surfId.release(); s->dArgs.release(); s->dbinMasks.release(); s->compInst.release();
   for(auto& g : s->graphs) (void)hipGraphExecDestroy(g.second);
   s->graphs.clear();
   s->ranges.release(); s->image.release(); s->ctr.release(); s->plans.release(); s->cpuDistDev.release();
@@ -490,9 +492,9 @@ int mgs_instance_add(MgsScene s, MgsSplatSet set, const float m[16], int* id)
     setError("mgs_instance_add: null argument");
     return MGS_ERR_INVALID_ARG;
   }
-  if((int)s->instances.size() >= kMaxInlineInstances)
+  if((int)s->instances.size() >= kMaxInstances)
   {
-    setError("mgs_instance_add: at most " + std::to_string(kMaxInlineInstances) + " instances per scene in this build");
+    setError("mgs_instance_add: at most " + std::to_string(kMaxInstances) + " instances per scene in this build");
     return MGS_ERR_UNSUPPORTED;
   }
   int idx = -1;
@@ -764,6 +766,20 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
   s->pStride              = (uint32_t)maxParts;
   if((rc = s->partHist.ensure(256ull * maxParts))) return rc;
   if((rc = s->blockCount.ensure(std::max<uint64_t>((total + kPart - 1) / kPart, 1)))) return rc;
+  {  // the compositor's SH table of all instances (it carries the first 16 by value)
+    std::vector<CompositeArgs::Inst> tab(s->instances.size());
+    uint32_t                         off = 0;
+    for(size_t k = 0; k < s->instances.size(); ++k)
+    {
+      const DeviceSet& d  = s->sets[s->instances[k].set];
+      tab[k].sh           = d.sh;
+      tab[k].globalOffset = off;
+      tab[k].shDegree     = d.shDegree;
+      off += d.count;
+    }
+    if((rc = s->compInst.ensure(tab.size()))) return rc;
+    HIPCHK(hipMemcpy(s->compInst.p, tab.data(), tab.size() * sizeof(tab[0]), hipMemcpyHostToDevice));
+  }
   HIPCHK(hipMemset(s->ctr.p, 0, sizeof(FrameCounters)));
   HIPCHK(hipMemset(s->plans.p, 0, 2 * sizeof(SortPlan)));
   // hipMemset on device memory is asynchronous on the NULL stream, and the render stream is non-blocking:
@@ -1256,7 +1272,7 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
   const bool  cpuModeOuter = (p->sort_mode == MGS_SORT_CPU_ASYNC);
   // this frame's constants: a 5 KB upload (pageable source: staged by the runtime before the call returns)
   if((rc = s->dArgs.ensure(1))) return rc;
-  HIPCHK(hipMemcpyAsync(s->dArgs.p, &A, sizeof(FrameArgs), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(s->dArgs.p, &A, offsetof(FrameArgs, inst) + (size_t)A.f.nInstances * sizeof(InstanceConst), hipMemcpyHostToDevice, st));
   auto issue = [&](bool withEvents) -> int {
     if(withEvents) HIPCHK(hipEventRecord(fev[0], st));
     // per-frame device state: counters, both sort plans (adjacent), bin ranges.  The partition cull, when it runs, is
@@ -1334,7 +1350,7 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
     }
     if(withEvents) HIPCHK(hipEventRecord(fev[4], st));
     launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat, ctr,
-                    F.surfaceOutputs ? s->surfDepth.p : nullptr, F.surfaceOutputs ? s->surfId.p : nullptr);
+                    F.surfaceOutputs ? s->surfDepth.p : nullptr, F.surfaceOutputs ? s->surfId.p : nullptr, s->compInst.p);
     if(withEvents) HIPCHK(hipEventRecord(fev[5], st));
     return MGS_OK;
   };
@@ -1622,7 +1638,7 @@ int mgs_sort_keys(MgsScene s, const MgsFrameParams* p, MgsSortOut* out)
   hipStream_t st = s->stream;
   if((rc = s->ranges.ensure(1))) return rc;
   if((rc = s->dArgs.ensure(1))) return rc;
-  HIPCHK(hipMemcpyAsync(s->dArgs.p, &A, sizeof(FrameArgs), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(s->dArgs.p, &A, offsetof(FrameArgs, inst) + (size_t)A.f.nInstances * sizeof(InstanceConst), hipMemcpyHostToDevice, st));
   HIPCHK(hipEventRecord(s->ev[0], st));
   if(A.f.partitionCull && s->totalParts > 0)
     launchPartitionCull(st, A, s->dArgs.p, s->partSkip.p, reinterpret_cast<uint32_t*>(s->ctr.p),
