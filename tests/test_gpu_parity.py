@@ -366,6 +366,29 @@ def test_eight_instances_trs_unified_sort_and_4k(ob):
     scene.close()
 
 
+def test_8k_frame_properties(scene_small, ob):
+    """7680x4320 (512x512-px bins keep the direct binning) and the 8192 limit: finite, a strip equals the same rows of
+    the full frame bit for bit, and the frame box-filtered 16x resembles the 480x270 frame"""
+    scene, sc = scene_small
+    W, H = 7680, 4320
+    p, V, P, eye = camera(9, W, H)
+    o = scene.render(p, want_stats=True)
+    full = scene.download_frame(p).view(np.uint16).copy()
+    assert o.error_flags == 0 and np.isfinite(full.view(np.float16).astype(np.float32)).all() and full.any()
+    p.strip_row_begin, p.strip_row_end = 120, 200
+    scene.render(p)
+    part = scene.download_frame(p).view(np.uint16)
+    assert np.array_equal(part[120 * 16:200 * 16], full[120 * 16:200 * 16])
+    p2, _, _, _ = camera(9, 480, 270)
+    scene.render(p2)
+    small = scene.download_frame(p2).astype(np.float32)
+    lo = full.view(np.float16).astype(np.float32).reshape(270, 16, 480, 16, 4).mean(axis=(1, 3))
+    assert ob.psnr_rgb(lo, small) >= 25.0
+    p3, _, _, _ = camera(9, 8193, 100)
+    with pytest.raises(mgs.MgsError):
+        scene.render(p3)
+
+
 def test_forty_instances_beyond_the_inline_table(ob):
     """more instances than the 16 the compositor carries by value: the projection walks the device-resident instance
     table, the compositor binary-searches its SH table; the limit of this build is 256"""

@@ -973,9 +973,9 @@ static void mapIdsToStorage(MgsScene s, uint32_t* ids, size_t n)
 // ------------------------------------------------------------------------------------------------
 static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
 {
-  if(p->width <= 0 || p->height <= 0 || p->width > 4096 || p->height > 4096)
+  if(p->width <= 0 || p->height <= 0 || p->width > 8192 || p->height > 8192)
   {
-    setError("frame: width/height must be in [1,4096] (tile coordinates are 8-bit)");
+    setError("frame: width/height must be in [1,8192] (8-bit bin coordinates, bins of at least 32 pixels)");
     return MGS_ERR_INVALID_ARG;
   }
   std::memset(&A, 0, sizeof(A));
@@ -999,24 +999,30 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
   F.stripRow0       = r0;
   F.stripRow1       = r1;
   // bins: lists are built per (16<<shift)-pixel bin; the compositor culls per 16x16 tile on chip.
-  // Default 128x128 px (MGS_BIN_SHIFT="x,y" overrides, 0..4 each; measured sweep in DESIGN.md §3.3).
+  // Default 256x128 px (MGS_BIN_SHIFT="x,y" overrides, x 1..5, y 0..5; measured sweep in DESIGN.md §3.3).
   int bsx = 4, bsy = 3;  // 256x128 px
   if(const char* e = std::getenv("MGS_BIN_SHIFT"))
     std::sscanf(e, "%d,%d", &bsx, &bsy);
   else
   {  // keep the frame at <= 256 bins so that the direct (record-free) binning applies: 4K -> 256x128 px bins
-    while(((F.tilesX + (1 << bsx) - 1) >> bsx) * ((F.tilesY + (1 << bsy) - 1) >> bsy) > 256 && (bsx < 4 || bsy < 4))
+    // (8K UHD: 512x512 px bins)
+    while(((F.tilesX + (1 << bsx) - 1) >> bsx) * ((F.tilesY + (1 << bsy) - 1) >> bsy) > 256 && (bsx < 5 || bsy < 5))
     {
-      if(bsx <= bsy && bsx < 4)
+      if(bsx <= bsy && bsx < 5)
         ++bsx;
-      else if(bsy < 4)
+      else if(bsy < 5)
         ++bsy;
       else
         ++bsx;
     }
   }
-  bsx         = std::min(std::max(bsx, 1), 4);  // the compositor's 32x16-px regions must not straddle bins
-  bsy         = std::min(std::max(bsy, 0), 4);
+  bsx         = std::min(std::max(bsx, 1), 5);  // the compositor's 32x16-px regions must not straddle bins
+  bsy         = std::min(std::max(bsy, 0), 5);
+  if(((F.tilesX + (1 << bsx) - 1) >> bsx) > 256 || ((F.tilesY + (1 << bsy) - 1) >> bsy) > 256)
+  {
+    setError("frame: more than 256 bins along an axis (raise MGS_BIN_SHIFT)");
+    return MGS_ERR_INVALID_ARG;
+  }
   F.binShiftX = bsx;
   F.binShiftY = bsy;
   F.binsX     = (F.tilesX + (1 << bsx) - 1) >> bsx;
