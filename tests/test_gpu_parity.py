@@ -414,6 +414,38 @@ def test_randomized_differential_vs_oracle(ob, seed):
     scene.close()
 
 
+def test_graph_replay_equals_plain_launches(scene_small):
+    """a frame replayed from the captured hipGraph (collect_timings = 0) and the same frame issued as plain launches
+    (collect_timings = 1) are bit-identical while every knob that travels through the per-frame constant block changes
+    between frames and the graph cache is revisited (three resolutions, strips, modes)"""
+    scene, sc = scene_small
+    rng = np.random.default_rng(7)
+    sizes = [(640, 360), (333, 217), (1280, 720)]
+    for it in range(18):
+        W, H = sizes[it % 3]
+        p, V, P, eye = camera(int(rng.integers(0, 64)), W, H, flip=bool(it & 1))
+        p.splat_scale = float(rng.uniform(0.5, 1.5))
+        p.frustum_dilation = float(rng.uniform(0.0, 0.4))
+        p.sh_degree = int(rng.integers(0, 4))
+        p.ms_antialiasing = int(rng.integers(0, 2))
+        p.frustum_culling = int(rng.integers(0, 3))
+        p.alpha_cull_threshold = float(rng.choice([1.0 / 255.0, 0.05]))
+        p.debug_flags = int(rng.choice([0, 0, 1, 2, 4]))
+        p.alpha_mode = int(rng.integers(0, 2))
+        p.size_culling = int(rng.integers(0, 2))
+        if it % 5 == 4:
+            p.strip_row_begin, p.strip_row_end = 3, 11
+        if it % 7 == 6:
+            p.surface_outputs = 1
+        p.collect_timings = 0
+        scene.render(p)
+        a = scene.download_frame(p).view(np.uint16).copy()
+        p.collect_timings = 1
+        scene.render(p)
+        b = scene.download_frame(p).view(np.uint16)
+        assert np.array_equal(a, b), it
+
+
 def test_8k_frame_properties(scene_small, ob):
     """7680x4320 (512x512-px bins keep the direct binning) and the 8192 limit: finite, a strip equals the same rows of
     the full frame bit for bit, and the frame box-filtered 16x resembles the 480x270 frame"""
