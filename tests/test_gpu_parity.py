@@ -411,6 +411,18 @@ def test_randomized_differential_vs_oracle(ob, seed):
     oimg, st = ob.render(ob.make_frame(target_fp16=1, **fk), ob.make_instances([(ps, m) for m in mats]), order=ois)
     assert out.error_flags == 0 and np.isfinite(img).all()
     assert ob.psnr_rgb(img, oimg) >= 50.0, (seed, ob.psnr_rgb(img, oimg))
+    # the same frame as G tile-row strips (the multi-GPU partition) must reassemble bit for bit
+    from vk_gaussian_splatting_amd import multigpu
+    G = int(rng.choice([2, 3, 5, 8]))
+    full = scene.download_frame(p).view(np.uint16).copy()
+    for g in range(G):
+        b, e = multigpu.strip_rows(H, G, g)
+        if b == e:
+            continue
+        p.strip_row_begin, p.strip_row_end = b, e
+        scene.render(p)
+        part = scene.download_frame(p).view(np.uint16)
+        assert np.array_equal(part[b * 16:min(e * 16, H)], full[b * 16:min(e * 16, H)]), (seed, G, g)
     scene.close()
 
 
