@@ -269,14 +269,16 @@ struct LaneBins
 };
 __device__ __forceinline__ LaneBins laneBins(int binsX, int nb)
 {
-  LaneBins L;
+  LaneBins       L;
+  const uint32_t inv = (65536u + (uint32_t)binsX - 1u) / (uint32_t)binsX;  // wave-uniform; (b*inv)>>16 == b/binsX for b < 256, binsX <= 32
 #pragma unroll
   for(int j = 0; j < 4; ++j)
   {
     const int b = laneId() + 64 * j;
     L.on[j]     = b < nb;
-    L.bx[j]     = L.on[j] ? b % binsX : 0;
-    L.by[j]     = L.on[j] ? b / binsX : 0;
+    const int q = (int)(((uint32_t)b * inv) >> 16);
+    L.by[j]     = L.on[j] ? q : 0;
+    L.bx[j]     = L.on[j] ? b - q * binsX : 0;
   }
   return L;
 }
