@@ -47,7 +47,8 @@ enum { MGS_SORT_GPU_RADIX = 0, MGS_SORT_CPU_ASYNC = 1 };
 /* frustum culling — shaders/shaderio.h:84-86 / parameters.h:184 */
 enum { MGS_CULL_NONE = 0, MGS_CULL_AT_DIST = 1, MGS_CULL_AT_RASTER = 2 };
 /* colour target — src/gaussian_splatting.h:338-340 (RGBA16F default, RGBA32F optional) */
-enum { MGS_TARGET_RGBA16F = 0, MGS_TARGET_RGBA32F = 1 };
+/* colour target (gaussian_splatting.h:338-340, doc/overview: RGBA8 / RGBA16F (default) / RGBA32F); RGBA8 is linear UNORM */
+enum { MGS_TARGET_RGBA16F = 0, MGS_TARGET_RGBA32F = 1, MGS_TARGET_RGBA8 = 2 };
 /* visualisation modes: POINT_CLOUD_MODE (threedgs.h.slang:108-110), SHOW_SH_ONLY (mesh.slang:205-207),
  * DISABLE_OPACITY_GAUSSIAN (frag.slang:248-255) */
 enum { MGS_DEBUG_POINT_CLOUD = 1, MGS_DEBUG_SH_ONLY = 2, MGS_DEBUG_OPACITY_GAUSSIAN_DISABLED = 4 };

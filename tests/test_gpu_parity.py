@@ -426,6 +426,23 @@ def test_randomized_differential_vs_oracle(ob, seed):
     scene.close()
 
 
+def test_rgba8_target(scene_small):
+    """the third colour target of the reference (RGBA8): linear UNORM of the same frame, rounded once at the end"""
+    scene, sc = scene_small
+    p, V, P, eye = camera(13, 500, 300)
+    p.target_format = capi.TARGET_RGBA32F
+    scene.render(p)
+    f32img = scene.download_frame(p)
+    p.target_format = capi.TARGET_RGBA8
+    scene.render(p)
+    u8 = scene.download_frame(p)
+    assert u8.dtype == np.uint8 and u8.shape == (300, 500, 4)
+    assert np.array_equal(u8, (np.clip(f32img, 0, 1) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8))
+    p.target_format = 7
+    with pytest.raises(mgs.MgsError):
+        scene.render(p)
+
+
 def test_graph_replay_equals_plain_launches(scene_small):
     """a frame replayed from the captured hipGraph (collect_timings = 0) and the same frame issued as plain launches
     (collect_timings = 1) are bit-identical while every knob that travels through the per-frame constant block changes

@@ -10,7 +10,7 @@ import numpy as np
 FORMAT_FLOAT32, FORMAT_FLOAT16, FORMAT_UINT8 = 0, 1, 2
 SORT_GPU_RADIX, SORT_CPU_ASYNC = 0, 1
 CULL_NONE, CULL_AT_DIST, CULL_AT_RASTER = 0, 1, 2
-TARGET_RGBA16F, TARGET_RGBA32F = 0, 1
+TARGET_RGBA16F, TARGET_RGBA32F, TARGET_RGBA8 = 0, 1, 2
 ALPHA_COVERAGE, ALPHA_SUM = 0, 1
 DEBUG_POINT_CLOUD, DEBUG_SH_ONLY, DEBUG_OPACITY_GAUSSIAN_DISABLED = 1, 2, 4
 STAGE_NAMES = ["project", "sort", "bin", "pairsort", "composite", "total"]
@@ -296,7 +296,9 @@ class Scene:
         return [float(x) for x in ms[:6]]
 
     def download_frame(self, params):
-        if params.target_format == TARGET_RGBA16F:
+        if params.target_format == TARGET_RGBA8:
+            img = np.zeros((params.height, params.width, 4), np.uint8)
+        elif params.target_format == TARGET_RGBA16F:
             img = np.zeros((params.height, params.width, 4), np.float16)
         else:
             img = np.zeros((params.height, params.width, 4), np.float32)

@@ -927,7 +927,12 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
     {
       const float  r = h ? cr.y : cr.x, g = h ? cg.y : cg.x, b = h ? cb.y : cb.x, ao = h ? aout.y : aout.x;
       const size_t o = (size_t)py * (size_t)F.width + (size_t)(px + 8 * h);
-      if(halfOut)
+      if(halfOut == 2)
+      {  // RGBA8 UNORM: clamp, scale, round to nearest
+        auto q8 = [](float v) { return (uint32_t)(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f + 0.5f); };
+        reinterpret_cast<uint32_t*>(outImage)[o] = q8(r) | (q8(g) << 8) | (q8(b) << 16) | (q8(ao) << 24);
+      }
+      else if(halfOut == 1)
       {
         const __half2 lo = __floats2half2_rn(r, g), hi2 = __floats2half2_rn(b, ao);
         uint2         pk;
@@ -998,7 +1003,7 @@ void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* 
 }
 
 void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
-                     const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, bool halfOut,
+                     const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, int halfOut,
                      int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId, const void* instTable)
 {
   const FrameConst& F = A.f;
@@ -1025,7 +1030,7 @@ void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges
   C.instTable = static_cast<const CompositeArgs::Inst*>(instTable);
 #define MGS_CMP(M, S)                                                                                                  \
   hipLaunchKernelGGL((k_composite<M, S>), dim3(per * 8), dim3(256), 0, stream, C, ranges, valX, valY, planPairs, rec, image, \
-                     halfOut ? 1 : 0, ctr, outDepth, outSplatId)
+                     halfOut, ctr, outDepth, outSplatId)
 #define MGS_CMP_FMT(M)                                                                                                 \
   switch(shFormat)                                                                                                     \
   {                                                                                                                    \

@@ -49,7 +49,7 @@ void launchDirectBinning(hipStream_t stream, const uint32_t* idsX, const uint32_
 void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* keyY, const SortPlan* planPairs,
                       uint2* ranges);
 void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
-                     const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, bool halfOut,
+                     const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, int halfOut,
                      int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId, const void* instTable);
 constexpr uint32_t kPart = 2048;  // == kPrjPart == kSortPart == kBinPart
 }  // namespace mgs
@@ -1229,8 +1229,14 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
     return rc;
   const FrameConst& F      = A.f;
   const uint32_t    nTiles = (uint32_t)(F.binsX * F.binsY);  // lists (and ranges) exist per bin
-  const bool        half   = (p->target_format == MGS_TARGET_RGBA16F);
-  const size_t      pixB   = half ? 8 : 16;
+  if(p->target_format < MGS_TARGET_RGBA16F || p->target_format > MGS_TARGET_RGBA8)
+  {
+    setError("frame: target_format must be MGS_TARGET_RGBA16F / RGBA32F / RGBA8");
+    return MGS_ERR_INVALID_ARG;
+  }
+  // compositor output mode: 1 = RGBA16F, 0 = RGBA32F, 2 = RGBA8 (linear UNORM, rounded once at the end)
+  const int         half   = (p->target_format == MGS_TARGET_RGBA16F) ? 1 : (p->target_format == MGS_TARGET_RGBA8 ? 2 : 0);
+  const size_t      pixB   = half == 1 ? 8 : (half == 2 ? 4 : 16);
   s->imageRowBytes         = (size_t)F.width * pixB;
   s->imageBytes            = s->imageRowBytes * (size_t)F.height;
   const void* before[4] = {s->ranges.p, s->image.p, s->surfDepth.p, s->surfId.p};
@@ -1374,7 +1380,7 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
     std::memcpy(&isoBits, &F.depthIsoThreshold, 4);
     // everything the compositor receives by value (CompositeArgs) must be part of the key
     const int32_t kv[16] = {F.width, F.height, F.stripRow0, F.stripRow1, F.binShiftX, F.binShiftY, F.partitionCull, F.alphaMode,
-                            F.debugFlags & (4 | 256), F.surfaceOutputs, half ? 1 : 0, F.nInstances, F.shDegree, isoBits, 0, 0};
+                            F.debugFlags & (4 | 256), F.surfaceOutputs, half, F.nInstances, F.shDegree, isoBits, 0, 0};
     std::memcpy(key.v, kv, sizeof(kv));
     key.p[0] = s->image.p;
     key.p[1] = s->surfDepth.p;
