@@ -144,7 +144,7 @@ typedef struct MgsFrameParams {
                                    (threedgs_raster.frag.slang:320-349): picked depth + the splat that set it */
   float   depth_iso_threshold;  /* default 0.7 (parameters.h:200): depth = ndc z of the first fragment after which
                                    the pixel's transmittance is below this */
-  int32_t reserved[1];
+  int32_t cpu_lazy_sort;        /* CPU_ASYNC only, default 1 (parameters.h:183): start a new sort only if the viewpoint changed */
 } MgsFrameParams;
 
 void mgs_frame_params_default(MgsFrameParams* p); /* fills the defaults cited above */

@@ -596,6 +596,28 @@ def test_cpu_async_sort_mode(scene_small, ob):
     assert ob.psnr_rgb(img, oimg) >= 45.0   # std::sort is not stable: tie order may differ from the oracle's run
 
 
+def test_cpu_lazy_sort_only_resorts_when_the_viewpoint_changes(scene_small):
+    """parameters.h:183 / splat_sorter_async.h:81-97: with lazy sorting a second frame from the same viewpoint starts no
+    new sort (the sorter's timings stay those of the first), a moved camera does; lazy off always re-sorts"""
+    scene, sc = scene_small
+    p, V, P, eye = camera(22, 320, 200)
+    p.sort_mode, p.cpu_sort_blocking = capi.SORT_CPU_ASYNC, 1
+    a = scene.sort_keys(p)
+    _, ids_a = scene.sort_download(a.count)
+    b = scene.sort_keys(p)                       # same viewpoint, lazy: the previous result is reused as is
+    _, ids_b = scene.sort_download(b.count)
+    assert np.array_equal(ids_a, ids_b) and (b.key_ms, b.sort_ms) == (a.key_ms, a.sort_ms)
+    p2, _, _, _ = camera(23, 320, 200)
+    p2.sort_mode, p2.cpu_sort_blocking = capi.SORT_CPU_ASYNC, 1
+    c = scene.sort_keys(p2)
+    _, ids_c = scene.sort_download(c.count)
+    assert not np.array_equal(ids_a, ids_c)
+    p2.cpu_lazy_sort = 0
+    d = scene.sort_keys(p2)
+    _, ids_d = scene.sort_download(d.count)
+    assert np.array_equal(ids_c, ids_d)
+
+
 def test_cpu_async_sort_nonblocking_protocol(scene_small):
     """READY -> SORTING -> SORTED like SplatSorterAsync (splat_sorter_async.h:41-48): frames never wait for the
     sorter; the first frames draw in identity order, later ones pick up the sorted indices (>= 1 frame lag)."""

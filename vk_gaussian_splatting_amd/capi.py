@@ -38,7 +38,7 @@ class FrameParams(C.Structure):
                 ("strip_row_begin", C.c_int32), ("strip_row_end", C.c_int32),
                 ("collect_timings", C.c_int32), ("cpu_sort_blocking", C.c_int32), ("debug_flags", C.c_int32),
                 ("size_culling", C.c_int32), ("size_culling_min_pixels", C.c_float),
-                ("surface_outputs", C.c_int32), ("depth_iso_threshold", C.c_float), ("reserved", C.c_int32 * 1)]
+                ("surface_outputs", C.c_int32), ("depth_iso_threshold", C.c_float), ("cpu_lazy_sort", C.c_int32)]
 
 
 class FrameOut(C.Structure):

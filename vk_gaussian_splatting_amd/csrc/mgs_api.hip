@@ -149,6 +149,8 @@ struct CpuSorter
     std::vector<Inst> inst;
     uint32_t          total;
   } job;
+  float                 lastDir[3] = {0, 0, 0}, lastCop[3] = {0, 0, 0};  // viewpoint of the last sort that was started
+  bool                  haveLast   = false;
   std::vector<float>    distances;
   std::vector<uint32_t> indices;
   double                distMs = 0, sortMs = 0;
@@ -786,6 +788,11 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
   // without this the memsets above can land in the middle of the first frame (caught by the test suite)
   HIPCHK(hipDeviceSynchronize());
   s->committed = true;
+  {  // a changed scene invalidates the CPU sorter's last result (lazy sorting must not reuse it)
+    std::lock_guard<std::mutex> lk(s->cpu.mtx);
+    s->cpu.haveLast   = false;
+    s->cpuHaveIndices = false;
+  }
   s->haveFrame = false;
   return MGS_OK;
 }
@@ -927,6 +934,7 @@ void mgs_frame_params_default(MgsFrameParams* p)
   p->target_format        = MGS_TARGET_RGBA16F;
   p->alpha_mode           = MGS_ALPHA_COVERAGE;
   p->size_culling_min_pixels = 1.0f;
+  p->cpu_lazy_sort           = 1;     // parameters.h:183
   p->surface_outputs         = 0;
   p->depth_iso_threshold     = 0.7f;  // parameters.h:200
 }
@@ -1178,9 +1186,20 @@ static int cpuSortStep(MgsScene s, const MgsFrameParams* p, bool blocking)
     s->cpuHaveIndices = true;
     c.state           = CpuSorter::READY;
   }
-  if(c.state == CpuSorter::READY)
+  // lazy (parameters.h:183, splat_sorter_async.h:81-97): a new sort starts only if the viewpoint changed since the
+  // last one that was started (direction, centre of projection, order — instance transforms are not compared there either)
+  const float dirNow[3] = {-p->view[2], -p->view[6], -p->view[10]};
+  const bool  sameView  = c.haveLast && std::memcmp(dirNow, c.lastDir, sizeof(dirNow)) == 0
+                        && std::memcmp(p->camera_pos, c.lastCop, sizeof(float) * 3) == 0;
+  const bool  lazySkip  = p->cpu_lazy_sort != 0 && sameView && s->cpuHaveIndices;
+  if(c.state == CpuSorter::READY && !lazySkip)
+  {
     submit();
-  if(blocking)
+    std::memcpy(c.lastDir, dirNow, sizeof(dirNow));
+    std::memcpy(c.lastCop, p->camera_pos, sizeof(float) * 3);
+    c.haveLast = true;
+  }
+  if(blocking && c.state == CpuSorter::SORTING)
   {
     c.cv.wait(lk, [&] { return c.state == CpuSorter::SORTED; });
     s->cpuIndices.swap(c.indices);
