@@ -601,15 +601,15 @@ __global__ void k_tile_ranges(const uint32_t* __restrict__ keyX, const uint32_t*
 // A wave retires when all 128 pixels have T < 1e-4; the workgroup stops fetching when all 4 have
 // (not in MGS_ALPHA_SUM mode, where the reference's additive alpha must see every fragment).
 #ifndef MGS_CMP_ENTRIES
-#define MGS_CMP_ENTRIES 4
+#define MGS_CMP_ENTRIES 2
 #endif
-constexpr int kCmpEntries = MGS_CMP_ENTRIES;                  // list entries per thread per stage-A round (4 gathers in flight per lane)
+constexpr int kCmpEntries = MGS_CMP_ENTRIES;                  // list entries per thread per stage-A round (sweep with shading in the kernel: 1/2/3/4/6 -> 0.137/0.134/0.140/0.142/0.157 ms; 4K 0.374/0.379/-/0.42/-)
 constexpr int kCmpRound   = 256 * kCmpEntries;  // 1024 entries scanned per round
 #ifndef MGS_CMP_CAP
-#define MGS_CMP_CAP 320
+#define MGS_CMP_CAP 288
 #endif
 #ifndef MGS_CMP_GO
-#define MGS_CMP_GO 64
+#define MGS_CMP_GO 32
 #endif
 constexpr int kCmpCap     = MGS_CMP_CAP;                // LDS batch capacity (records): 18 KB -> 8 workgroups per CU (sweep: 384/512/768 -> 0.220/0.230/0.275 ms)
 constexpr int kCmpGo      = MGS_CMP_GO;                // blend as soon as this many records are staged (<= kCmpCap-256)
