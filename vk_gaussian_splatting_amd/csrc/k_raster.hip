@@ -618,7 +618,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // MODE bit 0: additive alpha (no early-out), bit 1: DISABLE_OPACITY_GAUSSIAN, bit 2: surface side outputs; SHF: SH storage format
 constexpr bool surf_lds(int mode) { return (mode & 4) != 0; }
 #ifndef MGS_CMP_WAVES
-#define MGS_CMP_WAVES 5
+#define MGS_CMP_WAVES 6
 #endif
 template <int MODE, int SHF>
 __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const CompositeArgs F, const uint2* __restrict__ ranges,

@@ -78,9 +78,9 @@ __device__ __forceinline__ void addShRadiance(const void* sh, uint32_t li, int d
   const int nEl = degree >= 3 ? 45 : (degree == 2 ? 24 : (degree == 1 ? 9 : 0));
   float     acc[3] = {0.f, 0.f, 0.f};
 #ifndef MGS_SH_GROUP
-#define MGS_SH_GROUP 6
+#define MGS_SH_GROUP 3
 #endif
-  constexpr int GROUP = FMT == 0 ? MGS_SH_GROUP : (FMT == 1 ? 6 : 3);  // fp32: two groups of 96 B, fp16 / uint8: the whole record
+  constexpr int GROUP = FMT == 0 ? MGS_SH_GROUP : (FMT == 1 ? 6 : 3);  // fp32: four groups of 48 B (fewer live registers: the compositor runs 6 waves per SIMD with 16 B of spill), fp16 / uint8: the whole record
 #pragma unroll
   for(int v0 = 0; v0 < REC; v0 += GROUP)
   {
