@@ -233,9 +233,15 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_expand(const uint32_t* __re
 // screen is one more bit in every mask (per-lane loops over the rect were tried: every round of 64
 // depth-neighbours contains some large splat, and the wave pays its trip count).  Gone with the records:
 // their 8-byte round trips, the output-partitioned expansion and the whole pair sort.
-constexpr int kDbRounds = 4;                 // rounds of 64 splats per wave
+#ifndef MGS_DB_ROUNDS
+#define MGS_DB_ROUNDS 4
+#endif
+#ifndef MGS_DB_STAGE
+#define MGS_DB_STAGE 3072
+#endif
+constexpr int kDbRounds = MGS_DB_ROUNDS;     // rounds of 64 splats per wave
 constexpr int kDbChunk  = 256 * kDbRounds;   // sorted splats per workgroup
-constexpr int kDbStage  = 4096;              // list entries staged in LDS per chunk so that the appends are coalesced
+constexpr int kDbStage  = MGS_DB_STAGE;      // list entries staged in LDS per chunk so that the appends are coalesced
 constexpr int kDbMaxDim = 32;
 
 // column / row hit masks of one round of 64 rects -> wave-private LDS (the ballots are wave-uniform)

@@ -762,7 +762,7 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
   s->pairCapacity = (uint32_t)cap;
   if((rc = s->pairVal1.ensure(cap))) return rc;  // the per-bin lists
   // bit masks handed from k_dbin_count to k_dbin_emit: <= 64 x 8 B per 64 sorted splats
-  if((rc = s->dbinMasks.ensure(((size_t)total / 1024 + 1) * 16 * 64))) return rc;
+  if((rc = s->dbinMasks.ensure((size_t)total + 8192))) return rc;  // 64 masks per 64 sorted splats at most, chunk size independent
   // the record path's buffers (16 B per record + per-splat offsets) are allocated when a frame first needs them
   const uint64_t maxParts = std::max<uint64_t>((cap + kPart - 1) / kPart, std::max<uint64_t>(parts, (total + 1023) / 1024 + 1));  // direct binning scans rows of 1024-splat chunks
   s->pStride              = (uint32_t)maxParts;
