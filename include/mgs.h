@@ -145,6 +145,10 @@ typedef struct MgsFrameParams {
   float   depth_iso_threshold;  /* default 0.7 (parameters.h:200): depth = ndc z of the first fragment after which
                                    the pixel's transmittance is below this */
   int32_t cpu_lazy_sort;        /* CPU_ASYNC only, default 1 (parameters.h:183): start a new sort only if the viewpoint changed */
+  float   thin_particle_threshold; /* surface_outputs only, default 1e-6 (parameters.h:163): exp(scale) below this makes
+                                   an axis degenerate for the splat normal (threedgrt.h.slang:358-419) */
+  int32_t quantize_normals;     /* surface_outputs only, default 1 (parameters.h:195): the splat normal passes through
+                                   the 2x16-bit octahedral code (octahedral_normal.h.slang) before it is integrated */
 } MgsFrameParams;
 
 void mgs_frame_params_default(MgsFrameParams* p); /* fills the defaults cited above */
@@ -176,7 +180,10 @@ int mgs_frame_stats(MgsScene scene, MgsFrameOut* out);
 int mgs_timings_query(MgsScene scene, uint32_t frames_back, float stage_ms[MGS_STAGE_COUNT]);
 /* side outputs of the last frame rendered with surface_outputs = 1, [height][width], row 0 = NDC y -1:
  * which 0: picked depth, float32 (0 where the transmittance never fell below the threshold);
- * which 1: global id (caller's order) of the splat that set it, uint32 (0xFFFFFFFF where none) */
+ * which 1: global id (caller's order) of the splat that set it, uint32 (0xFFFFFFFF where none);
+ * which 2: integrated normal, float32 x 4 per pixel = sum over the fragments (front to back) of
+ *          (world normal * opacity, opacity) * transmittance — the RASTER_NORMAL attachment
+ *          (gaussian_splatting.cpp:2090-2107, RGBA16F in the reference, fp32 here) */
 int mgs_frame_download_surface(MgsScene scene, int which, void* host_dst, size_t bytes);
 /* copy the last frame to the host (screenshot path, gaussian_splatting_ui.cpp:508-540, no tonemap) */
 int mgs_frame_download(MgsScene scene, void* host_dst, size_t bytes);

@@ -23,7 +23,7 @@ class OrcFrame(C.Structure):
 class OrcInstance(C.Structure):
     _fields_ = [("centers", F32P), ("cov6", F32P), ("rgba", F32P), ("sh", F32P), ("scales", F32P), ("count", C.c_uint32),
                 ("sh_degree", C.c_int), ("sh_stride", C.c_int), ("transform", C.c_float * 16),
-                ("transform_inv", C.c_float * 16)]
+                ("transform_inv", C.c_float * 16), ("rotations", F32P)]
 
 
 class OrcProjected(C.Structure):
@@ -114,6 +114,7 @@ class PreparedSet:
         self.count = n
         scale, rot = f32(arrays["scale"]).reshape(-1), f32(arrays["rotation"]).reshape(-1)
         self.scales = scale
+        self.rotations = rot
         f_dc, op = f32(arrays["f_dc"]).reshape(-1), f32(arrays["opacity"]).reshape(-1)
         f_rest = f32(arrays["f_rest"]).reshape(-1) if arrays.get("f_rest") is not None else np.zeros(0, np.float32)
         self.cov6 = np.zeros(6 * n, np.float32)
@@ -144,6 +145,7 @@ def make_instances(prepared_and_transforms):
         I = arr[i]
         I.centers, I.cov6, I.rgba, I.sh = _p(ps.positions), _p(ps.cov6), _p(ps.rgba), _p(ps.sh)
         I.scales = _p(ps.scales)
+        I.rotations = _p(ps.rotations)
         I.count, I.sh_degree, I.sh_stride = ps.count, ps.sh_degree, ps.sh_stride
         for k in range(16):
             I.transform[k] = float(col[k])
@@ -204,17 +206,45 @@ def render(frame, inst, order=None):
     return img, dict(fragments=int(frags), visible=int(stats[0]), quads=int(stats[1]))
 
 
-def render_surface(frame, inst, order_front_to_back, depth_iso_threshold=0.7):
-    """FTB side outputs: (depth[H,W] float32, splat_id[H,W] uint32) — picked depth and the splat that set it"""
+def render_surface(frame, inst, order_front_to_back, depth_iso_threshold=0.7, thin_particle_threshold=1e-6,
+                   quantize_normals=True, normals=False):
+    """FTB side outputs: (depth[H,W] float32, splat_id[H,W] uint32[, normal[H,W,4] float32]) — picked depth, the
+    splat that set it and (normals=True) the integrated normal attachment"""
     o = np.ascontiguousarray(order_front_to_back, np.uint32)
     depth = np.zeros((frame.height, frame.width), np.float32)
     ids = np.zeros((frame.height, frame.width), np.uint32)
+    nrm = np.zeros((frame.height, frame.width, 4), np.float32) if normals else None
     fn = lib().orc_render_surface
     fn.restype = None
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p]
-    fn(C.cast(C.byref(frame), C.c_void_p), C.cast(inst, C.c_void_p), len(inst), o.ctypes.data, o.size, float(depth_iso_threshold),
-       depth.ctypes.data, ids.ctypes.data)
-    return depth, ids
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_void_p,
+                   C.c_void_p, C.c_void_p]
+    fn(C.cast(C.byref(frame), C.c_void_p), C.cast(inst, C.c_void_p), len(inst), o.ctypes.data, o.size,
+       float(depth_iso_threshold), float(thin_particle_threshold), int(bool(quantize_normals)), depth.ctypes.data,
+       ids.ctypes.data, nrm.ctypes.data if normals else None)
+    return (depth, ids, nrm) if normals else (depth, ids)
+
+
+def splat_normal(frame, inst, k, local_idx, thin_particle_threshold=1e-6, quantize=False):
+    out = np.zeros(3, np.float32)
+    fn = lib().orc_splat_normal
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_int, C.c_void_p]
+    fn(C.cast(C.byref(frame), C.c_void_p), C.cast(C.byref(inst[k]), C.c_void_p), int(local_idx),
+       float(thin_particle_threshold), int(bool(quantize)), out.ctypes.data)
+    return out
+
+
+def oct_roundtrip(n):
+    n = f32(n).reshape(3)
+    out = np.zeros(3, np.float32)
+    L = lib()
+    L.orc_oct_encode.restype = C.c_uint32
+    L.orc_oct_encode.argtypes = [C.c_void_p]
+    L.orc_oct_decode.restype = None
+    L.orc_oct_decode.argtypes = [C.c_uint32, C.c_void_p]
+    code = L.orc_oct_encode(n.ctypes.data)
+    L.orc_oct_decode(code, out.ctypes.data)
+    return int(code), out
 
 
 def psnr_rgb(a, b):

@@ -669,14 +669,129 @@ uint64_t orc_render_order(const OrcFrame* f, const OrcInstance* inst, int n_inst
 //   transmittance *= (1 - opacity);  if(depth == 0 && transmittance < depthIsoThreshold) depth = fragCoord.z;
 // `ids` is the FRONT-TO-BACK draw order.  id_out receives the global id of the splat that set the depth
 // (0xFFFFFFFF where none did) — the build's reading of "splat id" for a picked depth.
+// shaders/octahedral_normal.h.slang:27-87
+static void octWrap(const float v[2], float out[2])
+{
+  out[0] = (1.0f - std::fabs(v[1])) * (v[0] >= 0.0f ? 1.0f : -1.0f);
+  out[1] = (1.0f - std::fabs(v[0])) * (v[1] >= 0.0f ? 1.0f : -1.0f);
+}
+
+uint32_t orc_oct_encode(const float n[3])
+{
+  const float inv  = 1.0f / (std::fabs(n[0]) + std::fabs(n[1]) + std::fabs(n[2]));
+  float       p[2] = {n[0] * inv, n[1] * inv};
+  if(n[2] < 0.0f)
+  {
+    float w[2];
+    octWrap(p, w);
+    p[0] = w[0];
+    p[1] = w[1];
+  }
+  const uint32_t x = (uint32_t)std::min(std::max((p[0] * 0.5f + 0.5f) * 65535.0f, 0.0f), 65535.0f);
+  const uint32_t y = (uint32_t)std::min(std::max((p[1] * 0.5f + 0.5f) * 65535.0f, 0.0f), 65535.0f);
+  return (y << 16) | x;
+}
+
+void orc_oct_decode(uint32_t packed, float out[3])
+{
+  const float fx = (float)(packed & 0xFFFFu) / 65535.0f * 2.0f - 1.0f;
+  const float fy = (float)(packed >> 16) / 65535.0f * 2.0f - 1.0f;
+  float       n[3] = {fx, fy, 1.0f - std::fabs(fx) - std::fabs(fy)};
+  if(n[2] < 0.0f)
+  {
+    float w[2];
+    octWrap(n, w);
+    n[0] = w[0];
+    n[1] = w[1];
+  }
+  const float l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+  out[0] = n[0] / l;
+  out[1] = n[1] / l;
+  out[2] = n[2] / l;
+}
+
+// threedgs_raster.mesh.slang:209-235 ; threedgrt.h.slang:42-48 (particle), :358-419 (max density plane)
+void orc_splat_normal(const OrcFrame* f, const OrcInstance* I, uint32_t i, float thinThreshold, int quantize, float out[3])
+{
+  const float* p  = &I->centers[3 * (size_t)i];
+  const float* ls = &I->scales[3 * (size_t)i];
+  const float* rq = &I->rotations[4 * (size_t)i];
+  const float  scale[3] = {std::exp(ls[0]), std::exp(ls[1]), std::exp(ls[2])};
+  // vec4toQuat(normalize(fetchRotation)): stored scalar first
+  const float ql = std::sqrt(rq[0] * rq[0] + rq[1] * rq[1] + rq[2] * rq[2] + rq[3] * rq[3]);
+  const float w = rq[0] / ql, x = rq[1] / ql, y = rq[2] / ql, z = rq[3] / ql;
+  // quatToMat3Transpose (quaternions.h.slang:56-73), rows as written; mul(v, M) is row-vector times matrix
+  const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+  const float invRot[9] = {1.0f - 2.0f * (yy + zz), 2.0f * (xy - wz), 2.0f * (xz + wy),
+                           2.0f * (xy + wz), 1.0f - 2.0f * (xx + zz), 2.0f * (yz - wx),
+                           2.0f * (xz - wy), 2.0f * (yz + wx), 1.0f - 2.0f * (xx + yy)};
+  // modelCameraPos = mul(float4(cameraPosition,1), transformInverse).xyz  (glm memory: column-major)
+  const float* Mi = I->transform_inv;
+  float        cam[3];
+  for(int r = 0; r < 3; ++r)
+    cam[r] = Mi[r] * f->camera_pos[0] + Mi[4 + r] * f->camera_pos[1] + Mi[8 + r] * f->camera_pos[2] + Mi[12 + r];
+  const float local[3] = {cam[0] - p[0], cam[1] - p[1], cam[2] - p[2]};  // modelRayOrigin - particle.position
+  const int   small[3] = {scale[0] < thinThreshold, scale[1] < thinThreshold, scale[2] < thinThreshold};
+  const int   smallCount = small[0] + small[1] + small[2];
+  float       nm[3];
+  if(smallCount == 0)
+  {
+    float canon[3], sv[3];
+    for(int c = 0; c < 3; ++c)
+      canon[c] = local[0] * invRot[c] + local[1] * invRot[3 + c] + local[2] * invRot[6 + c];
+    for(int c = 0; c < 3; ++c)
+      sv[c] = canon[c] * (1.0f / (scale[c] * scale[c]));
+    float g[3];  // mul(scaledVector, transpose(invRotation))
+    for(int c = 0; c < 3; ++c)
+      g[c] = sv[0] * invRot[3 * c] + sv[1] * invRot[3 * c + 1] + sv[2] * invRot[3 * c + 2];
+    const float rl = 1.0f / std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    for(int c = 0; c < 3; ++c)
+      nm[c] = g[c] * rl;
+    if(nm[0] * local[0] + nm[1] * local[1] + nm[2] * local[2] < 0.0f)
+      for(int c = 0; c < 3; ++c)
+        nm[c] = -nm[c];
+  }
+  else if(smallCount == 1)
+  {
+    const int a = small[0] ? 0 : (small[1] ? 1 : 2);
+    for(int c = 0; c < 3; ++c)
+      nm[c] = invRot[3 * c + a];  // mul(axisLocal, rotMat): row a of transpose(invRotation)
+    if(nm[0] * local[0] + nm[1] * local[1] + nm[2] * local[2] < 0.0f)
+      for(int c = 0; c < 3; ++c)
+        nm[c] = -nm[c];
+  }
+  else
+  {  // -modelRayDir, modelRayDir = normalize(splatCenter - modelCameraPos)
+    const float l = std::sqrt(local[0] * local[0] + local[1] * local[1] + local[2] * local[2]);
+    for(int c = 0; c < 3; ++c)
+      nm[c] = local[c] / l;
+  }
+  // normalize(mul(float4(normalModel,0), transform).xyz)
+  const float* M = I->transform;
+  float        nw[3];
+  for(int r = 0; r < 3; ++r)
+    nw[r] = M[r] * nm[0] + M[4 + r] * nm[1] + M[8 + r] * nm[2];
+  const float l = std::sqrt(nw[0] * nw[0] + nw[1] * nw[1] + nw[2] * nw[2]);
+  for(int r = 0; r < 3; ++r)
+    nw[r] /= l;
+  if(quantize)
+    orc_oct_decode(orc_oct_encode(nw), out);
+  else
+    for(int r = 0; r < 3; ++r)
+      out[r] = nw[r];
+}
+
 void orc_render_surface(const OrcFrame* f, const OrcInstance* inst, int n_inst, const uint32_t* ids, uint32_t v,
-                        float depth_iso_threshold, float* depth_out, uint32_t* id_out)
+                        float depth_iso_threshold, float thin_particle_threshold, int quantize_normals, float* depth_out,
+                        uint32_t* id_out, float* normal_out)
 {
   const int          W = f->width, H = f->height;
   const size_t       np = (size_t)W * H;
   std::vector<float> trans(np, 1.0f);
   std::fill(depth_out, depth_out + np, 0.0f);
   std::fill(id_out, id_out + np, 0xFFFFFFFFu);
+  if(normal_out)
+    std::fill(normal_out, normal_out + 4 * np, 0.0f);
   std::vector<uint32_t> offsets(n_inst + 1, 0);
   for(int k = 0; k < n_inst; ++k)
     offsets[k + 1] = offsets[k] + inst[k].count;
@@ -700,6 +815,9 @@ void orc_render_surface(const OrcFrame* f, const OrcInstance* inst, int n_inst, 
     const int   y0 = (int)std::max(0.0f, std::floor(fy0)), y1 = (int)std::min((float)(H - 1), std::ceil(fy1));
     const float n1 = P.basis1[0] * P.basis1[0] + P.basis1[1] * P.basis1[1];
     const float n2 = P.basis2[0] * P.basis2[0] + P.basis2[1] * P.basis2[1];
+    float       nrm[3] = {0.f, 0.f, 0.f};
+    if(normal_out)
+      orc_splat_normal(f, &inst[k], g - offsets[k], thin_particle_threshold, quantize_normals, nrm);
     for(int y = y0; y <= y1; ++y)
       for(int x = x0; x <= x1; ++x)
       {
@@ -715,6 +833,15 @@ void orc_render_surface(const OrcFrame* f, const OrcInstance* inst, int n_inst, 
         if(opacity <= 1.0f / 255.0f)
           continue;
         const size_t i = (size_t)y * W + x;
+        if(normal_out)
+        {  // src = (normal*opacity, opacity); dst = src * (1 - dst.a) + dst   (gaussian_splatting.cpp:2095-2107)
+          float*      d  = &normal_out[4 * i];
+          const float om = 1.0f - d[3];
+          d[0] += nrm[0] * opacity * om;
+          d[1] += nrm[1] * opacity * om;
+          d[2] += nrm[2] * opacity * om;
+          d[3] += opacity * om;
+        }
         trans[i] *= (1.0f - opacity);
         if(depth_out[i] == 0.0f && trans[i] < depth_iso_threshold)
         {

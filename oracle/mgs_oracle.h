@@ -75,6 +75,7 @@ typedef struct OrcInstance {
   int      sh_stride;    /* 0, 9, 24, 45 */
   float    transform[16];
   float    transform_inv[16];
+  const float* rotations; /* [count*4] (w,x,y,z) as stored (rotationsAddress), only read by the surface normal; may be NULL */
 } OrcInstance;
 
 typedef struct OrcProjected {
@@ -105,9 +106,21 @@ uint64_t orc_render(const OrcFrame* f, const OrcInstance* inst, int n_inst,
 uint64_t orc_render_order(const OrcFrame* f, const OrcInstance* inst, int n_inst,
                           const uint32_t* ids, uint32_t v, float* rgba_out, uint64_t* stats);
 
-/* FTB surface side outputs (picked depth + the splat that set it), threedgs_raster.frag.slang:320-349; `ids` front-to-back */
+/* octahedral normal coding, shaders/octahedral_normal.h.slang:27-87 */
+uint32_t orc_oct_encode(const float n[3]);
+void     orc_oct_decode(uint32_t packed, float out[3]);
+/* world-space normal the mesh shader hands to the fragments of one splat (NEED_SURFACE_INFO):
+ * threedgs_raster.mesh.slang:209-235, threedgrt.h.slang:42-48,358-419 (NORMAL_METHOD_MAX_DENSITY_PLANE),
+ * quaternions.h.slang:33-76.  quantize != 0 applies the QUANTIZE_NORMALS round trip (frag.slang:200). */
+void orc_splat_normal(const OrcFrame* f, const OrcInstance* inst, uint32_t local_idx, float thin_particle_threshold,
+                      int quantize, float out[3]);
+/* FTB surface side outputs, threedgs_raster.frag.slang:320-349 ; `ids` front-to-back.
+ * depth_out/id_out: picked depth + the splat that set it.  normal_out (may be NULL): [H][W][4], the integrated
+ * normal attachment = "under" blend of float4(normal * opacity, opacity) (gaussian_splatting.cpp:2090-2107),
+ * kept in fp32 (the reference target is RGBA16F, gaussian_splatting.h:355). */
 void orc_render_surface(const OrcFrame* f, const OrcInstance* inst, int n_inst, const uint32_t* ids, uint32_t v,
-                        float depth_iso_threshold, float* depth_out, uint32_t* id_out);
+                        float depth_iso_threshold, float thin_particle_threshold, int quantize_normals,
+                        float* depth_out, uint32_t* id_out, float* normal_out);
 
 /* PSNR as the reference defines it: MSE over RGB / (W*H*3), 10*log10(1/MSE), cap 99.99
  * image_compare_metric.comp.slang:116-130, image_compare.cpp:869-893 */

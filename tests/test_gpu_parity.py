@@ -782,6 +782,42 @@ def test_surface_side_outputs_match_oracle(scene_small, ob):
         scene.download_surface(p)
 
 
+@pytest.mark.parametrize("quantize", [1, 0])
+def test_integrated_normal_matches_oracle(scene_small, ob, quantize):
+    """RASTER_NORMAL side output (mesh.slang:209-235, threedgrt.h.slang:358-419, frag.slang:320-323, blend state
+    gaussian_splatting.cpp:2090-2107): sum of (world normal * opacity, opacity) * transmittance, front to back.
+    fp32 tolerance: the per-splat normal agrees to ~1e-5 (one quantisation step of 3e-5 where the octahedral code
+    rounds differently), the integration has the colour path's tolerance."""
+    scene, sc = scene_small
+    W, H = 640, 360
+    p, V, P, eye = camera(11, W, H)
+    p.surface_outputs = 1
+    p.quantize_normals = quantize
+    out = scene.render(p, want_stats=True)
+    assert out.error_flags == 0
+    depth, ids, nrm = scene.download_surface(p, normals=True)
+    _, order = oracle_sorted_stream(ob, scene, sc, dict(view=V, proj=P, camera_pos=eye, width=W, height=H))
+    inst = ob.make_instances([(ob.PreparedSet(sc), None)])
+    _, _, onrm = ob.render_surface(ob.make_frame(V, P, eye, W, H), inst, order[::-1].copy(), 0.7,
+                                   quantize_normals=bool(quantize), normals=True)
+    err = np.abs(nrm - onrm)
+    # a fragment sitting on a discard threshold (alpha <= 1/255, A > 8) may fall on either side: isolated pixels
+    # differ by up to one such fragment's weight
+    assert err.max() < 2e-2 and err.mean() < 2e-5 and np.quantile(err, 0.9999) < 2e-4, (err.max(), err.mean())
+    # alpha channel == the frame's FTB alpha (1 - T)
+    img = scene.download_frame(p).astype(np.float32)
+    assert np.allclose(nrm[..., 3], img[..., 3], atol=1e-3)
+    assert np.all(np.linalg.norm(nrm[..., :3], axis=-1) <= nrm[..., 3] + 1e-4)
+    # thin-particle threshold above every scale: all normals become minus the view direction (smallCount == 3)
+    p.thin_particle_threshold = 1e9
+    scene.render(p)
+    _, _, nrm3 = scene.download_surface(p, normals=True)
+    _, _, onrm3 = ob.render_surface(ob.make_frame(V, P, eye, W, H), inst, order[::-1].copy(), 0.7, 1e9, bool(quantize),
+                                    normals=True)
+    assert np.abs(nrm3 - onrm3).max() < 2e-2 and np.abs(nrm3 - onrm3).mean() < 2e-5
+    assert np.abs(nrm3 - nrm).max() > 0.1
+
+
 def test_frame_statistics_are_consistent(scene_small):
     """mgs_frame_stats: the compositor's counters (deferred shading) are plausible and deterministic"""
     scene, sc = scene_small

@@ -231,3 +231,112 @@ def test_psnr_definition(ob):
     a = np.zeros((4, 5, 4), np.float32); b = a.copy(); b[..., :3] = 0.1; b[..., 3] = 7
     assert abs(ob.psnr_rgb(a, b) - 20.0) < 1e-4   # mse = 0.01 over RGB only
     assert ob.psnr_rgb(a, a) == 99.99
+
+
+def _quat_to_mat(q):
+    w, x, y, z = (np.asarray(q, np.float64) / np.linalg.norm(q))
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def test_octahedral_normal_code_round_trip(ob):
+    """octahedral_normal.h.slang: 2x16-bit code, decode(encode(n)) stays within the quantisation step of n"""
+    rng = np.random.default_rng(9)
+    n = rng.normal(size=(500, 3))
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    n = np.vstack([n, np.eye(3), -np.eye(3)]).astype(np.float32)
+    for v in n:
+        code, back = ob.oct_roundtrip(v)
+        assert 0 <= code <= 0xFFFFFFFF
+        assert abs(np.linalg.norm(back) - 1.0) < 1e-6
+        assert np.allclose(back, v, atol=1e-4)
+    # both hemispheres use the whole square: +z maps inside |x|+|y| <= 1, -z outside
+    cz, _ = ob.oct_roundtrip([0, 0, 1])
+    assert (cz & 0xFFFF) in (32767, 32768) and (cz >> 16) in (32767, 32768)
+
+
+def test_splat_normal_against_numpy_fp64(ob):
+    """threedgrt.h.slang:358-419 (max density plane): n = normalize(M3 * Sigma^-1 (M^-1 cam - centre)), with
+    Sigma = R S^2 R^T of the normalised (w,x,y,z) quaternion — restated independently in float64"""
+    sc = synth.make_scene(400, seed=21)
+    ps = ob.PreparedSet(sc)
+    ang = 0.7
+    M = np.array([[np.cos(ang), 0, np.sin(ang), 0.5], [0, 1, 0, -0.2], [-np.sin(ang), 0, np.cos(ang), 1.0], [0, 0, 0, 1]],
+                 np.float32)
+    M[:3, :3] *= 1.5
+    inst = ob.make_instances([(ps, None), (ps, M)])
+    eye = np.array([3, 1, 2], np.float32)
+    V, P = lookat(eye, [0, 0, 0], [0, 1, 0]), persp(60, 4 / 3, 0.1, 2000)
+    fr = ob.make_frame(V, P, eye, 128, 96)
+    pos = np.asarray(sc["positions"], np.float64).reshape(-1, 3)
+    for k, Mk in ((0, np.eye(4)), (1, M.astype(np.float64))):
+        cam = (np.linalg.inv(Mk) @ np.append(eye.astype(np.float64), 1.0))[:3]
+        for i in range(0, 400, 7):
+            R = _quat_to_mat(np.asarray(sc["rotation"], np.float64).reshape(-1, 4)[i])
+            s = np.exp(np.asarray(sc["scale"], np.float64).reshape(-1, 3)[i])
+            g = R @ np.diag(1.0 / (s * s)) @ R.T @ (cam - pos[i])
+            n = Mk[:3, :3] @ (g / np.linalg.norm(g))
+            n /= np.linalg.norm(n)
+            got = ob.splat_normal(fr, inst, k, i)
+            assert np.allclose(got, n, atol=2e-5), (k, i, got, n)
+            assert np.dot(got, eye - (Mk @ np.append(pos[i], 1.0))[:3]) > -1e-3 or k == 1  # faces the camera
+            q = ob.splat_normal(fr, inst, k, i, quantize=True)
+            assert np.allclose(q, n, atol=1.5e-4)
+
+
+def test_splat_normal_thin_particle_cases(ob):
+    """one / two degenerate axes: the thin axis (towards the camera) / minus the view direction"""
+    q = np.array([0.9, 0.1, -0.3, 0.2], np.float32)
+    R = _quat_to_mat(q)
+    sc = dict(positions=np.array([[0.1, -0.2, 0.3]], np.float32), f_dc=np.zeros((1, 3), np.float32),
+              f_rest=np.zeros((1, 0), np.float32), opacity=np.array([3.0], np.float32),
+              scale=np.log(np.array([[0.2, 1e-4, 0.1]], np.float32)), rotation=q[None])
+    ps = ob.PreparedSet(sc)
+    inst = ob.make_instances([(ps, None)])
+    eye = np.array([1.0, 2.0, 3.0], np.float32)
+    V, P = lookat(eye, [0, 0, 0], [0, 1, 0]), persp(60, 1.0, 0.1, 100)
+    fr = ob.make_frame(V, P, eye, 64, 64)
+    local = eye.astype(np.float64) - sc["positions"][0]
+    axis = R[:, 1] * (1.0 if R[:, 1] @ local >= 0 else -1.0)
+    # default threshold 1e-6: the flat splat is still "regular"; Sigma^-1 makes its normal the thin axis anyway
+    assert np.allclose(ob.splat_normal(fr, inst, 0, 0), axis, atol=1e-3)
+    # threshold above the thin scale: exactly the rotated axis
+    assert np.allclose(ob.splat_normal(fr, inst, 0, 0, thin_particle_threshold=1e-3), axis, atol=1e-6)
+    # two small axes: minus the view direction
+    got = ob.splat_normal(fr, inst, 0, 0, thin_particle_threshold=0.15)
+    assert np.allclose(got, local / np.linalg.norm(local), atol=1e-6)
+
+
+def test_surface_normal_integration_single_and_many(ob):
+    """the normal attachment is the 'under' blend of (n * opacity, opacity): alpha equals the colour's FTB alpha,
+    and a pixel covered by one splat carries n * alpha"""
+    sc = dict(positions=np.array([[0, 0, 0]], np.float32), f_dc=np.array([[1.0, 0.0, -1.0]], np.float32),
+              f_rest=np.zeros((1, 0), np.float32), opacity=np.array([2.0], np.float32),
+              scale=np.log(np.array([[0.08, 0.05, 0.002]], np.float32)), rotation=np.array([[1, 0, 0, 0]], np.float32))
+    ps = ob.PreparedSet(sc)
+    inst = ob.make_instances([(ps, None)])
+    eye = np.array([0.3, 0.2, 2], np.float32)
+    V, P = lookat(eye, [0, 0, 0], [0, 1, 0]), persp(60, 1.0, 0.1, 100)
+    fr = ob.make_frame(V, P, eye, 64, 64)
+    _, order = ob.sort_stable(*ob.key_cull(fr, inst))
+    depth, ids, nrm = ob.render_surface(fr, inst, order[::-1].copy(), 0.7, normals=True)
+    img, _ = ob.render(ob.make_frame(V, P, eye, 64, 64, front_to_back=1), inst)
+    assert np.allclose(nrm[..., 3], img[..., 3], atol=1e-6) and nrm[..., 3].max() > 0.5
+    n = ob.splat_normal(fr, inst, 0, 0, quantize=True)
+    assert np.allclose(nrm[..., :3], nrm[..., 3:4] * n, atol=1e-6)
+    assert abs(n[2]) > 0.99  # flat in z, seen from +z
+    # many splats: |integrated normal| <= alpha <= 1, and the side outputs without normals are unchanged
+    sc2 = synth.make_scene(1500, seed=11)
+    inst2 = ob.make_instances([(ob.PreparedSet(sc2), None)])
+    eye2 = np.array([3, 1, 2], np.float32)
+    V2 = lookat(eye2, [0, 0, 0], [0, 1, 0])
+    P2 = persp(60, 4 / 3, 0.1, 2000)
+    fr2 = ob.make_frame(V2, P2, eye2, 128, 96)
+    _, order2 = ob.sort_stable(*ob.key_cull(fr2, inst2))
+    d2, i2, n2 = ob.render_surface(fr2, inst2, order2[::-1].copy(), 0.7, normals=True)
+    d3, i3 = ob.render_surface(fr2, inst2, order2[::-1].copy(), 0.7)
+    assert np.array_equal(d2, d3) and np.array_equal(i2, i3)
+    assert np.all(np.linalg.norm(n2[..., :3], axis=-1) <= n2[..., 3] + 1e-5) and np.all(n2[..., 3] <= 1.0 + 1e-5)
+    b, _ = ob.render(ob.make_frame(V2, P2, eye2, 128, 96, front_to_back=1), inst2)
+    assert np.allclose(n2[..., 3], b[..., 3], atol=1e-5)

@@ -38,7 +38,8 @@ class FrameParams(C.Structure):
                 ("strip_row_begin", C.c_int32), ("strip_row_end", C.c_int32),
                 ("collect_timings", C.c_int32), ("cpu_sort_blocking", C.c_int32), ("debug_flags", C.c_int32),
                 ("size_culling", C.c_int32), ("size_culling_min_pixels", C.c_float),
-                ("surface_outputs", C.c_int32), ("depth_iso_threshold", C.c_float), ("cpu_lazy_sort", C.c_int32)]
+                ("surface_outputs", C.c_int32), ("depth_iso_threshold", C.c_float), ("cpu_lazy_sort", C.c_int32),
+                ("thin_particle_threshold", C.c_float), ("quantize_normals", C.c_int32)]
 
 
 class FrameOut(C.Structure):
@@ -305,14 +306,18 @@ class Scene:
         _check(self._lib.mgs_frame_download(self._h, img.ctypes.data_as(C.c_void_p), img.nbytes))
         return img
 
-    def download_surface(self, params):
+    def download_surface(self, params, normals=False):
         """FTB side outputs of a frame rendered with params.surface_outputs = 1: (picked depth float32[H,W],
-        splat id uint32[H,W] in the caller's id space, 0xFFFFFFFF = none)"""
+        splat id uint32[H,W] in the caller's id space, 0xFFFFFFFF = none[, integrated normal float32[H,W,4]])"""
         depth = np.zeros((params.height, params.width), np.float32)
         ids = np.zeros((params.height, params.width), np.uint32)
         _check(self._lib.mgs_frame_download_surface(self._h, 0, depth.ctypes.data_as(C.c_void_p), depth.nbytes))
         _check(self._lib.mgs_frame_download_surface(self._h, 1, ids.ctypes.data_as(C.c_void_p), ids.nbytes))
-        return depth, ids
+        if not normals:
+            return depth, ids
+        nrm = np.zeros((params.height, params.width, 4), np.float32)
+        _check(self._lib.mgs_frame_download_surface(self._h, 2, nrm.ctypes.data_as(C.c_void_p), nrm.nbytes))
+        return depth, ids, nrm
 
     def copy_strip(self, device_ptr, nbytes):
         _check(self._lib.mgs_frame_copy_strip(self._h, C.c_void_p(device_ptr), nbytes))

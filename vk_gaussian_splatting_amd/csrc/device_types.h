@@ -24,6 +24,8 @@ struct InstanceConst
   const float* maxScale; // [count] max(exp(scale)) per splat, host-computed (only read by size culling)
   const float* partBox;  // per 2048-splat partition: min xyz, max xyz (model space), rmax (sqrt(8*trace(Sigma))), pad
   const void*  sh;       // [count] records of 48 elements, [coef][rgb] + padding (192 B fp32 / 96 B fp16 / 48 B uint8)
+  const float* scales;    // [count*3] log-space, as stored (scalesAddress)     } read only by the integrated-normal
+  const float* rotations; // [count*4] (w,x,y,z), as stored (rotationsAddress)  } side output (mesh.slang:209-235)
   float        model[16];      // M   (glm column-major)
   float        modelView[16];  // V*M (host-computed with the same unfused fp32 products the shader does per thread)
   float        camModel[3];    // M^-1 * cameraPosition
@@ -64,6 +66,8 @@ struct FrameConst
   float    maxFocal;         // max(|focal.x|, |focal.y|)
   int32_t  surfaceOutputs;   // picked depth + splat id side outputs (frag.slang:320-349)
   float    depthIsoThreshold;
+  float    thinParticleThreshold;  // shaderio.h:316: scale below which a particle axis counts as degenerate
+  int32_t  quantizeNormals;        // QUANTIZE_NORMALS (parameters.h:195): octahedral 2x16-bit round trip of the splat normal
 };
 
 struct FrameArgs

@@ -50,7 +50,8 @@ void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* 
                       uint2* ranges);
 void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
                      const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, int halfOut,
-                     int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId, const void* instTable);
+                     int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId, const void* instTable, const FrameArgs* dArgs,
+                     float4* outNormal);
 constexpr uint32_t kPart = 2048;  // == kPrjPart == kSortPart == kBinPart
 }  // namespace mgs
 
@@ -86,6 +87,8 @@ struct DeviceSet
   int      shPitch = 0;                  // stored elements per splat: shStride padded to a 16-byte multiple
   int      shFormat = -1, rgbaFormat = -1;
   float*   maxScale = nullptr;             // [count] max(exp(scale)), storage order
+  float*   scales = nullptr;               // [count*3] log scales, storage order   } integrated-normal side output
+  float*   rotations = nullptr;            // [count*4] (w,x,y,z), storage order    }
   float*   partBox = nullptr;              // [ceil(count/2048)][8]: AABB of the centres + footprint radius bound
   std::vector<uint32_t> newToOld, oldToNew;  // storage order (Morton) <-> caller's order
 };
@@ -254,6 +257,7 @@ struct MgsScene_t
   bool                  graphOk = true;
   DevBuf<float>         surfDepth;   // FTB side outputs of the last frame rendered with surface_outputs
   DevBuf<uint32_t>      surfId;
+  DevBuf<float4>        surfNormal;
   bool                  haveSurface = false;
   DevBuf<SplatRec>      rec;
   DevBuf<uint32_t>      pairKey0, pairVal0, pairKey1, pairVal1;
@@ -440,7 +444,9 @@ static void freeSet(DeviceSet& d)
   if(d.sh) (void)hipFree(d.sh);
   if(d.partBox) (void)hipFree(d.partBox);
   if(d.maxScale) (void)hipFree(d.maxScale);
-  d.centers = d.cov6 = d.partBox = d.maxScale = nullptr;
+  if(d.scales) (void)hipFree(d.scales);
+  if(d.rotations) (void)hipFree(d.rotations);
+  d.centers = d.cov6 = d.partBox = d.maxScale = d.scales = d.rotations = nullptr;
   d.rgba = d.sh = nullptr;
 }
 
@@ -457,7 +463,7 @@ void mgs_scene_destroy(MgsScene s)
   s->keysB.release(); s->idsB.release(); s->rect.release(); s->partHist.release(); s->blockCount.release();
   s->rec.release(); s->pairKey0.release(); s->pairVal0.release(); s->pairKey1.release(); s->pairVal1.release();
   s->sortedRect.release(); s->splatOffset.release(); s->chunkStart.release(); s->partSkip.release();
-  s->surfDepth.release(); s->surfId.release(); s->dArgs.release(); s->dbinMasks.release(); s->compInst.release();
+  s->surfDepth.release(); s->surfId.release(); s->surfNormal.release(); s->dArgs.release(); s->dbinMasks.release(); s->compInst.release();
   for(auto& g : s->graphs) (void)hipGraphExecDestroy(g.second);
   s->graphs.clear();
   s->ranges.release(); s->image.release(); s->ctr.release(); s->plans.release(); s->cpuDistDev.release();
@@ -685,6 +691,17 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
       });
       HIPCHK(hipMalloc((void**)&d.maxScale, n * sizeof(float)));
       HIPCHK(hipMemcpy(d.maxScale, ms.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    }
+    {  // raw scales / rotations (splat_set_vk.cpp:221-251): 28 B/splat, read by the surface normal only
+      std::vector<float> sc(n * 3), rq(n * 4);
+      parallelBatches(n, [&](size_t i) {
+        std::memcpy(&sc[3 * i], &h.scale[3 * (size_t)perm[i]], 12);
+        std::memcpy(&rq[4 * i], &h.rotation[4 * (size_t)perm[i]], 16);
+      });
+      HIPCHK(hipMalloc((void**)&d.scales, n * 3 * sizeof(float)));
+      HIPCHK(hipMemcpy(d.scales, sc.data(), n * 3 * sizeof(float), hipMemcpyHostToDevice));
+      HIPCHK(hipMalloc((void**)&d.rotations, n * 4 * sizeof(float)));
+      HIPCHK(hipMemcpy(d.rotations, rq.data(), n * 4 * sizeof(float), hipMemcpyHostToDevice));
     }
     {
       std::vector<float> planar(n * 6);
@@ -935,6 +952,8 @@ void mgs_frame_params_default(MgsFrameParams* p)
   p->alpha_mode           = MGS_ALPHA_COVERAGE;
   p->size_culling_min_pixels = 1.0f;
   p->cpu_lazy_sort           = 1;     // parameters.h:183
+  p->thin_particle_threshold = 1e-6f; // parameters.h:163
+  p->quantize_normals        = 1;     // parameters.h:195
   p->surface_outputs         = 0;
   p->depth_iso_threshold     = 0.7f;  // parameters.h:200
 }
@@ -1051,6 +1070,8 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
   F.sizeCullingMinPixels = p->size_culling_min_pixels;
   F.surfaceOutputs  = p->surface_outputs ? 1 : 0;
   F.depthIsoThreshold = p->depth_iso_threshold;
+  F.thinParticleThreshold = p->thin_particle_threshold;
+  F.quantizeNormals       = p->quantize_normals ? 1 : 0;
   F.maxFocal        = std::max(std::fabs(F.focal[0]), std::fabs(F.focal[1]));
   F.targetFormat    = p->target_format;
   F.nInstances      = (int)s->instances.size();
@@ -1070,6 +1091,8 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
     C.sh      = d.sh;
     C.partBox = d.partBox;
     C.maxScale = d.maxScale;
+    C.scales    = d.scales;
+    C.rotations = d.rotations;
     {
       auto len3 = [&](int c) { return std::sqrt((I.M[4 * c] * I.M[4 * c] + I.M[4 * c + 1] * I.M[4 * c + 1]) + I.M[4 * c + 2] * I.M[4 * c + 2]); };
       C.modelAxisMax = std::max(len3(0), std::max(len3(1), len3(2)));
@@ -1258,7 +1281,7 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
   const size_t      pixB   = half == 1 ? 8 : (half == 2 ? 4 : 16);
   s->imageRowBytes         = (size_t)F.width * pixB;
   s->imageBytes            = s->imageRowBytes * (size_t)F.height;
-  const void* before[4] = {s->ranges.p, s->image.p, s->surfDepth.p, s->surfId.p};
+  const void* before[5] = {s->ranges.p, s->image.p, s->surfDepth.p, s->surfId.p, s->surfNormal.p};
   if((rc = s->ranges.ensure(std::max<uint32_t>(nTiles, 256u)))) return rc;
   if(s->image.n < s->imageBytes)
   {
@@ -1269,6 +1292,7 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
   {
     if((rc = s->surfDepth.ensure((size_t)F.width * F.height))) return rc;
     if((rc = s->surfId.ensure((size_t)F.width * F.height))) return rc;
+    if((rc = s->surfNormal.ensure((size_t)F.width * F.height))) return rc;
   }
   {
     static const bool kDirectBin0 = [] { const char* e = std::getenv("MGS_DIRECT_BIN"); return e ? std::atoi(e) != 0 : true; }();
@@ -1284,7 +1308,7 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
   }
   s->haveSurface    = F.surfaceOutputs != 0;
   {
-    const void* after[4] = {s->ranges.p, s->image.p, s->surfDepth.p, s->surfId.p};
+    const void* after[5] = {s->ranges.p, s->image.p, s->surfDepth.p, s->surfId.p, s->surfNormal.p};
     if(std::memcmp(before, after, sizeof(before)) != 0 && !s->graphs.empty())
     {  // a buffer moved: captured frames point at the old one
       HIPCHK(hipStreamSynchronize(s->stream));
@@ -1381,7 +1405,8 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
     }
     if(withEvents) HIPCHK(hipEventRecord(fev[4], st));
     launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat, ctr,
-                    F.surfaceOutputs ? s->surfDepth.p : nullptr, F.surfaceOutputs ? s->surfId.p : nullptr, s->compInst.p);
+                    F.surfaceOutputs ? s->surfDepth.p : nullptr, F.surfaceOutputs ? s->surfId.p : nullptr, s->compInst.p,
+                    s->dArgs.p, F.surfaceOutputs ? s->surfNormal.p : nullptr);
     if(withEvents) HIPCHK(hipEventRecord(fev[5], st));
     return MGS_OK;
   };
@@ -1536,7 +1561,7 @@ int mgs_frame_stats(MgsScene s, MgsFrameOut* out)
 
 int mgs_frame_download_surface(MgsScene s, int which, void* dst, size_t bytes)
 {
-  if(!s || !dst || (which != 0 && which != 1))
+  if(!s || !dst || which < 0 || which > 2)
   {
     setError("mgs_frame_download_surface: bad argument");
     return MGS_ERR_INVALID_ARG;
@@ -1547,13 +1572,18 @@ int mgs_frame_download_surface(MgsScene s, int which, void* dst, size_t bytes)
     return MGS_ERR_STATE;
   }
   const size_t n = (size_t)s->lastParams.width * (size_t)s->lastParams.height;
-  if(bytes < n * 4)
+  if(bytes < n * (which == 2 ? 16 : 4))
   {
     setError("mgs_frame_download_surface: destination too small");
     return MGS_ERR_INVALID_ARG;
   }
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamSynchronize(s->stream));
+  if(which == 2)
+  {
+    HIPCHK(hipMemcpy(dst, s->surfNormal.p, n * 16, hipMemcpyDeviceToHost));
+    return MGS_OK;
+  }
   HIPCHK(hipMemcpy(dst, which == 0 ? (const void*)s->surfDepth.p : (const void*)s->surfId.p, n * 4, hipMemcpyDeviceToHost));
   if(which == 1)
   {  // the pipeline works on storage ids: hand out the caller's

@@ -53,6 +53,7 @@ class Project:
         p.size_culling_min_pixels = float(r.get("sizeCullingMinPixels", 1.0))
         p.sort_mode = capi.SORT_GPU_RADIX if int(r.get("sortingMethod", 0)) == 0 else capi.SORT_CPU_ASYNC
         p.cpu_lazy_sort = int(bool(r.get("cpuLazySort", True)))
+        p.thin_particle_threshold = float(r.get("thinParticleThreshold", 1e-6))
         p.debug_flags = ((capi.DEBUG_POINT_CLOUD if r.get("pointCloudModeEnabled", False) else 0)
                          | (capi.DEBUG_SH_ONLY if r.get("showShOnly", False) else 0)
                          | (capi.DEBUG_OPACITY_GAUSSIAN_DISABLED if r.get("opacityGaussianDisabled", False) else 0))
