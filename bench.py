@@ -267,15 +267,15 @@ def main():
     # algorithmic bytes per launch of each stage (SURVEY.md §8d per-unit figures)
     N = N * args.instances  # total global splats from here on
     alg = {
-        # centres of every splat; rgba + covariance of the frustum survivors; 64-B record + rect + (key, id) of the sorted ones
-        # (the 180-B SH records are no longer streamed here: shading is deferred to the compositor)
-        "project": 12 * N + (16 + 24) * Vf + (64 + 4 + 8) * Vs,
+        # centres of every splat; opacity + covariance of the frustum survivors; 32-B record + rect + (key, id) of the sorted
+        # ones (colour, view direction and the 180-B SH records are not touched here: shading is deferred to the compositor)
+        "project": 12 * N + (4 + 24) * Vf + (32 + 4 + 8) * Vs,
         "sort": 68 * Vs,
         # direct binning: ids + rect gather + sorted rect (count), sorted rect + ids + list append (emit)
         "bin": 20 * Vs + 4 * D,
         "pairsort": 0,
-        # list entries actually walked + first 16 B of their record; 48 B more + the 192-B SH record of the staged ones; RGBA16F frame
-        "composite": (4 + 16) * scanned + (48 + 192) * shaded + 8 * Ppix,
+        # list entries actually walked + their 32-B record; colour + centre + the 192-B SH record of the staged ones; RGBA16F frame
+        "composite": (4 + 32) * scanned + (16 + 12 + 192) * shaded + 8 * Ppix,
     }
     # `roofline` describes the dominant HBM-bound KERNEL: k_project (the project stage is that one kernel plus a 7 us
     # cull; the sort and binning stages are 11 and 3 kernels of at most ~60 us each, reported by `roofline_sort`).  The

@@ -255,3 +255,23 @@ def test_cpp_caller_builds_against_the_header_and_prints_usage():
     assert r.returncode == 0, r.stdout + r.stderr
     r = subprocess.run([os.path.join(root, "examples", "mgs_render")], capture_output=True, text=True)
     assert r.returncode == 2 and "usage:" in r.stderr and "gfx950" in r.stderr
+
+
+def test_div255_refinement_is_exact():
+    """sh_eval.h::div255 — q = b*r; q + fma(-q,255,b)*r with r = fl(1/255) — equals the correctly rounded b/255 for every
+    byte value (the uint8 SH / colour dequantisation, threedgs_particle_buffers.h.slang:82-86,128-131); exact rational
+    arithmetic stands in for the device's fused multiply-adds"""
+    from fractions import Fraction
+
+    def r32(fr):
+        x = np.float32(float(fr))
+        cands = [x, np.nextafter(x, np.float32(np.inf)), np.nextafter(x, np.float32(-np.inf))]
+        return np.float32(min(cands, key=lambda v: (abs(Fraction(float(v)) - fr), int(np.float32(v).view(np.uint32)) & 1)))
+
+    r = np.float32(1.0) / np.float32(255.0)
+    for b in range(256):
+        fb = np.float32(b)
+        q = np.float32(fb * r)
+        rem = r32(Fraction(float(-q)) * 255 + Fraction(float(fb)))
+        q2 = r32(Fraction(float(rem)) * Fraction(float(r)) + Fraction(float(q)))
+        assert q2 == np.float32(fb / np.float32(255.0)), b

@@ -20,7 +20,11 @@ struct InstanceConst
 {
   const float* centers;  // [count*3]
   const float* cov6;     // planar: float4 covA[count] = (S00,S01,S02,S11) then float2 covB[count] = (S12,S22)
-  const void*  rgba;     // [count*4] fp32 | fp16 | u8
+  const void*  rgba;     // [count*4] fp32 | fp16 | u8 as stored
+  const float* rgbaF32;  // [count*4] the same, dequantised the way fetchColor does (== rgba for fp32 storage): what the
+                         // compositor's shading phase reads for the records it stages
+  const float* alpha;    // [count] opacity as the shaders read it back from `rgba` (dequantised), planar: all the
+                         // projection needs of the colour
   const float* maxScale; // [count] max(exp(scale)) per splat, host-computed (only read by size culling)
   const float* partBox;  // per 2048-splat partition: min xyz, max xyz (model space), rmax (sqrt(8*trace(Sigma))), pad
   const void*  sh;       // [count] records of 48 elements, [coef][rgb] + padding (192 B fp32 / 96 B fp16 / 48 B uint8)
@@ -91,25 +95,29 @@ struct CompositeArgs
   int32_t shDegree;
   int32_t looseMask;          // A/B knob (MGS_LOOSE_MASK)
   float   depthIsoThreshold;
+  int32_t shOnly;             // SHOW_SH_ONLY (mesh.slang:205-207): base colour 0.5
   struct Inst
   {
-    const void* sh;
-    uint32_t    globalOffset;
-    int32_t     shDegree;
+    const void*   sh;
+    const float4* rgba;     // colours as fetchColor returns them (dequantised fp32; the fp32 storage buffer itself when
+                            // the set is stored as fp32)
+    const float*  centers;
+    uint32_t     globalOffset;
+    int32_t      shDegree;
   } inst[kMaxInlineInstances];
   const Inst* instTable;      // all instances (device memory, rebuilt at commit); used when nInstances > kMaxInlineInstances
 };
 
-// projected splat record consumed by the compositor (64 B = one sector, 16-B aligned)
+// projected splat record consumed by the compositor: 32 B = half a 64-byte sector, 16-B aligned.  It holds only what
+// the per-fragment arithmetic and the region cull need; base colour, view direction and fragCoord.z are rebuilt by the
+// compositor for the records it stages (a quarter of them), from the splat's own buffers.
 struct alignas(16) SplatRec
 {
-  float cx, cy;    // centre in pixels
-  float ex, ey;    // tight half extents of the visible footprint in pixels   -- first 16 B: all a cull test needs
-  float p1x, p1y;  // 2*b1/|b1|^2 : (d.p1)^2 + (d.p2)^2 == A/2 of threedgs_raster.frag.slang:236
-  float p2x, p2y;
-  float r, g, b, a;  // base colour (before the SH sum) and opacity
-  float dx, dy, dz;  // unit direction camera -> splat in model space (mesh.slang:240-241): input of the deferred SH sum
-  float ndcZ;        // fragCoord.z of the splat's quad (the picked-depth side output)
+  float    cx, cy;    // centre in pixels
+  float    p1x, p1y;  // 2*b1/|b1|^2 : (d.p1)^2 + (d.p2)^2 == A/2 of threedgs_raster.frag.slang:236
+  float    p2x, p2y;
+  float    a;         // opacity (after MS_ANTIALIASING)
+  uint32_t exey;      // half2: tight half extents of the visible footprint in pixels, rounded UP (cull tests only)
 };
 
 // device-resident counters of one frame

@@ -31,28 +31,6 @@ struct Projected
   uint32_t rect;  // bin rectangle x0 | y0<<8 | x1<<16 | y1<<24 (inclusive, in bins)
 };
 
-template <int FMT>
-__device__ __forceinline__ float4 loadRgba(const void* base, uint32_t i)
-{
-  if constexpr(FMT == 0)
-  {
-    return reinterpret_cast<const float4*>(base)[i];
-  }
-  else if constexpr(FMT == 1)
-  {
-    const uint2  raw = reinterpret_cast<const uint2*>(base)[i];
-    const __half2 lo = *reinterpret_cast<const __half2*>(&raw.x), hi = *reinterpret_cast<const __half2*>(&raw.y);
-    const float2  a = __half22float2(lo), b = __half22float2(hi);
-    return make_float4(a.x, a.y, b.x, b.y);
-  }
-  else
-  {
-    const uint32_t raw = reinterpret_cast<const uint32_t*>(base)[i];
-    return make_float4((float)(raw & 255u) / 255.0f, (float)((raw >> 8) & 255u) / 255.0f,
-                       (float)((raw >> 16) & 255u) / 255.0f, (float)(raw >> 24) / 255.0f);
-  }
-}
-
 // The per-splat raster front end.  Returns false when the splat cannot produce a fragment.
 // Written BRANCH-FREE with every load issued first: rocprof showed the waves of this kernel waiting on
 // memory 70 % of their cycles when the fetches were staged behind the early-outs (rgba -> centre -> cov
@@ -60,16 +38,15 @@ __device__ __forceinline__ float4 loadRgba(const void* base, uint32_t i)
 // speculative SH fetch of the rest costs ~4 % extra traffic and buys one round trip instead of four.
 struct SplatFetch
 {
-  float4 col;
+  float  alpha;
   float  px, py, pz;
   float4 cA;
   float2 cB;
 };
-template <int RGBAF>
 __device__ __forceinline__ SplatFetch fetchSplat(const InstanceConst& I, uint32_t li)
 {
   SplatFetch f;
-  f.col = loadRgba<RGBAF>(I.rgba, li);
+  f.alpha = I.alpha[li];
   f.px  = I.centers[3 * (size_t)li + 0];
   f.py  = I.centers[3 * (size_t)li + 1];
   f.pz  = I.centers[3 * (size_t)li + 2];
@@ -81,7 +58,7 @@ __device__ __forceinline__ SplatFetch fetchSplat(const InstanceConst& I, uint32_
 __device__ __forceinline__ bool projectSplat(const FrameConst& F, const InstanceConst& I, int instIdx, const SplatFetch& in,
                                              Projected& out)
 {
-  float4       col = in.col;
+  float4       col = make_float4(0.f, 0.f, 0.f, in.alpha);  // the colour itself is fetched by the compositor
   const float  px = in.px, py = in.py, pz = in.pz;
   const float4 cA = in.cA;
   const float2 cB = in.cB;
@@ -177,17 +154,8 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   const int sx = 4 + F.binShiftX, sy = 4 + F.binShiftY;
   out.rect = (uint32_t)(x0 >> sx) | ((uint32_t)(y0 >> sy) << 8) | ((uint32_t)(x1 >> sx) << 16) | ((uint32_t)(y1 >> sy) << 24);
 
-  // view-dependent colour (mesh.slang:240-243): direction in model space, no clamp afterwards
-  float dx = px - I.camModel[0], dy = py - I.camModel[1], dz = pz - I.camModel[2];
-  const float dl = rsqrtf(dx * dx + dy * dy + dz * dz);
-  dx *= dl;
-  dy *= dl;
-  dz *= dl;
-  if(F.debugFlags & 2)  // SHOW_SH_ONLY, mesh.slang:205-207
-    col.x = col.y = col.z = 0.5f;
-  // the SH sum itself (mesh.slang:243) is added by the compositor when the splat is staged: rec carries the
-  // base colour, the direction and the instance the record belongs to
-
+  // base colour, view direction and the SH sum (mesh.slang:205-207,240-243) are the compositor's business: it
+  // shades the records it stages (kernels_common.h: viewDirection, k_raster.hip: shading phase)
   const float n1 = 2.0f / (b1x * b1x + b1y * b1y), n2 = 2.0f / (b2x * b2x + b2y * b2y);
   out.rec.cx  = pcx;
   out.rec.cy  = pcy;
@@ -195,16 +163,11 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   out.rec.p1y = b1y * n1;
   out.rec.p2x = b2x * n2;
   out.rec.p2y = b2y * n2;
-  out.rec.r   = col.x;
-  out.rec.g   = col.y;
-  out.rec.b   = col.z;
   out.rec.a   = col.w;
-  out.rec.ex  = ex;
-  out.rec.ey  = ey;
-  out.rec.dx  = dx;
-  out.rec.dy  = dy;
-  out.rec.dz  = dz;
-  out.rec.ndcZ = ndcz;
+  {  // cull-only extents, rounded up to fp16: conservative, so the frame does not depend on the rounding
+    const __half2 h = __halves2half2(__float2half_ru(ex), __float2half_ru(ey));
+    out.rec.exey    = *reinterpret_cast<const uint32_t*>(&h);
+  }
   return true;
 }
 
@@ -231,7 +194,7 @@ __device__ __forceinline__ uint32_t scanRoundWaveCounts(uint32_t* s_cnt /*32*/, 
 // Output: survivors of partition p, ascending id, in keysSlot/idsSlot[p*2048 ...], count in slotCount[p].
 // No barrier sits inside a loop that waits on memory: all 8 centre loads of a thread are issued up front,
 // and the heavy per-survivor loop runs barrier-free (waves drift apart and overlap each other's loads).
-template <bool FULL, int RGBAF>
+template <bool FULL>
 __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __restrict__ Ap, FrameCounters* __restrict__ ctr,
                                                          uint32_t* __restrict__ keysSlot, uint32_t* __restrict__ idsSlot,
                                                          uint32_t* __restrict__ slotCount, SplatRec* __restrict__ rec,
@@ -249,7 +212,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
     return;
   }
   __shared__ uint32_t s_hist[256];
-  __shared__ float4   s_rec[FULL ? 4 : 1][FULL ? 64 * 5 : 1];  // per wave: 64 records at an 80-byte pitch
+  __shared__ float4   s_rec[FULL ? 4 : 1][FULL ? 64 * 3 : 1];  // per wave: 64 records at a 48-byte pitch
   __shared__ uint32_t s_gid[FULL ? 4 : 1][64];
   s_hist[threadIdx.x] = 0u;  // ordered before its first use by the barriers of phase 1
   __shared__ uint16_t s_li[kPrjPart];   // bit 15: survived phase 2
@@ -341,9 +304,9 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   else
   {
     // ---- phase 2: dense raster front end over the survivors (no barriers inside) ------------------------
-    // The 64-byte records leave through LDS: every lane computes one record, then the wave stores them four
-    // lanes per record, so a store instruction covers whole 64-byte sectors (16 records = 1 KB contiguous when the
-    // survivors are).  Written lane-per-record, each instruction put 16 bytes into 64 different sectors and
+    // The 32-byte records leave through LDS: every lane computes one record, then the wave stores them two
+    // lanes per record, so a store instruction covers whole 64-byte sectors wherever neighbouring ids both survive
+    // (32 records = 1 KB contiguous when the survivors are).  Written lane-per-record, each instruction put 16 bytes into 64 different sectors and
     // the kernel spent half its time on those partial-sector writes (0.20 ms -> 0.11 ms with the stores removed).
     // The fetches of the NEXT batch of 256 survivors are issued before this batch is computed (13 registers):
     // otherwise every batch starts with a full memory round trip and the kernel spent half its wave cycles parked.
@@ -352,7 +315,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
     if(t < M)
     {
       liCur = local0 + s_li[t];
-      cur   = fetchSplat<RGBAF>(I, liCur);
+      cur   = fetchSplat(I, liCur);
     }
     for(uint32_t j0 = 0; j0 < M; j0 += kPrjThreads)
     {
@@ -363,7 +326,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
       const bool     haveNxt = j + kPrjThreads < M;
       liNxt = local0 + s_li[haveNxt ? j + kPrjThreads : 0u];
       liNxt = min(liNxt, I.count - 1u);
-      nxt   = fetchSplat<RGBAF>(I, liNxt);  // clamped, not predicated: straight-line loads
+      nxt   = fetchSplat(I, liNxt);  // clamped, not predicated: straight-line loads
       if(j < M)
       {
         const uint32_t li = liCur;
@@ -371,11 +334,9 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
         if(projectSplat(A.f, I, k, cur, pr))
         {
           gidOk       = I.globalOffset + li;
-          float4* dst = &s_rec[w][lane * 5];  // 80-byte pitch: conflict-free 16-byte accesses
-          dst[0]      = make_float4(pr.rec.cx, pr.rec.cy, pr.rec.ex, pr.rec.ey);
-          dst[1]      = make_float4(pr.rec.p1x, pr.rec.p1y, pr.rec.p2x, pr.rec.p2y);
-          dst[2]      = make_float4(pr.rec.r, pr.rec.g, pr.rec.b, pr.rec.a);
-          dst[3]      = make_float4(pr.rec.dx, pr.rec.dy, pr.rec.dz, pr.rec.ndcZ);
+          float4* dst = &s_rec[w][lane * 3];  // 48-byte pitch: conflict-free 16-byte accesses
+          dst[0]      = make_float4(pr.rec.cx, pr.rec.cy, pr.rec.p1x, pr.rec.p1y);
+          dst[1]      = make_float4(pr.rec.p2x, pr.rec.p2y, pr.rec.a, __uint_as_float(pr.rec.exey));
           rect[gidOk] = pr.rect;
           s_li[j] |= 0x8000u;  // own entry only: no race
         }
@@ -383,12 +344,12 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
       s_gid[w][lane] = gidOk;
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for(int i = 0; i < 4; ++i)
+      for(int i = 0; i < 2; ++i)
       {
-        const int      rr = 16 * i + (lane >> 2), part = lane & 3;
+        const int      rr = 32 * i + (lane >> 1), part = lane & 1;
         const uint32_t g  = s_gid[w][rr];
         if(g != 0xFFFFFFFFu)
-          reinterpret_cast<float4*>(rec + g)[part] = s_rec[w][rr * 5 + part];
+          reinterpret_cast<float4*>(rec + g)[part] = s_rec[w][rr * 3 + part];
       }
       __builtin_amdgcn_wave_barrier();
       cur   = nxt;
@@ -531,20 +492,14 @@ void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* d
   const dim3 grid(args.f.totalPartitions), block(kPrjThreads);
   if(args.f.totalPartitions == 0)
     return;
-#define MGS_LAUNCH(FULLV, R)                                                                                             \
-  hipLaunchKernelGGL((k_project<FULLV, R>), grid, block, 0, stream, dArgs, ctr, keysSlot, idsSlot, slotCount, rec, rect, partSkip, \
+#define MGS_LAUNCH(FULLV)                                                                                                \
+  hipLaunchKernelGGL((k_project<FULLV>), grid, block, 0, stream, dArgs, ctr, keysSlot, idsSlot, slotCount, rec, rect, partSkip, \
                      slotHist, histStride)
-  if(!full)
-  {
-    MGS_LAUNCH(false, 0);
-    return;
-  }
-  switch(rgbaFormat)
-  {
-    case 0: MGS_LAUNCH(true, 0); break;
-    case 1: MGS_LAUNCH(true, 1); break;
-    default: MGS_LAUNCH(true, 2); break;
-  }
+  (void)rgbaFormat;  // the projection reads the planar alpha only; the colour format matters to the compositor
+  if(full)
+    MGS_LAUNCH(true);
+  else
+    MGS_LAUNCH(false);
 #undef MGS_LAUNCH
 }
 

@@ -715,7 +715,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
   __shared__ float4   s_a[kCmpCap];  // cx, cy, ex, ey
   __shared__ float4   s_b[kCmpCap];  // p1, p2 (scaled by sqrt(log2 e))
   __shared__ float4   s_c[kCmpCap];  // r, g, b, a
-  __shared__ float4   s_d[kCmpCap];  // direction (model space), global id: what the deferred SH sum needs
+  __shared__ uint32_t s_g[kCmpCap];  // global id: what the deferred shading needs
   __shared__ float    s_z[surf_lds(MODE) ? kCmpCap : 1];  // fragCoord.z of the record (surface outputs only)
   __shared__ float4   s_n[surf_lds(MODE) ? kCmpCap : 1];  // world normal of the record (surface outputs only)
   __shared__ uint32_t s_wc[2][kCmpEntries][4];
@@ -798,7 +798,8 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
     {
       const uint32_t avail = hi - range.x;
       uint32_t       g[kCmpEntries];
-      float4         a[kCmpEntries];
+      float4         a[kCmpEntries], pb[kCmpEntries];  // (cx, cy, ex, ey), (p1, p2)
+      float          al[kCmpEntries];                  // opacity
       bool           ok[kCmpEntries];
       uint64_t       bal[kCmpEntries];
 #pragma unroll
@@ -810,7 +811,16 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
       }
 #pragma unroll
       for(int k = 0; k < kCmpEntries; ++k)
-        a[k] = ok[k] ? *reinterpret_cast<const float4*>(rec + g[k]) : make_float4(0.f, 0.f, -1.f, -1.f);
+      {  // the whole 32-byte record (half a sector): centre + p1 | p2 + opacity + fp16 extents
+        const float4* r  = reinterpret_cast<const float4*>(rec + g[k]);
+        const float4  r0 = ok[k] ? r[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4  r1 = ok[k] ? r[1] : make_float4(0.f, 0.f, 0.f, __uint_as_float(0xBC00BC00u));  // extents -1: fails the test
+        const uint32_t eb = __float_as_uint(r1.w);
+        const float2   e  = __half22float2(*reinterpret_cast<const __half2*>(&eb));
+        a[k]  = make_float4(r0.x, r0.y, e.x, e.y);
+        pb[k] = make_float4(r0.z, r0.w, r1.x, r1.y);
+        al[k] = r1.z;
+      }
       // speculative prefetch of the next round's ids (valid if this round is consumed completely)
       {
         const uint32_t hiN = hi - min(avail, (uint32_t)kCmpRound);
@@ -849,16 +859,11 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
           if(ok[k])
           {
             const uint32_t pos = base + wb + lanesBelow(bal[k]);
-            const float4*  r   = reinterpret_cast<const float4*>(rec + g[k]);
-            const float4   pb  = r[1];
-            const float4   sb  = make_float4(pb.x * kSqrtLog2e, pb.y * kSqrtLog2e, pb.z * kSqrtLog2e, pb.w * kSqrtLog2e);
+            const float4   sb  = make_float4(pb[k].x * kSqrtLog2e, pb[k].y * kSqrtLog2e, pb[k].z * kSqrtLog2e, pb[k].w * kSqrtLog2e);
             s_a[pos]           = a[k];
             s_b[pos]           = sb;
-            s_c[pos]           = r[2];
-            const float4 rd    = r[3];
-            s_d[pos]           = make_float4(rd.x, rd.y, rd.z, __uint_as_float(g[k]));
-            if constexpr(surf)
-              s_z[pos] = rd.w;
+            s_c[pos]           = make_float4(0.f, 0.f, 0.f, al[k]);  // rgb: shading phase
+            s_g[pos]           = g[k];
             // quarter (qx,qy): pixel centres x in [bcx-15.5,bcx-0.5] / [bcx+0.5,bcx+15.5], y in [bcy-7.5,bcy-0.5] / [bcy+0.5,bcy+7.5].
             // Footprint box first, then a bound in the ellipse's own frame: over the quarter (centre m, half
             // extents 7.5 x 3.5) s = d.p1 stays within |s_m| -+ (7.5|p1x| + 3.5|p1y|), likewise u = d.p2, so
@@ -867,7 +872,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
             // evaluations were empty before this test (corner overlaps of slanted ellipses).
             const bool  xl = a[k].x - a[k].z <= bcx - 0.5f, xr = a[k].x + a[k].z >= bcx + 0.5f;
             const bool  yt = a[k].y - a[k].w <= bcy - 0.5f, yb = a[k].y + a[k].w >= bcy + 0.5f;
-            const float rc = r[2].w;
+            const float rc = al[k];
             const float qLim = noGauss ? kQMax : fminf(kQMax, __log2f(fmaxf(rc * 255.0f, 1.0f))) * 1.001f + 1e-3f;
             const float rs = 7.5f * fabsf(sb.x) + 3.5f * fabsf(sb.y), ru = 7.5f * fabsf(sb.z) + 3.5f * fabsf(sb.w);
             uint32_t    qm = 0;
@@ -900,8 +905,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
     // the frustum survivors on the garden-sized bench), and their 192-byte SH records are the bulk of a splat.
     for(uint32_t j = t; j < fill; j += 256)
     {
-      const float4   dd  = s_d[j];
-      const uint32_t gid = __float_as_uint(dd.w);
+      const uint32_t gid = s_g[j];
       CompositeArgs::Inst I = F.inst[0];
       int                 instIdx = 0;
       if(F.nInstances <= kMaxInlineInstances)
@@ -927,15 +931,41 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
         I       = F.instTable[lo];
         instIdx = lo;
       }
-      if constexpr(surf)
-        s_n[j] = splatWorldNormal(Ap->f, Ap->inst[instIdx], gid - I.globalOffset);
-      const int            deg = (I.sh == nullptr) ? 0 : min(I.shDegree, F.shDegree);
+      const uint32_t li = gid - I.globalOffset;
+      // base colour (mesh.slang:162,205-207) and the view direction in model space (mesh.slang:240-241); the
+      // camera position of the instance is per-frame data, read through the frame-argument pointer.
+      // (Fetching the first part of the SH record together with these loads — it does not depend on the direction —
+      // was measured: the extra live registers spill, 0.140 -> 0.179 ms.)
+      const float4 col = I.rgba[li];  // fetchColor, dequantised at commit
+      const float  cpx = I.centers[3 * (size_t)li], cpy = I.centers[3 * (size_t)li + 1], cpz = I.centers[3 * (size_t)li + 2];
+      const float* cam = Ap->inst[instIdx].camModel;
+      float        dx = cpx - cam[0], dy = cpy - cam[1], dz = cpz - cam[2];
+      const float  dl = rsqrtf(dx * dx + dy * dy + dz * dz);
+      dx *= dl;
+      dy *= dl;
+      dz *= dl;
+      float4 c = s_c[j];
+      c.x = F.shOnly ? 0.5f : col.x;
+      c.y = F.shOnly ? 0.5f : col.y;
+      c.z = F.shOnly ? 0.5f : col.z;
+      const int deg = (I.sh == nullptr) ? 0 : min(I.shDegree, F.shDegree);
       if(deg > 0)
+        addShRadiance<SHF>(I.sh, li, deg, dx, dy, dz, c.x, c.y, c.z);
+      s_c[j] = c;
+      if constexpr(surf)
       {
-        const uint32_t li = gid - I.globalOffset;
-        float4         c  = s_c[j];
-        addShRadiance<SHF>(I.sh, li, deg, dd.x, dd.y, dd.z, c.x, c.y, c.z);
-        s_c[j] = c;
+        const InstanceConst& IC = Ap->inst[instIdx];
+        s_n[j] = splatWorldNormal(Ap->f, IC, li);
+        // fragCoord.z of the splat's quad: clip.z / clip.w of the centre (mesh.slang:175-178,276-289)
+        const float* MV = IC.modelView;
+        const float* P  = Ap->f.proj;
+        const float  tx = MV[0] * cpx + MV[4] * cpy + MV[8] * cpz + MV[12];
+        const float  ty = MV[1] * cpx + MV[5] * cpy + MV[9] * cpz + MV[13];
+        const float  tz = MV[2] * cpx + MV[6] * cpy + MV[10] * cpz + MV[14];
+        const float  tw = MV[3] * cpx + MV[7] * cpy + MV[11] * cpz + MV[15];
+        const float  cz = P[2] * tx + P[6] * ty + P[10] * tz + P[14] * tw;
+        const float  cw = P[3] * tx + P[7] * ty + P[11] * tz + P[15] * tw;
+        s_z[j]          = cz * (1.0f / cw);
       }
     }
     __syncthreads();
@@ -982,7 +1012,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
             nz += wgt * n1.z;
             // transmittance *= (1 - opacity); if(depth == 0 && transmittance < threshold) depth = fragCoord.z
             const float    zr  = s_z[j];
-            const uint32_t gid = __float_as_uint(s_d[j].w);
+            const uint32_t gid = s_g[j];
             if(ah.x > 0.0f && pickZ.x == 0.0f && T.x < F.depthIsoThreshold)
             {
               pickZ.x = zr;
@@ -1103,8 +1133,8 @@ void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* 
 
 void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
                      const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, int halfOut,
-                     int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId, const void* instTable,
-                     const FrameArgs* dArgs, float4* outNormal)
+                     int shFormat, int rgbaFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId,
+                     const void* instTable, const FrameArgs* dArgs, float4* outNormal)
 {
   const FrameConst& F = A.f;
   if(F.stripRow1 <= F.stripRow0)
@@ -1121,9 +1151,13 @@ void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges
   C.stripRow0 = F.stripRow0; C.stripRow1 = F.stripRow1;
   C.nInstances = F.nInstances; C.shDegree = F.shDegree; C.looseMask = (F.debugFlags & 256) ? 1 : 0;
   C.depthIsoThreshold = F.depthIsoThreshold;
+  (void)rgbaFormat;
+  C.shOnly     = (F.debugFlags & 2) ? 1 : 0;
   for(int i = 0; i < F.nInstances && i < kMaxInlineInstances; ++i)
   {
     C.inst[i].sh           = A.inst[i].sh;
+    C.inst[i].rgba         = reinterpret_cast<const float4*>(A.inst[i].rgbaF32);
+    C.inst[i].centers      = A.inst[i].centers;
     C.inst[i].globalOffset = A.inst[i].globalOffset;
     C.inst[i].shDegree     = A.inst[i].shDegree;
   }

@@ -50,7 +50,7 @@ void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* 
                       uint2* ranges);
 void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
                      const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, int halfOut,
-                     int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId, const void* instTable, const FrameArgs* dArgs,
+                     int shFormat, int rgbaFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId, const void* instTable, const FrameArgs* dArgs,
                      float4* outNormal);
 constexpr uint32_t kPart = 2048;  // == kPrjPart == kSortPart == kBinPart
 }  // namespace mgs
@@ -87,6 +87,8 @@ struct DeviceSet
   int      shPitch = 0;                  // stored elements per splat: shStride padded to a 16-byte multiple
   int      shFormat = -1, rgbaFormat = -1;
   float*   maxScale = nullptr;             // [count] max(exp(scale)), storage order
+  float*   rgbaF32 = nullptr;              // [count*4] colours as the shaders read them back (== rgba when stored as fp32)
+  float*   alpha = nullptr;                // [count] dequantised opacity, storage order (the projection's view of rgba)
   float*   scales = nullptr;               // [count*3] log scales, storage order   } integrated-normal side output
   float*   rotations = nullptr;            // [count*4] (w,x,y,z), storage order    }
   float*   partBox = nullptr;              // [ceil(count/2048)][8]: AABB of the centres + footprint radius bound
@@ -444,9 +446,12 @@ static void freeSet(DeviceSet& d)
   if(d.sh) (void)hipFree(d.sh);
   if(d.partBox) (void)hipFree(d.partBox);
   if(d.maxScale) (void)hipFree(d.maxScale);
+  if(d.alpha) (void)hipFree(d.alpha);
+  if(d.rgbaF32 && (void*)d.rgbaF32 != d.rgba) (void)hipFree(d.rgbaF32);
+  d.rgbaF32 = nullptr;
   if(d.scales) (void)hipFree(d.scales);
   if(d.rotations) (void)hipFree(d.rotations);
-  d.centers = d.cov6 = d.partBox = d.maxScale = d.scales = d.rotations = nullptr;
+  d.centers = d.cov6 = d.partBox = d.maxScale = d.scales = d.rotations = d.alpha = nullptr;
   d.rgba = d.sh = nullptr;
 }
 
@@ -720,6 +725,23 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
       int rc = uploadFormatted(re, rgbaFormat, false, &d.rgba);
       if(rc != MGS_OK)
         return rc;
+      // the colours exactly as fetchColor reads them back from the formatted buffer (threedgs_particle_buffers.h.slang:
+      // 72-90): fp32 for the compositor's shading phase, and the opacity as a plane of its own — all the projection needs
+      std::vector<float> al(n);
+      if(rgbaFormat != MGS_FORMAT_FLOAT32)
+        parallelBatches(n * 4, [&](size_t i) {
+          re[i] = rgbaFormat == MGS_FORMAT_FLOAT16 ? halfToFloat(floatToHalf(re[i])) : (float)toUint8(re[i], 0.f, 1.f) / 255.0f;
+        });
+      parallelBatches(n, [&](size_t i) { al[i] = re[4 * i + 3]; });
+      if(rgbaFormat == MGS_FORMAT_FLOAT32)
+        d.rgbaF32 = static_cast<float*>(d.rgba);
+      else
+      {
+        HIPCHK(hipMalloc((void**)&d.rgbaF32, n * 4 * sizeof(float)));
+        HIPCHK(hipMemcpy(d.rgbaF32, re.data(), n * 4 * sizeof(float), hipMemcpyHostToDevice));
+      }
+      HIPCHK(hipMalloc((void**)&d.alpha, n * sizeof(float)));
+      HIPCHK(hipMemcpy(d.alpha, al.data(), n * sizeof(float), hipMemcpyHostToDevice));
     }
     if(d.shStride)
     {
@@ -792,6 +814,8 @@ int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
     {
       const DeviceSet& d  = s->sets[s->instances[k].set];
       tab[k].sh           = d.sh;
+      tab[k].rgba         = reinterpret_cast<const float4*>(d.rgbaF32);
+      tab[k].centers      = d.centers;
       tab[k].globalOffset = off;
       tab[k].shDegree     = d.shDegree;
       off += d.count;
@@ -1092,6 +1116,8 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
     C.partBox = d.partBox;
     C.maxScale = d.maxScale;
     C.scales    = d.scales;
+    C.alpha     = d.alpha;
+    C.rgbaF32   = d.rgbaF32;
     C.rotations = d.rotations;
     {
       auto len3 = [&](int c) { return std::sqrt((I.M[4 * c] * I.M[4 * c] + I.M[4 * c + 1] * I.M[4 * c + 1]) + I.M[4 * c + 2] * I.M[4 * c + 2]); };
@@ -1404,7 +1430,7 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
       }
     }
     if(withEvents) HIPCHK(hipEventRecord(fev[4], st));
-    launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat, ctr,
+    launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat, s->rgbaFormat, ctr,
                     F.surfaceOutputs ? s->surfDepth.p : nullptr, F.surfaceOutputs ? s->surfId.p : nullptr, s->compInst.p,
                     s->dArgs.p, F.surfaceOutputs ? s->surfNormal.p : nullptr);
     if(withEvents) HIPCHK(hipEventRecord(fev[5], st));
@@ -1424,7 +1450,7 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
     std::memcpy(&isoBits, &F.depthIsoThreshold, 4);
     // everything the compositor receives by value (CompositeArgs) must be part of the key
     const int32_t kv[16] = {F.width, F.height, F.stripRow0, F.stripRow1, F.binShiftX, F.binShiftY, F.partitionCull, F.alphaMode,
-                            F.debugFlags & (4 | 256), F.surfaceOutputs, half, F.nInstances, F.shDegree, isoBits, 0, 0};
+                            F.debugFlags & (2 | 4 | 256), F.surfaceOutputs, half, F.nInstances, F.shDegree, isoBits, 0, 0};
     std::memcpy(key.v, kv, sizeof(kv));
     key.p[0] = s->image.p;
     key.p[1] = s->surfDepth.p;

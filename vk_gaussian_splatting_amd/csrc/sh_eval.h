@@ -12,6 +12,17 @@ namespace mgs {
 // Register-lean evaluation: the 15 basis values are computed first, then the record is consumed in groups of
 // four 16-byte vectors (scheduling fences keep the compiler from hoisting all 12 loads, which cost the
 // compositor 70 VGPRs and half its occupancy); the first group's miss brings the whole record's sectors in.
+// b / 255.0f for an integer-valued b in [0, 255], correctly rounded like the IEEE division the shader compiles to, in
+// three instructions instead of the ~10 of a division: one Newton step on b * (1/255).  Equal to b / 255.0f for all 256
+// inputs (exhaustive check: tests/test_host_cpu.py::test_div255_refinement_is_exact).
+__device__ __forceinline__ float div255(float b)
+{
+  constexpr float r   = 1.0f / 255.0f;
+  const float     q   = __fmul_rn(b, r);
+  const float     rem = __fmaf_rn(-q, 255.0f, b);
+  return __fmaf_rn(rem, r, q);
+}
+
 template <int FMT>
 __device__ __forceinline__ void decodeShVector(const uint4& x, float (&e)[FMT == 0 ? 4 : (FMT == 1 ? 8 : 16)])
 {
@@ -38,7 +49,7 @@ __device__ __forceinline__ void decodeShVector(const uint4& x, float (&e)[FMT ==
     for(int q = 0; q < 4; ++q)
 #pragma unroll
       for(int k = 0; k < 4; ++k)  // threedgs_particle_buffers.h.slang:128-131: v/255*2-1
-        e[4 * q + k] = (float)((w[q] >> (8 * k)) & 255u) / 255.0f * 2.0f - 1.0f;
+        e[4 * q + k] = __fmaf_rn(div255((float)((w[q] >> (8 * k)) & 255u)), 2.0f, -1.0f);  // x*2 is exact: == (x*2)-1
   }
 }
 
@@ -80,7 +91,7 @@ __device__ __forceinline__ void addShRadiance(const void* sh, uint32_t li, int d
 #ifndef MGS_SH_GROUP
 #define MGS_SH_GROUP 3
 #endif
-  constexpr int GROUP = FMT == 0 ? MGS_SH_GROUP : (FMT == 1 ? 6 : 3);  // fp32: four groups of 48 B (fewer live registers: the compositor runs 6 waves per SIMD with 16 B of spill), fp16 / uint8: the whole record
+  constexpr int GROUP = FMT == 0 ? MGS_SH_GROUP : (FMT == 1 ? 3 : 1);  // 16-byte vectors per round trip, chosen by the compositor's spill count at 6 waves per SIMD (fp32 3 / fp16 3 / uint8 1)
 #pragma unroll
   for(int v0 = 0; v0 < REC; v0 += GROUP)
   {
