@@ -104,6 +104,41 @@ def test_radix_sort_ties_constant_digits_and_bit_ranges(scene_small, ob):
     assert np.array_equal(ks, k8[o]) and np.array_equal(vs, v[o])
 
 
+def test_radix_sort_depth_like_keys_with_outliers(scene_small, ob):
+    """depth-like keys (one dominant top byte) with a few / many / no outliers, several outlier classes on both sides of
+    the dominant one, outliers spanning many partitions, and the case where no class dominates — the distributions a
+    pass-skipping or class-splitting sort has to get right (a 9-bit pass 2 + outlier-only pass 3 variant was measured
+    against this test and dropped: DESIGN.md §9)"""
+    scene, _ = scene_small
+    rng = np.random.default_rng(2024)
+    n = 700_001
+    v = np.arange(n, dtype=np.uint32)
+    base = (0x40000000 | rng.integers(0, 1 << 24, n)).astype(np.uint32)
+    for frac in (0.0, 1e-5, 1e-3, 0.02, 0.45):
+        k = base.copy()
+        m = rng.random(n) < frac
+        tops = rng.choice(np.array([0x00, 0x3F, 0x41, 0x42, 0x7F, 0xFF], np.uint32), int(m.sum()))
+        k[m] = (k[m] & np.uint32(0x00FFFFFF)) | (tops << np.uint32(24))
+        ks, vs, _ = scene.radix_sort_host(k, v)
+        o = np.argsort(k, kind="stable")
+        assert np.array_equal(ks, k[o]) and np.array_equal(vs, v[o]), frac
+    # the dominant class is the very last value (padding keys share its top byte) and the very first
+    for top in (0xFF, 0x00):
+        k = ((top << 24) | rng.integers(0, 1 << 24, n)).astype(np.uint32)
+        k[::1000] = rng.integers(0, 2**32, k[::1000].size, dtype=np.uint32)
+        ks, vs, _ = scene.radix_sort_host(k, v)
+        o = np.argsort(k, kind="stable")
+        assert np.array_equal(ks, k[o]) and np.array_equal(vs, v[o]), top
+    # a 3 M-element sort takes the 4096-key partitions
+    n2 = 3_000_017
+    k = (0x40000000 | rng.integers(0, 1 << 24, n2)).astype(np.uint32)
+    k[rng.random(n2) < 0.01] |= np.uint32(0x01000000)
+    v2 = rng.integers(0, 2**32, n2, dtype=np.uint32)
+    ks, vs, _ = scene.radix_sort_host(k, v2)
+    o = np.argsort(k, kind="stable")
+    assert np.array_equal(ks, k[o]) and np.array_equal(vs, v2[o])
+
+
 def test_upload_transform_matches_oracle_bitwise(scene_small, ob):
     scene, sc = scene_small
     ps = ob.PreparedSet(sc)
