@@ -484,7 +484,7 @@ void launchPartitionCull(hipStream_t stream, const FrameArgs& args, const FrameA
 
 // ---------------------------------------------------------------------------------------------
 // host-callable launcher
-void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full, int shFormat, int rgbaFormat,
+void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full,
                    FrameCounters* ctr,
                    uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, SplatRec* rec, uint32_t* rect,
                    const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride)
@@ -495,7 +495,6 @@ void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* d
 #define MGS_LAUNCH(FULLV)                                                                                                \
   hipLaunchKernelGGL((k_project<FULLV>), grid, block, 0, stream, dArgs, ctr, keysSlot, idsSlot, slotCount, rec, rect, partSkip, \
                      slotHist, histStride)
-  (void)rgbaFormat;  // the projection reads the planar alpha only; the colour format matters to the compositor
   if(full)
     MGS_LAUNCH(true);
   else

@@ -1133,7 +1133,7 @@ void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* 
 
 void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
                      const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, int halfOut,
-                     int shFormat, int rgbaFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId,
+                     int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId,
                      const void* instTable, const FrameArgs* dArgs, float4* outNormal)
 {
   const FrameConst& F = A.f;
@@ -1151,7 +1151,6 @@ void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges
   C.stripRow0 = F.stripRow0; C.stripRow1 = F.stripRow1;
   C.nInstances = F.nInstances; C.shDegree = F.shDegree; C.looseMask = (F.debugFlags & 256) ? 1 : 0;
   C.depthIsoThreshold = F.depthIsoThreshold;
-  (void)rgbaFormat;
   C.shOnly     = (F.debugFlags & 2) ? 1 : 0;
   for(int i = 0; i < F.nInstances && i < kMaxInlineInstances; ++i)
   {

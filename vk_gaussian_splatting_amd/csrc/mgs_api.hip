@@ -29,7 +29,7 @@
 
 namespace mgs {
 // kernels_*.hip
-void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full, int shFormat, int rgbaFormat,
+void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full,
                    FrameCounters* ctr,
                    uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, SplatRec* rec, uint32_t* rect,
                    const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride);
@@ -50,7 +50,7 @@ void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* 
                       uint2* ranges);
 void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
                      const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, int halfOut,
-                     int shFormat, int rgbaFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId, const void* instTable, const FrameArgs* dArgs,
+                     int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId, const void* instTable, const FrameArgs* dArgs,
                      float4* outNormal);
 constexpr uint32_t kPart = 2048;  // == kPrjPart == kSortPart == kBinPart
 }  // namespace mgs
@@ -1368,7 +1368,7 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
     const bool cpuMode = (p->sort_mode == MGS_SORT_CPU_ASYNC);
     if(cpuMode)  // rejected splats must look empty to the binning stage: rect with x0 > x1
       hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, st, s->rect.p, 1u, s->totalSplats);
-    launchProject(st, A, s->dArgs.p, true, s->shFormat, s->rgbaFormat, ctr, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p,
+    launchProject(st, A, s->dArgs.p, true, ctr, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p,
                   s->rect.p, F.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride);
     if(withEvents) HIPCHK(hipEventRecord(fev[1], st));
     static const bool kFuseRect = [] { const char* e = std::getenv("MGS_FUSE_RECT"); return e ? std::atoi(e) != 0 : false; }();  // measured: +43 us in the scatter for -17 us in the count kernel
@@ -1430,7 +1430,7 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
       }
     }
     if(withEvents) HIPCHK(hipEventRecord(fev[4], st));
-    launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat, s->rgbaFormat, ctr,
+    launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat, ctr,
                     F.surfaceOutputs ? s->surfDepth.p : nullptr, F.surfaceOutputs ? s->surfId.p : nullptr, s->compInst.p,
                     s->dArgs.p, F.surfaceOutputs ? s->surfNormal.p : nullptr);
     if(withEvents) HIPCHK(hipEventRecord(fev[5], st));
@@ -1733,7 +1733,7 @@ int mgs_sort_keys(MgsScene s, const MgsFrameParams* p, MgsSortOut* out)
                         (uint32_t)(2 * sizeof(SortPlan) / 4), nullptr, 0u);
   else
     launchFrameInit(st, s->ctr.p, &s->plans.p[0], &s->plans.p[1], s->ranges.p, 0);
-  launchProject(st, A, s->dArgs.p, false, 0, 0, s->ctr.p, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p, s->rect.p,
+  launchProject(st, A, s->dArgs.p, false, s->ctr.p, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p, s->rect.p,
                 A.f.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride);
   HIPCHK(hipEventRecord(s->ev[1], st));
   keySort(s, st, false);
