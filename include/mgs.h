@@ -154,7 +154,9 @@ typedef struct MgsFrameParams {
 void mgs_frame_params_default(MgsFrameParams* p); /* fills the defaults cited above */
 
 enum { MGS_STAGE_PROJECT = 0, MGS_STAGE_SORT = 1, MGS_STAGE_BIN = 2, MGS_STAGE_PAIRSORT = 3,
-       MGS_STAGE_COMPOSITE = 4, MGS_STAGE_TOTAL = 5, MGS_STAGE_COUNT = 8 };
+       MGS_STAGE_COMPOSITE = 4, MGS_STAGE_TOTAL = 5,
+       MGS_STAGE_CULL = 6, /* the partition cull + per-frame state reset at the head of MGS_STAGE_PROJECT (included in it) */
+       MGS_STAGE_COUNT = 8 };
 
 typedef struct MgsFrameOut {
   void*    rgba_device;     /* device pointer: [height][width][4] fp16 (or fp32), row 0 = NDC y -1, linear */

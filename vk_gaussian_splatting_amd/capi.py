@@ -296,6 +296,12 @@ class Scene:
         _check(self._lib.mgs_timings_query(self._h, frames_back, ms))
         return [float(x) for x in ms[:6]]
 
+    def timings_all(self, frames_back=0):
+        """all MGS_STAGE_COUNT slots: the six of timings() + [6] = MGS_STAGE_CULL (the head of the project stage)"""
+        ms = (C.c_float * 8)()
+        _check(self._lib.mgs_timings_query(self._h, frames_back, ms))
+        return [float(x) for x in ms]
+
     def download_frame(self, params):
         if params.target_format == TARGET_RGBA8:
             img = np.zeros((params.height, params.width, 4), np.uint8)

@@ -275,7 +275,7 @@ struct MgsScene_t
 
   static constexpr int kRing = 128;
   hipEvent_t ev[8] = {};              // [0..2] sort-only hook, [6..7] raw radix sort
-  hipEvent_t evRing[kRing][6] = {};   // per-frame stage brackets, so timed frames need no host sync
+  hipEvent_t evRing[kRing][7] = {};   // per-frame stage brackets ([6]: end of the partition cull), so timed frames need no host sync
   uint64_t   frameIndex = 0;          // frames rendered with collect_timings
   bool       evReady = false;
 
@@ -1365,6 +1365,7 @@ int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
                           reinterpret_cast<uint32_t*>(s->ranges.p), 2u * nTiles);
     else
       launchFrameInit(st, ctr, planK, planP, s->ranges.p, nTiles);
+    if(withEvents) HIPCHK(hipEventRecord(fev[6], st));  // MGS_STAGE_CULL ends here; it is part of MGS_STAGE_PROJECT too
     const bool cpuMode = (p->sort_mode == MGS_SORT_CPU_ASYNC);
     if(cpuMode)  // rejected splats must look empty to the binning stage: rect with x0 > x1
       hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, st, s->rect.p, 1u, s->totalSplats);
@@ -1535,6 +1536,8 @@ int mgs_timings_query(MgsScene s, uint32_t framesBack, float* stageMs)
   }
   HIPCHK(hipEventElapsedTime(&ms, fev[0], fev[5]));
   stageMs[MGS_STAGE_TOTAL] = ms;
+  HIPCHK(hipEventElapsedTime(&ms, fev[0], fev[6]));
+  stageMs[MGS_STAGE_CULL] = ms;
   return MGS_OK;
 }
 
