@@ -68,6 +68,9 @@ def main():
                     "(configs[4]: 8 -> ~46.6 M splats under one unified depth sort)")
     ap.add_argument("--sh-format", type=int, default=0, help="0 fp32 (benchmark setting), 1 fp16, 2 uint8")
     ap.add_argument("--rgba-format", type=int, default=0)
+    ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3, 4],
+                    help="shorthand for the BASELINE.json configs: 1 train-sized 1080p, 2 garden-sized 1080p (the default), "
+                         "3 garden-sized 3840x2160, 4 eight garden instances (46.6 M splats) 1080p")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=3, help="frames in flight per GPU (each on its own HIP stream with "
                     "its own working buffers); >1 overlaps one frame's tails/launch gaps/all-gather with the next frame")
@@ -78,6 +81,12 @@ def main():
                     "single-stream calibration frames")
     ap.add_argument("--check-gather", action="store_true", help="N>1: verify the gathered frame == a full-frame render")
     args = ap.parse_args()
+    if args.config == 1:
+        args.splats = 1_030_000
+    elif args.config == 3:
+        args.width, args.height = 3840, 2160
+    elif args.config == 4:
+        args.instances = 8
 
     import torch
     import torch.distributed as dist
