@@ -593,6 +593,31 @@ def test_strips_are_bit_identical_to_full_frame(scene_small):
     p.strip_row_begin = p.strip_row_end = 0
 
 
+def test_surface_outputs_of_strips_are_bit_identical_to_full_frame(scene_small):
+    """the side outputs (picked depth, splat id, integrated normal) follow the same rule as the colour: a strip's rows
+    equal the full frame's, bit for bit"""
+    from vk_gaussian_splatting_amd import multigpu
+    scene, _ = scene_small
+    W, H = 640, 360
+    p, *_ = camera(29, W, H)
+    p.surface_outputs = 1
+    scene.render(p)
+    fd, fi, fn = (a.copy() for a in scene.download_surface(p, normals=True))
+    assert (fi != 0xFFFFFFFF).any()
+    G = 4
+    for r in range(G):
+        b, e = multigpu.strip_rows(H, G, r)
+        p.strip_row_begin, p.strip_row_end = b, e
+        scene.render(p)
+        d, i, n = scene.download_surface(p, normals=True)
+        y0, y1 = b * 16, min(e * 16, H)
+        assert np.array_equal(d[y0:y1].view(np.uint32), fd[y0:y1].view(np.uint32)), r
+        assert np.array_equal(i[y0:y1], fi[y0:y1]), r
+        assert np.array_equal(n[y0:y1].view(np.uint32), fn[y0:y1].view(np.uint32)), r
+    p.strip_row_begin = p.strip_row_end = 0
+    p.surface_outputs = 0
+
+
 def test_determinism_and_empty_view(scene_small):
     scene, _ = scene_small
     p, *_ = camera(2, 320, 240)
