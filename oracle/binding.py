@@ -206,6 +206,19 @@ def render(frame, inst, order=None):
     return img, dict(fragments=int(frags), visible=int(stats[0]), quads=int(stats[1]))
 
 
+def render_window(frame, inst, order, window):
+    """orc_render_order restricted to the inclusive pixel window (x0, y0, x1, y1) -> [h][w][4] float32"""
+    x0, y0, x1, y1 = [int(v) for v in window]
+    o = np.ascontiguousarray(order, np.uint32)
+    img = np.zeros((y1 - y0 + 1, x1 - x0 + 1, 4), np.float32)
+    fn = lib().orc_render_window
+    fn.restype = C.c_uint64
+    fn.argtypes = [C.POINTER(OrcFrame), C.POINTER(OrcInstance), C.c_int, U32P, C.c_uint32, C.POINTER(C.c_int), F32P]
+    win = (C.c_int * 4)(x0, y0, x1, y1)
+    frags = fn(C.byref(frame), inst, len(inst), _u(o), o.size, win, _p(img))
+    return img, int(frags)
+
+
 def render_surface(frame, inst, order_front_to_back, depth_iso_threshold=0.7, thin_particle_threshold=1e-6,
                    quantize_normals=True, normals=False):
     """FTB side outputs: (depth[H,W] float32, splat_id[H,W] uint32[, normal[H,W,4] float32]) — picked depth, the

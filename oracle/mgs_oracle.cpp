@@ -578,7 +578,10 @@ void orc_project(const OrcFrame* f, const OrcInstance* Ip, uint32_t i, OrcProjec
 }
 
 // fragments + blending: shaders/threedgs_raster.frag.slang:223-309, src/gaussian_splatting.cpp:2066-2087
-static uint64_t raster_one(const OrcFrame* f, const OrcProjected& P, float* img)
+// `win` (optional) = {x0, y0, x1, y1}: only pixels inside this inclusive window are evaluated, and `img` is then the
+// window's own [y1-y0+1][x1-x0+1][4] buffer.  The per-pixel arithmetic is the same either way; pixels are independent
+// given the draw order, so a windowed render equals the crop of the full one bit for bit.
+static uint64_t raster_one(const OrcFrame* f, const OrcProjected& P, float* img, const int* win = nullptr)
 {
   const int   W = f->width, H = f->height;
   const float ex = std::fabs(P.basis1[0]) + std::fabs(P.basis2[0]);
@@ -589,13 +592,25 @@ static uint64_t raster_one(const OrcFrame* f, const OrcProjected& P, float* img)
   if(!(fx1 >= 0.f && fy1 >= 0.f && fx0 <= (float)(W - 1) && fy0 <= (float)(H - 1)))
     return 0;
   const int   x0 = (int)std::max(0.0f, std::floor(fx0)), x1 = (int)std::min((float)(W - 1), std::ceil(fx1));
-  const int   y0 = (int)std::max(0.0f, std::floor(fy0)), y1 = (int)std::min((float)(H - 1), std::ceil(fy1));
+  int         y0 = (int)std::max(0.0f, std::floor(fy0)), y1 = (int)std::min((float)(H - 1), std::ceil(fy1));
+  int         ox = 0, oy = 0, pitch = W;
+  int         xa = x0, xb = x1;
+  if(win)
+  {
+    xa = std::max(xa, win[0]);
+    xb = std::min(xb, win[2]);
+    y0 = std::max(y0, win[1]);
+    y1 = std::min(y1, win[3]);
+    ox = win[0];
+    oy = win[1];
+    pitch = win[2] - win[0] + 1;
+  }
   const float n1 = P.basis1[0] * P.basis1[0] + P.basis1[1] * P.basis1[1];
   const float n2 = P.basis2[0] * P.basis2[0] + P.basis2[1] * P.basis2[1];
   uint64_t    frags = 0;
   for(int y = y0; y <= y1; ++y)
   {
-    for(int x = x0; x <= x1; ++x)
+    for(int x = xa; x <= xb; ++x)
     {
       const float dx = ((float)x + 0.5f) - P.center_px[0];
       const float dy = ((float)y + 0.5f) - P.center_px[1];
@@ -609,7 +624,7 @@ static uint64_t raster_one(const OrcFrame* f, const OrcProjected& P, float* img)
       const float opacity = P.opacity_disabled ? 1.0f : std::exp(-0.5f * A) * P.rgba[3];  // :248-254
       if(opacity <= 1.0f / 255.0f)                            // :258-262
         continue;
-      float* dst = img + ((size_t)y * W + x) * 4;
+      float* dst = img + ((size_t)(y - oy) * pitch + (x - ox)) * 4;
       if(f->front_to_back)
       {  // src rgb premultiplied (:303); C = Cs*(1-Ad) + Cd ; A = As*(1-Ad) + Ad
         const float oma = 1.0f - dst[3];
@@ -660,6 +675,31 @@ uint64_t orc_render_order(const OrcFrame* f, const OrcInstance* inst, int n_inst
   {
     stats[0] = v;
     stats[1] = quads;
+  }
+  return frags;
+}
+
+// orc_render_order restricted to the inclusive pixel window {x0,y0,x1,y1}; rgba_out is the window's own buffer.
+// Used to pin full-size frames with a few crops (a whole 5.8 M-splat frame is ~7 G fragments on one core).
+uint64_t orc_render_window(const OrcFrame* f, const OrcInstance* inst, int n_inst, const uint32_t* ids, uint32_t v,
+                           const int win[4], float* rgba_out)
+{
+  const int ww = win[2] - win[0] + 1, wh = win[3] - win[1] + 1;
+  std::memset(rgba_out, 0, (size_t)ww * wh * 4 * sizeof(float));
+  std::vector<uint32_t> offsets(n_inst + 1, 0);
+  for(int k = 0; k < n_inst; ++k)
+    offsets[k + 1] = offsets[k] + inst[k].count;
+  uint64_t frags = 0;
+  for(uint32_t s = 0; s < v; ++s)
+  {
+    const uint32_t g = ids[s];
+    int            k = 0;
+    while(k + 1 < n_inst && g >= offsets[k + 1])
+      ++k;
+    OrcProjected P;
+    orc_project(f, &inst[k], g - offsets[k], &P);
+    if(P.valid)
+      frags += raster_one(f, P, rgba_out, win);
   }
   return frags;
 }

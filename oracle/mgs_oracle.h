@@ -106,6 +106,11 @@ uint64_t orc_render(const OrcFrame* f, const OrcInstance* inst, int n_inst,
 uint64_t orc_render_order(const OrcFrame* f, const OrcInstance* inst, int n_inst,
                           const uint32_t* ids, uint32_t v, float* rgba_out, uint64_t* stats);
 
+/* the same restricted to the inclusive pixel window win = {x0,y0,x1,y1}; rgba_out is the window's own
+ * [y1-y0+1][x1-x0+1][4] buffer (== the crop of orc_render_order's image, bit for bit) */
+uint64_t orc_render_window(const OrcFrame* f, const OrcInstance* inst, int n_inst,
+                           const uint32_t* ids, uint32_t v, const int win[4], float* rgba_out);
+
 /* octahedral normal coding, shaders/octahedral_normal.h.slang:27-87 */
 uint32_t orc_oct_encode(const float n[3]);
 void     orc_oct_decode(uint32_t packed, float out[3]);

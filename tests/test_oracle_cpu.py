@@ -340,3 +340,132 @@ def test_surface_normal_integration_single_and_many(ob):
     assert np.all(np.linalg.norm(n2[..., :3], axis=-1) <= n2[..., 3] + 1e-5) and np.all(n2[..., 3] <= 1.0 + 1e-5)
     b, _ = ob.render(ob.make_frame(V2, P2, eye2, 128, 96, front_to_back=1), inst2)
     assert np.allclose(n2[..., 3], b[..., 3], atol=1e-5)
+
+
+# ---- cross-check of the oracle against the independent float64 restatement (tests/np_reference.py) ----------
+def _trs(scale, axis, angle, t):
+    axis = np.asarray(axis, np.float64) / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    R = np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * (K @ K)
+    M = np.eye(4)
+    M[:3, :3] = R @ np.diag(scale)
+    M[:3, 3] = t
+    return M.astype(np.float32)
+
+
+def _oracle_project_all(ob, fr, inst, k, n):
+    out = dict(valid=np.zeros(n, bool), center_px=np.zeros((n, 2)), b1=np.zeros((n, 2)), b2=np.zeros((n, 2)),
+               rgba=np.zeros((n, 4)), ndc_z=np.zeros(n))
+    for i in range(n):
+        p = ob.project(fr, inst, k, i)
+        out["valid"][i] = bool(p.valid)
+        if p.valid:
+            out["center_px"][i] = list(p.center_px)
+            out["b1"][i], out["b2"][i] = list(p.basis1), list(p.basis2)
+            out["rgba"][i] = list(p.rgba)
+            out["ndc_z"][i] = p.ndc_z
+    return out
+
+
+@pytest.mark.parametrize("case", ["identity", "trs", "msaa_flipy", "cull_at_raster_deg1"])
+def test_projection_and_sh_against_independent_numpy_fp64(ob, case):
+    """a12/a13/a11 per splat: view/clip centre, Sigma2D eigen basis (incl. the 0.1 floor and the |b|<1e-3 branch),
+    SH radiance, opacity — oracle (fp32, column vectors) vs np_reference (fp64, the shaders' row-vector form)"""
+    import np_reference as npr
+    n = 3000
+    sc = synth.make_scene(n, seed=31)
+    ps = ob.PreparedSet(sc)
+    M = None if case in ("identity", "msaa_flipy") else _trs([1.3, 0.7, 1.1], [0.3, 1.0, -0.2], 0.8, [0.4, -0.2, 0.3])
+    inst = ob.make_instances([(ps, M)])
+    W, H = 320, 200
+    eye = np.array([3.5, 1.2, 0.8], np.float32)
+    V, P = lookat(eye, [0, 0, 0], [0, 1, 0]), persp(55, W / H, 0.1, 2000, flip=(case == "msaa_flipy"))
+    kw = dict(ms_antialiasing=1) if case == "msaa_flipy" else {}
+    deg = 1 if case == "cull_at_raster_deg1" else 3
+    fr = ob.make_frame(V, P, eye, W, H, sh_degree=deg, frustum_culling=2 if case == "cull_at_raster_deg1" else 1, **kw)
+    o = _oracle_project_all(ob, fr, inst, 0, n)
+    r = npr.project(ps.positions, ps.cov6, ps.rgba, ps.sh.reshape(n, -1), ps.sh_degree, np.eye(4) if M is None else M,
+                    V, P, eye, W, H, sh_degree=deg, cull_at_raster=(case == "cull_at_raster_deg1"),
+                    ms_aa=(case == "msaa_flipy"))
+    # validity may flip only for splats sitting on a threshold in fp32
+    flips = np.flatnonzero(o["valid"] != r["valid"])
+    assert flips.size <= 3, flips
+    both = o["valid"] & r["valid"]
+    assert both.sum() > 500
+    # a splat far behind/beside the camera can be 'valid' with a huge or ill-conditioned footprint: compare the
+    # well-conditioned ones tightly and everything through the stable quantity (the 2x2 extent matrix)
+    c_o, c_r = o["center_px"][both], r["center_px"][both]
+    assert np.allclose(c_o, c_r, rtol=2e-5, atol=2e-3)
+    assert np.allclose(o["ndc_z"][both], r["ndc_z"][both], rtol=0, atol=5e-5)  # fp32 cancellation in P22*z+P23 (near 0.1, far 2000)
+    assert np.allclose(o["rgba"][both], r["rgba"][both], rtol=1e-4, atol=2e-5)  # base colour + SH + (AA) opacity
+    Eo = np.einsum("ni,nj->nij", o["b1"][both], o["b1"][both]) + np.einsum("ni,nj->nij", o["b2"][both], o["b2"][both])
+    Er = np.einsum("ni,nj->nij", r["b1"][both], r["b1"][both]) + np.einsum("ni,nj->nij", r["b2"][both], r["b2"][both])
+    scale = np.abs(Er).max(axis=(1, 2))[:, None, None]
+    assert (np.abs(Eo - Er) / scale).max() < 2e-3
+    # direct basis comparison where the eigen decomposition is well conditioned (gap >> rounding, b clear of 1e-3)
+    ev, cov2 = r["ev"][both], r["cov2"][both]
+    good = ((ev[:, 0] - ev[:, 1]) > 0.05 * ev[:, 0]) & (np.abs(np.abs(cov2[:, 1]) - 1e-3) > 1e-4) & (ev[:, 0] < 1e5)
+    assert good.sum() > 300
+    for name in ("b1", "b2"):
+        bo, br = o[name][both][good], r[name][both][good]
+        assert np.allclose(bo, br, rtol=2e-3, atol=2e-3 * np.abs(br).max(axis=1, keepdims=True)), name
+
+
+def test_extent_basis_special_cases_against_numpy(ob):
+    """the branches an image PSNR would not notice: |b| < 1e-3 (eigenvector x := 1), the max(0.1, .) discriminant floor,
+    the 2048-px clamp — isolated with hand-made splats"""
+    import np_reference as npr
+    # isotropic splat on the optical axis -> b == 0 exactly, discriminant 0 -> floored to 0.1
+    # huge splat close to the camera -> sqrt8*sqrt(ev1) > 2048 -> clamped
+    # flat disc seen obliquely -> strongly anisotropic, b far from 0
+    pos = np.array([[0, 0, 0], [0.05, 0.02, 1.0], [0.3, -0.2, 0.1]], np.float32)
+    scale = np.log(np.array([[0.05, 0.05, 0.05], [40.0, 30.0, 35.0], [0.4, 0.4, 0.004]], np.float32))
+    rot = np.array([[1, 0, 0, 0], [1, 0, 0, 0], [0.9, 0.3, 0.2, 0.1]], np.float32)
+    rot /= np.linalg.norm(rot, axis=1, keepdims=True)
+    sc = dict(positions=pos, f_dc=np.zeros((3, 3), np.float32), f_rest=np.zeros((3, 0), np.float32),
+              opacity=np.full(3, 3.0, np.float32), scale=scale, rotation=rot)
+    ps = ob.PreparedSet(sc)
+    inst = ob.make_instances([(ps, None)])
+    eye = np.array([0, 0, 3], np.float32)
+    W, H = 256, 256
+    V, P = lookat(eye, [0, 0, 0], [0, 1, 0]), persp(60, 1.0, 0.1, 100)
+    fr = ob.make_frame(V, P, eye, W, H)
+    r = npr.project(ps.positions, ps.cov6, ps.rgba, np.zeros((3, 45)), 0, np.eye(4), V, P, eye, W, H)
+    for i in range(3):
+        p = ob.project(fr, inst, 0, i)
+        assert bool(p.valid) and bool(r["valid"][i]), i
+        for got, want in ((list(p.basis1), r["b1"][i]), (list(p.basis2), r["b2"][i])):
+            # direction and length to 1e-3 of the vector's own length (the eigenvector angle of a 2048-px basis is
+            # an fp32 quantity: the components are not individually meaningful to 1e-3 relative)
+            assert np.allclose(got, want, rtol=0, atol=1e-3 * max(1.0, np.hypot(*want))), (i, got, want)
+    assert abs(r["cov2"][0, 1]) < 1e-3 and np.isclose(r["ev"][0, 0] - r["ev"][0, 1], 2 * np.sqrt(0.1), rtol=1e-6)
+    assert np.isclose(np.hypot(*r["b1"][1]), 2048.0)  # clamped
+    assert abs(r["cov2"][2, 1]) > 1.0  # anisotropic, oblique
+
+
+def test_oracle_frame_against_independent_numpy_render(ob):
+    """whole small frame: oracle (fp32, unfused) vs np_reference (fp64) through key/cull order -> projection -> SH ->
+    per-fragment alpha -> 'over' blend.  Two instances, one transformed."""
+    import np_reference as npr
+    n = 1500
+    sc = synth.make_scene(n, seed=77)
+    ps = ob.PreparedSet(sc)
+    M1 = _trs([0.8, 1.2, 1.0], [0.1, 1.0, 0.3], -0.6, [1.0, 0.1, -0.5])
+    inst = ob.make_instances([(ps, None), (ps, M1)])
+    W, H = 160, 100
+    eye = np.array([3.8, 1.4, 1.0], np.float32)
+    V, P = lookat(eye, [0, 0, 0], [0, 1, 0]), persp(60, W / H, 0.1, 2000)
+    fr = ob.make_frame(V, P, eye, W, H)  # fp32 target: no per-blend fp16 rounding on either side
+    keys, ids = ob.key_cull(fr, inst)
+    ks, vs = ob.sort_stable(keys, ids)
+    oimg, st = ob.render(fr, inst, order=vs)
+    pr = [npr.project(ps.positions, ps.cov6, ps.rgba, ps.sh.reshape(n, -1), ps.sh_degree, m, V, P, eye, W, H)
+          for m in (np.eye(4), M1)]
+    merged = {k: np.concatenate([pr[0][k], pr[1][k]]) for k in ("valid", "center_px", "b1", "b2", "rgba")}
+    nimg = npr.render(merged, vs, W, H)
+    assert st["fragments"] > 20000
+    err = np.abs(oimg - nimg)
+    # identical draw order and discards; the two sides differ by fp32-vs-fp64 rounding (fragments exactly on a
+    # discard threshold are the only place a visible difference could come from)
+    assert ob.psnr_rgb(oimg, nimg.astype(np.float32)) > 80.0
+    assert err[..., :3].max() < 5e-3 and np.percentile(err, 99.9) < 1e-4

@@ -326,6 +326,23 @@ int loadPly(const std::string& path, HostSplatSet& out)
       setError("ply: invalid 3DGS PLY file (missing x/y/z, opacity, scale_*, rot_* or f_dc_*): " + path);
       return MGS_ERR_FORMAT;
     }
+    // the header's count is untrusted: check it against what the file can actually hold BEFORE sizing anything
+    // (a 100-byte file declaring 4e9 vertices must be a format error, not an allocation of 1 TB)
+    {
+      const std::streamoff here = f.tellg();
+      f.seekg(0, std::ios::end);
+      const std::streamoff fileEnd = f.tellg();
+      f.seekg(here, std::ios::beg);
+      const uint64_t remaining = (here >= 0 && fileEnd >= here) ? (uint64_t)(fileEnd - here) : 0ull;
+      // binary: rowSize bytes per vertex; ascii: at least one digit + one separator per property
+      const uint64_t minRow = (fmt == ASCII) ? (uint64_t)e.props.size() * 2ull : (uint64_t)e.rowSize;
+      if(minRow == 0 || n > remaining / minRow)
+      {
+        setError("ply: header declares " + std::to_string(n) + " vertices but only " + std::to_string(remaining)
+                 + " bytes of vertex data follow in " + path);
+        return MGS_ERR_FORMAT;
+      }
+    }
     out.positions.resize(n * 3);
     out.opacity.resize(n);
     out.scale.resize(n * 3);
@@ -404,7 +421,23 @@ int loadPly(const std::string& path, HostSplatSet& out)
 }
 
 // ------------------------------------------------------------------------------------ SPZ
-static bool gunzip(const std::vector<uint8_t>& in, std::vector<uint8_t>& out)
+// SPZ payload size the 16-byte header promises (0 = header invalid); shared by the inflate cap and the loader
+static size_t spzPayloadBytes(const uint8_t* hdr)
+{
+  uint32_t magic, version, numPoints;
+  std::memcpy(&magic, hdr, 4);
+  std::memcpy(&version, hdr + 4, 4);
+  std::memcpy(&numPoints, hdr + 8, 4);
+  const uint8_t shDegree = hdr[12];
+  if(magic != 0x5053474eu || version < 1 || version > 3 || shDegree > 3 || numPoints > 10000000u)
+    return 0;
+  const size_t n = numPoints, shDim = shDegree == 0 ? 0 : shDegree == 1 ? 3 : shDegree == 2 ? 8 : 15;
+  return 16 + n * 3 * (version == 1 ? 2 : 3) + n + n * 3 + n * 3 + n * (version >= 3 ? 4 : 3) + n * shDim * 3;
+}
+
+// Inflates a gzip stream, never beyond what the SPZ header (the first 16 inflated bytes) says the payload holds:
+// the output of an untrusted stream is capped (a few KB of zeros can inflate to gigabytes otherwise).
+static bool gunzipSpz(const std::vector<uint8_t>& in, std::vector<uint8_t>& out)
 {
   z_stream zs;
   std::memset(&zs, 0, sizeof(zs));
@@ -413,7 +446,9 @@ static bool gunzip(const std::vector<uint8_t>& in, std::vector<uint8_t>& out)
   zs.next_in  = const_cast<Bytef*>(in.data());
   zs.avail_in = (uInt)in.size();
   std::vector<uint8_t> chunk(1 << 20);
-  bool                 ok = false;
+  bool                 ok    = false;
+  size_t               limit = 16;  // until the header is known
+  bool                 haveLimit = false;
   for(;;)
   {
     zs.next_out  = chunk.data();
@@ -422,8 +457,24 @@ static bool gunzip(const std::vector<uint8_t>& in, std::vector<uint8_t>& out)
     if(rc != Z_OK && rc != Z_STREAM_END)
       break;
     out.insert(out.end(), chunk.data(), chunk.data() + (chunk.size() - zs.avail_out));
+    if(!haveLimit && out.size() >= 16)
+    {
+      limit     = spzPayloadBytes(out.data());
+      haveLimit = true;
+      if(limit == 0)
+      {  // not an SPZ header: the caller reports it; nothing more to inflate
+        out.resize(16);
+        ok = true;
+        break;
+      }
+    }
     if(rc == Z_STREAM_END)
     {
+      ok = true;
+      break;
+    }
+    if(haveLimit && out.size() >= limit)
+    {  // everything the header promises is here; whatever follows is not ours to expand
       ok = true;
       break;
     }
@@ -447,7 +498,7 @@ int loadSpz(const std::string& path, HostSplatSet& out)
   std::vector<uint8_t> gz((size_t)sz);
   f.read((char*)gz.data(), sz);
   std::vector<uint8_t> raw;
-  if(!gunzip(gz, raw) || raw.size() < 16)
+  if(!gunzipSpz(gz, raw) || raw.size() < 16)
   {
     setError("spz: not a gzip stream / truncated: " + path);
     return MGS_ERR_FORMAT;

@@ -285,12 +285,47 @@ struct MgsScene_t
   size_t         imageBytes = 0, imageRowBytes = 0;
   MgsSortOut     lastSort{};
 
+  DevBuf<uint32_t>      rsKeys, rsVals, rsHist, rsCount;  // mgs_radix_sort_u32 scratch
+  DevBuf<SortPlan>      rsPlan;
+
   CpuSorter             cpu;
+  std::vector<float>    cpuDistances;  // distances of the consumed sort (swapped out under the sorter's lock, like the indices)
   std::vector<uint32_t> cpuIndices;  // consumed result (caller's id space)
   std::vector<uint32_t> cpuStorageIds;
   bool                  cpuHaveIndices = false;
   DevBuf<float>         cpuDistDev;
 };
+
+// No exception crosses the C ABI (include/mgs.h): every entry point that can allocate host memory or parse untrusted
+// input runs inside this guard.
+template <typename Fn>
+static int guarded(const char* what, Fn&& fn) noexcept
+{
+  try
+  {
+    return fn();
+  }
+  catch(const std::bad_alloc&)
+  {
+    setError(std::string(what) + ": out of host memory");
+    return MGS_ERR_OOM;
+  }
+  catch(const std::length_error&)
+  {
+    setError(std::string(what) + ": size exceeds what the host can allocate");
+    return MGS_ERR_OOM;
+  }
+  catch(const std::exception& e)
+  {
+    setError(std::string(what) + ": " + e.what());
+    return MGS_ERR_FORMAT;
+  }
+  catch(...)
+  {
+    setError(std::string(what) + ": unknown failure");
+    return MGS_ERR_FORMAT;
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 extern "C" {
@@ -298,7 +333,12 @@ extern "C" {
 const char* mgs_last_error(void) { return lastError(); }
 const char* mgs_version(void) { return "mgs 0.1 (gfx950, ABI 1)"; }
 
+static int mgs_splatset_load_impl(const char* path, MgsSplatSet* out);
 int mgs_splatset_load(const char* path, MgsSplatSet* out)
+{
+  return guarded("mgs_splatset_load", [&] { return mgs_splatset_load_impl(path, out); });
+}
+static int mgs_splatset_load_impl(const char* path, MgsSplatSet* out)
 {
   if(!path || !out)
   {
@@ -325,7 +365,12 @@ int mgs_splatset_load(const char* path, MgsSplatSet* out)
   return MGS_OK;
 }
 
+static int mgs_splatset_from_arrays_impl(const MgsSplatSetView* v, MgsSplatSet* out);
 int mgs_splatset_from_arrays(const MgsSplatSetView* v, MgsSplatSet* out)
+{
+  return guarded("mgs_splatset_from_arrays", [&] { return mgs_splatset_from_arrays_impl(v, out); });
+}
+static int mgs_splatset_from_arrays_impl(const MgsSplatSetView* v, MgsSplatSet* out)
 {
   if(!v || !out || !v->positions || !v->f_dc || !v->opacity || !v->scale || !v->rotation)
   {
@@ -383,7 +428,12 @@ int mgs_splatset_view(MgsSplatSet set, MgsSplatSetView* out)
 void mgs_splatset_destroy(MgsSplatSet set) { delete set; }
 
 // ------------------------------------------------------------------------------------------------
+static int mgs_scene_create_impl(int device, MgsScene* out);
 int mgs_scene_create(int device, MgsScene* out)
+{
+  return guarded("mgs_scene_create", [&] { return mgs_scene_create_impl(device, out); });
+}
+static int mgs_scene_create_impl(int device, MgsScene* out)
 {
   if(!out)
   {
@@ -406,6 +456,7 @@ int mgs_scene_create(int device, MgsScene* out)
   s->device = device;
   if(hipStreamCreateWithFlags(&s->ownStream, hipStreamNonBlocking) != hipSuccess)
   {
+    s->ownStream = nullptr;
     delete s;
     setError("mgs_scene_create: hipStreamCreate failed");
     return MGS_ERR_DEVICE;
@@ -414,25 +465,31 @@ int mgs_scene_create(int device, MgsScene* out)
   if(hipHostMalloc((void**)&s->hCtr, sizeof(FrameCounters)) != hipSuccess
      || hipHostMalloc((void**)&s->hPlans, 2 * sizeof(SortPlan)) != hipSuccess)
   {
+    if(s->hCtr) (void)hipHostFree(s->hCtr);
+    (void)hipStreamDestroy(s->ownStream);
     delete s;
     setError("mgs_scene_create: pinned allocation failed");
     return MGS_ERR_OOM;
   }
   std::memset(s->hCtr, 0, sizeof(FrameCounters));
   std::memset(s->hPlans, 0, 2 * sizeof(SortPlan));
+  bool evOk = true;
   for(auto& e : s->ev)
-    if(hipEventCreate(&e) != hipSuccess)
-    {
-      setError("mgs_scene_create: hipEventCreate failed");
-      return MGS_ERR_DEVICE;
-    }
+    evOk = evOk && hipEventCreate(&e) == hipSuccess;
   for(auto& set : s->evRing)
     for(auto& e : set)
-      if(hipEventCreate(&e) != hipSuccess)
-      {
-        setError("mgs_scene_create: hipEventCreate failed");
-        return MGS_ERR_DEVICE;
-      }
+      evOk = evOk && hipEventCreate(&e) == hipSuccess;
+  if(!evOk)
+  {
+    for(auto& e : s->ev)
+      if(e) (void)hipEventDestroy(e);
+    for(auto& set : s->evRing)
+      for(auto& e : set)
+        if(e) (void)hipEventDestroy(e);
+    mgs_scene_destroy(s);  // evReady is still false: the events are not touched again
+    setError("mgs_scene_create: hipEventCreate failed");
+    return MGS_ERR_DEVICE;
+  }
   s->evReady = true;
   *out       = s;
   return MGS_OK;
@@ -453,6 +510,7 @@ static void freeSet(DeviceSet& d)
   if(d.rotations) (void)hipFree(d.rotations);
   d.centers = d.cov6 = d.partBox = d.maxScale = d.scales = d.rotations = d.alpha = nullptr;
   d.rgba = d.sh = nullptr;
+  d.shFormat = d.rgbaFormat = -1;  // a freed (or half-built) set never matches a requested format: commit rebuilds it
 }
 
 void mgs_scene_destroy(MgsScene s)
@@ -472,6 +530,7 @@ void mgs_scene_destroy(MgsScene s)
   for(auto& g : s->graphs) (void)hipGraphExecDestroy(g.second);
   s->graphs.clear();
   s->ranges.release(); s->image.release(); s->ctr.release(); s->plans.release(); s->cpuDistDev.release();
+  s->rsKeys.release(); s->rsVals.release(); s->rsHist.release(); s->rsCount.release(); s->rsPlan.release();
   if(s->hCtr) (void)hipHostFree(s->hCtr);
   if(s->hPlans) (void)hipHostFree(s->hPlans);
   if(s->evReady)
@@ -498,7 +557,12 @@ int mgs_scene_set_stream(MgsScene s, void* stream)
   return MGS_OK;
 }
 
+static int mgs_instance_add_impl(MgsScene s, MgsSplatSet set, const float m[16], int* id);
 int mgs_instance_add(MgsScene s, MgsSplatSet set, const float m[16], int* id)
+{
+  return guarded("mgs_instance_add", [&] { return mgs_instance_add_impl(s, set, m, id); });
+}
+static int mgs_instance_add_impl(MgsScene s, MgsSplatSet set, const float m[16], int* id)
 {
   if(!s || !set || !m)
   {
@@ -595,7 +659,12 @@ static int uploadFormatted(const std::vector<float>& src, int format, bool isSh,
   return MGS_OK;
 }
 
+static int mgs_scene_commit_impl(MgsScene s, int shFormat, int rgbaFormat);
 int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
+{
+  return guarded("mgs_scene_commit", [&] { return mgs_scene_commit_impl(s, shFormat, rgbaFormat); });
+}
+static int mgs_scene_commit_impl(MgsScene s, int shFormat, int rgbaFormat)
 {
   if(!s)
   {
@@ -1232,6 +1301,7 @@ static int cpuSortStep(MgsScene s, const MgsFrameParams* p, bool blocking)
   if(c.state == CpuSorter::SORTED)
   {
     s->cpuIndices.swap(c.indices);  // consume()
+    s->cpuDistances.swap(c.distances);  // the worker resizes and rewrites its own copy on the next job
     s->cpuHaveIndices = true;
     c.state           = CpuSorter::READY;
   }
@@ -1252,6 +1322,7 @@ static int cpuSortStep(MgsScene s, const MgsFrameParams* p, bool blocking)
   {
     c.cv.wait(lk, [&] { return c.state == CpuSorter::SORTED; });
     s->cpuIndices.swap(c.indices);
+    s->cpuDistances.swap(c.distances);
     s->cpuHaveIndices = true;
     c.state           = CpuSorter::READY;
   }
@@ -1278,7 +1349,12 @@ __global__ void k_iota_u32(uint32_t* p, uint32_t n)
     p[i] = i;
 }
 
+static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out);
 int mgs_render(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
+{
+  return guarded("mgs_render", [&] { return mgs_render_impl(s, p, out); });
+}
+static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
 {
   if(!s || !p)
   {
@@ -1781,9 +1857,13 @@ int mgs_sort_download(MgsScene s, uint32_t* keys, uint32_t* ids, uint32_t capaci
       return MGS_ERR_INVALID_ARG;
     }
     std::memcpy(ids, s->cpuIndices.data(), n * 4);
-    if(keys)
+    if(keys)  // the snapshot taken together with the indices (the worker may already be rewriting its own array)
       for(size_t i = 0; i < n; ++i)
-        std::memcpy(&keys[i], &s->cpu.distances[s->cpuIndices[i]], 4);
+      {
+        const uint32_t g = s->cpuIndices[i];
+        const float    d = g < s->cpuDistances.size() ? s->cpuDistances[g] : 0.0f;
+        std::memcpy(&keys[i], &d, 4);
+      }
     return MGS_OK;
   }
   if(!s->lastWasSortOnly)
@@ -1819,8 +1899,9 @@ int mgs_radix_sort_u32(MgsScene s, void* keysDev, void* valsDev, uint32_t count,
   HIPCHK(hipSetDevice(s->device));
   if(count == 0)
     return MGS_OK;
-  static thread_local DevBuf<uint32_t> kX, vX, hist, nDev;
-  static thread_local DevBuf<SortPlan> plan;
+  // scratch of the stand-alone sort: owned by the scene (its device, its stream), released in mgs_scene_destroy
+  DevBuf<uint32_t>&kX = s->rsKeys, &vX = s->rsVals, &hist = s->rsHist, &nDev = s->rsCount;
+  DevBuf<SortPlan>& plan = s->rsPlan;
   int rc;
   const uint32_t parts = (count + kPart - 1) / kPart;
   if((rc = kX.ensure(count))) return rc;
@@ -1874,19 +1955,25 @@ int mgs_radix_sort_host(MgsScene s, uint32_t* keys, uint32_t* vals, uint32_t cou
   if(count == 0)
     return MGS_OK;
   HIPCHK(hipSetDevice(s->device));
-  uint32_t *dk = nullptr, *dv = nullptr;
-  HIPCHK(hipMalloc((void**)&dk, (size_t)count * 4));
-  HIPCHK(hipMalloc((void**)&dv, (size_t)count * 4));
-  HIPCHK(hipMemcpy(dk, keys, (size_t)count * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dv, vals, (size_t)count * 4, hipMemcpyHostToDevice));
-  int rc = mgs_radix_sort_u32(s, dk, dv, count, beginBit, endBit, ms);
+  DevBuf<uint32_t> dk, dv;  // released on every exit path
+  int              rc = dk.ensure(count);
   if(rc == MGS_OK)
-  {
-    HIPCHK(hipMemcpy(keys, dk, (size_t)count * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(vals, dv, (size_t)count * 4, hipMemcpyDeviceToHost));
-  }
-  (void)hipFree(dk);
-  (void)hipFree(dv);
+    rc = dv.ensure(count);
+  auto copy = [&](void* dst, const void* src, hipMemcpyKind kind) {
+    if(rc == MGS_OK && hipMemcpy(dst, src, (size_t)count * 4, kind) != hipSuccess)
+    {
+      setError("mgs_radix_sort_host: hipMemcpy failed");
+      rc = MGS_ERR_DEVICE;
+    }
+  };
+  copy(dk.p, keys, hipMemcpyHostToDevice);
+  copy(dv.p, vals, hipMemcpyHostToDevice);
+  if(rc == MGS_OK)
+    rc = mgs_radix_sort_u32(s, dk.p, dv.p, count, beginBit, endBit, ms);
+  copy(keys, dk.p, hipMemcpyDeviceToHost);
+  copy(vals, dv.p, hipMemcpyDeviceToHost);
+  dk.release();
+  dv.release();
   return rc;
 }
 
