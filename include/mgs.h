@@ -191,6 +191,13 @@ int mgs_frame_download_surface(MgsScene scene, int which, void* host_dst, size_t
 int mgs_frame_download(MgsScene scene, void* host_dst, size_t bytes);
 /* copy this device's strip of the last frame into a caller-owned device buffer (all-gather staging) */
 int mgs_frame_copy_strip(MgsScene scene, void* device_dst, size_t bytes);
+/* test/debug hook (no reference counterpart: these are the mesh shader's per-quad outputs,
+ * threedgs_raster.mesh.slang:243-289, which the reference never stores): the projected records the last full frame
+ * built for the given global splat ids (caller's id space; meaningful only for ids that frame sorted, see
+ * mgs_sort_download).  out10[i] = { centre_px.x, centre_px.y, basisVector1.xy, basisVector2.xy (pixels),
+ * opacity (after MS antialiasing), conservative half extents x/y of the visible footprint (pixels), 0 };
+ * rect_out[i] (may be NULL) = the footprint's bin rectangle x0 | y0<<8 | x1<<16 | y1<<24. */
+int mgs_frame_download_projected(MgsScene scene, const uint32_t* global_ids, size_t count, float* out10, uint32_t* rect_out);
 int mgs_sync(MgsScene scene);
 
 /* ---- sort only (metric hook): vrdxCmdSortKeyValueIndirect (3rdparty/vrdx/include/vk_radix_sort.h:73-78)

@@ -163,8 +163,7 @@ def test_depth_keys_cull_and_sort_bit_exact(scene_small, ob, pose, flip):
     ps = ob.PreparedSet(sc)
     k2, i2 = ob.sort_stable(*ob.key_cull(ob.make_frame(V, P, eye, 640, 480), ob.make_instances([(ps, None)])))
     assert np.array_equal(k2, gk)
-    assert np.array_equal(np.lexsort((i2, k2)), np.lexsort((i2, k2))) and np.array_equal(
-        i2[np.lexsort((i2, k2))], gi[np.lexsort((gi, gk))])
+    assert np.array_equal(i2[np.lexsort((i2, k2))], gi[np.lexsort((gi, gk))])  # same ids inside every tie run
 
 
 def test_size_culling_bit_exact(scene_small, ob):

@@ -103,6 +103,7 @@ def load_library():
         "mgs_frame_download_surface": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
         "mgs_frame_copy_strip": (C.c_int, [vp, vp, C.c_size_t]),
         "mgs_sync": (C.c_int, [vp]),
+        "mgs_frame_download_projected": (C.c_int, [vp, P(C.c_uint32), C.c_size_t, P(F), P(C.c_uint32)]),
         "mgs_sort_keys": (C.c_int, [vp, P(FrameParams), P(SortOut)]),
         "mgs_sort_download": (C.c_int, [vp, P(C.c_uint32), P(C.c_uint32), C.c_uint32]),
         "mgs_radix_sort_u32": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_int, C.c_int, P(F)]),
@@ -123,7 +124,7 @@ EXPORTED_SYMBOLS = [
     "mgs_splatset_destroy", "mgs_scene_create", "mgs_scene_destroy", "mgs_scene_set_stream", "mgs_instance_add",
     "mgs_instance_set_transform", "mgs_scene_commit", "mgs_scene_splat_count", "mgs_scene_storage_order", "mgs_scene_download_set",
     "mgs_frame_params_default", "mgs_render", "mgs_frame_stats", "mgs_timings_query", "mgs_frame_download", "mgs_frame_download_surface", "mgs_frame_copy_strip",
-    "mgs_sync", "mgs_sort_keys", "mgs_sort_download", "mgs_radix_sort_u32", "mgs_radix_sort_host",
+    "mgs_frame_download_projected", "mgs_sync", "mgs_sort_keys", "mgs_sort_download", "mgs_radix_sort_u32", "mgs_radix_sort_host",
     "mgs_camera_lookat_perspective", "mgs_compute_transform"]
 
 
@@ -330,6 +331,15 @@ class Scene:
 
     def sync(self):
         _check(self._lib.mgs_sync(self._h))
+
+    def download_projected(self, global_ids):
+        """debug hook: (records[n,10] float32, rect[n] uint32) of the last frame for the given global ids"""
+        ids = np.ascontiguousarray(global_ids, np.uint32)
+        out = np.zeros((ids.size, 10), np.float32)
+        rect = np.zeros(ids.size, np.uint32)
+        _check(self._lib.mgs_frame_download_projected(self._h, ids.ctypes.data_as(C.POINTER(C.c_uint32)), ids.size,
+                                                      _fp(out), rect.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out, rect
 
     def sort_keys(self, params):
         out = SortOut()

@@ -1756,6 +1756,61 @@ int mgs_frame_copy_strip(MgsScene s, void* dst, size_t bytes)
   return MGS_OK;
 }
 
+// test/debug hook: the projected records of the last full frame for the given global ids (caller's id space)
+static int mgs_frame_download_projected_impl(MgsScene s, const uint32_t* ids, size_t count, float* out10, uint32_t* rectOut)
+{
+  if(!s || !ids || !out10)
+  {
+    setError("mgs_frame_download_projected: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(!s->haveFrame || s->lastWasSortOnly)
+  {
+    setError("mgs_frame_download_projected: no frame rendered yet");
+    return MGS_ERR_STATE;
+  }
+  for(size_t i = 0; i < count; ++i)
+    if(ids[i] >= s->totalSplats)
+    {
+      setError("mgs_frame_download_projected: id out of range");
+      return MGS_ERR_INVALID_ARG;
+    }
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  std::vector<uint32_t> sid(ids, ids + count);
+  mapIdsToStorage(s, sid.data(), count);
+  std::vector<SplatRec> rec(s->totalSplats);
+  std::vector<uint32_t> rect(s->totalSplats);
+  HIPCHK(hipMemcpy(rec.data(), s->rec.p, (size_t)s->totalSplats * sizeof(SplatRec), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(rect.data(), s->rect.p, (size_t)s->totalSplats * 4, hipMemcpyDeviceToHost));
+  for(size_t i = 0; i < count; ++i)
+  {
+    const SplatRec& r = rec[sid[i]];
+    float*          o = out10 + 10 * i;
+    // p = 2 b / |b|^2  =>  b = 2 p / |p|^2
+    const double n1 = (double)r.p1x * r.p1x + (double)r.p1y * r.p1y, n2 = (double)r.p2x * r.p2x + (double)r.p2y * r.p2y;
+    o[0] = r.cx;
+    o[1] = r.cy;
+    o[2] = (float)(2.0 * r.p1x / n1);
+    o[3] = (float)(2.0 * r.p1y / n1);
+    o[4] = (float)(2.0 * r.p2x / n2);
+    o[5] = (float)(2.0 * r.p2y / n2);
+    o[6] = r.a;
+    uint16_t h[2];
+    std::memcpy(h, &r.exey, 4);
+    o[7] = halfToFloat(h[0]);
+    o[8] = halfToFloat(h[1]);
+    o[9] = 0.0f;
+    if(rectOut)
+      rectOut[i] = rect[sid[i]];
+  }
+  return MGS_OK;
+}
+int mgs_frame_download_projected(MgsScene s, const uint32_t* ids, size_t count, float* out10, uint32_t* rectOut)
+{
+  return guarded("mgs_frame_download_projected", [&] { return mgs_frame_download_projected_impl(s, ids, count, out10, rectOut); });
+}
+
 int mgs_sync(MgsScene s)
 {
   if(!s)
