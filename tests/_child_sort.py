@@ -1,0 +1,75 @@
+"""child process of test_gpu_parity.test_sample_sort_path_is_bit_identical_to_the_stable_sort: runs under
+MGS_SORT=sample (and once under the default) and checks every sort against numpy's stable sort"""
+import hashlib
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import vk_gaussian_splatting_amd as mgs  # noqa: E402
+from vk_gaussian_splatting_amd import capi, synth  # noqa: E402
+
+scene = mgs.Scene(0)
+
+
+def check(k, v, name):
+    k = np.ascontiguousarray(k, np.uint32)
+    ks, vs, _ = scene.radix_sort_host(k, v)
+    o = np.argsort(k, kind="stable")
+    assert np.array_equal(ks, k[o]), name
+    assert np.array_equal(vs, v[o]), name
+
+
+# sizes around the structural thresholds: one bucket, the LDS capacity of a finisher, the sample capacity, strip-sized,
+# multi-million
+for n in [0, 1, 2, 1791, 1792, 1793, 6143, 6144, 6145, 16383, 16385, 40_000, 2_500_000, 5_000_011]:
+    rng = np.random.default_rng(n)
+    check(rng.integers(0, 2**32, n, dtype=np.uint32), rng.integers(0, 2**32, n, dtype=np.uint32), f"n={n}")
+rng = np.random.default_rng(99)
+n = 400_003
+v = np.arange(n, dtype=np.uint32)[::-1].copy()  # values deliberately NOT in index order
+cases = {
+    "three values": rng.choice(np.array([7, 0x3F800000, 0xFFFFFFFF], np.uint32), n),
+    "one giant run + random rest": np.where(rng.random(n) < 0.6, np.uint32(0x40490FDB), rng.integers(0, 2**32, n, dtype=np.uint32)),
+    "two giant runs of adjacent values": (np.uint32(1000) + (rng.random(n) < 0.5)),
+    "narrow range (10 bits)": (np.uint32(0xC0000000) + rng.integers(0, 1024, n)),
+    "narrow range across a byte boundary, heavy ties": (np.uint32(0x00FFFFF0) + rng.integers(0, 34, n)),
+    "zeros and max": np.where(rng.random(n) < 0.5, np.uint32(0), np.uint32(0xFFFFFFFF)),
+    "giant run inside a dense ramp": np.concatenate([np.arange(150_000, dtype=np.uint32) * 3, np.full(100_003, 200_000, np.uint32),
+                                                     np.arange(150_000, dtype=np.uint32) * 3 + 1]),
+    "sorted": np.sort(rng.integers(0, 2**32, n, dtype=np.uint32)),
+    "reverse sorted": np.sort(rng.integers(0, 2**32, n, dtype=np.uint32))[::-1].copy(),
+    "float bit patterns of depths": np.float32(1.0 - 0.1 / rng.uniform(0.2, 40.0, n)).view(np.uint32),
+}
+for name, k in cases.items():
+    assert k.size == n, name
+    check(k.astype(np.uint32), v, name)
+# a streaming bucket fed by thousands of slices
+n2 = 6_000_000
+k2 = np.full(n2, 5, np.uint32)
+k2[rng.integers(0, n2, 1000)] = rng.integers(0, 2**32, 1000, dtype=np.uint32)
+check(k2, np.arange(n2, dtype=np.uint32), "6 M keys, one value")
+print("SORTS_OK")
+
+# frames: the in-frame key sort feeds binning and compositing
+sc = synth.make_scene(300_000, seed=5)
+scene.add_instance(mgs.SplatSet.from_arrays(**sc))
+scene.commit()
+hh = hashlib.sha1()
+for pose, (w, h) in ((1, (1280, 720)), (17, (640, 480)), (40, (1920, 1080))):
+    eye = synth.orbit_pose(pose)
+    V, P = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, w, h)
+    p = capi.default_params(w, h)
+    capi.set_camera(p, V, P, eye)
+    so = scene.sort_keys(p)
+    gk, gi = scene.sort_download(so.count)
+    hh.update(gk.tobytes())
+    hh.update(gi.tobytes())
+    print("STATS pose", pose, "count", so.count, "slices/buckets/streamed", list(so.reserved))
+    o = scene.render(p)
+    hh.update(np.ascontiguousarray(scene.download_frame(p)).tobytes())
+    for strip in ((0, 8), (20, 30)):
+        p.strip_row_begin, p.strip_row_end = strip
+        scene.render(p)
+        hh.update(np.ascontiguousarray(scene.download_frame(p)).tobytes())
+print("FRAMES_SHA1", hh.hexdigest())

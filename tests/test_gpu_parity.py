@@ -139,6 +139,25 @@ def test_radix_sort_depth_like_keys_with_outliers(scene_small, ob):
     assert np.array_equal(ks, k[o]) and np.array_equal(vs, v2[o])
 
 
+def test_sample_sort_path_is_bit_identical_to_the_stable_sort():
+    """the opt-in sample sort (k_ssort.hip, MGS_SORT=sample; libmgs reads its knobs once per process, hence the child
+    interpreter): sizes around its structural thresholds, distributions on which quantile splitters cannot balance
+    the buckets (streaming path, all-equal buckets, duplicate splitters), and whole frames — every sorted stream must
+    equal the stable sort bit for bit, every frame must equal the default (LSD) build's frame"""
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_child_sort.py")
+    out = {}
+    for mode in ("sample", "lsd"):
+        env = dict(os.environ, MGS_SORT=mode)
+        r = subprocess.run([sys.executable, child], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        assert "SORTS_OK" in r.stdout, r.stdout[-3000:]
+        out[mode] = [l for l in r.stdout.splitlines() if l.startswith("FRAMES_SHA1")]
+        print(mode, [l for l in r.stdout.splitlines() if l.startswith("STATS")])
+    assert out["sample"] and out["sample"] == out["lsd"]
+
+
 def test_upload_transform_matches_oracle_bitwise(scene_small, ob):
     scene, sc = scene_small
     ps = ob.PreparedSet(sc)

@@ -15,8 +15,11 @@ for i in range(0, 24):
     p = capi.default_params(W, H); capi.set_camera(p, V, P, eye)
     so = scene.sort_keys(p)
     res.append((so.key_ms, so.sort_ms, so.count, so.passes))
+print("sample sort stats (last frame): slices %d buckets %d streamed buckets %d" % tuple(so.reserved))
 r = np.array(res[4:])
 print("sort-only hook: key(phase1 only) %.3f ms  sort %.3f ms  count %.0f passes %.1f -> %.2f Gkeys/s" % (r[:,0].mean(), r[:,1].mean(), r[:,2].mean(), r[:,3].mean(), r[:,2].mean()/r[:,1].mean()/1e6))
+if os.environ.get("PROBE_SORT_ONLY"):
+    sys.exit(0)
 for deg in (3, 0):
     ts = []
     for i in range(0, 24):

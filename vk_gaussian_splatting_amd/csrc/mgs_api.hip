@@ -286,7 +286,34 @@ struct MgsScene_t
   MgsSortOut     lastSort{};
 
   DevBuf<uint32_t>      rsKeys, rsVals, rsHist, rsCount;  // mgs_radix_sort_u32 scratch
+  DevBuf<uint32_t>      rsKeysY, rsValsY;
   DevBuf<SortPlan>      rsPlan;
+  // sample-sort scratch (k_ssort.hip): [0] the frame's key sort, [1] mgs_radix_sort_u32
+  struct SsBufs
+  {
+    DevBuf<uint32_t>           samples, splitters;
+    DevBuf<unsigned long long> bucketCount;
+    DevBuf<uint2>              desc;
+    uint32_t                   maxBuckets = 0;
+    int ensure(uint32_t maxElems, uint32_t parts)
+    {
+      maxBuckets = sampleSortBuckets(maxElems);
+      int rc;
+      if((rc = samples.ensure(16384))) return rc;
+      if((rc = splitters.ensure(4096))) return rc;
+      if((rc = bucketCount.ensure(4096))) return rc;
+      return desc.ensure((size_t)maxBuckets * std::max<uint32_t>(parts, 1u));
+    }
+    void fill(SampleSortBuffers& o) const
+    {
+      o.samples     = samples.p;
+      o.splitters   = splitters.p;
+      o.bucketCount = bucketCount.p;
+      o.desc        = desc.p;
+      o.maxBuckets  = maxBuckets;
+    }
+    void release() { samples.release(); splitters.release(); bucketCount.release(); desc.release(); }
+  } ssFrame, ssRaw;
 
   CpuSorter             cpu;
   std::vector<float>    cpuDistances;  // distances of the consumed sort (swapped out under the sorter's lock, like the indices)
@@ -531,6 +558,7 @@ void mgs_scene_destroy(MgsScene s)
   s->graphs.clear();
   s->ranges.release(); s->image.release(); s->ctr.release(); s->plans.release(); s->cpuDistDev.release();
   s->rsKeys.release(); s->rsVals.release(); s->rsHist.release(); s->rsCount.release(); s->rsPlan.release();
+  s->rsKeysY.release(); s->rsValsY.release(); s->ssFrame.release(); s->ssRaw.release();
   if(s->hCtr) (void)hipHostFree(s->hCtr);
   if(s->hPlans) (void)hipHostFree(s->hPlans);
   if(s->evReady)
@@ -862,6 +890,11 @@ static int mgs_scene_commit_impl(MgsScene s, int shFormat, int rgbaFormat)
   if((rc = s->sortedRect.ensure(total))) return rc;
   if((rc = s->ctr.ensure(1))) return rc;
   if((rc = s->plans.ensure(2))) return rc;
+  {
+    const char* e = std::getenv("MGS_SORT");
+    if(e && std::strcmp(e, "sample") == 0)
+      if((rc = s->ssFrame.ensure((uint32_t)total, (uint32_t)parts))) return rc;
+  }
 
   uint64_t cap = std::max<uint64_t>(32ull * total, 64ull << 20);  // 16 B per pair: 3 GB for a garden-sized scene
   if(const char* e = std::getenv("MGS_PAIR_CAPACITY"))
@@ -1264,7 +1297,15 @@ static void keySort(MgsScene s, hipStream_t st, bool fuseRectGather)
   L.maxElems     = s->totalSplats;
   L.beginBit     = 0;
   L.endBit       = 32;
-  launchRadixSort(st, L);
+  // default: four LSD passes (k_sort.hip).  MGS_SORT=sample selects the two-round-trip sample sort (k_ssort.hip):
+  // bit-identical results, measured slower on depth keys of Morton-ordered splats
+  static const bool kSample = [] { const char* e = std::getenv("MGS_SORT"); return e && std::strcmp(e, "sample") == 0; }();
+  if(kSample)
+    s->ssFrame.fill(L.ss);
+  if(kSample && sampleSortSupported(L))
+    launchSampleSort(st, L);
+  else
+    launchRadixSort(st, L);
 }
 
 // CPU_ASYNC path: tryConsumeAndUploadCpuSortingResult (src/splat_set_manager_vk.cpp:3334-3416)
@@ -1883,6 +1924,9 @@ int mgs_sort_keys(MgsScene s, const MgsFrameParams* p, MgsSortOut* out)
   out->sort_ms = ms;
   out->count   = s->hCtr->sortedCount;
   out->passes  = s->hPlans[0].passesRun;
+  out->reserved[0] = s->hPlans[0].pad[0];       // sample sort: (partition, bucket) slices
+  out->reserved[1] = s->hPlans[0].reserved[2];  //              buckets in use
+  out->reserved[2] = s->hPlans[0].reserved[3];  //              buckets that took the streaming path
   s->lastSort  = *out;
   s->lastWasSortOnly = true;
   s->haveFrame       = true;
@@ -1964,6 +2008,14 @@ int mgs_radix_sort_u32(MgsScene s, void* keysDev, void* valsDev, uint32_t count,
   if((rc = hist.ensure(256ull * parts))) return rc;
   if((rc = nDev.ensure(1))) return rc;
   if((rc = plan.ensure(1))) return rc;
+  static const bool kSampleRaw = [] { const char* e = std::getenv("MGS_SORT"); return e && std::strcmp(e, "sample") == 0; }();
+  const bool sample = kSampleRaw && beginBit == 0 && endBit == 32 && parts <= 131072u && count <= 7000000u;
+  if(sample)
+  {  // the sample sort keeps its input intact until the finishers have read it: Y cannot alias the caller's arrays
+    if((rc = s->rsKeysY.ensure(count))) return rc;
+    if((rc = s->rsValsY.ensure(count))) return rc;
+    if((rc = s->ssRaw.ensure(count, parts))) return rc;
+  }
   hipStream_t st = s->stream;
   HIPCHK(hipMemcpyAsync(nDev.p, &count, 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -1983,7 +2035,15 @@ int mgs_radix_sort_u32(MgsScene s, void* keysDev, void* valsDev, uint32_t count,
   L.maxElems = count;
   L.beginBit = beginBit;
   L.endBit   = endBit;
-  launchRadixSort(st, L);
+  if(sample)
+  {
+    L.keysY = s->rsKeysY.p;
+    L.valsY = s->rsValsY.p;
+    s->ssRaw.fill(L.ss);
+    launchSampleSort(st, L);
+  }
+  else
+    launchRadixSort(st, L);
   HIPCHK(hipEventRecord(s->ev[7], st));
   SortPlan hp;
   HIPCHK(hipMemcpyAsync(&hp, plan.p, sizeof(SortPlan), hipMemcpyDeviceToHost, st));

@@ -10,11 +10,21 @@ struct SortPlan
 {
   uint32_t ghist[4][256];  // digit totals of every pass, written by that pass's scan kernel
   uint32_t skip[4];        // pass is the identity permutation (single occupied digit) -> its scatter exits
-  uint32_t reserved[4];    // [0]: the last pass left gatherDst filled (fused gather)
+  uint32_t reserved[4];    // [0]: the last pass left gatherDst filled (fused gather); [1..3]: sample sort (cursor, buckets, streamed buckets)
   uint32_t finalSel;       // result lives in X (0) or Y (1); written by the last pass
   uint32_t passesRun;
   uint32_t n;
   uint32_t pad[5];
+};
+
+// scratch of the sample sort (k_ssort.hip); all device pointers, owned by the caller
+struct SampleSortBuffers
+{
+  uint32_t*           samples     = nullptr;  // [16384]
+  uint32_t*           splitters   = nullptr;  // [maxBuckets]
+  unsigned long long* bucketCount = nullptr;  // [maxBuckets]: slices << 32 | keys, per bucket
+  uint2*              desc        = nullptr;  // [maxBuckets][parts]: (source index, partition << 11 | count - 1)
+  uint32_t            maxBuckets  = 0;        // sampleSortBuckets(maxElems)
 };
 
 struct SortLaunch
@@ -37,9 +47,14 @@ struct SortLaunch
   uint2*          ranges    = nullptr;  // optional, single-pass sorts: ranges[digit] = [begin,end) in the sorted output
   const uint32_t* gatherSrc = nullptr;  // optional (multi-pass sorts): the LAST pass writes gatherDst[pos] = gatherSrc[value]
   uint32_t*       gatherDst = nullptr;  //   instead of the keys, and sets plan->reserved[0] when it ran (not skipped)
+  SampleSortBuffers ss;                 // non-null desc: full 32-bit sorts take the sample sort (k_ssort.hip)
 };
 
 void launchSortClearPlan(hipStream_t stream, SortPlan* plan);
 void launchRadixSort(hipStream_t stream, const SortLaunch& s);
+// sample sort: 4 launches, 32 B/key; src0 is permuted in place inside its 2048-key partitions, result in X
+uint32_t sampleSortBuckets(uint32_t maxElems);
+bool     sampleSortSupported(const SortLaunch& s);
+void     launchSampleSort(hipStream_t stream, const SortLaunch& s);
 
 }  // namespace mgs
