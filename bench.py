@@ -8,11 +8,13 @@ the next pose of the fixed 64-pose orbit.  Inputs are resident 
 region.  W untimed warm-up frames, then EXACTLY K frames between barrier+synchronize pairs; rank 0
 prints ONE JSON line.
 
-N>1, two partitions are measured in the same run (replicated splat buffers in both):
-  * `value`: alternate-frame rendering — the orbit's frames are independent units, rank r renders poses
-    r, r+N, ... with NO data-path collective (weak scaling: every GPU does K whole frames);
-  * `strips`: the north_star's screen-strip partition — every rank renders its tile rows of the SAME frame and
-    one RCCL all-gather of the strips per frame assembles it on every rank (strong scaling of a ~1 ms frame).
+N>1 (replicated splat buffers): `value` is the north_star's partition — every rank renders its tile-row strip of
+the SAME frame with the whole path and the strips are exchanged in place with RCCL (libmgs: one grouped collective per
+frame on the render stream, mgs_render_gathered; torch.distributed all_gather as the fallback) so that every rank ends
+up with the whole frame: strong scaling of a sub-millisecond frame ("scaling": "strong").  Strip boundaries are
+cost-balanced from the per-row list lengths of untimed calibration frames (--equal-strips turns that
+off).  The throughput partition (alternate frames: rank r renders poses r, r+N, ... with no collective) is measured in
+the same run and reported in the secondary `alternate_frames` object.
 
 The JSON line also carries
   roofline      — the dominant kernel's algorithmic bytes / its mean HIP-event duration in the timed region
@@ -38,19 +40,21 @@ STAGES = ["project", "sort", "bin", "pairsort", "composite", "total"]
 
 
 def composite_roofline(ms, alg_bytes, world, N, args):
-    """k_composite against the fp32 VALU issue rate: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles per SIMD
-    at the 2.4 GHz peak engine clock = 614 G wave-instructions/s.  SQ_INSTS_VALU per launch comes from the committed
-    rocprofv3 --pmc pass of this command (profiles/); its HBM side is reported next to it."""
-    out = {"bound": "valu", "peak": 614.4, "unit": "G wave-instr/s", "launch_ms": float(ms), "achieved": None, "frac": None,
-           "hbm_algorithmic_bytes_per_launch": float(alg_bytes),
+    """k_composite is bound by fp32 VALU issue, not by HBM.  Its fraction is the VALU-busy fraction of the SIMDs over the
+    kernel's duration: SQ_ACTIVE_INST_VALU (quad-cycles, summed over the chip; committed rocprofv3 --pmc pass of this
+    command) x 4 / (launch duration x 2.4 GHz x 1024 SIMDs) — a counter ratio, no assumed issue rate."""
+    out = {"bound": "valu", "unit": "fraction of SIMD cycles issuing VALU", "peak": 1.0, "launch_ms": float(ms), "achieved": None,
+           "frac": None, "hbm_algorithmic_bytes_per_launch": float(alg_bytes),
            "hbm_achieved_GBps": (alg_bytes / (ms * 1e-3)) / 1e9 if ms > 0 else None}
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", PMC_SQ_FILE)))
-        if world == 1 and N == 5_830_000 and args.instances == 1 and ms > 0:
-            insts = pj["k_composite"]["SQ_INSTS_VALU"]
-            out["valu_insts_per_launch"] = insts
-            out["achieved"] = insts / (ms * 1e-3) / 1e9
-            out["frac"] = out["achieved"] / out["peak"]
+        if world == 1 and N == 5_830_000 and args.instances == 1 and ms > 0 and (args.width, args.height) == (1920, 1080):
+            busy = pj["k_composite"]["SQ_ACTIVE_INST_VALU"] * 4.0
+            out["valu_busy_quad_cycles_per_launch"] = pj["k_composite"]["SQ_ACTIVE_INST_VALU"]
+            out["valu_insts_per_launch"] = pj["k_composite"]["SQ_INSTS_VALU"]
+            out["achieved"] = busy / (ms * 1e-3 * 2.4e9 * 1024)
+            out["frac"] = out["achieved"]
+            out["valu_source"] = f"profiles/{PMC_SQ_FILE} (committed rocprofv3 --pmc pass of `bench.py --inflight 1`; the duration is this run's)"
     except Exception:
         pass
     return out
@@ -80,6 +84,9 @@ def main():
                     "(plain launches); default: the timed frames are replayed hipGraphs and the per-stage times come from the "
                     "single-stream calibration frames")
     ap.add_argument("--check-gather", action="store_true", help="N>1: verify the gathered frame == a full-frame render")
+    ap.add_argument("--equal-strips", action="store_true", help="N>1: equal tile-row strips instead of cost-balanced ones")
+    ap.add_argument("--torch-gather", action="store_true", help="N>1: exchange the strips with torch.distributed instead of "
+                    "libmgs's own RCCL call (the fallback path)")
     args = ap.parse_args()
     if args.config == 1:
         args.splats = 1_030_000
@@ -139,35 +146,9 @@ def main():
         capi.set_camera(p, V, P, eye)
         p.collect_timings = 2 if args.stage_events else 0
         poses.append(p)
-    strip_rows = multigpu.strip_rows(H, world, rank) if world > 1 else (0, 0)
-
-    def set_strips(on):
-        for p in poses:
-            p.strip_row_begin, p.strip_row_end = strip_rows if on else (0, 0)
-
-    R = multigpu.strip_pixel_rows(H, world)
-    strips = [torch.zeros((R, W, 4), dtype=torch.float16, device="cuda") if world > 1 else None for _ in range(K)]
-    strip_bytes = R * W * 8
-
-    def frame(i):
-        """alternate-frame step: this rank's i-th whole frame (pose i*world + rank of the orbit)"""
-        c = i % K
-        with torch.cuda.stream(streams[c]):
-            scenes[c].render(poses[(i * world + rank) % 64])
-        return None
-
-    def strip_frame(i):
-        """strip step: this rank's tile rows of frame i + one all-gather"""
-        p = poses[i % 64]
-        c = i % K
-        with torch.cuda.stream(streams[c]):
-            if strip_rows[0] == strip_rows[1]:
-                return multigpu.gather_strips(strips[c], world)  # this rank owns no rows (more ranks than tile rows)
-            scenes[c].render(p)
-            scenes[c].copy_strip(strips[c].data_ptr(), strip_bytes)
-            if args.backend != "nccl":  # functional path: stage through the host
-                return multigpu.gather_strips(strips[c].cpu(), world)
-            return multigpu.gather_strips(strips[c], world)
+    tiles_y = multigpu.tile_rows(H)
+    bounds = [multigpu.strip_rows(H, world, r)[0] for r in range(world)] + [tiles_y]  # equal strips
+    gather_mode = "none"
 
     def fence():
         torch.cuda.synchronize()
@@ -175,38 +156,117 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def frame(i):
+        """alternate-frame / single-GPU step: this rank's i-th whole frame (pose i*world + rank of the orbit)"""
+        c = i % K
+        with torch.cuda.stream(streams[c]):
+            scenes[c].render(poses[(i * world + rank) % 64])
+
+    # ---- N>1: communicators + strip table --------------------------------------------------------------------
+    if world > 1:
+        if args.backend == "nccl" and not args.torch_gather:
+            try:  # libmgs's own RCCL exchange: one communicator per frame context (each has its own stream)
+                ids = [capi.comm_unique_id() if rank == 0 else None for _ in range(K)]
+                dist.broadcast_object_list(ids, src=0)
+                for c in range(K):
+                    scenes[c].comm_init(rank, world, ids[c])
+                gather_mode = "libmgs: grouped ncclBroadcast of every rank's rows, in place in the frame buffer, on the render stream"
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] libmgs RCCL exchange unavailable ({type(e).__name__}: {e}); falling back to torch.distributed",
+                      file=sys.stderr)
+                gather_mode = "none"
+        # every rank agrees on the outcome (a rank that failed must not leave the others waiting in a collective)
+        flag = torch.tensor([1 if gather_mode.startswith("libmgs") else 0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if gather_mode.startswith("libmgs"):
+                for c in range(K):
+                    scenes[c].comm_destroy()
+            gather_mode = ("torch.distributed all_gather_into_tensor (RCCL)" if args.backend == "nccl"
+                           else f"torch.distributed all_gather over {args.backend}, strips staged through host memory (functional check)")
+        if not args.equal_strips:
+            # cost-balanced strips: per-tile-row list lengths of untimed full frames (every rank renders the same
+            # frames, so every rank derives the same table; no exchange needed)
+            cost = np.zeros(tiles_y, np.float64)
+            for i in range(0, 64, 8):
+                scenes[0].render(poses[i])
+                cost += scenes[0].row_costs(H)
+            bounds = multigpu.balanced_bounds(cost, world)
+        if gather_mode.startswith("libmgs"):
+            for c in range(K):
+                scenes[c].set_strip_rows(bounds)
+    my_rows = (bounds[rank], bounds[rank + 1]) if world > 1 else (0, 0)
+    Rmax = multigpu.padded_strip_rows(bounds) if world > 1 else 0
+    strips = [torch.zeros((Rmax, W, 4), dtype=torch.float16, device="cuda") if world > 1 and not gather_mode.startswith("libmgs")
+              else None for _ in range(K)]
+    gathered = [None] * K
+
+    def strip_frame(i):
+        """strip step: this rank's tile rows of frame i + the exchange; afterwards every rank holds the whole frame"""
+        p = poses[i % 64]
+        c = i % K
+        with torch.cuda.stream(streams[c]):
+            if gather_mode.startswith("libmgs"):
+                scenes[c].render_gathered(p)
+                return
+            p.strip_row_begin, p.strip_row_end = my_rows
+            if my_rows[1] > my_rows[0]:
+                scenes[c].render(p)
+                scenes[c].copy_strip(strips[c].data_ptr(), (min(my_rows[1] * 16, H) - my_rows[0] * 16) * W * 8)
+            p.strip_row_begin, p.strip_row_end = 0, 0
+            src = strips[c].cpu() if args.backend != "nccl" else strips[c]
+            gathered[c] = multigpu.gather_strips(src, world)  # padded to the tallest strip
+
+    def assembled(c):
+        """the whole frame on this rank after strip_frame (host tensor, int16 view of the fp16 pixels)"""
+        if gather_mode.startswith("libmgs"):
+            pf = capi.default_params(W, H)
+            return torch.from_numpy(scenes[c].download_frame(pf).view(np.int16))
+        return multigpu.assemble(gathered[c].cpu(), bounds, H).view(torch.int16)
+
+    step = strip_frame if world > 1 else frame
     for i in range(args.warmup):
-        frame(i)
+        step(i)
     fence()
     # calibration (untimed, single stream): which stage dominates a frame when nothing else shares the GPU
     calib = []
     for i in range(8):
-        poses[i % 64].collect_timings = 2
+        pc = poses[i % 64]
+        pc.collect_timings = 2
+        pc.strip_row_begin, pc.strip_row_end = my_rows
         with torch.cuda.stream(streams[0]):
-            scenes[0].render(poses[i % 64])
+            scenes[0].render(pc)
         torch.cuda.synchronize()
         calib.append(scenes[0].timings_all(0))
-        poses[i % 64].collect_timings = 2 if args.stage_events else 0
+        pc.collect_timings = 2 if args.stage_events else 0
+        pc.strip_row_begin, pc.strip_row_end = 0, 0
     calib_ms = np.array(calib[2:], np.float64).mean(axis=0)
     fence()
     if world > 1 and args.check_gather:
-        set_strips(True)
-        g = strip_frame(0)
-        set_strips(False)
+        strip_frame(0)
         torch.cuda.synchronize()
+        got = assembled(0)
         pf = capi.default_params(W, H)
         for kk in range(16):
             pf.view[kk], pf.proj[kk] = poses[0].view[kk], poses[0].proj[kk]
         for kk in range(3):
             pf.camera_pos[kk] = poses[0].camera_pos[kk]
-        scene.render(pf)
-        full = torch.from_numpy(scene.download_frame(pf).view(np.int16))
-        same = torch.equal(g[:H].cpu().view(torch.int16), full)
-        print(f"[rank {rank}] gathered frame == full frame: {same}", file=sys.stderr)
-        assert same, "strip all-gather does not reproduce the single-GPU frame"
+        scenes[K - 1].render(pf) if K > 1 else None
+        ref_scene = scenes[K - 1] if K > 1 else mgs.Scene(local)
+        if K == 1:
+            ref_scene.add_instance(ss)
+            ref_scene.commit(args.sh_format, args.rgba_format)
+            ref_scene.render(pf)
+        full = torch.from_numpy(ref_scene.download_frame(pf).view(np.int16))
+        same = torch.equal(got, full)
+        print(f"[rank {rank}] gathered frame == full frame: {same}  (strip rows {my_rows}, table {bounds}, {gather_mode})", file=sys.stderr)
+        assert same, "the strip exchange does not reproduce the single-GPU frame"
+        if K == 1:
+            ref_scene.close()
+        fence()
     t1 = time.perf_counter()
     for i in range(args.steps):
-        frame(args.warmup + i)
+        step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t1
     if world > 1:
@@ -229,9 +289,11 @@ def main():
         pp = poses[(args.warmup + args.steps - 1 - i) % 64]
         # counters are per pose; re-render untimed to read them back (outside the timed region)
         pp.collect_timings = 0
+        pp.strip_row_begin, pp.strip_row_end = my_rows  # N>1: this rank's strip (what the stage times describe)
         o = scene.render(pp, want_stats=True)
         counts.append((o.frustum_count, o.sorted_count, o.tile_pairs, o.error_flags, o.shaded_count, o.scanned_entries))
         pp.collect_timings = 2 if args.stage_events else 0
+        pp.strip_row_begin, pp.strip_row_end = 0, 0
     counts = np.array(counts, np.float64)
     Vf, Vs, D = counts[:, 0].mean(), counts[:, 1].mean(), counts[:, 2].mean()
     shaded, scanned = counts[:, 4].mean(), counts[:, 5].mean()
@@ -243,36 +305,31 @@ def main():
     else:
         Vs_all = Vs
 
-    fps = args.steps * world / elapsed  # whole-job aggregate: every rank rendered `steps` whole frames
+    # whole-job aggregate: single GPU = frames of this GPU; N>1 = frames of the strip partition (every step produces ONE
+    # frame, complete on every rank)
+    fps = args.steps / elapsed
     Ppix = W * H
 
-    strips_out = None
+    alt_out = None
     if world > 1:
-        # the strip partition is the secondary measurement of an N>1 run: a failure here (a collective that times out,
-        # an allocation) must not take the headline line with it
+        # the throughput partition (no collective) as the secondary measurement: a failure here must not take the
+        # headline line with it
         try:
-            set_strips(True)
             for i in range(args.warmup):
-                strip_frame(i)
+                frame(i)
             fence()
             t2 = time.perf_counter()
             for i in range(args.steps):
-                strip_frame(args.warmup + i)
+                frame(args.warmup + i)
             fence()
             el2 = time.perf_counter() - t2
             tt = torch.tensor([el2], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el2 = float(tt.item())
-            st2 = np.array([scenes[c].timings(b) for c in range(K) for b in range(min(per_ctx[c], 128))], np.float64) \
-                if args.stage_events else np.zeros((0, 6))
-            st2 = st2.mean(axis=0) if st2.size else np.full(6, float("nan"))
-            strips_out = {"value": args.steps / el2, "unit": "frames/s", "scaling": "strong", "ms_per_step": 1e3 * el2 / args.steps,
-                          "partition": f"{world} tile-row strips + one RCCL all_gather per frame",
-                          "this_rank_rows": list(strip_rows), "this_rank_stage_ms": {STAGES[j]: (float(st2[j]) if np.isfinite(st2[j]) else None) for j in range(6)}}
+            alt_out = {"value": args.steps * world / el2, "unit": "frames/s", "scaling": "weak", "ms_per_step": 1e3 * el2 / args.steps,
+                       "partition": f"alternate frames: rank r renders poses r, r+{world}, ... (no data-path collective)"}
         except Exception as e:  # noqa: BLE001
-            strips_out = {"error": f"{type(e).__name__}: {e}"[:300]}
-        finally:
-            set_strips(False)
+            alt_out = {"error": f"{type(e).__name__}: {e}"[:300]}
     # algorithmic bytes per launch of each stage (SURVEY.md §8d per-unit figures)
     N = N * args.instances  # total global splats from here on
     alg = {
@@ -303,6 +360,7 @@ def main():
     dom_ms = float(calib_ms[dom]) - cull_ms
     achieved = alg[dom_name] / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
     b_frame = 12 * N + Vs * (16 + 24 + 180) + 8 * Vs + 68 * Vs + 2 * 48 * Vs + 8 * Ppix
+    b_moved = alg["project"] + alg["sort"] + alg["bin"] + alg["composite"]  # what this build's kernels move (deferred shading: no 180 B/splat SH stream)
     frame_gpu_ms = stage_ms[5]
     sort_ms = calib_ms[1] if K > 1 else stage_ms[1]  # isolated sort time: overlapped spans are not kernel time
 
@@ -325,7 +383,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if world > 1 else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -334,10 +392,11 @@ def main():
         "config": {"workload": f"syn_garden N={N} x {args.instances} instance(s) SH deg 3, storage sh/rgba format {args.sh_format}/{args.rgba_format}, "
                                f"{W}x{H}, 64-pose orbit r=4 h=1.5 fov60, GPU radix sort, cull at dist (configs[2])",
                    "partition": "single GPU" if world == 1 else
-                   f"alternate-frame: rank r renders poses r, r+{world}, ... (no data-path collective); strips+all_gather in `strips`"},
-        "strips": strips_out,
+                   f"{world} tile-row strips of every frame ({'equal' if args.equal_strips else 'cost-balanced'} rows {bounds}) + strip exchange: {gather_mode}"},
+        "alternate_frames": alt_out,
+        "this_rank_strip_rows": list(my_rows) if world > 1 else None,
         "sorted_gsplats_per_s": (Vs / (sort_ms * 1e-3)) / 1e9 if sort_ms > 0 else None,
-        "sorted_gsplats_per_s_in_frame_aggregate": Vs_all * fps / 1e9,
+        "sorted_gsplats_per_s_in_frame_aggregate": Vs_all * fps / 1e9,  # all ranks' sorted elements x frames/s
         "visible_splats": {"frustum": Vf, "sorted": Vs, "tile_pairs": D, "shaded": shaded, "list_entries_scanned": scanned},
         "stage_ms": {STAGES[j]: float(stage_ms[j]) for j in range(6)},
         "stage_ms_single_stream": {STAGES[j]: float(calib_ms[j]) for j in range(6)},
@@ -345,6 +404,8 @@ def main():
                                       "min": float(st[:, 5].min()), "max": float(st[:, 5].max())},
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
+                     "traffic_source": (f"profiles/{PMC_FILE}: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --inflight 1` "
+                                        "(2*FETCH + WRITE per launch, MI355X_MICROARCH.md HBM section); not measured in this run") if traffic else None,
                      "algorithmic_bytes_per_launch": alg[dom_name], "launch_ms": float(dom_ms),
                      "stage_ms_incl_partition_cull": float(calib_ms[dom]), "partition_cull_ms": cull_ms,
                      "stage_span_ms_in_timed_region": float(stage_ms[dom]),
@@ -357,10 +418,15 @@ def main():
                           "frac": (68 * Vs / (sort_ms * 1e-3)) / HBM_PEAK if sort_ms > 0 else None},
         # throughput form: bytes SURVEY.md 8d says a frame must move x frames/s per GPU (== the latency form when one
         # frame is in flight); `frac_single_frame` is the same bytes over the GPU time of one frame in the timed region
-        "roofline_frame": {"bound": "hbm", "achieved": b_frame * fps / world / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                           "frac": b_frame * fps / world / HBM_PEAK,
+        "roofline_frame": {"bound": "hbm", "achieved": b_frame * fps / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                           "frac": b_frame * fps / HBM_PEAK if world == 1 else None,
                            "frac_single_frame": (b_frame / (frame_gpu_ms * 1e-3)) / HBM_PEAK if frame_gpu_ms > 0 else None,
-                           "algorithmic_bytes_per_frame": b_frame},
+                           "algorithmic_bytes_per_frame": b_frame,
+                           "bytes_moved_per_frame": b_moved,
+                           "frac_bytes_moved": b_moved * fps / HBM_PEAK if world == 1 else None,
+                           "frac_bytes_moved_single_frame": (b_moved / (frame_gpu_ms * 1e-3)) / HBM_PEAK if frame_gpu_ms > 0 else None,
+                           "note": "algorithmic_bytes_per_frame is SURVEY.md 8d's B_frame (includes 180 B/splat of SH the build no longer "
+                                   "streams); bytes_moved_per_frame sums the per-stage algorithmic bytes of the kernels as built"},
         "error_flags": err,
         "setup_s": setup_s,
     }
@@ -368,7 +434,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: restated SplatSorterAsync::innerSort on a bounded sample of the same workload
         from oracle import binding as ob
-        nb = min(N, 2_000_000)
+        nb = min(N, args.splats)  # the whole splat set of the workload (0.45 s at 5.83 M on this box's host)
         V0 = np.array(poses[0].view, np.float32).reshape(4, 4).T
         fwd = -V0[2, :3]
         eye0 = synth.orbit_pose(0)
@@ -378,7 +444,7 @@ def main():
             best = (dms + sms) if best is None else min(best, dms + sms)
         out["cpu_baseline"] = {"value": nb / (best * 1e-3) / 1e9, "unit": "Gsplats/s (depth key + sort)",
                                "cores": os.cpu_count(), "kind": "port",
-                               "sample": f"first {nb} splats of the workload, pose 0, best of {reps}; distance loop on all "
+                               "sample": f"all {nb} splats of the workload's splat set, pose 0, best of {reps}; distance loop on all "
                                          f"cores, std::sort(par_unseq) serial unless libstdc++ finds TBB",
                                "ms": best}
     if rank == 0:

@@ -191,6 +191,27 @@ int mgs_frame_download_surface(MgsScene scene, int which, void* host_dst, size_t
 int mgs_frame_download(MgsScene scene, void* host_dst, size_t bytes);
 /* copy this device's strip of the last frame into a caller-owned device buffer (all-gather staging) */
 int mgs_frame_copy_strip(MgsScene scene, void* device_dst, size_t bytes);
+/* ---- multi-GPU strip partition (no reference counterpart: the reference is single-GPU).  One process
+ * per GPU, replicated splat buffers; every rank renders its tile rows of the SAME frame with the whole path, and the
+ * strips are exchanged with RCCL (one grouped collective per frame on the scene's stream, in place in the frame buffer:
+ * no staging copy).  Afterwards every rank's frame buffer holds the complete frame, bit-identical to a single-GPU
+ * frame.  librccl is loaded on first use (dlopen); MGS_ERR_UNSUPPORTED when it is absent. */
+#define MGS_COMM_ID_BYTES 128
+/* ncclGetUniqueId: call on ONE rank, hand the 128 bytes to every rank out of band (MPI, torch.distributed, a file) */
+int mgs_comm_unique_id(void* id_out);
+/* ncclCommInitRank on the scene's device (collective: every rank calls it with the same id).  world_size 1 is valid. */
+int mgs_scene_comm_init(MgsScene scene, int rank, int world_size, const void* id);
+int mgs_scene_comm_destroy(MgsScene scene);
+/* tile-row boundaries of all ranks, row_bounds[world_size + 1], ascending, [0] = 0, [world_size] >= tile rows of the
+ * frame (16-pixel rows).  NULL restores the default: equal strips of ceil(rows / world_size).  Cost-balanced tables
+ * come from mgs_frame_row_costs of earlier frames ("optionally cost-balanced from last frame's D"). */
+int mgs_scene_set_strip_rows(MgsScene scene, const int32_t* row_bounds, int count);
+/* mgs_render of this rank's strip + the exchange.  params->strip_row_* are ignored (the table decides). */
+int mgs_render_gathered(MgsScene scene, const MgsFrameParams* params, MgsFrameOut* out);
+/* per 16-pixel tile row of the last full frame: bin-list entries attributed to that row (a bin's entries spread
+ * evenly over its tile rows) — the cost proxy the strip balancing uses.  Waits for the frame. */
+int mgs_frame_row_costs(MgsScene scene, uint32_t* cost_per_tile_row, size_t rows);
+
 /* test/debug hook (no reference counterpart: these are the mesh shader's per-quad outputs,
  * threedgs_raster.mesh.slang:243-289, which the reference never stores): the projected records the last full frame
  * built for the given global splat ids (caller's id space; meaningful only for ids that frame sorted, see

@@ -928,6 +928,7 @@ def test_bench_prints_one_strict_json_line_with_the_contract_keys():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
+    assert d["scaling"] == "weak" and d["roofline"]["traffic"] is None or "traffic_source" in d["roofline"]
     assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2 and d["value"] > 0 and d["higher_is_better"] is True
     assert "workload" in d["config"] and d["vs_baseline"] is None and d["data"] == "synthetic"
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
@@ -936,6 +937,58 @@ def test_bench_prints_one_strict_json_line_with_the_contract_keys():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
     assert d["error_flags"] == 0
+
+
+@pytest.mark.parametrize("world,extra", [(2, []), (4, ["--equal-strips"]), (8, [])])
+def test_bench_multi_rank_strip_partition_reassembles_the_frame(world, extra):
+    """the N>1 path of bench.py end to end with several ranks sharing this one GPU (gloo: the strips are staged through
+    host memory; RCCL itself cannot put two ranks on one device): every rank renders its cost-balanced strip with the
+    HIP path, the exchange reassembles the frame, --check-gather asserts it equals the single-GPU frame bit for bit,
+    and the JSON line reports the strip partition as `value` with "scaling": "strong"."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + world), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2",
+           "--splats", "400000", "--backend", "gloo", "--check-gather", "--inflight", "2", "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert out.stderr.count("gathered frame == full frame: True") == world, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["value"] > 0 and d["error_flags"] == 0
+    assert "tile-row strips" in d["config"]["partition"] and d["alternate_frames"]["value"] > 0
+    assert d["alternate_frames"]["scaling"] == "weak"
+
+
+def test_rccl_strip_exchange_inside_libmgs_single_rank(scene_small):
+    """mgs_render_gathered (ncclCommInitRank + grouped ncclBroadcast on the render stream, include/mgs.h) with a
+    one-rank communicator: the RCCL call path itself runs on this box; with one rank the exchange must leave the frame
+    untouched.  Also the strip table API and the per-row costs it is fed from."""
+    scene, sc = scene_small
+    p, V, P, eye = camera(7, 1280, 720)
+    scene.render(p)
+    want = scene.download_frame(p).view(np.uint16).copy()
+    cost = scene.row_costs(720)
+    assert cost.size == 45 and cost.sum() > 0
+    out = scene.frame_stats()
+    assert abs(int(cost.sum()) - int(out.tile_pairs)) <= 45  # every list entry is attributed to exactly one tile row (rounding)
+    scene.comm_init(0, 1, capi.comm_unique_id())
+    try:
+        scene.render_gathered(p)
+        got = scene.download_frame(p).view(np.uint16)
+        assert np.array_equal(got, want)
+        with pytest.raises(mgs.MgsError):
+            scene.set_strip_rows([0, 10, 45])   # world_size + 1 entries expected
+        scene.set_strip_rows([0, 45])
+        scene.render_gathered(p)
+        assert np.array_equal(scene.download_frame(p).view(np.uint16), want)
+    finally:
+        scene.comm_destroy()
+    with pytest.raises(mgs.MgsError):
+        scene.render_gathered(p)   # no communicator
 
 
 def test_cpp_caller_renders_the_same_frame(tmp_path):

@@ -19,13 +19,21 @@ dist.init_process_group("gloo")
 rank, ws = dist.get_rank(), dist.get_world_size()
 H, W = 120, 160
 full = np.load(os.environ["MGS_FRAME"])            # [H,W,4] float16
-b, e = multigpu.strip_rows(H, ws, rank)
-R = multigpu.strip_pixel_rows(H, ws)
-strip = torch.zeros((R, W, 4), dtype=torch.float16)
-y0, y1 = b * 16, min(e * 16, H)
-strip[: y1 - y0] = torch.from_numpy(full[y0:y1])
-out = multigpu.gather_strips(strip, ws)[:H]
-ok = torch.equal(out, torch.from_numpy(full))
+ok = True
+# equal strips and cost-balanced (unequal) strips: the table every rank derives from the same per-row costs
+cost = np.abs(full.astype(np.float32)).sum(axis=(1, 2)).reshape(-1, 8).sum(axis=1)[: multigpu.tile_rows(H)] if H % 8 == 0 else None
+tables = [[multigpu.strip_rows(H, ws, r)[0] for r in range(ws)] + [multigpu.tile_rows(H)],
+          multigpu.balanced_bounds(np.concatenate([np.zeros(2), np.arange(multigpu.tile_rows(H) - 2) ** 2.0]), ws)]
+for bounds in tables:
+    b, e = bounds[rank], bounds[rank + 1]
+    R = multigpu.padded_strip_rows(bounds)
+    strip = torch.zeros((R, W, 4), dtype=torch.float16)
+    y0, y1 = b * 16, min(e * 16, H)
+    if y1 > y0:
+        strip[: y1 - y0] = torch.from_numpy(full[y0:y1])
+    out = multigpu.assemble(multigpu.gather_strips(strip, ws), bounds, H)
+    ok = ok and out.shape[0] == H and torch.equal(out, torch.from_numpy(full))
+    ok = ok and bounds[0] == 0 and bounds[-1] == multigpu.tile_rows(H) and all(bounds[i] <= bounds[i + 1] for i in range(ws))
 flag = torch.tensor([1 if ok else 0]); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 if rank == 0:
     print("GATHER_OK" if int(flag) == 1 else "GATHER_MISMATCH")

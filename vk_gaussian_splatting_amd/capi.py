@@ -104,6 +104,12 @@ def load_library():
         "mgs_frame_copy_strip": (C.c_int, [vp, vp, C.c_size_t]),
         "mgs_sync": (C.c_int, [vp]),
         "mgs_frame_download_projected": (C.c_int, [vp, P(C.c_uint32), C.c_size_t, P(F), P(C.c_uint32)]),
+        "mgs_comm_unique_id": (C.c_int, [vp]),
+        "mgs_scene_comm_init": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+        "mgs_scene_comm_destroy": (C.c_int, [vp]),
+        "mgs_scene_set_strip_rows": (C.c_int, [vp, P(C.c_int32), C.c_int]),
+        "mgs_render_gathered": (C.c_int, [vp, P(FrameParams), P(FrameOut)]),
+        "mgs_frame_row_costs": (C.c_int, [vp, P(C.c_uint32), C.c_size_t]),
         "mgs_sort_keys": (C.c_int, [vp, P(FrameParams), P(SortOut)]),
         "mgs_sort_download": (C.c_int, [vp, P(C.c_uint32), P(C.c_uint32), C.c_uint32]),
         "mgs_radix_sort_u32": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_int, C.c_int, P(F)]),
@@ -124,7 +130,8 @@ EXPORTED_SYMBOLS = [
     "mgs_splatset_destroy", "mgs_scene_create", "mgs_scene_destroy", "mgs_scene_set_stream", "mgs_instance_add",
     "mgs_instance_set_transform", "mgs_scene_commit", "mgs_scene_splat_count", "mgs_scene_storage_order", "mgs_scene_download_set",
     "mgs_frame_params_default", "mgs_render", "mgs_frame_stats", "mgs_timings_query", "mgs_frame_download", "mgs_frame_download_surface", "mgs_frame_copy_strip",
-    "mgs_frame_download_projected", "mgs_sync", "mgs_sort_keys", "mgs_sort_download", "mgs_radix_sort_u32", "mgs_radix_sort_host",
+    "mgs_frame_download_projected", "mgs_sync", "mgs_comm_unique_id", "mgs_scene_comm_init", "mgs_scene_comm_destroy",
+    "mgs_scene_set_strip_rows", "mgs_render_gathered", "mgs_frame_row_costs", "mgs_sort_keys", "mgs_sort_download", "mgs_radix_sort_u32", "mgs_radix_sort_host",
     "mgs_camera_lookat_perspective", "mgs_compute_transform"]
 
 
@@ -229,6 +236,13 @@ def camera_lookat_perspective(eye, center, up, fov_deg, z_near, z_far, width, he
     return v.reshape(4, 4).T.copy(), p.reshape(4, 4).T.copy()
 
 
+def comm_unique_id():
+    """ncclGetUniqueId through libmgs: 128 bytes; call on one rank and distribute"""
+    buf = C.create_string_buffer(128)
+    _check(load_library().mgs_comm_unique_id(C.cast(buf, C.c_void_p)))
+    return bytes(buf.raw)
+
+
 def compute_transform(scale, rotation_deg, translation):
     lib = load_library()
     m = np.zeros(16, np.float32)
@@ -331,6 +345,33 @@ class Scene:
 
     def sync(self):
         _check(self._lib.mgs_sync(self._h))
+
+    # ---- multi-GPU strips (RCCL inside libmgs) ----
+    def comm_init(self, rank, world_size, unique_id):
+        """unique_id: 128 bytes from comm_unique_id() of ONE rank, distributed out of band"""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _check(self._lib.mgs_scene_comm_init(self._h, rank, world_size, C.cast(buf, C.c_void_p)))
+
+    def comm_destroy(self):
+        _check(self._lib.mgs_scene_comm_destroy(self._h))
+
+    def set_strip_rows(self, bounds):
+        if bounds is None:
+            _check(self._lib.mgs_scene_set_strip_rows(self._h, None, 0))
+            return
+        b = np.ascontiguousarray(bounds, np.int32)
+        _check(self._lib.mgs_scene_set_strip_rows(self._h, b.ctypes.data_as(C.POINTER(C.c_int32)), b.size))
+
+    def render_gathered(self, params):
+        out = FrameOut()
+        _check(self._lib.mgs_render_gathered(self._h, C.byref(params), C.byref(out)))
+        return out
+
+    def row_costs(self, height):
+        rows = (height + 15) // 16
+        out = np.zeros(rows, np.uint32)
+        _check(self._lib.mgs_frame_row_costs(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32)), rows))
+        return out
 
     def download_projected(self, global_ids):
         """debug hook: (records[n,10] float32, rect[n] uint32) of the last frame for the given global ids"""

@@ -5,6 +5,8 @@
 // counts stay on the device (IndirectParams, shaders/shaderio.h:343-356) and are read back only
 // for statistics, like readBackIndirectParametersIfNeeded (:1536).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library itself is resolved with dlopen on first use
 
 #include <atomic>
 #include <chrono>
@@ -315,6 +317,11 @@ struct MgsScene_t
     void release() { samples.release(); splitters.release(); bucketCount.release(); desc.release(); }
   } ssFrame, ssRaw;
 
+  // multi-GPU strips (RCCL)
+  ncclComm_t            comm = nullptr;
+  int                   commRank = 0, commWorld = 1;
+  std::vector<int32_t>  stripBounds;  // [world + 1] tile rows; empty = equal strips
+
   CpuSorter             cpu;
   std::vector<float>    cpuDistances;  // distances of the consumed sort (swapped out under the sorter's lock, like the indices)
   std::vector<uint32_t> cpuIndices;  // consumed result (caller's id space)
@@ -545,6 +552,8 @@ void mgs_scene_destroy(MgsScene s)
   if(!s)
     return;
   s->cpu.shutdown();
+  if(s->comm)
+    (void)mgs_scene_comm_destroy(s);
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->stream);  // like vkDeviceWaitIdle before destruction (gaussian_splatting.cpp:1096)
   for(auto& d : s->sets)
@@ -1795,6 +1804,280 @@ int mgs_frame_copy_strip(MgsScene s, void* dst, size_t bytes)
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipMemcpyAsync(dst, s->image.p + (size_t)y0 * s->imageRowBytes, n, hipMemcpyDeviceToDevice, s->stream));
   return MGS_OK;
+}
+
+// ---- RCCL, resolved at first use ------------------------------------------------------------------------------------
+namespace {
+struct Rccl
+{
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*)                                                             = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int)                                      = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t)                                                                = nullptr;
+  ncclResult_t (*GroupStart)()                                                                           = nullptr;
+  ncclResult_t (*GroupEnd)()                                                                             = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)    = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t)         = nullptr;
+  const char* (*GetErrorString)(ncclResult_t)                                                            = nullptr;
+  bool ok = false;
+};
+Rccl& rccl()
+{
+  static Rccl R = [] {
+    Rccl r;
+    for(const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+      if((r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL)))
+        break;
+    if(!r.lib)
+      return r;
+    auto sym = [&](const char* n) { return dlsym(r.lib, n); };
+    r.GetUniqueId    = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank   = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommDestroy    = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.GroupStart     = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd       = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.Broadcast      = (decltype(r.Broadcast))sym("ncclBroadcast");
+    r.AllGather      = (decltype(r.AllGather))sym("ncclAllGather");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Broadcast && r.AllGather;
+    return r;
+  }();
+  return R;
+}
+int rcclFail(const char* what, ncclResult_t e)
+{
+  setError(std::string(what) + ": RCCL error " + std::to_string((int)e) + (rccl().GetErrorString ? std::string(" (") + rccl().GetErrorString(e) + ")" : ""));
+  return MGS_ERR_DEVICE;
+}
+}  // namespace
+
+int mgs_comm_unique_id(void* idOut)
+{
+  static_assert(sizeof(ncclUniqueId) == MGS_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+  if(!idOut)
+  {
+    setError("mgs_comm_unique_id: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(!rccl().ok)
+  {
+    setError("mgs_comm_unique_id: librccl could not be loaded");
+    return MGS_ERR_UNSUPPORTED;
+  }
+  ncclUniqueId id;
+  const ncclResult_t e = rccl().GetUniqueId(&id);
+  if(e != ncclSuccess)
+    return rcclFail("ncclGetUniqueId", e);
+  std::memcpy(idOut, &id, sizeof(id));
+  return MGS_OK;
+}
+
+int mgs_scene_comm_destroy(MgsScene s)
+{
+  if(!s)
+  {
+    setError("mgs_scene_comm_destroy: null scene");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(s->comm)
+  {
+    (void)hipSetDevice(s->device);
+    (void)hipStreamSynchronize(s->stream);
+    (void)rccl().CommDestroy(s->comm);
+    s->comm = nullptr;
+  }
+  s->commRank  = 0;
+  s->commWorld = 1;
+  return MGS_OK;
+}
+
+int mgs_scene_comm_init(MgsScene s, int rank, int world, const void* id)
+{
+  if(!s || !id || world < 1 || rank < 0 || rank >= world)
+  {
+    setError("mgs_scene_comm_init: bad argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(!rccl().ok)
+  {
+    setError("mgs_scene_comm_init: librccl could not be loaded");
+    return MGS_ERR_UNSUPPORTED;
+  }
+  (void)mgs_scene_comm_destroy(s);
+  HIPCHK(hipSetDevice(s->device));
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  const ncclResult_t e = rccl().CommInitRank(&s->comm, world, uid, rank);
+  if(e != ncclSuccess)
+  {
+    s->comm = nullptr;
+    return rcclFail("ncclCommInitRank", e);
+  }
+  s->commRank  = rank;
+  s->commWorld = world;
+  s->stripBounds.clear();
+  return MGS_OK;
+}
+
+int mgs_scene_set_strip_rows(MgsScene s, const int32_t* bounds, int count)
+{
+  if(!s)
+  {
+    setError("mgs_scene_set_strip_rows: null scene");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(!bounds)
+  {
+    s->stripBounds.clear();
+    return MGS_OK;
+  }
+  if(count != s->commWorld + 1 || bounds[0] != 0)
+  {
+    setError("mgs_scene_set_strip_rows: need world_size + 1 ascending tile-row bounds starting at 0");
+    return MGS_ERR_INVALID_ARG;
+  }
+  for(int i = 0; i < count - 1; ++i)
+    if(bounds[i + 1] < bounds[i])
+    {
+      setError("mgs_scene_set_strip_rows: bounds must be ascending");
+      return MGS_ERR_INVALID_ARG;
+    }
+  s->stripBounds.assign(bounds, bounds + count);
+  return MGS_OK;
+}
+
+static void stripOfRank(MgsScene s, int tilesY, int r, int& b, int& e)
+{
+  if(!s->stripBounds.empty())
+  {
+    b = std::min(s->stripBounds[r], tilesY);
+    e = std::min(s->stripBounds[r + 1], tilesY);
+    if(r == s->commWorld - 1)
+      e = tilesY;  // the last strip takes whatever the table left over
+    return;
+  }
+  const int per = (tilesY + s->commWorld - 1) / s->commWorld;
+  b             = std::min(r * per, tilesY);
+  e             = std::min(b + per, tilesY);
+}
+
+static int mgs_render_gathered_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
+{
+  if(!s || !p)
+  {
+    setError("mgs_render_gathered: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(!s->comm)
+  {
+    setError("mgs_render_gathered: call mgs_scene_comm_init first");
+    return MGS_ERR_STATE;
+  }
+  const int tilesY = (p->height + kTilePx - 1) / kTilePx;
+  MgsFrameParams q = *p;
+  int b, e;
+  stripOfRank(s, tilesY, s->commRank, b, e);
+  int rc = MGS_OK;
+  if(e > b)
+  {
+    q.strip_row_begin = b;
+    q.strip_row_end   = e;
+    rc                = mgs_render(s, &q, out);
+    if(rc != MGS_OK)
+      return rc;
+  }
+  else
+  {  // more ranks than tile rows: this rank owns nothing but still takes part in the exchange
+    q.strip_row_begin = 0;
+    q.strip_row_end   = 0;
+    if(!s->haveFrame || s->lastParams.width != p->width || s->lastParams.height != p->height
+       || s->lastParams.target_format != p->target_format)
+    {  // make sure the frame buffer exists at this size
+      rc = mgs_render(s, &q, out);
+      if(rc != MGS_OK)
+        return rc;
+    }
+  }
+  // exchange in place: rank r's rows are broadcast from r into the same rows of everybody's frame buffer.  One group
+  // = one fused launch on the render stream; it overlaps with the next frame's key/sort when frames are in flight.
+  HIPCHK(hipSetDevice(s->device));
+  ncclResult_t ne = rccl().GroupStart();
+  if(ne != ncclSuccess)
+    return rcclFail("ncclGroupStart", ne);
+  for(int r = 0; r < s->commWorld; ++r)
+  {
+    int rb, re;
+    stripOfRank(s, tilesY, r, rb, re);
+    const int    y0 = rb * kTilePx, y1 = std::min(re * kTilePx, p->height);
+    if(y1 <= y0)
+      continue;
+    uint8_t*     ptr = s->image.p + (size_t)y0 * s->imageRowBytes;
+    const size_t n   = (size_t)(y1 - y0) * s->imageRowBytes;
+    ne               = rccl().Broadcast(ptr, ptr, n, ncclUint8, r, s->comm, s->stream);
+    if(ne != ncclSuccess)
+    {
+      (void)rccl().GroupEnd();
+      return rcclFail("ncclBroadcast", ne);
+    }
+  }
+  ne = rccl().GroupEnd();
+  if(ne != ncclSuccess)
+    return rcclFail("ncclGroupEnd", ne);
+  // the frame is whole again: downloads address all rows
+  s->lastParams.strip_row_begin = 0;
+  s->lastParams.strip_row_end   = tilesY;
+  return MGS_OK;
+}
+int mgs_render_gathered(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
+{
+  return guarded("mgs_render_gathered", [&] { return mgs_render_gathered_impl(s, p, out); });
+}
+
+int mgs_frame_row_costs(MgsScene s, uint32_t* cost, size_t rows)
+{
+  if(!s || !cost)
+  {
+    setError("mgs_frame_row_costs: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(!s->haveFrame || s->lastWasSortOnly)
+  {
+    setError("mgs_frame_row_costs: no frame rendered yet");
+    return MGS_ERR_STATE;
+  }
+  return guarded("mgs_frame_row_costs", [&]() -> int {
+    FrameArgs A;
+    int       rc = buildFrameArgs(s, &s->lastParams, A);
+    if(rc != MGS_OK)
+      return rc;
+    const FrameConst& F = A.f;
+    if(rows < (size_t)F.tilesY)
+    {
+      setError("mgs_frame_row_costs: need one entry per 16-pixel tile row");
+      return MGS_ERR_INVALID_ARG;
+    }
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    const int          bins = F.binsX * F.binsY;
+    std::vector<uint2> rg((size_t)bins);
+    HIPCHK(hipMemcpy(rg.data(), s->ranges.p, (size_t)bins * sizeof(uint2), hipMemcpyDeviceToHost));
+    std::vector<double> acc((size_t)F.tilesY, 0.0);
+    const int           rowsPerBin = 1 << F.binShiftY;
+    for(int by = 0; by < F.binsY; ++by)
+    {
+      double len = 0;
+      for(int bx = 0; bx < F.binsX; ++bx)
+        len += (double)(rg[(size_t)by * F.binsX + bx].y - rg[(size_t)by * F.binsX + bx].x);
+      const int r0 = by * rowsPerBin, r1 = std::min(r0 + rowsPerBin, F.tilesY);
+      for(int r = r0; r < r1; ++r)
+        acc[(size_t)r] += len / (double)(r1 - r0);
+    }
+    for(int r = 0; r < F.tilesY; ++r)
+      cost[r] = (uint32_t)std::min(acc[(size_t)r], 4.0e9);
+    for(size_t r = (size_t)F.tilesY; r < rows; ++r)
+      cost[r] = 0u;
+    return MGS_OK;
+  });
 }
 
 // test/debug hook: the projected records of the last full frame for the given global ids (caller's id space)
