@@ -17,7 +17,9 @@ class OrcFrame(C.Structure):
                 ("width", C.c_int), ("height", C.c_int), ("splat_scale", C.c_float), ("frustum_dilation", C.c_float),
                 ("alpha_cull_threshold", C.c_float), ("sh_degree", C.c_int), ("front_to_back", C.c_int),
                 ("frustum_culling", C.c_int), ("target_fp16", C.c_int), ("ms_antialiasing", C.c_int),
-                ("size_culling", C.c_int), ("size_culling_min_pixels", C.c_float), ("debug_flags", C.c_int)]
+                ("size_culling", C.c_int), ("size_culling_min_pixels", C.c_float), ("debug_flags", C.c_int),
+                ("camera_model", C.c_int), ("extent_method", C.c_int), ("fov_rad", C.c_float), ("alpha_clamp", C.c_float),
+                ("kernel_min_response", C.c_float)]
 
 
 class OrcInstance(C.Structure):
@@ -29,6 +31,12 @@ class OrcInstance(C.Structure):
 class OrcProjected(C.Structure):
     _fields_ = [("valid", C.c_int), ("center_px", C.c_float * 2), ("ndc_z", C.c_float), ("basis1", C.c_float * 2),
                 ("basis2", C.c_float * 2), ("rgba", C.c_float * 4), ("opacity_disabled", C.c_int)]
+
+
+class OrcGutProjected(C.Structure):
+    _fields_ = [("valid", C.c_int), ("center_px", C.c_float * 2), ("ndc_z", C.c_float), ("half1", C.c_float * 2),
+                ("half2", C.c_float * 2), ("rgba", C.c_float * 4), ("position", C.c_float * 3), ("scale", C.c_float * 3),
+                ("inv_rot", C.c_float * 9)]
 
 
 class OrcSortInstance(C.Structure):
@@ -157,7 +165,8 @@ def make_instances(prepared_and_transforms):
 
 def make_frame(view, proj, camera_pos, width, height, splat_scale=1.0, frustum_dilation=0.2,
                alpha_cull=1.0 / 255.0, sh_degree=3, front_to_back=0, frustum_culling=1, target_fp16=0,
-               ms_antialiasing=0, debug_flags=0, size_culling=0, size_culling_min_pixels=1.0):
+               ms_antialiasing=0, debug_flags=0, size_culling=0, size_culling_min_pixels=1.0,
+               camera_model=0, extent_method=1, fov_rad=None, alpha_clamp=0.99, kernel_min_response=0.0113):
     f = OrcFrame()
     v = f32(view).T.reshape(-1)
     p = f32(proj).T.reshape(-1)
@@ -171,6 +180,10 @@ def make_frame(view, proj, camera_pos, width, height, splat_scale=1.0, frustum_d
     f.sh_degree, f.front_to_back, f.frustum_culling = sh_degree, front_to_back, frustum_culling
     f.target_fp16, f.ms_antialiasing, f.debug_flags = target_fp16, ms_antialiasing, debug_flags
     f.size_culling, f.size_culling_min_pixels = size_culling, size_culling_min_pixels
+    f.camera_model, f.extent_method = camera_model, extent_method
+    # fovRad of the perspective matrix (what cameraManip->getRadFov() returns for the camera that produced proj)
+    f.fov_rad = float(fov_rad) if fov_rad is not None else float(2.0 * np.arctan(1.0 / abs(float(p[5]))))
+    f.alpha_clamp, f.kernel_min_response = alpha_clamp, kernel_min_response
     return f
 
 
@@ -203,6 +216,37 @@ def render(frame, inst, order=None):
     else:
         o = np.ascontiguousarray(order, np.uint32)
         frags = lib().orc_render_order(C.byref(frame), inst, len(inst), _u(o), o.size, _p(img), stats)
+    return img, dict(fragments=int(frags), visible=int(stats[0]), quads=int(stats[1]))
+
+
+def project_gut(frame, inst, k, local_idx):
+    P = OrcGutProjected()
+    fn = lib().orc_project_gut
+    fn.restype = None
+    fn.argtypes = [C.POINTER(OrcFrame), C.POINTER(OrcInstance), C.c_uint32, C.POINTER(OrcGutProjected)]
+    fn(C.byref(frame), C.byref(inst[k]), local_idx, C.byref(P))
+    return P
+
+
+def gut_fragment(frame, inst, k, P, px, py):
+    """opacity of the fragment of projected splat P at pixel (px, py), or None when the hit is rejected"""
+    fn = lib().orc_gut_fragment
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(OrcFrame), C.POINTER(OrcInstance), C.POINTER(OrcGutProjected), C.c_int, C.c_int, F32P]
+    op = C.c_float()
+    ok = fn(C.byref(frame), C.byref(inst[k]), C.byref(P), int(px), int(py), C.byref(op))
+    return float(op.value) if ok else None
+
+
+def render_gut(frame, inst, order):
+    """3DGUT frame (threedgut_raster.{mesh,frag}.slang) in the supplied draw order"""
+    img = np.zeros((frame.height, frame.width, 4), np.float32)
+    stats = (C.c_uint64 * 2)()
+    o = np.ascontiguousarray(order, np.uint32)
+    fn = lib().orc_render_gut_order
+    fn.restype = C.c_uint64
+    fn.argtypes = [C.POINTER(OrcFrame), C.POINTER(OrcInstance), C.c_int, U32P, C.c_uint32, F32P, C.POINTER(C.c_uint64)]
+    frags = fn(C.byref(frame), inst, len(inst), _u(o), o.size, _p(img), stats)
     return img, dict(fragments=int(frags), visible=int(stats[0]), quads=int(stats[1]))
 
 

@@ -679,6 +679,398 @@ uint64_t orc_render_order(const OrcFrame* f, const OrcInstance* inst, int n_inst
   return frags;
 }
 
+// =======================================================================================================
+// 3DGUT: unscented-transform projection + per-pixel particle response
+// =======================================================================================================
+namespace {
+const float GUT_DELTA = 1.73205080757f, GUT_LAMBDA = 0.0f, GUT_ALPHA = 1.0f, GUT_BETA = 2.0f;  // threedgut_definitions.h.slang:45-50
+const int   GUT_D = 3;
+const float GUT_IN_IMAGE_MARGIN_FACTOR = 0.1f, GUT_COVARIANCE_DILATION = 0.3f, GUT_ALPHA_THRESHOLD = 0.01f;  // :51-57
+
+struct GutSensor
+{
+  int   fisheye;
+  float focal[2], principal[2], resolution[2], maxAngle;
+};
+
+// threedgut_camera_projections.h.slang:32-44
+float stableNorm2(float x, float y)
+{
+  const float ax = std::fabs(x), ay = std::fabs(y);
+  const float mn = std::min(ax, ay), mx = std::max(ax, ay);
+  if(mx <= 0.0f)
+    return 0.0f;
+  const float r = mn / mx;
+  return mx * std::sqrt(1.0f + r * r);
+}
+// :78-83
+bool withinResolution(const float res[2], float tol, const float p[2])
+{
+  const float mx = res[0] * tol, my = res[1] * tol;
+  return (p[0] > -mx) && (p[1] > -my) && (p[0] < res[0] + mx) && (p[1] < res[1] + my);
+}
+// projectPointPinhole with every distortion coefficient zero (initPerfectPinholeCamera, camera_models.h.slang:65-83):
+// icD = 1, delta = 0 -> uvND = uv; :85-137
+bool projectPinhole(const GutSensor& S, const float pos[3], float out[2])
+{
+  if(pos[2] <= 0.0f)
+  {
+    out[0] = out[1] = 0.0f;
+    return false;
+  }
+  const float u = pos[0] / pos[2], v = pos[1] / pos[2];
+  out[0] = u * S.focal[0] + S.principal[0];
+  out[1] = v * S.focal[1] + S.principal[1];
+  return withinResolution(S.resolution, GUT_IN_IMAGE_MARGIN_FACTOR, out);
+}
+// projectPointFisheye with radialCoeffs = 0 (initPerfectFisheyeCamera, camera_models.h.slang:120-136): delta = theta / rho; :151-176
+bool projectFisheye(const GutSensor& S, const float pos[3], float out[2])
+{
+  const float eps = 1e-7f;
+  const float rho = std::max(stableNorm2(pos[0], pos[1]), eps);
+  const float thetaFull = std::atan2(rho, pos[2]);
+  const float theta = std::min(thetaFull, S.maxAngle);
+  const float theta2 = theta * theta;
+  const float delta = (theta * (0.0f * theta2 + 1.0f)) / rho;
+  out[0] = S.focal[0] * pos[0] * delta + S.principal[0];
+  out[1] = S.focal[1] * pos[1] * delta + S.principal[1];
+  return (theta < S.maxAngle) && withinResolution(S.resolution, GUT_IN_IMAGE_MARGIN_FACTOR, out);
+}
+
+GutSensor makeSensor(const OrcFrame* f)
+{
+  GutSensor S;
+  S.fisheye       = f->camera_model == 1;
+  S.resolution[0] = (float)f->width;
+  S.resolution[1] = (float)f->height;
+  S.principal[0]  = S.resolution[0] / 2.0f;
+  S.principal[1]  = S.resolution[1] / 2.0f;
+  if(S.fisheye)
+  {  // gaussian_splatting.cpp:1243: focal = (1,-1) * viewport / fovRad
+    S.focal[0] = S.resolution[0] / f->fov_rad;
+    S.focal[1] = -S.resolution[1] / f->fov_rad;
+  }
+  else
+  {  // :1248-1250
+    S.focal[0] = f->proj[0] * 0.5f * S.resolution[0];
+    S.focal[1] = f->proj[5] * 0.5f * S.resolution[1];
+  }
+  // computeMaxAngle, camera_models.h.slang:87-118 (principal point at the centre: max distance = the half size)
+  const float mdx = S.resolution[0] - S.principal[0], mdy = S.resolution[1] - S.principal[1];
+  const float maxR = std::sqrt(mdx * mdx + mdy * mdy);
+  S.maxAngle = std::max(2.0f * maxR / S.focal[0], 2.0f * maxR / S.focal[1]) / 2.0f;
+  return S;
+}
+
+// projectPointWithShutter, global shutter (:186-201): the RUB -> RUF flip of position, translation and quaternion is
+// F (R p + t) with F = diag(1,1,-1), i.e. the view-space point with z negated
+bool projectWorldPoint(const OrcFrame* f, const GutSensor& S, const float world[3], float out[2])
+{
+  const float p[4] = {world[0], world[1], world[2], 1.0f};
+  float       v[4];
+  mat4_mul_vec4(f->view, p, v);
+  const float cam[3] = {v[0], v[1], -v[2]};
+  return S.fisheye ? projectFisheye(S, cam, out) : projectPinhole(S, cam, out);
+}
+}  // namespace
+
+void orc_project_gut(const OrcFrame* f, const OrcInstance* Ip, uint32_t i, OrcGutProjected* out)
+{
+  const OrcInstance& I = *Ip;
+  std::memset(out, 0, sizeof(*out));
+  // threedgut_raster.mesh.slang:116-122 — colour, centre, exp(scale), rotation matrix of the normalised quaternion
+  float rgba[4] = {I.rgba[4 * i + 0], I.rgba[4 * i + 1], I.rgba[4 * i + 2], I.rgba[4 * i + 3]};
+  const float p[3] = {I.centers[3 * i + 0], I.centers[3 * i + 1], I.centers[3 * i + 2]};
+  const float sc[3] = {std::exp(I.scales[3 * i + 0]), std::exp(I.scales[3 * i + 1]), std::exp(I.scales[3 * i + 2])};
+  float qw = I.rotations[4 * i + 0], qx = I.rotations[4 * i + 1], qy = I.rotations[4 * i + 2], qz = I.rotations[4 * i + 3];
+  {
+    const float ql = std::sqrt(((qw * qw + qx * qx) + qy * qy) + qz * qz);
+    qw /= ql; qx /= ql; qy /= ql; qz /= ql;
+  }
+  // quatToMat3, quaternions.h.slang:39-58 — rows of the Slang matrix (used as mul(v, M)); row i = i-th principal axis
+  const float xx = qx * qx, yy = qy * qy, zz = qz * qz, xy = qx * qy, xz = qx * qz, yz = qy * qz, wx = qw * qx, wy = qw * qy, wz = qw * qz;
+  const float R[3][3] = {{1.0f - 2.0f * (yy + zz), 2.0f * (xy + wz), 2.0f * (xz - wy)},
+                         {2.0f * (xy - wz), 1.0f - 2.0f * (xx + zz), 2.0f * (yz + wx)},
+                         {2.0f * (xz + wy), 2.0f * (yz - wx), 1.0f - 2.0f * (xx + yy)}};
+  // SH in model coordinates (:142-148), then the alpha cull (:150-155)
+  const float cam[4] = {f->camera_pos[0], f->camera_pos[1], f->camera_pos[2], 1.0f};
+  float       camM[4];
+  mat4_mul_vec4(I.transform_inv, cam, camM);
+  float       dir[3] = {p[0] - camM[0], p[1] - camM[1], p[2] - camM[2]};
+  const float dl     = std::sqrt((dir[0] * dir[0] + dir[1] * dir[1]) + dir[2] * dir[2]);
+  dir[0] /= dl; dir[1] /= dl; dir[2] /= dl;
+  if(f->debug_flags & 2)
+    rgba[0] = rgba[1] = rgba[2] = 0.5f;
+  float sh[3];
+  sh_radiance(I, i, f->sh_degree, dir, sh);
+  rgba[0] += sh[0]; rgba[1] += sh[1]; rgba[2] += sh[2];
+  if(rgba[3] < f->alpha_cull_threshold)
+    return;
+  // threedgutParticleProjection, threedgut.h.slang:26-110
+  const GutSensor S = makeSensor(f);
+  float           sp[2 * GUT_D + 1][2];
+  int             numValid = 0;
+  auto projectModel = [&](const float m[3], float o[2]) {
+    const float mp[4] = {m[0], m[1], m[2], 1.0f};
+    float       w[4];
+    mat4_mul_vec4(I.transform, mp, w);
+    return projectWorldPoint(f, S, w, o);
+  };
+  if(projectModel(p, sp[0]))
+    ++numValid;
+  float       c[2]    = {sp[0][0] * (GUT_LAMBDA / (GUT_D + GUT_LAMBDA)), sp[0][1] * (GUT_LAMBDA / (GUT_D + GUT_LAMBDA))};
+  const float weightI = 1.0f / (2.0f * (GUT_D + GUT_LAMBDA));
+  for(int a = 0; a < GUT_D; ++a)
+  {
+    const float d[3] = {GUT_DELTA * sc[a] * R[a][0], GUT_DELTA * sc[a] * R[a][1], GUT_DELTA * sc[a] * R[a][2]};
+    const float pp[3] = {p[0] + d[0], p[1] + d[1], p[2] + d[2]}, pm[3] = {p[0] - d[0], p[1] - d[1], p[2] - d[2]};
+    if(projectModel(pp, sp[a + 1]))
+      ++numValid;
+    c[0] += weightI * sp[a + 1][0];
+    c[1] += weightI * sp[a + 1][1];
+    if(projectModel(pm, sp[a + 1 + GUT_D]))
+      ++numValid;
+    c[0] += weightI * sp[a + 1 + GUT_D][0];
+    c[1] += weightI * sp[a + 1 + GUT_D][1];
+  }
+  if(numValid == 0)  // GUT_REQUIRE_ALL_SIGMA_POINTS_VALID false
+    return;
+  float cov[3];
+  {
+    const float cx = sp[0][0] - c[0], cy = sp[0][1] - c[1];
+    const float w0 = GUT_LAMBDA / (GUT_D + GUT_LAMBDA) + (1.0f - GUT_ALPHA * GUT_ALPHA + GUT_BETA);
+    cov[0] = w0 * (cx * cx);
+    cov[1] = w0 * (cx * cy);
+    cov[2] = w0 * (cy * cy);
+  }
+  for(int a = 0; a < 2 * GUT_D; ++a)
+  {
+    const float cx = sp[a + 1][0] - c[0], cy = sp[a + 1][1] - c[1];
+    cov[0] += weightI * (cx * cx);
+    cov[1] += weightI * (cx * cy);
+    cov[2] += weightI * (cy * cy);
+  }
+  if(f->extent_method == 1)
+  {  // threedgutProjectedExtentConicOpacity, threedgut.h.slang:113-160 (TIGHT_OPACITY_BOUNDING, RECT_BOUNDING)
+    const float dx = cov[0] + GUT_COVARIANCE_DILATION, dy = cov[1], dz = cov[2] + GUT_COVARIANCE_DILATION;
+    const float det = dx * dz - dy * dy;
+    if(det == 0.0f)
+      return;
+    float w = rgba[3];
+    if(f->ms_antialiasing)
+    {
+      const float covDet = cov[0] * cov[2] - cov[1] * cov[1];
+      w = rgba[3] * std::sqrt(std::max(0.000025f, covDet / det));
+    }
+    if(w < GUT_ALPHA_THRESHOLD)
+      return;
+    const float maxPower = std::log(w / GUT_ALPHA_THRESHOLD);
+    const float factor   = std::min(3.33f, std::sqrt(2.0f * maxPower));
+    const float mid      = 0.5f * (dx + dz);
+    const float lambda   = mid + std::sqrt(std::max(0.01f, mid * mid - det));
+    const float radius   = factor * std::sqrt(lambda);
+    const float ex = std::min(factor * std::sqrt(dx), radius), ey = std::min(factor * std::sqrt(dz), radius);
+    if(!(radius > 0.0f))
+      return;
+    if(f->ms_antialiasing)
+      rgba[3] = w;  // mesh.slang:193-195
+    out->half1[0] = ex; out->half1[1] = 0.f;
+    out->half2[0] = 0.f; out->half2[1] = ey;
+  }
+  else
+  {  // threedgsProjectedExtentBasis(cov, 3.33, splatScale, a, ...), threedgs.h.slang:60-121
+    float a = cov[0], b = cov[1], d = cov[2], detOrig = 0.f;
+    if(f->ms_antialiasing)
+      detOrig = a * d - b * b;
+    a += 0.3f;
+    d += 0.3f;
+    if(f->ms_antialiasing)
+      rgba[3] *= std::sqrt(std::max(detOrig / (a * d - b * b), 0.0f));
+    const float D = a * d - b * b, half = 0.5f * (a + d);
+    const float term2 = std::sqrt(std::max(0.1f, half * half - D));
+    float ev1 = half + term2, ev2 = half - term2;
+    if(ev2 <= 0.0f)
+      return;
+    if(f->debug_flags & 1)
+      ev1 = ev2 = 0.2f;
+    float       e1[2] = {(std::fabs(b) < 0.001f) ? 1.0f : b, ev1 - a};
+    const float el    = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1]);
+    e1[0] /= el; e1[1] /= el;
+    const float l1 = std::min(3.33f * std::sqrt(ev1), 2048.0f), l2 = std::min(3.33f * std::sqrt(ev2), 2048.0f);
+    out->half1[0] = e1[0] * f->splat_scale * l1; out->half1[1] = e1[1] * f->splat_scale * l1;
+    out->half2[0] = e1[1] * f->splat_scale * l2; out->half2[1] = -e1[0] * f->splat_scale * l2;
+  }
+  // quad centre: the UT mean in pixels; depth from the (pinhole) projection matrix, "a coarse approx" for fisheye (:205-214)
+  float MV[16], viewC[4], clip[4];
+  orc_mat4_mul(f->view, I.transform, MV);
+  const float p4[4] = {p[0], p[1], p[2], 1.0f};
+  mat4_mul_vec4(MV, p4, viewC);
+  mat4_mul_vec4(f->proj, viewC, clip);
+  const float ndcz = clip[2] / clip[3];
+  if(!(ndcz >= 0.0f && ndcz <= 1.0f))  // fixed-function clip of the quad emitted at z = ndc.z, w = 1 (see orc_project)
+    return;
+  out->ndc_z        = ndcz;
+  out->center_px[0] = c[0];
+  out->center_px[1] = c[1];
+  std::memcpy(out->rgba, rgba, sizeof(rgba));
+  std::memcpy(out->position, p, sizeof(p));
+  std::memcpy(out->scale, sc, sizeof(sc));
+  for(int r = 0; r < 3; ++r)  // splatInvRotation = transpose(splatRotation)
+    for(int k = 0; k < 3; ++k)
+      out->inv_rot[3 * r + k] = R[k][r];
+  out->valid = 1;
+}
+
+// threedgut_raster.frag.slang:87-127 for pixel (px, py): ray, model-space ray, particleProcessHitGut
+int orc_gut_fragment(const OrcFrame* f, const OrcInstance* I, const OrcGutProjected* P, int px, int py, float* opacity)
+{
+  float viewInv[16], projInv[16];
+  orc_mat4_inverse(f->view, viewInv);   // gaussian_splatting.cpp:1166
+  orc_mat4_inverse(f->proj, projInv);   // :1200
+  float       ro[3], rd[3];
+  const float posx = (float)px + 0.5f, posy = (float)py + 0.5f;  // SV_Position of the fragment
+  const float o4[4] = {0.f, 0.f, 0.f, 1.f};
+  float       t4[4];
+  mat4_mul_vec4(viewInv, o4, t4);
+  ro[0] = t4[0]; ro[1] = t4[1]; ro[2] = t4[2];
+  if(f->camera_model == 1)
+  {  // generateFisheyeRay(input.position.xy, viewport, fovRad, principalPoint = 0, viewInverse), cameras.h.slang:46-82
+    const float u = (posx / ((float)f->width - 1.0f)) * 2.0f - 1.0f, v = (posy / ((float)f->height - 1.0f)) * 2.0f - 1.0f;
+    const float r = std::sqrt(u * u + v * v);
+    if(r > 1.0f)
+      return 0;  // out of fov: discard
+    float phiCos = std::fabs(r) > 1e-9f ? u / r : 0.0f;
+    phiCos       = std::min(std::max(phiCos, -1.0f), 1.0f);
+    float phi    = std::acos(phiCos);
+    phi          = v < 0.0f ? -phi : phi;
+    const float theta = r * f->fov_rad * 0.5f;
+    const float d4[4] = {std::cos(phi) * std::sin(theta), -std::sin(phi) * std::sin(theta), -std::cos(theta), 0.f};
+    mat4_mul_vec4(viewInv, d4, t4);
+  }
+  else
+  {  // generatePinholeRay(input.position.xy, float2(0.5), ...), cameras.h.slang:27-43 — the 0.5 is added to SV_Position literally
+    const float inu = (posx + 0.5f) / (float)f->width, inv = (posy + 0.5f) / (float)f->height;
+    const float d4[4] = {inu * 2.0f - 1.0f, inv * 2.0f - 1.0f, 1.f, 1.f};
+    float       target[4];
+    mat4_mul_vec4(projInv, d4, target);
+    const float tg[4] = {target[0], target[1], target[2], 0.f};
+    mat4_mul_vec4(viewInv, tg, t4);
+  }
+  {
+    const float l = std::sqrt((t4[0] * t4[0] + t4[1] * t4[1]) + t4[2] * t4[2]);
+    rd[0] = t4[0] / l; rd[1] = t4[1] / l; rd[2] = t4[2] / l;
+  }
+  // model-space ray (:113-118)
+  const float ro4[4] = {ro[0], ro[1], ro[2], 1.f};
+  float       mo[4];
+  mat4_mul_vec4(I->transform_inv, ro4, mo);
+  float md[3];
+  for(int r = 0; r < 3; ++r)
+    md[r] = (rd[0] * m_at(I->transform_inv, r, 0) + rd[1] * m_at(I->transform_inv, r, 1)) + rd[2] * m_at(I->transform_inv, r, 2);
+  {
+    const float l = std::sqrt((md[0] * md[0] + md[1] * md[1]) + md[2] * md[2]);
+    md[0] /= l; md[1] /= l; md[2] /= l;
+  }
+  // particleProcessHitGut, threedgrt.h.slang:238-278
+  const float density = P->rgba[3];
+  if(density <= f->alpha_cull_threshold)
+    return 0;
+  // particleCannonicalRay, :57-75 — mul(v, invRotation) = sum_r v[r] * row r
+  const float g[3] = {mo[0] - P->position[0], mo[1] - P->position[1], mo[2] - P->position[2]};
+  float       gr[3], dr[3];
+  for(int k = 0; k < 3; ++k)
+  {
+    gr[k] = (g[0] * P->inv_rot[0 + k] + g[1] * P->inv_rot[3 + k]) + g[2] * P->inv_rot[6 + k];
+    dr[k] = (md[0] * P->inv_rot[0 + k] + md[1] * P->inv_rot[3 + k]) + md[2] * P->inv_rot[6 + k];
+  }
+  const float pro[3] = {gr[0] / P->scale[0], gr[1] / P->scale[1], gr[2] / P->scale[2]};
+  float       prd[3] = {dr[0] / P->scale[0], dr[1] / P->scale[1], dr[2] / P->scale[2]};
+  {
+    const float l = std::sqrt((prd[0] * prd[0] + prd[1] * prd[1]) + prd[2] * prd[2]);
+    prd[0] /= l; prd[1] /= l; prd[2] /= l;
+  }
+  // particleRayMinSquaredDistance, :77-81
+  const float cr[3] = {prd[1] * pro[2] - prd[2] * pro[1], prd[2] * pro[0] - prd[0] * pro[2], prd[0] * pro[1] - prd[1] * pro[0]};
+  const float dist2 = (cr[0] * cr[0] + cr[1] * cr[1]) + cr[2] * cr[2];
+  const float maxResponse = std::exp(-0.5f * dist2);  // quadratic kernel (KERNEL_DEGREE 2), :127-131
+  const float alpha       = std::min(f->alpha_clamp, maxResponse * density);
+  const bool  accept      = ((double)alpha > (double)(1.0f / 255.0f)) && (maxResponse > f->kernel_min_response);
+  if(!accept)
+    return 0;
+  *opacity = (f->debug_flags & 4) ? 1.0f : alpha;
+  return 1;
+}
+
+uint64_t orc_render_gut_order(const OrcFrame* f, const OrcInstance* inst, int n_inst, const uint32_t* ids, uint32_t v,
+                              float* rgba_out, uint64_t* stats)
+{
+  const int W = f->width, H = f->height;
+  std::memset(rgba_out, 0, (size_t)W * H * 4 * sizeof(float));
+  std::vector<uint32_t> offsets(n_inst + 1, 0);
+  for(int k = 0; k < n_inst; ++k)
+    offsets[k + 1] = offsets[k] + inst[k].count;
+  uint64_t frags = 0, quads = 0;
+  for(uint32_t s = 0; s < v; ++s)
+  {
+    const uint32_t g = ids[s];
+    int            k = 0;
+    while(k + 1 < n_inst && g >= offsets[k + 1])
+      ++k;
+    OrcGutProjected P;
+    orc_project_gut(f, &inst[k], g - offsets[k], &P);
+    if(!P.valid)
+      continue;
+    ++quads;
+    // pixel centres covered by the quad centre +- half1 +- half2
+    const float ex = std::fabs(P.half1[0]) + std::fabs(P.half2[0]), ey = std::fabs(P.half1[1]) + std::fabs(P.half2[1]);
+    const float fx0 = P.center_px[0] - ex - 0.5f, fx1 = P.center_px[0] + ex - 0.5f;
+    const float fy0 = P.center_px[1] - ey - 0.5f, fy1 = P.center_px[1] + ey - 0.5f;
+    if(!(fx1 >= 0.f && fy1 >= 0.f && fx0 <= (float)(W - 1) && fy0 <= (float)(H - 1)))
+      continue;
+    const int   x0 = (int)std::max(0.0f, std::floor(fx0)), x1 = (int)std::min((float)(W - 1), std::ceil(fx1));
+    const int   y0 = (int)std::max(0.0f, std::floor(fy0)), y1 = (int)std::min((float)(H - 1), std::ceil(fy1));
+    const float n1 = P.half1[0] * P.half1[0] + P.half1[1] * P.half1[1], n2 = P.half2[0] * P.half2[0] + P.half2[1] * P.half2[1];
+    for(int y = y0; y <= y1; ++y)
+      for(int x = x0; x <= x1; ++x)
+      {
+        const float dx = ((float)x + 0.5f) - P.center_px[0], dy = ((float)y + 0.5f) - P.center_px[1];
+        const float u = (dx * P.half1[0] + dy * P.half1[1]) / n1, w = (dx * P.half2[0] + dy * P.half2[1]) / n2;
+        if(std::fabs(u) > 1.0f || std::fabs(w) > 1.0f)
+          continue;  // outside the quad: no fragment
+        float opacity;
+        if(!orc_gut_fragment(f, &inst[k], &P, x, y, &opacity))
+          continue;
+        float* dst = rgba_out + ((size_t)y * W + x) * 4;
+        if(f->front_to_back)
+        {
+          const float oma = 1.0f - dst[3];
+          dst[0] = (P.rgba[0] * opacity) * oma + dst[0];
+          dst[1] = (P.rgba[1] * opacity) * oma + dst[1];
+          dst[2] = (P.rgba[2] * opacity) * oma + dst[2];
+          dst[3] = opacity * oma + dst[3];
+        }
+        else
+        {
+          const float oma = 1.0f - opacity;
+          dst[0] = P.rgba[0] * opacity + dst[0] * oma;
+          dst[1] = P.rgba[1] * opacity + dst[1] * oma;
+          dst[2] = P.rgba[2] * opacity + dst[2] * oma;
+          dst[3] = opacity + dst[3];
+        }
+        if(f->target_fp16)
+          for(int c = 0; c < 4; ++c)
+            dst[c] = orc_half_to_float(orc_float_to_half(dst[c]));
+        ++frags;
+      }
+  }
+  if(stats)
+  {
+    stats[0] = v;
+    stats[1] = quads;
+  }
+  return frags;
+}
+
 // orc_render_order restricted to the inclusive pixel window {x0,y0,x1,y1}; rgba_out is the window's own buffer.
 // Used to pin full-size frames with a few crops (a whole 5.8 M-splat frame is ~7 G fragments on one core).
 uint64_t orc_render_window(const OrcFrame* f, const OrcInstance* inst, int n_inst, const uint32_t* ids, uint32_t v,

@@ -62,6 +62,12 @@ typedef struct OrcFrame {
   float size_culling_min_pixels; /* shaderio.h:266 */
   int   debug_flags;          /* 1 POINT_CLOUD_MODE (threedgs.h.slang:108-110), 2 SHOW_SH_ONLY (mesh.slang:205-207),
                                  4 DISABLE_OPACITY_GAUSSIAN (frag.slang:248-255) */
+  /* ---- 3DGUT pipeline only (PIPELINE_MESH_3DGUT; ignored by the 3DGS entry points) ---- */
+  int   camera_model;         /* 0 CAMERA_PINHOLE, 1 CAMERA_FISHEYE (shaderio.h; threedgut_raster.mesh.slang:161-165) */
+  int   extent_method;        /* 0 EXTENT_EIGEN, 1 EXTENT_CONIC (shaderio.h:96-97; default CONIC, parameters.h:190) */
+  float fov_rad;              /* frameInfo.fovRad (gaussian_splatting.cpp:1168): fisheye focal + ray generation */
+  float alpha_clamp;          /* shaderio.h:271, default 0.99 */
+  float kernel_min_response;  /* KERNEL_MIN_RESPONSE, parameters.h:216, default 0.0113 */
 } OrcFrame;
 
 typedef struct OrcInstance {
@@ -110,6 +116,33 @@ uint64_t orc_render_order(const OrcFrame* f, const OrcInstance* inst, int n_inst
  * [y1-y0+1][x1-x0+1][4] buffer (== the crop of orc_render_order's image, bit for bit) */
 uint64_t orc_render_window(const OrcFrame* f, const OrcInstance* inst, int n_inst,
                            const uint32_t* ids, uint32_t v, const int win[4], float* rgba_out);
+
+/* ---- 3DGUT (unscented-transform projection + per-pixel particle response), SURVEY.md 8f rank 3 ----
+ * per-splat front end: shaders/threedgut_raster.mesh.slang:111-254 with threedgut.h.slang:26-163 (sigma points,
+ * GUT_* constants of threedgut_definitions.h.slang), threedgut_camera_projections.h.slang:84-239 (perfect pinhole /
+ * fisheye of threedgut_camera_models.h.slang:65-136, global shutter), quaternions.h.slang:39-58.
+ * per-fragment: shaders/threedgut_raster.frag.slang:87-183 with cameras.h.slang:27-82 (ray generation) and
+ * threedgrt.h.slang:57-135,238-278 (canonical ray, quadratic kernel).
+ * Not restated: rolling shutter (the reference marks it untested), depth of field and stochastic splats (their random
+ * numbers come from nvshaders/random.h.slang of the absent nvpro_core2), kernel degrees other than the default 2.
+ * The camera pose reaches the reference's projector as translation + glm::quat_cast(viewMatrix); rotating by that
+ * quaternion is the view matrix product itself, which is what is evaluated here (glm is not in the reference tree). */
+typedef struct OrcGutProjected {
+  int   valid;
+  float center_px[2];
+  float ndc_z;
+  float half1[2], half2[2];   /* half axes of the emitted quad in pixels: CONIC (ex,0),(0,ey); EIGEN basisVector1/2 */
+  float rgba[4];              /* colour incl. SH; .a after the MS_ANTIALIASING compensation */
+  float position[3];          /* model space */
+  float scale[3];             /* exp(stored scale) */
+  float inv_rot[9];           /* splatInvRotation rows (row-major): mul(v, inv_rot) == R(q)^T v */
+} OrcGutProjected;
+void     orc_project_gut(const OrcFrame* f, const OrcInstance* inst, uint32_t local_idx, OrcGutProjected* out);
+/* one fragment: returns 1 and the opacity if the hit is accepted (threedgut_raster.frag.slang:87-127) */
+int      orc_gut_fragment(const OrcFrame* f, const OrcInstance* inst, const OrcGutProjected* P, int px, int py, float* opacity);
+/* whole frame in the supplied draw order (global ids); same blending / target semantics as orc_render_order */
+uint64_t orc_render_gut_order(const OrcFrame* f, const OrcInstance* inst, int n_inst,
+                              const uint32_t* ids, uint32_t v, float* rgba_out, uint64_t* stats);
 
 /* octahedral normal coding, shaders/octahedral_normal.h.slang:27-87 */
 uint32_t orc_oct_encode(const float n[3]);

@@ -138,3 +138,80 @@ def render(proj, order, W, H):
         dst[..., :3] = col[:3] * op + dst[..., :3] * (1.0 - op)
         dst[..., 3:4] = op + dst[..., 3:4]
     return img
+
+
+# ---- 3DGUT (threedgut_raster.{mesh,frag}.slang), float64, the shaders' row-vector form ---------------------------------
+def gut_project(centers, scales_log, rotations_wxyz, rgba, M, V, P, W, H, extent_conic=True, alpha_cull=1.0 / 255.0):
+    """unscented projection of every splat (perfect pinhole, global shutter): dict(valid, center_px, cov, half_x, half_y,
+    axes[n,3,3] (principal axes as rows), scale[n,3]).  SH is not repeated here (same function as 3DGS)."""
+    c = np.asarray(centers, np.float64).reshape(-1, 3)
+    n = c.shape[0]
+    s = np.exp(np.asarray(scales_log, np.float64).reshape(-1, 3))
+    q = np.asarray(rotations_wxyz, np.float64).reshape(-1, 4)
+    q = q / np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    # quatToMat3 (quaternions.h.slang:39-58): the Slang rows; row i = i-th principal axis of the ellipsoid
+    R = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y)], 1),
+                  np.stack([2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x)], 1),
+                  np.stack([2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)], 1)], 1)  # [n, row, col]
+    S_M, S_V = slang(M), slang(V)
+    focal = np.array([P[0][0] * 0.5 * W, P[1][1] * 0.5 * H], np.float64)
+    pp = np.array([W / 2.0, H / 2.0])
+
+    def proj(pts):  # model-space points [n,3] -> (pixels [n,2], valid)
+        h = np.concatenate([pts, np.ones((pts.shape[0], 1))], 1)
+        v = (h @ S_M) @ S_V
+        cam = np.stack([v[:, 0], v[:, 1], -v[:, 2]], 1)  # RUB -> RUF
+        ok = cam[:, 2] > 0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            uv = np.where(ok[:, None], cam[:, :2] / cam[:, 2:3], 0.0)
+        px = np.where(ok[:, None], uv * focal + pp, 0.0)
+        inside = (px[:, 0] > -0.1 * W) & (px[:, 1] > -0.1 * H) & (px[:, 0] < 1.1 * W) & (px[:, 1] < 1.1 * H)
+        return px, ok & inside
+
+    delta = np.sqrt(3.0)
+    pts = [c] + [c + sgn * delta * s[:, i:i + 1] * R[:, i, :] for i in range(3) for sgn in (+1, -1)]
+    pr = [proj(p) for p in pts]
+    nvalid = sum(ok.astype(int) for _, ok in pr)
+    wI = 1.0 / 6.0
+    center = sum(wI * px for px, _ in pr[1:])  # weight of the mean is lambda / (D + lambda) = 0
+    d0 = pr[0][0] - center
+    cov = 2.0 * np.stack([d0[:, 0] ** 2, d0[:, 0] * d0[:, 1], d0[:, 1] ** 2], 1)  # weight0 = 0 + (1 - 1 + 2)
+    for px, _ in pr[1:]:
+        d = px - center
+        cov += wI * np.stack([d[:, 0] ** 2, d[:, 0] * d[:, 1], d[:, 1] ** 2], 1)
+    a = np.asarray(rgba, np.float64).reshape(-1, 4)[:, 3]
+    valid = (nvalid > 0) & ~(a < alpha_cull)
+    dx, dy, dz = cov[:, 0] + 0.3, cov[:, 1], cov[:, 2] + 0.3
+    det = dx * dz - dy * dy
+    valid &= (det != 0) & ~(a < 0.01)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        factor = np.minimum(3.33, np.sqrt(2.0 * np.log(np.maximum(a, 1e-30) / 0.01)))
+        mid = 0.5 * (dx + dz)
+        radius = factor * np.sqrt(mid + np.sqrt(np.maximum(0.01, mid * mid - det)))
+        hx, hy = np.minimum(factor * np.sqrt(dx), radius), np.minimum(factor * np.sqrt(dz), radius)
+    return dict(valid=valid, center_px=center, cov=cov, half_x=hx, half_y=hy, axes=R, scale=s, position=c)
+
+
+def gut_opacity(g, i, density, M, V, P, W, H, px, py, alpha_clamp=0.99, min_response=0.0113):
+    """opacity of splat i at pixel (px, py) or None: ray of the fragment (SV_Position + 0.5, as the reference writes it),
+    canonical ray, quadratic kernel"""
+    S_V, S_P, S_M = slang(V), slang(P), slang(M)
+    vi, pi, mi = np.linalg.inv(S_V), np.linalg.inv(S_P), np.linalg.inv(S_M)
+    origin = (np.array([0, 0, 0, 1.0]) @ vi)[:3]
+    inuv = (np.array([px + 0.5, py + 0.5]) + 0.5) / np.array([W, H])
+    d = inuv * 2.0 - 1.0
+    target = np.array([d[0], d[1], 1.0, 1.0]) @ pi
+    rd = (np.array([target[0], target[1], target[2], 0.0]) @ vi)[:3]
+    rd /= np.linalg.norm(rd)
+    mo = (np.append(origin, 1.0) @ mi)[:3]
+    md = rd @ mi[:3, :3]
+    md /= np.linalg.norm(md)
+    A = g["axes"][i]  # rows = principal axes; mul(v, invRotation) = v @ A.T
+    ro = ((mo - g["position"][i]) @ A.T) / g["scale"][i]
+    r = (md @ A.T) / g["scale"][i]
+    r /= np.linalg.norm(r)
+    cr = np.cross(r, ro)
+    resp = np.exp(-0.5 * (cr @ cr))
+    alpha = min(alpha_clamp, resp * density)
+    return alpha if (alpha > 1.0 / 255.0 and resp > min_response) else None
