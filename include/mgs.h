@@ -55,6 +55,10 @@ enum { MGS_DEBUG_POINT_CLOUD = 1, MGS_DEBUG_SH_ONLY = 2, MGS_DEBUG_OPACITY_GAUSS
 /* alpha channel meaning: the reference's default back-to-front pipeline accumulates
  * A = sum(alpha) (src/gaussian_splatting.cpp:2083-2084); its FTB pipeline yields 1-T (:2071-2076). */
 enum { MGS_ALPHA_COVERAGE = 0 /* 1-T */, MGS_ALPHA_SUM = 1 /* sum(alpha); disables early termination */ };
+/* raster pipelines (parameters.h PIPELINE_MESH / PIPELINE_MESH_3DGUT), 3DGUT camera models and quad extents */
+enum { MGS_PIPELINE_3DGS = 0, MGS_PIPELINE_3DGUT = 1 };
+enum { MGS_CAMERA_PINHOLE = 0, MGS_CAMERA_FISHEYE = 1 };
+enum { MGS_EXTENT_EIGEN = 0, MGS_EXTENT_CONIC = 1 };
 
 typedef struct MgsSplatSet_t* MgsSplatSet; /* RAM model == struct SplatSet, src/splat_set.h:33-48 */
 typedef struct MgsScene_t*    MgsScene;    /* device scene == SplatSetManagerVk + renderer buffers  */
@@ -149,6 +153,17 @@ typedef struct MgsFrameParams {
                                    an axis degenerate for the splat normal (threedgrt.h.slang:358-419) */
   int32_t quantize_normals;     /* surface_outputs only, default 1 (parameters.h:195): the splat normal passes through
                                    the 2x16-bit octahedral code (octahedral_normal.h.slang) before it is integrated */
+  /* ---- 3DGUT raster pipeline (PIPELINE_MESH_3DGUT): unscented-transform projection
+   * (threedgut_raster.mesh.slang:111-254, threedgut.h.slang:26-163) + per-pixel particle response
+   * (threedgut_raster.frag.slang:87-183, threedgrt.h.slang:57-135,238-278).  Keys, cull, sort and binning are shared. */
+  int32_t pipeline;             /* MGS_PIPELINE_3DGS (default) | MGS_PIPELINE_3DGUT */
+  int32_t camera_model;         /* 3DGUT: MGS_CAMERA_PINHOLE (default) | MGS_CAMERA_FISHEYE (perfect equidistant fisheye,
+                                   threedgut_camera_models.h.slang:120-136; rays cameras.h.slang:46-82) */
+  int32_t extent_method;        /* 3DGUT: MGS_EXTENT_CONIC (default, parameters.h:190) | MGS_EXTENT_EIGEN (shaderio.h:96-97) */
+  float   fov_rad;              /* 3DGUT fisheye: frameInfo.fovRad (gaussian_splatting.cpp:1168,1243); 0 = derive the vertical
+                                   field of view from proj[5] */
+  float   alpha_clamp;          /* 3DGUT: default 0.99 (shaderio.h:271) */
+  float   kernel_min_response;  /* 3DGUT: default 0.0113 (parameters.h:216) */
 } MgsFrameParams;
 
 void mgs_frame_params_default(MgsFrameParams* p); /* fills the defaults cited above */

@@ -13,6 +13,9 @@ CULL_NONE, CULL_AT_DIST, CULL_AT_RASTER = 0, 1, 2
 TARGET_RGBA16F, TARGET_RGBA32F, TARGET_RGBA8 = 0, 1, 2
 ALPHA_COVERAGE, ALPHA_SUM = 0, 1
 DEBUG_POINT_CLOUD, DEBUG_SH_ONLY, DEBUG_OPACITY_GAUSSIAN_DISABLED = 1, 2, 4
+PIPELINE_3DGS, PIPELINE_3DGUT = 0, 1
+CAMERA_PINHOLE, CAMERA_FISHEYE = 0, 1
+EXTENT_EIGEN, EXTENT_CONIC = 0, 1
 STAGE_NAMES = ["project", "sort", "bin", "pairsort", "composite", "total"]
 
 
@@ -39,7 +42,9 @@ class FrameParams(C.Structure):
                 ("collect_timings", C.c_int32), ("cpu_sort_blocking", C.c_int32), ("debug_flags", C.c_int32),
                 ("size_culling", C.c_int32), ("size_culling_min_pixels", C.c_float),
                 ("surface_outputs", C.c_int32), ("depth_iso_threshold", C.c_float), ("cpu_lazy_sort", C.c_int32),
-                ("thin_particle_threshold", C.c_float), ("quantize_normals", C.c_int32)]
+                ("thin_particle_threshold", C.c_float), ("quantize_normals", C.c_int32),
+                ("pipeline", C.c_int32), ("camera_model", C.c_int32), ("extent_method", C.c_int32), ("fov_rad", C.c_float),
+                ("alpha_clamp", C.c_float), ("kernel_min_response", C.c_float)]
 
 
 class FrameOut(C.Structure):

@@ -31,6 +31,7 @@ struct InstanceConst
   const float* scales;    // [count*3] log-space, as stored (scalesAddress)     } read only by the integrated-normal
   const float* rotations; // [count*4] (w,x,y,z), as stored (rotationsAddress)  } side output (mesh.slang:209-235)
   float        model[16];      // M   (glm column-major)
+  float        modelInv[16];   // M^-1 (3DGUT: model-space ray of a fragment, frag.slang:113-118)
   float        modelView[16];  // V*M (host-computed with the same unfused fp32 products the shader does per thread)
   float        camModel[3];    // M^-1 * cameraPosition
   float        modelAxisMax;   // max length of the model matrix columns (size culling, dist.comp.slang:110-115)
@@ -72,6 +73,15 @@ struct FrameConst
   float    depthIsoThreshold;
   float    thinParticleThreshold;  // shaderio.h:316: scale below which a particle axis counts as degenerate
   int32_t  quantizeNormals;        // QUANTIZE_NORMALS (parameters.h:195): octahedral 2x16-bit round trip of the splat normal
+  // 3DGUT pipeline
+  int32_t  pipeline;               // 0 3DGS, 1 3DGUT
+  int32_t  cameraModel;            // 0 pinhole, 1 fisheye
+  int32_t  extentMethod;           // 0 eigen, 1 conic
+  float    fovRad;
+  float    alphaClamp, kernelMinResponse;
+  float    gutFocal[2];            // pinhole: == focal; fisheye: (1,-1) * viewport / fovRad (gaussian_splatting.cpp:1243)
+  float    gutMaxAngle;            // computeMaxAngle (threedgut_camera_models.h.slang:87-118)
+  float    viewInv[16], projInv[16];  // glm::inverse (gaussian_splatting.cpp:1166,1200)
 };
 
 struct FrameArgs
@@ -119,6 +129,22 @@ struct alignas(16) SplatRec
   float    a;         // opacity (after MS_ANTIALIASING)
   uint32_t exey;      // half2: tight half extents of the visible footprint in pixels, rounded UP (cull tests only)
 };
+
+// 3DGUT projected record: 96 B, indexed by global id.  The per-fragment evaluator needs the particle itself, not a 2D
+// conic: with A = S^-1 R^T (canonical frame), N = 3x3 of M^-1, o = camera origin, the canonical ray of a fragment with
+// world direction d is  origin ro = A (M^-1 o - p) (per splat)  and  direction ~ B d, B = A N (per splat), so
+// dist^2 = |B d x ro|^2 / |B d|^2 (threedgrt.h.slang:57-81) costs 9 FMAs + a cross product per fragment.
+struct alignas(16) GutRec
+{
+  float cx, cy;        // UT mean in pixels (quad centre)
+  float q1x, q1y;      // half1 / |half1|^2 : |d.q1| <= 1 and |d.q2| <= 1  <=>  the pixel centre is inside the quad
+  float q2x, q2y;
+  float bex, bey;      // half extents of the quad's bounding box in pixels (culling only)
+  float B[9];
+  float ro[3];
+  float r, g, b, a;    // colour incl. SH; opacity after MS antialiasing
+};
+static_assert(sizeof(GutRec) == 96, "six 16-byte vectors");
 
 // device-resident counters of one frame
 struct FrameCounters

@@ -1,0 +1,592 @@
+// k_gut.hip — the 3DGUT raster pipeline (PIPELINE_MESH_3DGUT) for gfx950: SURVEY.md §8f rank 3.
+//
+// Replaces
+//   shaders/threedgut_raster.mesh.slang:111-254   per-splat front end: colour + SH, alpha cull, unscented projection,
+//                                                  quad extent (conic / eigen), quad placement
+//   shaders/threedgut.h.slang:26-163              threedgutParticleProjection (7 sigma points, GUT_* of
+//                                                  threedgut_definitions.h.slang), threedgutProjectedExtentConicOpacity
+//   shaders/threedgut_camera_projections.h.slang:84-201  perfect pinhole / fisheye projection, global shutter
+//   shaders/threedgut_raster.frag.slang:87-183    per-fragment: ray generation (cameras.h.slang:27-82), model-space ray,
+//                                                  particleProcessHitGut (threedgrt.h.slang:57-135,238-278), blend source
+// Shared with the 3DGS path and unchanged: depth keys + frustum cull (dist.comp.slang), the key sort, the per-bin lists.
+// Structure: k_project_gut is k_project's phase 1 (key, cull, ordered compaction: same code, same bits) followed by the
+// 3DGUT front end for the survivors; it writes one 96-byte GutRec per sorted splat.  k_composite_gut walks the bin
+// lists nearest-first like k_composite (one workgroup per 16x16 tile, one pixel per thread, records staged through
+// LDS in list order) and evaluates the particle response per fragment.  This pipeline is a "next" row: correct and
+// reasonably fast, not tuned like the 3DGS compositor.
+// Not built (stated in DESIGN.md): rolling shutter (untested in the reference), depth of field and stochastic splats
+// (their random numbers come from nvshaders/random.h.slang in the absent nvpro_core2), kernel degrees other than 2.
+#include "kernels_common.h"
+#include "sh_eval.h"
+#include "sort_plan.h"
+
+namespace mgs {
+
+constexpr int kGutThreads = 256;
+constexpr int kGutItems   = 8;
+constexpr int kGutPart    = kGutThreads * kGutItems;  // == the project kernel's partition: same slots, same sort input
+
+// threedgut_camera_projections.h.slang:32-44
+__device__ __forceinline__ float gutStableNorm2(float x, float y)
+{
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mn = fminf(ax, ay), mx = fmaxf(ax, ay);
+  if(mx <= 0.0f)
+    return 0.0f;
+  const float r = mn / mx;
+  return mx * sqrtf(1.0f + r * r);
+}
+
+// projectPointWithShutter (global shutter) + projectPoint for the perfect pinhole / fisheye models.  `cam` is the
+// view-space point with z negated (RUB -> RUF: the flips of :188-196 amount to F (R p + t), F = diag(1,1,-1)).
+__device__ __forceinline__ bool gutProjectCam(const FrameConst& F, float cx, float cy, float cz, float& ox, float& oy)
+{
+  const float resx = (float)F.width, resy = (float)F.height;
+  bool        ok;
+  if(F.cameraModel == 1)
+  {  // projectPointFisheye, radial coefficients 0: :151-176
+    const float rho       = fmaxf(gutStableNorm2(cx, cy), 1e-7f);
+    const float thetaFull = atan2f(rho, cz);
+    const float theta     = fminf(thetaFull, F.gutMaxAngle);
+    const float delta     = theta / rho;
+    ox                    = F.gutFocal[0] * cx * delta + resx * 0.5f;
+    oy                    = F.gutFocal[1] * cy * delta + resy * 0.5f;
+    ok                    = theta < F.gutMaxAngle;
+  }
+  else
+  {  // projectPointPinhole, distortion coefficients 0 (icD = 1, delta = 0): :85-137
+    if(cz <= 0.0f)
+    {
+      ox = oy = 0.0f;
+      return false;
+    }
+    ox = (cx / cz) * F.gutFocal[0] + resx * 0.5f;
+    oy = (cy / cz) * F.gutFocal[1] + resy * 0.5f;
+    ok = true;
+  }
+  const float mx = resx * 0.1f, my = resy * 0.1f;  // withinResolution, GUT_IN_IMAGE_MARGIN_FACTOR
+  return ok && (ox > -mx) && (oy > -my) && (ox < resx + mx) && (oy < resy + my);
+}
+
+// the per-splat 3DGUT front end; returns false when the splat emits no quad
+template <int SHF>
+__device__ __forceinline__ bool projectSplatGut(const FrameConst& F, const InstanceConst& I, uint32_t li, GutRec& out, uint32_t& rectOut)
+{
+  // mesh.slang:116-122
+  const float4 col4 = reinterpret_cast<const float4*>(I.rgbaF32)[li];
+  const float  px = I.centers[3 * (size_t)li], py = I.centers[3 * (size_t)li + 1], pz = I.centers[3 * (size_t)li + 2];
+  const float  s0 = expf(I.scales[3 * (size_t)li]), s1 = expf(I.scales[3 * (size_t)li + 1]), s2 = expf(I.scales[3 * (size_t)li + 2]);
+  const float4 rq = *reinterpret_cast<const float4*>(I.rotations + 4 * (size_t)li);  // (w,x,y,z)
+  const float  ql = sqrtf(rq.x * rq.x + rq.y * rq.y + rq.z * rq.z + rq.w * rq.w);
+  const float  w = rq.x / ql, x = rq.y / ql, y = rq.z / ql, z = rq.w / ql;
+  const float  xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+  // quatToMat3 (quaternions.h.slang:39-58): row a = a-th principal axis
+  const float R[3][3] = {{1.0f - 2.0f * (yy + zz), 2.0f * (xy + wz), 2.0f * (xz - wy)},
+                         {2.0f * (xy - wz), 1.0f - 2.0f * (xx + zz), 2.0f * (yz + wx)},
+                         {2.0f * (xz + wy), 2.0f * (yz - wx), 1.0f - 2.0f * (xx + yy)}};
+  const float sc[3] = {s0, s1, s2};
+  // colour: base + SH in model coordinates (:142-148), then the alpha cull (:150-155)
+  float dx = px - I.camModel[0], dy = py - I.camModel[1], dz = pz - I.camModel[2];
+  {
+    const float dl = rsqrtf(dx * dx + dy * dy + dz * dz);
+    dx *= dl; dy *= dl; dz *= dl;
+  }
+  float cr = (F.debugFlags & 2) ? 0.5f : col4.x, cg = (F.debugFlags & 2) ? 0.5f : col4.y, cb = (F.debugFlags & 2) ? 0.5f : col4.z;
+  float alpha = col4.w;
+  const int deg = (I.sh == nullptr) ? 0 : min(I.shDegree, F.shDegree);
+  if(deg > 0)
+    addShRadiance<SHF>(I.sh, li, deg, dx, dy, dz, cr, cg, cb);
+  if(alpha < F.alphaCull)
+    return false;
+  // threedgutParticleProjection, threedgut.h.slang:26-110 (GUT_D 3, alpha 1, beta 2, kappa 0 -> lambda 0, delta sqrt 3)
+  const float* M = I.model;
+  const float* V = F.view;
+  auto project = [&](float mx, float my, float mz, float& ox, float& oy) {
+    const float wx_ = M[0] * mx + M[4] * my + M[8] * mz + M[12];
+    const float wy_ = M[1] * mx + M[5] * my + M[9] * mz + M[13];
+    const float wz_ = M[2] * mx + M[6] * my + M[10] * mz + M[14];
+    const float vx = V[0] * wx_ + V[4] * wy_ + V[8] * wz_ + V[12];
+    const float vy = V[1] * wx_ + V[5] * wy_ + V[9] * wz_ + V[13];
+    const float vz = V[2] * wx_ + V[6] * wy_ + V[10] * wz_ + V[14];
+    return gutProjectCam(F, vx, vy, -vz, ox, oy);
+  };
+  float spx[7], spy[7];
+  int   nValid = project(px, py, pz, spx[0], spy[0]) ? 1 : 0;
+  constexpr float kDelta = 1.73205080757f, kWI = 1.0f / 6.0f;
+  float ccx = 0.0f, ccy = 0.0f;  // weight of the mean: lambda / (D + lambda) = 0
+#pragma unroll
+  for(int a = 0; a < 3; ++a)
+  {
+    const float ex = kDelta * sc[a] * R[a][0], ey = kDelta * sc[a] * R[a][1], ez = kDelta * sc[a] * R[a][2];
+    nValid += project(px + ex, py + ey, pz + ez, spx[a + 1], spy[a + 1]) ? 1 : 0;
+    ccx += kWI * spx[a + 1];
+    ccy += kWI * spy[a + 1];
+    nValid += project(px - ex, py - ey, pz - ez, spx[a + 4], spy[a + 4]) ? 1 : 0;
+    ccx += kWI * spx[a + 4];
+    ccy += kWI * spy[a + 4];
+  }
+  if(nValid == 0)
+    return false;
+  float c0, c1, c2;
+  {
+    const float ex = spx[0] - ccx, ey = spy[0] - ccy;  // weight0 = 0 + (1 - alpha^2 + beta) = 2
+    c0 = 2.0f * (ex * ex);
+    c1 = 2.0f * (ex * ey);
+    c2 = 2.0f * (ey * ey);
+  }
+#pragma unroll
+  for(int a = 1; a < 7; ++a)
+  {
+    const float ex = spx[a] - ccx, ey = spy[a] - ccy;
+    c0 += kWI * (ex * ex);
+    c1 += kWI * (ex * ey);
+    c2 += kWI * (ey * ey);
+  }
+  float h1x, h1y, h2x, h2y;
+  if(F.extentMethod == 1)
+  {  // threedgutProjectedExtentConicOpacity, threedgut.h.slang:113-160
+    const float ddx = c0 + 0.3f, ddy = c1, ddz = c2 + 0.3f;
+    const float det = ddx * ddz - ddy * ddy;
+    if(det == 0.0f)
+      return false;
+    float wop = alpha;
+    if(F.msAA)
+      wop = alpha * sqrtf(fmaxf(0.000025f, (c0 * c2 - c1 * c1) / det));
+    if(wop < 0.01f)
+      return false;
+    const float maxPower = logf(wop / 0.01f);
+    const float factor   = fminf(3.33f, sqrtf(2.0f * maxPower));
+    const float mid      = 0.5f * (ddx + ddz);
+    const float lambda   = mid + sqrtf(fmaxf(0.01f, mid * mid - det));
+    const float radius   = factor * sqrtf(lambda);
+    if(!(radius > 0.0f))
+      return false;
+    if(F.msAA)
+      alpha = wop;
+    h1x = fminf(factor * sqrtf(ddx), radius);
+    h1y = 0.0f;
+    h2x = 0.0f;
+    h2y = fminf(factor * sqrtf(ddz), radius);
+  }
+  else
+  {  // threedgsProjectedExtentBasis(cov, 3.33, splatScale, ...), threedgs.h.slang:60-121
+    float a = c0, b = c1, d = c2, detOrig = 0.0f;
+    if(F.msAA)
+      detOrig = a * d - b * b;
+    a += 0.3f;
+    d += 0.3f;
+    if(F.msAA)
+      alpha *= sqrtf(fmaxf(detOrig / (a * d - b * b), 0.0f));
+    const float D = a * d - b * b, half = 0.5f * (a + d);
+    const float term2 = sqrtf(fmaxf(0.1f, half * half - D));
+    float ev1 = half + term2, ev2 = half - term2;
+    if(ev2 <= 0.0f)
+      return false;
+    if(F.debugFlags & 1)
+      ev1 = ev2 = 0.2f;
+    float       e1x = (fabsf(b) < 0.001f) ? 1.0f : b, e1y = ev1 - a;
+    const float el  = sqrtf(e1x * e1x + e1y * e1y);
+    e1x /= el;
+    e1y /= el;
+    const float l1 = F.splatScale * fminf(3.33f * sqrtf(ev1), 2048.0f), l2 = F.splatScale * fminf(3.33f * sqrtf(ev2), 2048.0f);
+    h1x = e1x * l1;
+    h1y = e1y * l1;
+    h2x = e1y * l2;
+    h2y = -e1x * l2;
+  }
+  // depth of the quad from the pinhole projection matrix (":205-214": a coarse approximation for fisheye) and the
+  // fixed-function clip of a quad emitted at z = ndc.z, w = 1
+  const float* MV = I.modelView;
+  const float* P  = F.proj;
+  const float  tx = MV[0] * px + MV[4] * py + MV[8] * pz + MV[12];
+  const float  ty = MV[1] * px + MV[5] * py + MV[9] * pz + MV[13];
+  const float  tz = MV[2] * px + MV[6] * py + MV[10] * pz + MV[14];
+  const float  tw = MV[3] * px + MV[7] * py + MV[11] * pz + MV[15];
+  const float  cz = P[2] * tx + P[6] * ty + P[10] * tz + P[14] * tw;
+  const float  cw = P[3] * tx + P[7] * ty + P[11] * tz + P[15] * tw;
+  const float  ndcz = cz / cw;
+  if(!(ndcz >= 0.0f && ndcz <= 1.0f))
+    return false;
+  const float n1 = h1x * h1x + h1y * h1y, n2 = h2x * h2x + h2y * h2y;
+  if(!(n1 > 0.0f && n2 > 0.0f))
+    return false;
+  // bounding box of the quad -> pixel centres covered -> bin rectangle (as the 3DGS path)
+  const float bex = fabsf(h1x) + fabsf(h2x), bey = fabsf(h1y) + fabsf(h2y);
+  const float fx0 = ceilf(ccx - bex - 0.5f), fx1 = floorf(ccx + bex - 0.5f);
+  const float fy0 = ceilf(ccy - bey - 0.5f), fy1 = floorf(ccy + bey - 0.5f);
+  const float ymin = (float)(F.stripRow0 * kTilePx), ymax = (float)(min(F.stripRow1 * kTilePx, F.height) - 1);
+  if(!(fx1 >= fx0 && fy1 >= fy0 && fx1 >= 0.f && fx0 <= (float)(F.width - 1) && fy1 >= ymin && fy0 <= ymax))
+    return false;
+  const int x0 = (int)fmaxf(fx0, 0.f), x1 = (int)fminf(fx1, (float)(F.width - 1));
+  const int y0 = (int)fmaxf(fy0, ymin), y1 = (int)fminf(fy1, ymax);
+  const int sx = 4 + F.binShiftX, sy = 4 + F.binShiftY;
+  rectOut = (uint32_t)(x0 >> sx) | ((uint32_t)(y0 >> sy) << 8) | ((uint32_t)(x1 >> sx) << 16) | ((uint32_t)(y1 >> sy) << 24);
+
+  out.cx  = ccx;
+  out.cy  = ccy;
+  out.q1x = h1x / n1;
+  out.q1y = h1y / n1;
+  out.q2x = h2x / n2;
+  out.q2y = h2y / n2;
+  out.bex = bex + 0.01f;
+  out.bey = bey + 0.01f;
+  // canonical frame: A = S^-1 R^T, i.e. A[k][r] = R[k][r] / s_k with R's rows the axes;  B = A N, ro = A (M^-1 o - p)
+  const float* Mi = I.modelInv;
+  float        A[3][3];
+#pragma unroll
+  for(int k = 0; k < 3; ++k)
+#pragma unroll
+    for(int r = 0; r < 3; ++r)
+      A[k][r] = R[k][r] / sc[k];
+#pragma unroll
+  for(int k = 0; k < 3; ++k)
+#pragma unroll
+    for(int c = 0; c < 3; ++c)  // N(r,c) = Mi[c*4 + r]
+      out.B[3 * k + c] = A[k][0] * Mi[c * 4 + 0] + A[k][1] * Mi[c * 4 + 1] + A[k][2] * Mi[c * 4 + 2];
+  // camera origin in model space: M^-1 * (V^-1 * (0,0,0,1))
+  const float ox = F.viewInv[12], oy = F.viewInv[13], oz = F.viewInv[14];
+  const float mox = Mi[0] * ox + Mi[4] * oy + Mi[8] * oz + Mi[12];
+  const float moy = Mi[1] * ox + Mi[5] * oy + Mi[9] * oz + Mi[13];
+  const float moz = Mi[2] * ox + Mi[6] * oy + Mi[10] * oz + Mi[14];
+  const float gx = mox - px, gy = moy - py, gz = moz - pz;
+#pragma unroll
+  for(int k = 0; k < 3; ++k)
+    out.ro[k] = A[k][0] * gx + A[k][1] * gy + A[k][2] * gz;
+  out.r = cr;
+  out.g = cg;
+  out.b = cb;
+  out.a = alpha;
+  return true;
+}
+
+// Phase 1 (key + frustum cull + ordered compaction) is k_project's, statement for statement: the sorted (key, id)
+// stream of a 3DGUT frame is bit-identical to the 3DGS frame's before the front-end rejections.
+template <int SHF>
+__global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __restrict__ Ap, FrameCounters* __restrict__ ctr,
+                                                             uint32_t* __restrict__ keysSlot, uint32_t* __restrict__ idsSlot,
+                                                             uint32_t* __restrict__ slotCount, GutRec* __restrict__ rec,
+                                                             uint32_t* __restrict__ rect, const uint32_t* __restrict__ partSkip,
+                                                             uint32_t* __restrict__ slotHist, uint32_t histStride)
+{
+  const FrameArgs& A = *Ap;
+  if(partSkip != nullptr && partSkip[blockIdx.x] != 0u)
+  {
+    if(threadIdx.x == 0)
+      slotCount[blockIdx.x] = 0u;
+    slotHist[(size_t)threadIdx.x * histStride + blockIdx.x] = 0u;
+    return;
+  }
+  __shared__ uint32_t s_hist[256];
+  __shared__ uint16_t s_li[kGutPart];
+  __shared__ uint32_t s_key[kGutPart];
+  __shared__ uint32_t s_cnt[32];
+  __shared__ uint32_t s_base[33];
+  s_hist[threadIdx.x] = 0u;
+  const int      t = threadIdx.x, lane = laneId(), w = t >> 6;
+  const uint32_t part = blockIdx.x;
+  int            k    = 0;
+  for(int i = 1; i < A.f.nInstances; ++i)
+    if(part >= A.inst[i].blockBegin)
+      k = i;
+  const InstanceConst& I      = A.inst[k];
+  const uint32_t       local0 = (part - I.blockBegin) * kGutPart;
+  float px[kGutItems], py[kGutItems], pz[kGutItems];
+#pragma unroll
+  for(int it = 0; it < kGutItems; ++it)
+  {
+    const uint32_t li = min(local0 + it * kGutThreads + t, I.count - 1u);
+    px[it] = I.centers[3 * (size_t)li];
+    py[it] = I.centers[3 * (size_t)li + 1];
+    pz[it] = I.centers[3 * (size_t)li + 2];
+  }
+  uint32_t key[kGutItems];
+  uint64_t bal[kGutItems];
+  bool     vis[kGutItems];
+#pragma unroll
+  for(int it = 0; it < kGutItems; ++it)
+  {
+    const uint32_t li = local0 + it * kGutThreads + t;
+    float          wp[4], vp[4], cp[4];
+    mulMat4Exact(I.model, px[it], py[it], pz[it], 1.0f, wp);  // dist.comp.slang:58
+    mulMat4Exact(A.f.view, wp[0], wp[1], wp[2], wp[3], vp);
+    mulMat4Exact(A.f.proj, vp[0], vp[1], vp[2], vp[3], cp);   // :60
+    const float nx = divExact(cp[0], cp[3]), ny = divExact(cp[1], cp[3]), nz = divExact(cp[2], cp[3]);  // :61
+    bool        v  = li < I.count;
+    if(A.f.cullMode == 1)
+    {
+      const float c = 1.0f + A.f.frustumDilation;
+      if(fabsf(nx) > c || fabsf(ny) > c || nz < 0.f - A.f.frustumDilation || nz > 1.0f)
+        v = false;
+    }
+    if(A.f.sizeCulling && v)
+      v = !sizeCulled(I.maxScale[min(li, I.count - 1u)], A.f.splatScale, I.modelAxisMax, vp[2], A.f.maxFocal, A.f.sizeCullingMinPixels);
+    vis[it] = v;
+    key[it] = A.f.frontToBack ? encodeKey(nz) : encodeKey(-nz);
+    bal[it] = __ballot(v);
+    if(lane == 0)
+      s_cnt[it * 4 + w] = (uint32_t)__popcll(bal[it]);
+  }
+  const uint32_t Mv = scanRoundWaveCounts(s_cnt, s_base);
+#pragma unroll
+  for(int it = 0; it < kGutItems; ++it)
+    if(vis[it])
+    {
+      const uint32_t pos = s_base[it * 4 + w] + lanesBelow(bal[it]);
+      s_li[pos]          = (uint16_t)(it * kGutThreads + t);
+      s_key[pos]         = key[it];
+    }
+  __syncthreads();
+  if(t == 0 && Mv)
+    atomicAdd(&ctr->frustumCount, Mv);
+  // ---- 3DGUT front end over the survivors ----
+  const size_t slotBase = (size_t)part * kGutPart;
+  for(uint32_t j0 = 0; j0 < Mv; j0 += kGutThreads)
+  {
+    const uint32_t j = j0 + t;
+    if(j < Mv)
+    {
+      const uint32_t li = local0 + s_li[j];
+      GutRec         r;
+      uint32_t       rc;
+      if(projectSplatGut<SHF>(A.f, I, li, r, rc))
+      {
+        const uint32_t gid = I.globalOffset + li;
+        float4*        dst = reinterpret_cast<float4*>(rec + gid);
+        dst[0]             = make_float4(r.cx, r.cy, r.q1x, r.q1y);
+        dst[1]             = make_float4(r.q2x, r.q2y, r.bex, r.bey);
+        dst[2]             = make_float4(r.B[0], r.B[1], r.B[2], r.B[3]);
+        dst[3]             = make_float4(r.B[4], r.B[5], r.B[6], r.B[7]);
+        dst[4]             = make_float4(r.B[8], r.ro[0], r.ro[1], r.ro[2]);
+        dst[5]             = make_float4(r.r, r.g, r.b, r.a);
+        rect[gid]          = rc;
+        s_li[j] |= 0x8000u;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for(int r = 0; r < kGutItems; ++r)
+  {
+    const uint32_t j = r * kGutThreads + t;
+    vis[r]           = (j < Mv) && (s_li[j] & 0x8000u);
+    bal[r]           = __ballot(vis[r]);
+    if(lane == 0)
+      s_cnt[r * 4 + w] = (uint32_t)__popcll(bal[r]);
+  }
+  const uint32_t outCount = scanRoundWaveCounts(s_cnt, s_base);
+#pragma unroll
+  for(int r = 0; r < kGutItems; ++r)
+    if(vis[r])
+    {
+      const uint32_t j         = r * kGutThreads + t;
+      const uint32_t pos       = s_base[r * 4 + w] + lanesBelow(bal[r]);
+      keysSlot[slotBase + pos] = s_key[j];
+      idsSlot[slotBase + pos]  = I.globalOffset + local0 + (s_li[j] & 0x7FFFu);
+      atomicAdd(&s_hist[s_key[j] & 255u], 1u);
+    }
+  if(t == 0)
+  {
+    slotCount[part] = outCount;
+    if(outCount)
+      atomicAdd(&ctr->sortedCount, outCount);
+  }
+  __syncthreads();
+  slotHist[(size_t)t * histStride + part] = s_hist[t];
+}
+
+// ---- compositor: one workgroup per 16x16 tile, one pixel per thread -------------------------------------------------------
+constexpr int kGutBatch = 256;  // list entries scanned per round == staging capacity
+
+__global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restrict__ Ap, const uint2* __restrict__ ranges,
+                                                       const uint32_t* __restrict__ valX, const uint32_t* __restrict__ valY,
+                                                       const SortPlan* __restrict__ plan, const GutRec* __restrict__ rec,
+                                                       void* __restrict__ outImage, int halfOut, FrameCounters* __restrict__ ctr)
+{
+  __shared__ float4   s_r[kGutBatch][6];
+  __shared__ uint32_t s_wc[4];
+  __shared__ uint32_t s_live;
+  const FrameConst& F = Ap->f;
+  const int t = threadIdx.x, lane = laneId(), w = t >> 6;
+  const int tilesInStrip = F.tilesX * (F.stripRow1 - F.stripRow0);
+  if((int)blockIdx.x >= tilesInStrip)
+    return;
+  const int tx = (int)blockIdx.x % F.tilesX, ty = F.stripRow0 + (int)blockIdx.x / F.tilesX;
+  const int px = tx * kTilePx + (t & 15), py = ty * kTilePx + (t >> 4);
+  const bool inside = px < F.width && py < F.height;
+  const float pcx = (float)px + 0.5f, pcy = (float)py + 0.5f;
+  const float bcx = (float)(tx * kTilePx) + 8.0f, bcy = (float)(ty * kTilePx) + 8.0f;
+  // ray of this pixel in world space (frag.slang:101-111)
+  float dxw, dyw, dzw;
+  bool  rayOk = true;
+  {
+    const float* Vi = F.viewInv;
+    float        cx, cy, cz;
+    if(F.cameraModel == 1)
+    {  // generateFisheyeRay(position.xy, viewport, fovRad, principal 0, viewInverse), cameras.h.slang:46-82
+      const float u = (pcx / ((float)F.width - 1.0f)) * 2.0f - 1.0f, v = (pcy / ((float)F.height - 1.0f)) * 2.0f - 1.0f;
+      const float r = sqrtf(u * u + v * v);
+      rayOk         = !(r > 1.0f);
+      float phiCos  = fabsf(r) > 1e-9f ? u / r : 0.0f;
+      phiCos        = fminf(fmaxf(phiCos, -1.0f), 1.0f);
+      float phi     = acosf(phiCos);
+      phi           = v < 0.0f ? -phi : phi;
+      const float theta = r * F.fovRad * 0.5f;
+      cx = cosf(phi) * sinf(theta);
+      cy = -sinf(phi) * sinf(theta);
+      cz = -cosf(theta);
+    }
+    else
+    {  // generatePinholeRay(position.xy, float2(0.5), ...): the 0.5 is added to SV_Position, as the reference writes it
+      const float ux = ((pcx + 0.5f) / (float)F.width) * 2.0f - 1.0f, uy = ((pcy + 0.5f) / (float)F.height) * 2.0f - 1.0f;
+      const float* Pi = F.projInv;
+      cx = Pi[0] * ux + Pi[4] * uy + Pi[8] + Pi[12];
+      cy = Pi[1] * ux + Pi[5] * uy + Pi[9] + Pi[13];
+      cz = Pi[2] * ux + Pi[6] * uy + Pi[10] + Pi[14];
+    }
+    dxw = Vi[0] * cx + Vi[4] * cy + Vi[8] * cz;
+    dyw = Vi[1] * cx + Vi[5] * cy + Vi[9] * cz;
+    dzw = Vi[2] * cx + Vi[6] * cy + Vi[10] * cz;
+    const float l = rsqrtf(dxw * dxw + dyw * dyw + dzw * dzw);
+    dxw *= l; dyw *= l; dzw *= l;
+  }
+  const bool  early   = F.alphaMode == 0;
+  const bool  noGauss = (F.debugFlags & 4) != 0;
+  const float tMin    = early ? 1.0e-4f : -1.0f;
+  const uint32_t* vals = plan->finalSel ? valY : valX;
+  const int      bin   = (ty >> F.binShiftY) * F.binsX + (tx >> F.binShiftX);
+  const uint2    range = ranges[bin];
+  float T = (inside && rayOk) ? 1.0f : 0.0f, cr = 0.f, cg = 0.f, cb = 0.f, asum = 0.f;
+  uint32_t hi = range.y;
+  uint32_t statScanned = 0, statStaged = 0;
+  while(hi > range.x)
+  {
+    // ---- stage: the next 256 nearest entries, culled against the tile, compacted in list order ----
+    const uint32_t avail = hi - range.x;
+    const bool     have  = (uint32_t)t < avail;
+    uint32_t       g     = have ? vals[hi - 1u - (uint32_t)t] : 0u;
+    float4         r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 0.f, -1.f, -1.f);
+    if(have)
+    {
+      const float4* rp = reinterpret_cast<const float4*>(rec + g);
+      r0 = rp[0];
+      r1 = rp[1];
+    }
+    const bool     ok  = have && fabsf(r0.x - bcx) <= r1.z + 7.5f && fabsf(r0.y - bcy) <= r1.w + 7.5f;
+    const uint64_t bal = __ballot(ok);
+    if(lane == 0)
+      s_wc[w] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t base = 0;
+    if(w > 0) base += s_wc[0];
+    if(w > 1) base += s_wc[1];
+    if(w > 2) base += s_wc[2];
+    const uint32_t fill = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+    if(ok)
+    {
+      const uint32_t pos = base + lanesBelow(bal);
+      const float4*  rp  = reinterpret_cast<const float4*>(rec + g);
+      s_r[pos][0] = r0;
+      s_r[pos][1] = r1;
+      s_r[pos][2] = rp[2];
+      s_r[pos][3] = rp[3];
+      s_r[pos][4] = rp[4];
+      s_r[pos][5] = rp[5];
+    }
+    if(t == 0)
+      s_live = 0u;
+    __syncthreads();
+    statScanned += min(avail, (uint32_t)kGutBatch);
+    statStaged += fill;
+    hi -= min(avail, (uint32_t)kGutBatch);
+    // ---- blend front to back ----
+    for(uint32_t j = 0; j < fill; ++j)
+    {
+      const float4 a0 = s_r[j][0], a1 = s_r[j][1];
+      const float  ddx = pcx - a0.x, ddy = pcy - a0.y;
+      const bool   inQuad = fabsf(ddx * a0.z + ddy * a0.w) <= 1.0f && fabsf(ddx * a1.x + ddy * a1.y) <= 1.0f;
+      const float4 b0 = s_r[j][2], b1 = s_r[j][3], b2 = s_r[j][4], c4 = s_r[j][5];
+      // canonical ray direction ~ B d, origin ro; dist^2 = |g x ro|^2 / |g|^2  (threedgrt.h.slang:57-81)
+      const float gx = b0.x * dxw + b0.y * dyw + b0.z * dzw;
+      const float gy = b0.w * dxw + b1.x * dyw + b1.y * dzw;
+      const float gz = b1.z * dxw + b1.w * dyw + b2.x * dzw;
+      const float kx = gy * b2.w - gz * b2.z, ky = gz * b2.y - gx * b2.w, kz = gx * b2.z - gy * b2.y;
+      const float dist2 = (kx * kx + ky * ky + kz * kz) / (gx * gx + gy * gy + gz * gz);
+      const float resp  = __expf(-0.5f * dist2);                     // quadratic kernel, :127-131
+      const float al    = fminf(F.alphaClamp, resp * c4.w);          // :263
+      const bool  hit   = inQuad && (c4.w > F.alphaCull) && (al > (1.0f / 255.0f)) && (resp > F.kernelMinResponse) && T >= tMin;
+      const float op    = hit ? (noGauss ? 1.0f : al) : 0.0f;
+      const float wgt   = op * T;
+      cr += wgt * c4.x;
+      cg += wgt * c4.y;
+      cb += wgt * c4.z;
+      asum += op;
+      T -= wgt;
+    }
+    if(early)
+    {
+      if(T >= tMin)
+        s_live = 1u;  // benign race: every writer stores 1
+      __syncthreads();
+      if(s_live == 0u)
+        break;
+    }
+    else
+      __syncthreads();
+  }
+  if(t == 0)
+  {
+    atomicAdd(&ctr->scannedSlots[blockIdx.x & 7], statScanned);
+    atomicAdd(&ctr->stagedSlots[blockIdx.x & 7], statStaged);
+  }
+  if(!inside)
+    return;
+  const float alphaOut = F.alphaMode == 1 ? asum : 1.0f - ((inside && rayOk) ? T : 1.0f);
+  const size_t pix = (size_t)py * F.width + px;
+  if(halfOut == 1)
+  {
+    const __half2 lo = __floats2half2_rn(cr, cg), hi2 = __floats2half2_rn(cb, alphaOut);
+    uint2         o;
+    o.x = *reinterpret_cast<const uint32_t*>(&lo);
+    o.y = *reinterpret_cast<const uint32_t*>(&hi2);
+    reinterpret_cast<uint2*>(outImage)[pix] = o;
+  }
+  else if(halfOut == 0)
+    reinterpret_cast<float4*>(outImage)[pix] = make_float4(cr, cg, cb, alphaOut);
+  else
+  {
+    auto q = [](float v) { return (uint32_t)(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f + 0.5f); };
+    reinterpret_cast<uint32_t*>(outImage)[pix] = q(cr) | (q(cg) << 8) | (q(cb) << 16) | (q(alphaOut) << 24);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+void launchProjectGut(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, int shFormat, FrameCounters* ctr,
+                      uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, GutRec* rec, uint32_t* rect,
+                      const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride)
+{
+  if(args.f.totalPartitions == 0)
+    return;
+  const dim3 grid(args.f.totalPartitions), block(kGutThreads);
+#define MGS_LAUNCH(SHF)                                                                                                     \
+  hipLaunchKernelGGL((k_project_gut<SHF>), grid, block, 0, stream, dArgs, ctr, keysSlot, idsSlot, slotCount, rec, rect, partSkip, \
+                     slotHist, histStride)
+  if(shFormat == 0)
+    MGS_LAUNCH(0);
+  else if(shFormat == 1)
+    MGS_LAUNCH(1);
+  else
+    MGS_LAUNCH(2);
+#undef MGS_LAUNCH
+}
+
+void launchCompositeGut(hipStream_t stream, const FrameArgs& A, const FrameArgs* dArgs, const uint2* ranges, const uint32_t* valX,
+                        const uint32_t* valY, const SortPlan* planPairs, const GutRec* rec, void* image, int halfOut,
+                        FrameCounters* ctr)
+{
+  const int tiles = A.f.tilesX * (A.f.stripRow1 - A.f.stripRow0);
+  if(tiles <= 0)
+    return;
+  hipLaunchKernelGGL(k_composite_gut, dim3(tiles), dim3(256), 0, stream, dArgs, ranges, valX, valY, planPairs, rec, image, halfOut, ctr);
+}
+
+}  // namespace mgs

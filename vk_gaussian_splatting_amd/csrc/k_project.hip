@@ -171,25 +171,6 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   return true;
 }
 
-// Ordered compaction of up to 8 rounds x 256 flags without a barrier per round: every wave posts its
-// per-round popcounts, ONE barrier, 32 lanes scan the 8x4 table, second barrier, then every thread knows
-// the base of its (round, wave).  Returns the total; bases land in s_base[round*4 + wave].
-__device__ __forceinline__ uint32_t scanRoundWaveCounts(uint32_t* s_cnt /*32*/, uint32_t* s_base /*33*/)
-{
-  __syncthreads();
-  if(threadIdx.x < 64)
-  {
-    const uint32_t v   = threadIdx.x < 32 ? s_cnt[threadIdx.x] : 0u;
-    const uint32_t inc = waveInclusiveScan(v);
-    if(threadIdx.x < 32)
-      s_base[threadIdx.x] = inc - v;
-    if(threadIdx.x == 31)
-      s_base[32] = inc;
-  }
-  __syncthreads();
-  return s_base[32];
-}
-
 // One workgroup = one partition of 2048 consecutive splats of one instance.
 // Output: survivors of partition p, ascending id, in keysSlot/idsSlot[p*2048 ...], count in slotCount[p].
 // No barrier sits inside a loop that waits on memory: all 8 centre loads of a thread are issued up front,

@@ -105,6 +105,25 @@ __device__ __forceinline__ bool sizeCulled(float maxExpScale, float splatScale, 
   return false;
 }
 
+// Ordered compaction of up to 8 rounds x 256 flags without a barrier per round: every wave posts its
+// per-round popcounts, ONE barrier, 32 lanes scan the 8x4 table, second barrier, then every thread knows
+// the base of its (round, wave).  Returns the total; bases land in s_base[round*4 + wave].
+__device__ __forceinline__ uint32_t scanRoundWaveCounts(uint32_t* s_cnt /*32*/, uint32_t* s_base /*33*/)
+{
+  __syncthreads();
+  if(threadIdx.x < 64)
+  {
+    const uint32_t v   = threadIdx.x < 32 ? s_cnt[threadIdx.x] : 0u;
+    const uint32_t inc = waveInclusiveScan(v);
+    if(threadIdx.x < 32)
+      s_base[threadIdx.x] = inc - v;
+    if(threadIdx.x == 31)
+      s_base[32] = inc;
+  }
+  __syncthreads();
+  return s_base[32];
+}
+
 // IEEE-correct fp32 division (hipcc default: -fhip-fp32-correctly-rounded-divide-sqrt)
 __device__ __forceinline__ float divExact(float a, float b)
 {

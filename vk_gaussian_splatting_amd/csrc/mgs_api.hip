@@ -54,6 +54,12 @@ void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges
                      const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, int halfOut,
                      int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId, const void* instTable, const FrameArgs* dArgs,
                      float4* outNormal);
+void launchProjectGut(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, int shFormat, FrameCounters* ctr,
+                      uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, GutRec* rec, uint32_t* rect,
+                      const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride);
+void launchCompositeGut(hipStream_t stream, const FrameArgs& A, const FrameArgs* dArgs, const uint2* ranges, const uint32_t* valX,
+                        const uint32_t* valY, const SortPlan* planPairs, const GutRec* rec, void* image, int halfOut,
+                        FrameCounters* ctr);
 constexpr uint32_t kPart = 2048;  // == kPrjPart == kSortPart == kBinPart
 }  // namespace mgs
 
@@ -264,6 +270,7 @@ struct MgsScene_t
   DevBuf<float4>        surfNormal;
   bool                  haveSurface = false;
   DevBuf<SplatRec>      rec;
+  DevBuf<GutRec>        recGut;  // 3DGUT records (96 B per splat), allocated by the first 3DGUT frame
   DevBuf<uint32_t>      pairKey0, pairVal0, pairKey1, pairVal1;
   DevBuf<uint2>         ranges;
   DevBuf<uint8_t>       image;
@@ -560,7 +567,7 @@ void mgs_scene_destroy(MgsScene s)
     freeSet(d);
   s->keysSlot.release(); s->idsSlot.release(); s->slotCount.release(); s->keysA.release(); s->idsA.release();
   s->keysB.release(); s->idsB.release(); s->rect.release(); s->partHist.release(); s->blockCount.release();
-  s->rec.release(); s->pairKey0.release(); s->pairVal0.release(); s->pairKey1.release(); s->pairVal1.release();
+  s->rec.release(); s->recGut.release(); s->pairKey0.release(); s->pairVal0.release(); s->pairKey1.release(); s->pairVal1.release();
   s->sortedRect.release(); s->splatOffset.release(); s->chunkStart.release(); s->partSkip.release();
   s->surfDepth.release(); s->surfId.release(); s->surfNormal.release(); s->dArgs.release(); s->dbinMasks.release(); s->compInst.release();
   for(auto& g : s->graphs) (void)hipGraphExecDestroy(g.second);
@@ -1089,6 +1096,12 @@ void mgs_frame_params_default(MgsFrameParams* p)
   p->cpu_lazy_sort           = 1;     // parameters.h:183
   p->thin_particle_threshold = 1e-6f; // parameters.h:163
   p->quantize_normals        = 1;     // parameters.h:195
+  p->pipeline                = MGS_PIPELINE_3DGS;
+  p->camera_model            = MGS_CAMERA_PINHOLE;
+  p->extent_method           = MGS_EXTENT_CONIC;  // parameters.h:190 (read by the 3DGUT pipeline only)
+  p->fov_rad                 = 0.0f;
+  p->alpha_clamp             = 0.99f;    // shaderio.h:271
+  p->kernel_min_response     = 0.0113f;  // parameters.h:216
   p->surface_outputs         = 0;
   p->depth_iso_threshold     = 0.7f;  // parameters.h:200
 }
@@ -1207,6 +1220,30 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
   F.depthIsoThreshold = p->depth_iso_threshold;
   F.thinParticleThreshold = p->thin_particle_threshold;
   F.quantizeNormals       = p->quantize_normals ? 1 : 0;
+  // 3DGUT
+  F.pipeline          = p->pipeline;
+  F.cameraModel       = p->camera_model;
+  F.extentMethod      = p->extent_method;
+  F.fovRad            = p->fov_rad > 0.0f ? p->fov_rad : 2.0f * std::atan(1.0f / std::fabs(p->proj[5]));
+  F.alphaClamp        = p->alpha_clamp;
+  F.kernelMinResponse = p->kernel_min_response;
+  if(p->camera_model == MGS_CAMERA_FISHEYE)
+  {  // gaussian_splatting.cpp:1243
+    F.gutFocal[0] = (float)p->width / F.fovRad;
+    F.gutFocal[1] = -(float)p->height / F.fovRad;
+  }
+  else
+  {
+    F.gutFocal[0] = F.focal[0];
+    F.gutFocal[1] = F.focal[1];
+  }
+  {  // computeMaxAngle, threedgut_camera_models.h.slang:87-118 (principal point at the viewport centre)
+    const float mdx = (float)p->width * 0.5f, mdy = (float)p->height * 0.5f;
+    const float maxR = std::sqrt(mdx * mdx + mdy * mdy);
+    F.gutMaxAngle = std::max(2.0f * maxR / F.gutFocal[0], 2.0f * maxR / F.gutFocal[1]) / 2.0f;
+  }
+  mat4Inverse(p->view, F.viewInv);
+  mat4Inverse(p->proj, F.projInv);
   F.maxFocal        = std::max(std::fabs(F.focal[0]), std::fabs(F.focal[1]));
   F.targetFormat    = p->target_format;
   F.nInstances      = (int)s->instances.size();
@@ -1238,6 +1275,7 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
     mat4Mul(p->view, I.M, C.modelView);  // mul(desc.transform, viewMatrix), mesh.slang:175
     float inv[16], cam[4] = {p->camera_pos[0], p->camera_pos[1], p->camera_pos[2], 1.0f}, cm[4];
     mat4Inverse(I.M, inv);
+    std::memcpy(C.modelInv, inv, sizeof(inv));
     mat4MulVec4(inv, cam, cm);  // mesh.slang:240-241
     C.camModel[0]  = cm[0];
     C.camModel[1]  = cm[1];
@@ -1433,6 +1471,30 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
   const size_t      pixB   = half == 1 ? 8 : (half == 2 ? 4 : 16);
   s->imageRowBytes         = (size_t)F.width * pixB;
   s->imageBytes            = s->imageRowBytes * (size_t)F.height;
+  const bool gut = p->pipeline == MGS_PIPELINE_3DGUT;
+  if(p->pipeline != MGS_PIPELINE_3DGS && !gut)
+  {
+    setError("frame: pipeline must be MGS_PIPELINE_3DGS or MGS_PIPELINE_3DGUT");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(gut)
+  {
+    if(p->surface_outputs)
+    {
+      setError("frame: surface_outputs are not built for the 3DGUT pipeline");
+      return MGS_ERR_UNSUPPORTED;
+    }
+    if(p->camera_model < MGS_CAMERA_PINHOLE || p->camera_model > MGS_CAMERA_FISHEYE || p->extent_method < MGS_EXTENT_EIGEN
+       || p->extent_method > MGS_EXTENT_CONIC)
+    {
+      setError("frame: camera_model / extent_method out of range");
+      return MGS_ERR_INVALID_ARG;
+    }
+    if(s->recGut.n < s->totalSplats)
+    {  // first 3DGUT frame of this scene: its record buffer (captured frames do not reference it yet)
+      if((rc = s->recGut.ensure(s->totalSplats))) return rc;
+    }
+  }
   const void* before[5] = {s->ranges.p, s->image.p, s->surfDepth.p, s->surfId.p, s->surfNormal.p};
   if((rc = s->ranges.ensure(std::max<uint32_t>(nTiles, 256u)))) return rc;
   if(s->image.n < s->imageBytes)
@@ -1495,8 +1557,12 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     const bool cpuMode = (p->sort_mode == MGS_SORT_CPU_ASYNC);
     if(cpuMode)  // rejected splats must look empty to the binning stage: rect with x0 > x1
       hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, st, s->rect.p, 1u, s->totalSplats);
-    launchProject(st, A, s->dArgs.p, true, ctr, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p,
-                  s->rect.p, F.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride);
+    if(gut)
+      launchProjectGut(st, A, s->dArgs.p, s->shFormat, ctr, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->recGut.p, s->rect.p,
+                       F.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride);
+    else
+      launchProject(st, A, s->dArgs.p, true, ctr, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p,
+                    s->rect.p, F.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride);
     if(withEvents) HIPCHK(hipEventRecord(fev[1], st));
     static const bool kFuseRect = [] { const char* e = std::getenv("MGS_FUSE_RECT"); return e ? std::atoi(e) != 0 : false; }();  // measured: +43 us in the scatter for -17 us in the count kernel
     const bool direct0 = directBinningSupported(F.binsX, F.binsY);
@@ -1557,9 +1623,12 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
       }
     }
     if(withEvents) HIPCHK(hipEventRecord(fev[4], st));
-    launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat, ctr,
-                    F.surfaceOutputs ? s->surfDepth.p : nullptr, F.surfaceOutputs ? s->surfId.p : nullptr, s->compInst.p,
-                    s->dArgs.p, F.surfaceOutputs ? s->surfNormal.p : nullptr);
+    if(gut)
+      launchCompositeGut(st, A, s->dArgs.p, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->recGut.p, s->image.p, half, ctr);
+    else
+      launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat, ctr,
+                      F.surfaceOutputs ? s->surfDepth.p : nullptr, F.surfaceOutputs ? s->surfId.p : nullptr, s->compInst.p,
+                      s->dArgs.p, F.surfaceOutputs ? s->surfNormal.p : nullptr);
     if(withEvents) HIPCHK(hipEventRecord(fev[5], st));
     return MGS_OK;
   };
@@ -1577,7 +1646,8 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     std::memcpy(&isoBits, &F.depthIsoThreshold, 4);
     // everything the compositor receives by value (CompositeArgs) must be part of the key
     const int32_t kv[16] = {F.width, F.height, F.stripRow0, F.stripRow1, F.binShiftX, F.binShiftY, F.partitionCull, F.alphaMode,
-                            F.debugFlags & (2 | 4 | 256), F.surfaceOutputs, half, F.nInstances, F.shDegree, isoBits, 0, 0};
+                            F.debugFlags & (2 | 4 | 256), F.surfaceOutputs, half, F.nInstances, F.shDegree, isoBits,
+                            F.pipeline, 0};
     std::memcpy(key.v, kv, sizeof(kv));
     key.p[0] = s->image.p;
     key.p[1] = s->surfDepth.p;
@@ -2088,9 +2158,9 @@ static int mgs_frame_download_projected_impl(MgsScene s, const uint32_t* ids, si
     setError("mgs_frame_download_projected: null argument");
     return MGS_ERR_INVALID_ARG;
   }
-  if(!s->haveFrame || s->lastWasSortOnly)
+  if(!s->haveFrame || s->lastWasSortOnly || s->lastParams.pipeline != MGS_PIPELINE_3DGS)
   {
-    setError("mgs_frame_download_projected: no frame rendered yet");
+    setError("mgs_frame_download_projected: no 3DGS frame rendered yet");
     return MGS_ERR_STATE;
   }
   for(size_t i = 0; i < count; ++i)
