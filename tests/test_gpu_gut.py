@@ -108,3 +108,25 @@ def test_gut_two_instances_and_strips(ob):
     with pytest.raises(mgs.MgsError):
         scene.render(p)
     scene.close()
+
+
+@pytest.mark.parametrize("pipeline,expected", [(capi.PIPELINE_3DGS, "expected_rgba16f.npy"), (capi.PIPELINE_3DGUT, "expected_3dgut_rgba16f.npy")])
+def test_vulkan_reproducible_fixture_on_the_gpu(ob, pipeline, expected):
+    """the committed .ply + .vkgs project (tests/golden/vkrepro — the inputs a Vulkan box can hand to the reference) through
+    the product's loader and both pipelines, against the committed expected frames"""
+    import os
+    from conftest import GOLDEN
+    from vk_gaussian_splatting_amd import project
+    d = os.path.join(GOLDEN, "vkrepro")
+    pr = project.load_project(os.path.join(d, "repro.vkgs"))
+    scene = pr.build_scene(0)
+    want = np.load(os.path.join(d, expected)).astype(np.float32)
+    H, W = want.shape[:2]
+    p = pr.frame_params(W, H)
+    p.pipeline = pipeline
+    out = scene.render(p, want_stats=True)
+    img = scene.download_frame(p).astype(np.float32)
+    psnr = ob.psnr_rgb(img, want)
+    print(f"vkrepro pipeline {pipeline}: PSNR {psnr:.2f} dB")
+    assert out.error_flags == 0 and psnr >= PSNR_MIN and np.abs(img[..., :3] - want[..., :3]).max() <= ABS_TOL
+    scene.close()
