@@ -48,7 +48,8 @@ def composite_roofline(ms, alg_bytes, world, N, args):
            "hbm_achieved_GBps": (alg_bytes / (ms * 1e-3)) / 1e9 if ms > 0 else None}
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", PMC_SQ_FILE)))
-        if world == 1 and N == 5_830_000 and args.instances == 1 and ms > 0 and (args.width, args.height) == (1920, 1080):
+        if (world == 1 and N == 5_830_000 and args.instances == 1 and ms > 0 and (args.width, args.height) == (1920, 1080)
+                and args.scene == "garden" and not args.alpha_sum and args.pipeline == 0):
             busy = pj["k_composite"]["SQ_ACTIVE_INST_VALU"] * 4.0
             out["valu_busy_quad_cycles_per_launch"] = pj["k_composite"]["SQ_ACTIVE_INST_VALU"]
             out["valu_insts_per_launch"] = pj["k_composite"]["SQ_INSTS_VALU"]
@@ -75,6 +76,13 @@ def main():
     ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3, 4],
                     help="shorthand for the BASELINE.json configs: 1 train-sized 1080p, 2 garden-sized 1080p (the default), "
                          "3 garden-sized 3840x2160, 4 eight garden instances (46.6 M splats) 1080p")
+    ap.add_argument("--scene", default="garden", choices=["garden", "fog", "sparse"],
+                    help="garden: syn_garden (SURVEY.md 8d, the benchmark workload); fog: the same splats with opacity logits "
+                         "shifted to mean -3 (low opacity: regions saturate late or never, the compositor's hard regime); "
+                         "sparse: 10 %% of the object splats + the whole background")
+    ap.add_argument("--alpha-sum", action="store_true", help="MGS_ALPHA_SUM: the reference's default additive alpha "
+                    "(gaussian_splatting.cpp:2083-2084); disables early termination")
+    ap.add_argument("--pipeline", type=int, default=0, help="0 3DGS (benchmark), 1 3DGUT")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=3, help="frames in flight per GPU (each on its own HIP stream with "
                     "its own working buffers); >1 overlaps one frame's tails/launch gaps/all-gather with the next frame")
@@ -116,6 +124,13 @@ def main():
     W, H, N = args.width, args.height, args.splats
     t0 = time.time()
     sc = synth.make_scene(N, seed=0xC0FFEE + 2)  # syn_garden; identical on every rank
+    if args.scene == "fog":
+        sc["opacity"] = (sc["opacity"] - 2.5).astype(np.float32)  # logit mean -0.5 -> -3
+    elif args.scene == "sparse":
+        r = np.linalg.norm(sc["positions"], axis=1)
+        keep = (r >= 4.0) | (np.random.default_rng(7).random(N) < 0.10)
+        sc = {k: np.ascontiguousarray(v[keep]) for k, v in sc.items()}
+        N = args.splats = int(keep.sum())
     ss = mgs.SplatSet.from_arrays(**sc)
     K = max(1, args.inflight)
     scenes, streams = [], []
@@ -145,6 +160,8 @@ def main():
         p = capi.default_params(W, H)
         capi.set_camera(p, V, P, eye)
         p.collect_timings = 2 if args.stage_events else 0
+        p.alpha_mode = capi.ALPHA_SUM if args.alpha_sum else capi.ALPHA_COVERAGE
+        p.pipeline = args.pipeline
         poses.append(p)
     tiles_y = multigpu.tile_rows(H)
     bounds = [multigpu.strip_rows(H, world, r)[0] for r in range(world)] + [tiles_y]  # equal strips
@@ -369,7 +386,8 @@ def main():
     traffic = None
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
-        if dom_name in pj["kernels"] and world == 1 and N == 5_830_000 and args.instances == 1:
+        if (dom_name in pj["kernels"] and world == 1 and N == 5_830_000 and args.instances == 1 and args.scene == "garden"
+                and args.pipeline == 0 and (W, H) == (1920, 1080)):
             traffic = pj["kernels"][dom_name]["traffic_bytes_per_launch_corrected"]
     except Exception:
         pass
@@ -390,7 +408,9 @@ def main():
         "frames_in_flight": K,
         "submission": "per-stage events + plain launches" if args.stage_events else "hipGraph replay (one upload + one graph launch per frame)",
         "config": {"workload": f"syn_garden N={N} x {args.instances} instance(s) SH deg 3, storage sh/rgba format {args.sh_format}/{args.rgba_format}, "
-                               f"{W}x{H}, 64-pose orbit r=4 h=1.5 fov60, GPU radix sort, cull at dist (configs[2])",
+                               f"{W}x{H}, 64-pose orbit r=4 h=1.5 fov60, GPU radix sort, cull at dist (configs[2])"
+                               + ("" if args.scene == "garden" else f", scene variant `{args.scene}`") + (", additive alpha (no early termination)" if args.alpha_sum else "")
+                               + (", 3DGUT pipeline" if args.pipeline == 1 else ""),
                    "partition": "single GPU" if world == 1 else
                    f"{world} tile-row strips of every frame ({'equal' if args.equal_strips else 'cost-balanced'} rows {bounds}) + strip exchange: {gather_mode}"},
         "alternate_frames": alt_out,

@@ -9,6 +9,11 @@ run train_if1 --splats 1030000 --inflight 1
 run garden_4k --width 3840 --height 2160
 run garden_u8 --sh-format 2 --rgba-format 2
 run garden_x8 --instances 8 --steps 48 --warmup 8
+run fog --scene fog --steps 48 --warmup 8
+run fog_if1 --scene fog --steps 48 --warmup 8 --inflight 1
+run sparse --scene sparse
+run garden_alphasum --alpha-sum --steps 16 --warmup 4 --inflight 1
+run garden_3dgut --pipeline 1 --steps 32 --warmup 4 --inflight 1
 python - <<'PY'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/matrix_*.json")):
