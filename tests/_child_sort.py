@@ -56,8 +56,10 @@ sc = synth.make_scene(300_000, seed=5)
 scene.add_instance(mgs.SplatSet.from_arrays(**sc))
 scene.commit()
 hh = hashlib.sha1()
-for pose, (w, h) in ((1, (1280, 720)), (17, (640, 480)), (40, (1920, 1080))):
-    eye = synth.orbit_pose(pose)
+views = [(synth.orbit_pose(1), (1280, 720)), (synth.orbit_pose(17), (640, 480)), (synth.orbit_pose(40), (1920, 1080)),
+         # inside the cloud, looking along it: depth keys over many exponents (the pass elision must fall back or cope)
+         (np.array([0.05, 0.02, 0.1], np.float32), (800, 600)), (np.array([0.0, 0.0, 0.35], np.float32), (640, 360))]
+for pose, (eye, (w, h)) in enumerate(views):
     V, P = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, w, h)
     p = capi.default_params(w, h)
     capi.set_camera(p, V, P, eye)
@@ -65,10 +67,10 @@ for pose, (w, h) in ((1, (1280, 720)), (17, (640, 480)), (40, (1920, 1080))):
     gk, gi = scene.sort_download(so.count)
     hh.update(gk.tobytes())
     hh.update(gi.tobytes())
-    print("STATS pose", pose, "count", so.count, "slices/buckets/streamed", list(so.reserved))
+    print("STATS view", pose, "count", so.count, "passes", so.passes, "slices/buckets/streamed", list(so.reserved))
     o = scene.render(p)
     hh.update(np.ascontiguousarray(scene.download_frame(p)).tobytes())
-    for strip in ((0, 8), (20, 30)):
+    for strip in ((0, 8), (10, 20)):
         p.strip_row_begin, p.strip_row_end = strip
         scene.render(p)
         hh.update(np.ascontiguousarray(scene.download_frame(p)).tobytes())

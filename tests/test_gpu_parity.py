@@ -148,14 +148,15 @@ def test_sample_sort_path_is_bit_identical_to_the_stable_sort():
     import sys
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_child_sort.py")
     out = {}
-    for mode in ("sample", "lsd"):
-        env = dict(os.environ, MGS_SORT=mode)
+    for mode in ("sample", "lsd", "lsd_plain"):
+        # lsd: the default (four LSD passes with the top-16-bit pass elision); lsd_plain: the elision switched off
+        env = dict(os.environ, MGS_SORT=mode.split("_")[0], MGS_SORT_REMAP="0" if mode == "lsd_plain" else "1")
         r = subprocess.run([sys.executable, child], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
         assert "SORTS_OK" in r.stdout, r.stdout[-3000:]
         out[mode] = [l for l in r.stdout.splitlines() if l.startswith("FRAMES_SHA1")]
         print(mode, [l for l in r.stdout.splitlines() if l.startswith("STATS")])
-    assert out["sample"] and out["sample"] == out["lsd"]
+    assert out["sample"] and out["sample"] == out["lsd"] == out["lsd_plain"]
 
 
 def test_upload_transform_matches_oracle_bitwise(scene_small, ob):

@@ -18,6 +18,7 @@
 //     outside the strip) are dropped BEFORE the sort.
 //   * the 180-byte SH record (62 % of a splat's bytes) is not read here: shading is deferred.
 #include "kernels_common.h"
+#include "sort_plan.h"
 
 namespace mgs {
 
@@ -171,6 +172,37 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   return true;
 }
 
+// Marks which values of key >> 16 this workgroup hands to the sort (pass elision, sort_plan.h).  A partition is a compact
+// cell of space, so its keys span one to three values: thread 0 marks the range.  A partition that spans many (a cell
+// around the camera) returns true instead and every thread marks its own keys.  s_red: >= 9 free words of LDS; two barriers.
+__device__ __forceinline__ bool markTop16(SortPlan* plan, uint32_t mn, uint32_t mx, uint32_t count, uint32_t* s_red)
+{
+  if(plan == nullptr)
+    return false;
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1)
+  {
+    mn = min(mn, (uint32_t)__shfl_xor(mn, o, 64));
+    mx = max(mx, (uint32_t)__shfl_xor(mx, o, 64));
+  }
+  __syncthreads();
+  if(laneId() == 0)
+  {
+    s_red[threadIdx.x >> 6]       = mn;
+    s_red[4 + (threadIdx.x >> 6)] = mx;
+  }
+  __syncthreads();
+  const uint32_t lo = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3])), hi = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+  if(count == 0u)
+    return false;
+  if(hi - lo > 24u)
+    return true;
+  if(threadIdx.x == 0)
+    for(uint32_t v = lo; v <= hi; ++v)
+      sortMarkTop16(plan, v);
+  return false;
+}
+
 // One workgroup = one partition of 2048 consecutive splats of one instance.
 // Output: survivors of partition p, ascending id, in keysSlot/idsSlot[p*2048 ...], count in slotCount[p].
 // No barrier sits inside a loop that waits on memory: all 8 centre loads of a thread are issued up front,
@@ -180,7 +212,8 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
                                                          uint32_t* __restrict__ keysSlot, uint32_t* __restrict__ idsSlot,
                                                          uint32_t* __restrict__ slotCount, SplatRec* __restrict__ rec,
                                                          uint32_t* __restrict__ rect, const uint32_t* __restrict__ partSkip,
-                                                         uint32_t* __restrict__ slotHist, uint32_t histStride)
+                                                         uint32_t* __restrict__ slotHist, uint32_t histStride,
+                                                         SortPlan* __restrict__ planKeys)
 {
   const FrameArgs& A = *Ap;  // frame constants live in device memory (same pointer every frame: graph-replayable)
   // slotHist[d * histStride + partition] = survivors of this partition whose low key byte is d: the radix
@@ -266,12 +299,18 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   if constexpr(!FULL)
   {
     // sort-only hook: survivors of the dist stage, exactly dist.comp.slang's (key, id) stream
+    uint32_t tmn = 0xFFFFu, tmx = 0u;
     for(uint32_t j = t; j < M; j += kPrjThreads)
     {
       keysSlot[slotBase + j] = s_key[j];
       idsSlot[slotBase + j]  = I.globalOffset + local0 + s_li[j];
       atomicAdd(&s_hist[s_key[j] & 255u], 1u);
+      tmn = min(tmn, s_key[j] >> 16);
+      tmx = max(tmx, s_key[j] >> 16);
     }
+    if(markTop16(planKeys, tmn, tmx, M, s_cnt))
+      for(uint32_t j = t; j < M; j += kPrjThreads)
+        sortMarkTop16(planKeys, s_key[j] >> 16);
     if(t == 0)
     {
       slotCount[part] = M;
@@ -348,6 +387,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
         s_cnt[r * 4 + w] = (uint32_t)__popcll(bal[r]);
     }
     const uint32_t outCount = scanRoundWaveCounts(s_cnt, s_base);
+    uint32_t       tmn = 0xFFFFu, tmx = 0u;
 #pragma unroll
     for(int r = 0; r < kPrjItems; ++r)
       if(vis[r])
@@ -357,7 +397,16 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
         keysSlot[slotBase + pos] = s_key[j];
         idsSlot[slotBase + pos]  = I.globalOffset + local0 + (s_li[j] & 0x7FFFu);
         atomicAdd(&s_hist[s_key[j] & 255u], 1u);
+        tmn = min(tmn, s_key[j] >> 16);
+        tmx = max(tmx, s_key[j] >> 16);
       }
+    if(markTop16(planKeys, tmn, tmx, outCount, s_cnt))
+    {
+#pragma unroll
+      for(int r = 0; r < kPrjItems; ++r)
+        if(vis[r])
+          sortMarkTop16(planKeys, s_key[r * kPrjThreads + t] >> 16);
+    }
     if(t == 0)
     {
       slotCount[part] = outCount;
@@ -468,14 +517,14 @@ void launchPartitionCull(hipStream_t stream, const FrameArgs& args, const FrameA
 void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full,
                    FrameCounters* ctr,
                    uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, SplatRec* rec, uint32_t* rect,
-                   const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride)
+                   const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride, SortPlan* planKeys)
 {
   const dim3 grid(args.f.totalPartitions), block(kPrjThreads);
   if(args.f.totalPartitions == 0)
     return;
 #define MGS_LAUNCH(FULLV)                                                                                                \
   hipLaunchKernelGGL((k_project<FULLV>), grid, block, 0, stream, dArgs, ctr, keysSlot, idsSlot, slotCount, rec, rect, partSkip, \
-                     slotHist, histStride)
+                     slotHist, histStride, planKeys)
   if(full)
     MGS_LAUNCH(true);
   else

@@ -54,6 +54,23 @@ __device__ __forceinline__ void histAddRuns(uint32_t* hist, uint32_t digit, bool
   }
 }
 
+// digit of pass 2 when the top 16 bits are remapped: the rank of key >> 16 among the occurring values, read from a
+// per-workgroup LDS table indexed by (key >> 16) - base (the occurring values span < 4096, checked by the scan kernel;
+// padding keys clamp to the last entry, which holds the largest rank)
+constexpr uint32_t kRemapSpan = 4096;
+__device__ __forceinline__ void remapBuildTable(uint8_t* s_tab, const SortPlan* plan, int t, int threads)
+{
+  const uint32_t count = plan->remapCount, base = plan->remapBase;
+  for(uint32_t i = t; i < count; i += threads)
+    s_tab[(uint32_t)plan->remapVals[i] - base] = (uint8_t)i;
+  if(t == 0)
+    s_tab[kRemapSpan - 1] = (uint8_t)(count - 1u);
+}
+__device__ __forceinline__ uint32_t remapDigit(const uint8_t* s_tab, uint32_t base, uint32_t key)
+{
+  return s_tab[min((key >> 16) - base, kRemapSpan - 1u)];
+}
+
 // where pass `pass` (> 0) reads from: 0 = X, 1 = Y.  Pass 0 writes X; every executed pass flips.
 __device__ __forceinline__ uint32_t planSrcSel(const SortPlan* __restrict__ plan, int pass)
 {
@@ -70,8 +87,15 @@ __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ 
                                                    uint32_t pStride, int pass, int beginBit, uint32_t part)
 {
   __shared__ uint32_t s_h[256];
+  __shared__ uint8_t s_rv[kRemapSpan];
   const int       t     = threadIdx.x;
   const uint32_t  n     = *nPtr;
+  const bool      remap = plan->remapOn != 0u;
+  if(remap && pass == 3)
+    return;  // pass 2 sorted on the rank of the top 16 bits: nothing left to do
+  const uint32_t rcount = plan->remapBase;
+  if(remap && pass == 2)
+    remapBuildTable(s_rv, plan, t, 256);
   const uint32_t* keys  = (pass == 0) ? keys0 : (planSrcSel(plan, pass) ? keysY : keysX);
   const uint32_t  parts = (uint32_t)(((uint64_t)n + part - 1) / part);
   const int       shift = beginBit + 8 * pass;
@@ -93,7 +117,8 @@ __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ 
       }
 #pragma unroll
       for(int u = 0; u < 8; ++u)
-        histAddRuns(s_h, (kk[u] >> shift) & 255u, i0 + (uint32_t)u * 256u + (uint32_t)t < count);
+        histAddRuns(s_h, (remap && pass == 2) ? remapDigit(s_rv, rcount, kk[u]) : ((kk[u] >> shift) & 255u),
+                    i0 + (uint32_t)u * 256u + (uint32_t)t < count);
     }
     __syncthreads();
     partHist[(size_t)t * pStride + p] = s_h[t];
@@ -105,11 +130,13 @@ __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ 
 // total goes to plan->ghist[pass][d]; a row that holds every key marks the pass as skippable.
 __global__ __launch_bounds__(256) void k_sort_scan(const uint32_t* __restrict__ nPtr, uint32_t partsSlotted,
                                                    SortPlan* __restrict__ plan, uint32_t* __restrict__ partHist,
-                                                   uint32_t pStride, int pass, uint32_t part)
+                                                   uint32_t pStride, int pass, uint32_t part, int allowRemap)
 {
   __shared__ uint32_t s_tmp[4];
   const int      t = threadIdx.x, d = blockIdx.x;
   const uint32_t n     = *nPtr;
+  if(pass == 3 && plan->remapOn != 0u)
+    return;  // skip[3] was set together with remapOn
   // slotted pass 0: the producer wrote one histogram per 2048-key slot; a partition takes spp = part/2048 slots.
   // In place is safe: slot index >= partition index, and the block scan's barriers sit between reads and writes.
   const uint32_t spp   = partsSlotted ? part / kSlotPart : 1u;
@@ -150,6 +177,69 @@ __global__ __launch_bounds__(256) void k_sort_scan(const uint32_t* __restrict__ 
     plan->ghist[pass][d] = carry;
     if(pass > 0 && n > 0 && carry == n)
       plan->skip[pass] = 1u;  // every key has this digit: the pass would be the identity permutation
+  }
+  // pass elision: after the producer's marks are complete (this kernel runs behind it), workgroup 0 of pass 1 turns the
+  // presence bitmap of key >> 16 into the ascending value table; <= 256 values -> pass 2 takes their rank as its digit
+  if(allowRemap && pass == 1 && d == 0)
+  {
+    uint32_t c[8], sum = 0;
+#pragma unroll
+    for(int q = 0; q < 8; ++q)
+    {
+      c[q] = (uint32_t)__popc(plan->topBitmap[t * 8 + q]);
+      sum += c[q];
+    }
+    uint32_t total;
+    uint32_t run = blockExclusiveScan256(sum, s_tmp, &total);
+    // smallest / largest occurring value (wave + block reductions over the per-thread words)
+    uint32_t vmin = 0xFFFFFFFFu, vmax = 0u;
+#pragma unroll
+    for(int q = 0; q < 8; ++q)
+    {
+      const uint32_t bits = plan->topBitmap[t * 8 + q];
+      if(bits)
+      {
+        vmin = min(vmin, (uint32_t)((t * 8 + q) * 32 + __builtin_ctz(bits)));
+        vmax = max(vmax, (uint32_t)((t * 8 + q) * 32 + 31 - __builtin_clz(bits)));
+      }
+    }
+#pragma unroll
+    for(int o = 32; o > 0; o >>= 1)
+    {
+      vmin = min(vmin, (uint32_t)__shfl_xor(vmin, o, 64));
+      vmax = max(vmax, (uint32_t)__shfl_xor(vmax, o, 64));
+    }
+    __shared__ uint32_t s_mm[8];
+    if((t & 63) == 0)
+    {
+      s_mm[t >> 6]       = vmin;
+      s_mm[4 + (t >> 6)] = vmax;
+    }
+    __syncthreads();
+    vmin = min(min(s_mm[0], s_mm[1]), min(s_mm[2], s_mm[3]));
+    vmax = max(max(s_mm[4], s_mm[5]), max(s_mm[6], s_mm[7]));
+    const bool on = total >= 1u && total <= 256u && (vmax - vmin) < kRemapSpan - 1u;
+    if(on)
+    {
+#pragma unroll
+      for(int q = 0; q < 8; ++q)
+      {
+        uint32_t bits = plan->topBitmap[t * 8 + q];
+        while(bits)
+        {
+          const uint32_t b = (uint32_t)__builtin_ctz(bits);
+          bits &= bits - 1u;
+          plan->remapVals[run++] = (uint16_t)((t * 8 + q) * 32 + b);
+        }
+      }
+    }
+    if(t == 0 && on)
+    {
+      plan->remapCount = total;
+      plan->remapBase  = vmin;
+      plan->remapOn    = 1u;
+      plan->skip[3]    = 1u;
+    }
   }
 }
 
@@ -197,6 +287,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
   __shared__ uint32_t s_gbase[256];
   __shared__ uint32_t s_tmp[WAVES];
   __shared__ uint8_t  s_dig[GATHER ? PART : 1];
+  __shared__ uint8_t  s_rv[FIRST ? 1 : kRemapSpan];
 
   const int t = threadIdx.x, lane = laneId(), w = t >> 6;
   const bool     skipped = !FIRST && plan->skip[pass] != 0u;
@@ -256,6 +347,12 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
     vout = valsY;
   }
   const int shift = beginBit + 8 * pass;
+  // pass 2 of a remapped sort: digit = rank of key >> 16 among the occurring values (see SortPlan)
+  const bool     remap  = !FIRST && pass == 2 && plan->remapOn != 0u;
+  const uint32_t rcount = plan->remapBase;
+  if constexpr(!FIRST)
+    if(remap)
+      remapBuildTable(s_rv, plan, t, THREADS);
 
   for(int i = t; i < WAVES * 256; i += THREADS)
     (&s_whist[0][0])[i] = 0;
@@ -296,11 +393,13 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
 
   // per-wave multi-split: rank of each key among the keys of its wave with the same digit
   uint32_t rank[KPT];
+  uint8_t  dig[KPT];
 #pragma unroll
   for(int i = 0; i < KPT; ++i)
   {
     // padding keys (idx >= count) carry digit 255 and sit behind every real key of the partition
-    const uint32_t d = (key[i] >> shift) & 255u;
+    const uint32_t d = remap ? remapDigit(s_rv, rcount, key[i]) : ((key[i] >> shift) & 255u);
+    dig[i]           = (uint8_t)d;
     uint64_t       m = ~0ull;
 #pragma unroll
     for(int b = 0; b < 8; ++b)
@@ -350,7 +449,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
 #pragma unroll
   for(int i = 0; i < KPT; ++i)
   {
-    const uint32_t d   = (key[i] >> shift) & 255u;
+    const uint32_t d   = dig[i];
     const uint32_t pos = s_loff[d] + s_whist[w][d] + rank[i];
     s_v[pos]           = val[i];
     if constexpr(GATHER)
@@ -372,7 +471,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
     {
       const uint32_t k   = s_k[idx];
       const uint32_t v   = s_v[idx];
-      const uint32_t d   = GATHER ? (uint32_t)s_dig[idx] : ((k >> shift) & 255u);
+      const uint32_t d   = GATHER ? (uint32_t)s_dig[idx] : (remap ? remapDigit(s_rv, rcount, k) : ((k >> shift) & 255u));
       const uint32_t dst = s_gbase[d] + idx;
       if constexpr(GATHER)
         gatherDst[dst] = k;
@@ -425,7 +524,7 @@ void launchRadixSort(hipStream_t stream, const SortLaunch& s)
       hipLaunchKernelGGL(k_sort_hist, dim3(parts), dim3(256), 0, stream, s.keysX, s.keysY, s.keys0, s.nPtr, s.plan, s.partHist,
                          s.pStride, pass, s.beginBit, pp);
     hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, stream, s.nPtr, (pass == 0 && slotted) ? s.partsSlotted : 0u, s.plan,
-                       s.partHist, s.pStride, pass, pp);
+                       s.partHist, s.pStride, pass, pp, (s.allowRemap && nPasses == 4 && s.beginBit == 0) ? 1 : 0);
 #define MGS_SCATTER(FIRSTV, TH, KP, SLOTS)                                                                                  \
   hipLaunchKernelGGL((k_sort_scatter<FIRSTV, TH, KP>), dim3(parts), dim3(TH), 0, stream, s.keys0, s.vals0, s.keysX, s.valsX, \
                      s.keysY, s.valsY, SLOTS, s.nPtr, s.partsSlotted, s.plan, s.partHist, s.pStride, pass, s.beginBit, nPasses, \

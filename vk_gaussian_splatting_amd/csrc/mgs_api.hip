@@ -34,7 +34,7 @@ namespace mgs {
 void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full,
                    FrameCounters* ctr,
                    uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, SplatRec* rec, uint32_t* rect,
-                   const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride);
+                   const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride, SortPlan* planKeys);
 void launchPartitionCull(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, uint32_t* partSkip, uint32_t* zero0,
                          uint32_t n0, uint32_t* zero1, uint32_t n1, uint32_t* zero2, uint32_t n2);
 void launchFrameInit(hipStream_t stream, FrameCounters* ctr, SortPlan* planKeys, SortPlan* planPairs, uint2* ranges,
@@ -1321,9 +1321,13 @@ static int pairSortBits(int nTiles)
   return ((bits + 7) / 8) * 8;
 }
 
-static void keySort(MgsScene s, hipStream_t st, bool fuseRectGather)
+// pass elision of the key sort (sort_plan.h): on by default, MGS_SORT_REMAP=0 keeps the four plain passes
+static const bool kRemap = [] { const char* e = std::getenv("MGS_SORT_REMAP"); return e ? std::atoi(e) != 0 : true; }();
+
+static void keySort(MgsScene s, hipStream_t st, bool fuseRectGather, bool allowRemap)
 {
   SortLaunch L{};
+  L.allowRemap = allowRemap;
   if(fuseRectGather)
   {
     L.gatherSrc = s->rect.p;
@@ -1562,12 +1566,12 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
                        F.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride);
     else
       launchProject(st, A, s->dArgs.p, true, ctr, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p,
-                    s->rect.p, F.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride);
+                    s->rect.p, F.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride, kRemap ? planK : nullptr);
     if(withEvents) HIPCHK(hipEventRecord(fev[1], st));
     static const bool kFuseRect = [] { const char* e = std::getenv("MGS_FUSE_RECT"); return e ? std::atoi(e) != 0 : false; }();  // measured: +43 us in the scatter for -17 us in the count kernel
     const bool direct0 = directBinningSupported(F.binsX, F.binsY);
     if(!cpuMode)
-      keySort(s, st, kFuseRect && direct0);
+      keySort(s, st, kFuseRect && direct0, kRemap && !gut);
     else
     {
       rc = cpuSortStep(s, p, p->cpu_sort_blocking != 0);
@@ -2262,9 +2266,9 @@ int mgs_sort_keys(MgsScene s, const MgsFrameParams* p, MgsSortOut* out)
   else
     launchFrameInit(st, s->ctr.p, &s->plans.p[0], &s->plans.p[1], s->ranges.p, 0);
   launchProject(st, A, s->dArgs.p, false, s->ctr.p, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p, s->rect.p,
-                A.f.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride);
+                A.f.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride, kRemap ? &s->plans.p[0] : nullptr);
   HIPCHK(hipEventRecord(s->ev[1], st));
-  keySort(s, st, false);
+  keySort(s, st, false, kRemap);
   HIPCHK(hipEventRecord(s->ev[2], st));
   HIPCHK(hipMemcpyAsync(s->hCtr, s->ctr.p, sizeof(FrameCounters), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(s->hPlans, s->plans.p, 2 * sizeof(SortPlan), hipMemcpyDeviceToHost, st));

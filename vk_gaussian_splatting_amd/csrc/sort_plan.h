@@ -15,7 +15,24 @@ struct SortPlan
   uint32_t passesRun;
   uint32_t n;
   uint32_t pad[5];
+  // Pass elision for depth keys (k_sort.hip): the producer marks which values of key >> 16 occur (as small ranges per
+  // partition); when at most 256 do, pass 2 sorts on the RANK of key >> 16 among them — an order-preserving 8-bit
+  // digit that covers the top 16 bits at once — and pass 3 is skipped.
+  uint32_t remapOn;          // decided by the pass-1 scan kernel
+  uint32_t remapCount;
+  uint32_t remapBase;        // smallest occurring value: the kernels index a 4096-entry LDS table with (key >> 16) - remapBase
+  uint32_t remapPad;
+  uint32_t topBitmap[2048];  // presence of key >> 16
+  uint16_t remapVals[256];   // the occurring values, ascending
 };
+
+// mark one value of key >> 16 as present.  Thousands of partitions mark the same handful of values: look first (a stale
+// miss only costs a redundant atomic), so that the atomics on those few words do not serialise the grid.
+__device__ __forceinline__ void sortMarkTop16(SortPlan* plan, uint32_t v)
+{
+  if(((__hip_atomic_load(&plan->topBitmap[v >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (v & 31u)) & 1u) == 0u)
+    atomicOr(&plan->topBitmap[v >> 5], 1u << (v & 31u));
+}
 
 // scratch of the sample sort (k_ssort.hip); all device pointers, owned by the caller
 struct SampleSortBuffers
@@ -48,6 +65,7 @@ struct SortLaunch
   const uint32_t* gatherSrc = nullptr;  // optional (multi-pass sorts): the LAST pass writes gatherDst[pos] = gatherSrc[value]
   uint32_t*       gatherDst = nullptr;  //   instead of the keys, and sets plan->reserved[0] when it ran (not skipped)
   SampleSortBuffers ss;                 // non-null desc: full 32-bit sorts take the sample sort (k_ssort.hip)
+  bool            allowRemap = false;   // the producer marked plan->topBitmap (full 32-bit key sorts of a frame only)
 };
 
 void launchSortClearPlan(hipStream_t stream, SortPlan* plan);
