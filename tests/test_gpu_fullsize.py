@@ -190,7 +190,11 @@ def test_projected_records_match_oracle_per_splat(ob, case):
     # half^2 - det, which cancels for nearly round footprints — the worst splat of 43 K sits at ~1e-4 relative
     assert cerr <= 2e-3 and aerr <= 1e-5
     assert eerr <= 1e-3 and np.percentile(eall, 99) <= 5e-5
-    assert d1[good].max() <= 2e-3 and d2[good].max() <= 2e-3 and np.percentile(d1[good], 99) <= 1e-4
+    # a vector's direction error is the extent-matrix error divided by the relative eigenvalue gap: bounded per splat,
+    # tight in the bulk
+    gap = (l1 ** 2 - l2 ** 2) / l1 ** 2
+    assert np.all(d1[good] <= 4.0 * eall[good] / gap[good] + 2e-5) and np.all(d2[good] <= 4.0 * eall[good] / gap[good] + 2e-5)
+    assert np.percentile(d1[good], 99) <= 1e-4 and np.percentile(d2[good], 99) <= 1e-4
     # lengths everywhere (the eigenvalues are well conditioned even when the vectors are not), incl. the 2048-px clamp
     gl1, gl2 = np.hypot(got[:, 2], got[:, 3]), np.hypot(got[:, 4], got[:, 5])
     assert np.allclose(gl1, l1, rtol=1e-4) and np.allclose(gl2, l2, rtol=1e-4)

@@ -37,6 +37,7 @@ struct InstanceConst
   float        modelAxisMax;   // max length of the model matrix columns (size culling, dist.comp.slang:110-115)
   float        modelScale;     // largest singular value of the model 3x3 (upper bound of any length stretch)
   uint32_t     count;
+  uint32_t     modelIsIdentity; // M is bitwise the identity: M*p == p + 0.0f for finite p (k_project skips the product)
   uint32_t     globalOffset;   // first global splat id of this instance
   uint32_t     blockBegin;     // first project-kernel partition of this instance
   int32_t      shDegree;       // of the splat set

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
                                                              uint32_t* __restrict__ slotHist, uint32_t histStride)
 {
   const FrameArgs& A = *Ap;
-  if(partSkip != nullptr && partSkip[blockIdx.x] != 0u)
+  if(partSkip != nullptr && (partSkip[blockIdx.x] & 1u) != 0u)
   {
     if(threadIdx.x == 0)
       slotCount[blockIdx.x] = 0u;

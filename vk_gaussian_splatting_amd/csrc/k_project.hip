@@ -218,7 +218,9 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   const FrameArgs& A = *Ap;  // frame constants live in device memory (same pointer every frame: graph-replayable)
   // slotHist[d * histStride + partition] = survivors of this partition whose low key byte is d: the radix
   // sort's pass-0 partition histogram, produced here while the keys are still on chip.
-  if(partSkip != nullptr && partSkip[blockIdx.x] != 0u)
+  // partition flags of k_partition_cull: bit 0 skip, bit 1 every centre passes the frustum test, bit 2 all centres finite
+  const uint32_t pflag = partSkip != nullptr ? partSkip[blockIdx.x] : 0u;
+  if(pflag & 1u)
   {  // k_partition_cull proved that no splat of this partition can survive the cull / reach the strip
     if(threadIdx.x == 0)
       slotCount[blockIdx.x] = 0u;
@@ -257,21 +259,43 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   uint32_t key[kPrjItems];
   uint64_t bal[kPrjItems];
   bool     vis[kPrjItems];
+  const bool identityFast = (pflag & 4u) != 0u && I.modelIsIdentity != 0u;
+  const bool insideFast   = (pflag & 2u) != 0u && A.f.cullMode == 1;
 #pragma unroll
   for(int it = 0; it < kPrjItems; ++it)
   {
     const uint32_t li = local0 + it * kPrjThreads + t;
     float          wp[4], vp[4], cp[4];
-    mulMat4Exact(I.model, px[it], py[it], pz[it], 1.0f, wp);  // dist.comp.slang:58
+    if(identityFast)
+    {  // M is bitwise the identity and the centres are finite: ((x*1 + y*0) + z*0) + 1*0 == x + 0.0f, bit for bit
+#pragma clang fp contract(off)
+      wp[0] = px[it] + 0.0f;
+      wp[1] = py[it] + 0.0f;
+      wp[2] = pz[it] + 0.0f;
+      wp[3] = 1.0f;
+    }
+    else
+      mulMat4Exact(I.model, px[it], py[it], pz[it], 1.0f, wp);  // dist.comp.slang:58
     mulMat4Exact(A.f.view, wp[0], wp[1], wp[2], wp[3], vp);   // :58
-    mulMat4Exact(A.f.proj, vp[0], vp[1], vp[2], vp[3], cp);   // :60
-    const float nx = divExact(cp[0], cp[3]), ny = divExact(cp[1], cp[3]), nz = divExact(cp[2], cp[3]);  // :61
-    bool        v  = li < I.count;
-    if(A.f.cullMode == 1)
-    {  // :71-73 (NaN compares false everywhere, as in the shader)
-      const float c = 1.0f + A.f.frustumDilation;
-      if(fabsf(nx) > c || fabsf(ny) > c || nz < 0.f - A.f.frustumDilation || nz > 1.0f)
-        v = false;
+    bool  v = li < I.count;
+    float nz;
+    if(insideFast)
+    {  // every centre of this partition passes :71-73 (all 8 corners of its box do, with margin, and the tests are linear
+       // in the point): only clip z and w — the key — are needed
+      mulMat4ExactZW(A.f.proj, vp[0], vp[1], vp[2], vp[3], cp[2], cp[3]);
+      nz = divExact(cp[2], cp[3]);
+    }
+    else
+    {
+      mulMat4Exact(A.f.proj, vp[0], vp[1], vp[2], vp[3], cp);   // :60
+      const float nx = divExact(cp[0], cp[3]), ny = divExact(cp[1], cp[3]);  // :61
+      nz             = divExact(cp[2], cp[3]);
+      if(A.f.cullMode == 1)
+      {  // :71-73 (NaN compares false everywhere, as in the shader)
+        const float c = 1.0f + A.f.frustumDilation;
+        if(fabsf(nx) > c || fabsf(ny) > c || nz < 0.f - A.f.frustumDilation || nz > 1.0f)
+          v = false;
+      }
     }
     if(A.f.sizeCulling && v)  // dist.comp.slang:93-134 (after the frustum test, like the shader)
       v = !sizeCulled(I.maxScale[min(li, I.count - 1u)], A.f.splatScale, I.modelAxisMax, vp[2], A.f.maxFocal,
@@ -449,13 +473,15 @@ __global__ __launch_bounds__(256) void k_partition_cull(const FrameArgs* __restr
       k = i;
   const InstanceConst& I  = A.inst[k];
   const float*         bx = I.partBox + 8 * (size_t)(part - I.blockBegin);
-  uint32_t             skip = 0;
+  uint32_t             skip = 0, inside = 0;
+  const uint32_t       finite = (bx[7] == 0.0f) ? 4u : 0u;
   if(bx[7] == 0.0f)
   {
     const float c = 1.0f + A.f.frustumDilation, dl = A.f.frustumDilation;
     const float m = 1.0e-3f;  // relative safety margin
     bool  allWpos = true;
     bool  outXp = true, outXn = true, outYp = true, outYn = true, outZf = true, outZn = true;
+    bool  allIn = true;  // every corner passes the per-splat test with margin -> so does every centre inside the box
     float ymin = 3.4e38f, ymax = -3.4e38f, zvmin = 3.4e38f, rx = 0.f, ry = 0.f;
     for(int q = 0; q < 8; ++q)
     {
@@ -478,6 +504,7 @@ __global__ __launch_bounds__(256) void k_partition_cull(const FrameArgs* __restr
       outYn   = outYn && (-cy > c * cw + tol);
       outZf   = outZf && (cz > cw + tol);
       outZn   = outZn && (cz < -dl * cw - tol);
+      allIn   = allIn && (cw > tol) && (fabsf(cx) < c * cw - tol) && (fabsf(cy) < c * cw - tol) && (cz > -dl * cw + tol) && (cz < cw - tol);
       const float yp = (cy / cw + 1.0f) * 0.5f * (float)A.f.height;
       ymin  = fminf(ymin, yp);
       ymax  = fmaxf(ymax, yp);
@@ -487,6 +514,7 @@ __global__ __launch_bounds__(256) void k_partition_cull(const FrameArgs* __restr
     }
     if(allWpos && (outXp || outXn || outYp || outYn || outZf || outZn))
       skip = 1;
+    inside = (allIn && !skip) ? 2u : 0u;
     const bool strip = (A.f.stripRow1 - A.f.stripRow0) < A.f.tilesY;
     if(!skip && strip && allWpos && zvmin > 1e-4f)
     {
@@ -500,7 +528,7 @@ __global__ __launch_bounds__(256) void k_partition_cull(const FrameArgs* __restr
         skip = 1;
     }
   }
-  partSkip[part] = skip;
+  partSkip[part] = skip | inside | finite;
 }
 
 void launchPartitionCull(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, uint32_t* partSkip, uint32_t* zero0,

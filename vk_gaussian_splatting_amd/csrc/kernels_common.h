@@ -88,6 +88,20 @@ __device__ __forceinline__ void mulMat4Exact(const float* m, float x, float y, f
   }
 }
 
+// rows 2 and 3 of mulMat4Exact only (clip z and w): what the depth key needs when the frustum test is known to pass
+__device__ __forceinline__ void mulMat4ExactZW(const float* m, float x, float y, float z, float w, float& oz, float& ow)
+{
+#pragma clang fp contract(off)
+  {
+    const float a = x * m[2], b = y * m[6], c = z * m[10], d = w * m[14];
+    oz            = ((a + b) + c) + d;
+  }
+  {
+    const float a = x * m[3], b = y * m[7], c = z * m[11], d = w * m[15];
+    ow            = ((a + b) + c) + d;
+  }
+}
+
 // size culling of dist.comp.slang:93-134 with the oracle's exact unfused operation order
 __device__ __forceinline__ bool sizeCulled(float maxExpScale, float splatScale, float axisMax, float viewZ, float maxFocal,
                                            float minPixels)

@@ -1303,6 +1303,10 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
         C.modelScale = fro;
     }
     C.count        = d.count;
+    {
+      static const float kId[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+      C.modelIsIdentity = std::memcmp(I.M, kId, sizeof(kId)) == 0 ? 1u : 0u;  // bitwise (+0 only)
+    }
     C.globalOffset = offset;
     C.blockBegin   = block;
     C.shDegree     = d.shDegree;
