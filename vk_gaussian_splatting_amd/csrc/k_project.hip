@@ -172,29 +172,31 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   return true;
 }
 
-// Marks which values of key >> 16 this workgroup hands to the sort (pass elision, sort_plan.h).  A partition is a compact
-// cell of space, so its keys span one to three values: thread 0 marks the range.  A partition that spans many (a cell
-// around the camera) returns true instead and every thread marks its own keys.  s_red: >= 9 free words of LDS; two barriers.
-__device__ __forceinline__ bool markTop16(SortPlan* plan, uint32_t mn, uint32_t mx, uint32_t count, uint32_t* s_red)
+// Pass elision of the key sort (sort_plan.h): the workgroup marks which values of key >> 16 it hands to the sort.  A
+// partition is a compact cell of space, so its keys span one to three values: thread 0 marks the range; a partition that
+// spans many (a cell around the camera) has every thread mark its own keys.  Split in two so that it needs no barrier of
+// its own and the marking's memory latency overlaps the kernel's last stores: post the per-wave min / max before the
+// kernel's final barrier, mark after it.
+__device__ __forceinline__ void top16Post(uint32_t mn, uint32_t mx, uint32_t* s_red /*8 free words*/)
 {
-  if(plan == nullptr)
-    return false;
 #pragma unroll
   for(int o = 32; o > 0; o >>= 1)
   {
     mn = min(mn, (uint32_t)__shfl_xor(mn, o, 64));
     mx = max(mx, (uint32_t)__shfl_xor(mx, o, 64));
   }
-  __syncthreads();
   if(laneId() == 0)
   {
     s_red[threadIdx.x >> 6]       = mn;
     s_red[4 + (threadIdx.x >> 6)] = mx;
   }
-  __syncthreads();
-  const uint32_t lo = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3])), hi = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
-  if(count == 0u)
+}
+// returns true when the caller's threads must mark their own keys
+__device__ __forceinline__ bool top16Mark(SortPlan* plan, uint32_t count, const uint32_t* s_red)
+{
+  if(plan == nullptr || count == 0u)
     return false;
+  const uint32_t lo = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3])), hi = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
   if(hi - lo > 24u)
     return true;
   if(threadIdx.x == 0)
@@ -332,9 +334,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
       tmn = min(tmn, s_key[j] >> 16);
       tmx = max(tmx, s_key[j] >> 16);
     }
-    if(markTop16(planKeys, tmn, tmx, M, s_cnt))
-      for(uint32_t j = t; j < M; j += kPrjThreads)
-        sortMarkTop16(planKeys, s_key[j] >> 16);
+    top16Post(tmn, tmx, s_cnt);
     if(t == 0)
     {
       slotCount[part] = M;
@@ -343,6 +343,9 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
     }
     __syncthreads();
     slotHist[(size_t)t * histStride + part] = s_hist[t];
+    if(top16Mark(planKeys, M, s_cnt))
+      for(uint32_t j = t; j < M; j += kPrjThreads)
+        sortMarkTop16(planKeys, s_key[j] >> 16);
     return;
   }
   else
@@ -424,13 +427,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
         tmn = min(tmn, s_key[j] >> 16);
         tmx = max(tmx, s_key[j] >> 16);
       }
-    if(markTop16(planKeys, tmn, tmx, outCount, s_cnt))
-    {
-#pragma unroll
-      for(int r = 0; r < kPrjItems; ++r)
-        if(vis[r])
-          sortMarkTop16(planKeys, s_key[r * kPrjThreads + t] >> 16);
-    }
+    top16Post(tmn, tmx, s_cnt);
     if(t == 0)
     {
       slotCount[part] = outCount;
@@ -439,6 +436,13 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
     }
     __syncthreads();
     slotHist[(size_t)t * histStride + part] = s_hist[t];
+    if(top16Mark(planKeys, outCount, s_cnt))
+    {
+#pragma unroll
+      for(int r = 0; r < kPrjItems; ++r)
+        if(vis[r])
+          sortMarkTop16(planKeys, s_key[r * kPrjThreads + t] >> 16);
+    }
   }
 }
 
