@@ -245,13 +245,13 @@ typedef struct MgsSortOut {
   float    sort_ms;    /* radix sort (GPU) / std::sort (CPU) */
   float    hist_ms;    /* GPU: the up-front histogram kernel, included in sort_ms */
   uint32_t passes;     /* GPU: radix passes executed */
-  uint32_t reserved[3];
+  uint32_t reserved[3]; /* opt-in sample sort (MGS_SORT=sample) statistics: slices, buckets, buckets streamed through HBM */
 } MgsSortOut;
 int mgs_sort_keys(MgsScene scene, const MgsFrameParams* params, MgsSortOut* out);
 /* download the sorted keys (GPU mode: u32 encodeMinMaxFp32 keys; CPU mode: fp32 distances) and global ids */
 int mgs_sort_download(MgsScene scene, uint32_t* keys, uint32_t* ids, uint32_t capacity);
 
-/* sort an arbitrary device-resident (key,value) u32 array with the same onesweep kernels
+/* sort an arbitrary device-resident (key,value) u32 array with the frame's sort kernels (reduce-then-scan LSD radix)
  * (keys_device/values_device are overwritten with the result) — used by the sort parity tests
  * and the sorted-Gsplats/s microbenchmark. */
 int mgs_radix_sort_u32(MgsScene scene, void* keys_device, void* values_device, uint32_t count,

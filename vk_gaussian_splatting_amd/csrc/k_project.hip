@@ -9,7 +9,7 @@
 // MI355X-first differences:
 //   * the reference runs dist in id order and the mesh shader in SORTED order, so its 232 B/splat
 //     attribute gather is uncoalesced; here the gather happens before the sort, in id order, and the
-//     sort only moves 8-byte (key,id) pairs.  The 64-byte projected record is indexed by global id.
+//     sort only moves 8-byte (key,id) pairs.  The 32-byte projected record (SplatRec) is indexed by global id.
 //   * survivors are compacted per 2048-splat partition into a fixed slot region (ascending id, so
 //     the order is deterministic); the radix sort's first pass consumes the slots directly — there
 //     is no global atomic append and no inter-workgroup chain — together with the partition's
@@ -33,10 +33,9 @@ struct Projected
 };
 
 // The per-splat raster front end.  Returns false when the splat cannot produce a fragment.
-// Written BRANCH-FREE with every load issued first: rocprof showed the waves of this kernel waiting on
-// memory 70 % of their cycles when the fetches were staged behind the early-outs (rgba -> centre -> cov
-// -> SH, four dependent round trips).  ~96 % of the frustum survivors pass every test, so the
-// speculative SH fetch of the rest costs ~4 % extra traffic and buys one round trip instead of four.
+// Written BRANCH-FREE with every load issued first (fetchSplat: opacity, centre, covariance — 40 B per survivor):
+// rocprof showed the waves of this kernel waiting on memory 70 % of their cycles when the fetches were staged behind
+// the early-outs.  Colour and SH are not touched here: shading is deferred to the compositor.
 struct SplatFetch
 {
   float  alpha;

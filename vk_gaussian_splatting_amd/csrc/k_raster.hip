@@ -598,7 +598,7 @@ __global__ void k_tile_ranges(const uint32_t* __restrict__ keyX, const uint32_t*
 // 16x16 tile it touches costs ~13 records per splat and made the (tile,id) sort the most expensive stage
 // (profiles/r1_a/b).  Instead each workgroup walks its bin's depth-ordered list nearest-first and does
 // the fine culling on chip:
-//   stage A  every thread fetches 4 list entries (id -> first 16 bytes of the record: centre + extent),
+//   stage A  every thread fetches 2 list entries (id -> the 32-byte record: centre, p1, p2, opacity, fp16 extents),
 //            tests the footprint against the workgroup's region, and the survivors are compacted
 //            IN ORDER (ballot + mbcnt) into an LDS batch together with the rest of their record;
 //   stage B  each wave walks the batch, skips splats that miss its quarter, and blends front-to-back:
