@@ -40,7 +40,7 @@ for name, b in tables.items():
         st = np.array(list(o.stage_ms)[:6])
         worst = max(worst, st[5])
         rec.append(dict(rank=r, rows=[b[r], b[r + 1]], sorted=int(o.sorted_count), pairs=int(o.tile_pairs), stage_ms=st.round(4).tolist()))
-        print(f"{name:9s} strip {r} rows [{b[r]},{b[r+1]}) sorted {o.sorted_count:8d} pairs {o.tile_pairs:8d} stages {st.round(3)}")
+        print(f"{name:9s} strip {r} rows [{b[r]},{b[r+1]}) frustum {o.frustum_count:8d} sorted {o.sorted_count:8d} pairs {o.tile_pairs:8d} stages {st.round(3)}")
     print(f"{name}: heaviest strip {worst:.3f} ms vs full frame {full[5]:.3f} ms -> {full[5] / worst:.2f}x before the exchange")
     res["tables"][name] = dict(bounds=b, strips=rec, heaviest_ms=float(worst), projected_speedup=float(full[5] / worst))
 os.makedirs("gpurun_out", exist_ok=True)
