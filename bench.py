@@ -182,9 +182,19 @@ def main():
     # ---- N>1: communicators + strip table --------------------------------------------------------------------
     if world > 1:
         if args.backend == "nccl" and not args.torch_gather:
-            try:  # libmgs's own RCCL exchange: one communicator per frame context (each has its own stream)
-                ids = [capi.comm_unique_id() if rank == 0 else None for _ in range(K)]
-                dist.broadcast_object_list(ids, src=0)
+            # libmgs's own RCCL exchange: one communicator per frame context (each has its own stream).  Rank 0 makes the
+            # ids; whatever happens there, every rank takes part in the broadcast (nobody is left waiting in it)
+            ids = [None] * K
+            if rank == 0:
+                try:
+                    ids = [capi.comm_unique_id() for _ in range(K)]
+                except Exception as e:  # noqa: BLE001
+                    print(f"[rank 0] mgs_comm_unique_id failed ({type(e).__name__}: {e})", file=sys.stderr)
+                    ids = [None] * K
+            dist.broadcast_object_list(ids, src=0)
+            try:
+                if any(i is None for i in ids):
+                    raise RuntimeError("no RCCL unique id from rank 0")
                 for c in range(K):
                     scenes[c].comm_init(rank, world, ids[c])
                 gather_mode = "libmgs: grouped ncclBroadcast of every rank's rows, in place in the frame buffer, on the render stream"

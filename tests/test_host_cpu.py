@@ -275,3 +275,28 @@ def test_div255_refinement_is_exact():
         rem = r32(Fraction(float(-q)) * 255 + Fraction(float(fb)))
         q2 = r32(Fraction(float(rem)) * Fraction(float(r)) + Fraction(float(q)))
         assert q2 == np.float32(fb / np.float32(255.0)), b
+
+
+def test_balanced_strip_bounds_properties():
+    """multigpu.balanced_bounds: ascending, covers all tile rows, deterministic, and actually balances a skewed cost profile"""
+    from vk_gaussian_splatting_amd import multigpu
+    rng = np.random.default_rng(5)
+    for rows, world in ((68, 8), (135, 8), (68, 3), (5, 8), (1, 2)):
+        cost = rng.random(rows) ** 4 * 1e5
+        cost[rows // 2] += 3e5
+        b = multigpu.balanced_bounds(cost, world)
+        assert len(b) == world + 1 and b[0] == 0 and b[-1] == rows and all(b[i] <= b[i + 1] for i in range(world))
+        assert b == multigpu.balanced_bounds(cost.copy(), world)
+        if rows >= 4 * world:
+            c = cost + 0.25 * cost.mean()
+            per = [c[b[i]:b[i + 1]].sum() for i in range(world)]
+            eq = [c[multigpu.strip_rows(rows * 16, world, r)[0]:multigpu.strip_rows(rows * 16, world, r)[1]].sum() for r in range(world)]
+            assert max(per) <= max(eq) + 1e-6   # never worse than equal strips on the charged cost
+            assert multigpu.padded_strip_rows(b) == max(b[i + 1] - b[i] for i in range(world)) * 16
+
+
+def test_frame_params_defaults_cover_the_new_pipeline_fields():
+    p = capi.default_params(640, 480)
+    assert p.pipeline == capi.PIPELINE_3DGS and p.camera_model == capi.CAMERA_PINHOLE and p.extent_method == capi.EXTENT_CONIC
+    assert abs(p.alpha_clamp - 0.99) < 1e-7 and abs(p.kernel_min_response - 0.0113) < 1e-7 and p.fov_rad == 0.0
+    assert p.frustum_culling == capi.CULL_AT_DIST and abs(p.frustum_dilation - 0.2) < 1e-7 and p.sh_degree == 3
