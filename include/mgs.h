@@ -94,6 +94,22 @@ int  mgs_splatset_from_arrays(const MgsSplatSetView* view, MgsSplatSet* out);
 int  mgs_splatset_view(MgsSplatSet set, MgsSplatSetView* out);
 void mgs_splatset_destroy(MgsSplatSet set);
 
+/* ---- asynchronous ingest with a request queue: PlyLoaderAsync (src/ply_loader_async.h:35-106: one loader thread,
+ * states E_READY / E_LOADING / E_LOADED / E_FAILURE, reset before the next load) plus the scene-load queue the UI drains
+ * one file at a time (prmScene.sceneLoadQueue, src/gaussian_splatting_ui.cpp:1149-1152,1235-1436: files are queued, the
+ * loader takes the next one when idle, a failure does not stop the queue).  Host only: no device is touched. */
+typedef struct MgsLoader_t* MgsLoader;
+enum { MGS_LOADER_READY = 1, MGS_LOADER_LOADING = 2, MGS_LOADER_LOADED = 3, MGS_LOADER_FAILURE = 4 };  /* ply_loader_async.h:37-44 */
+int  mgs_loader_create(MgsLoader* out);                 /* PlyLoaderAsync::initialize: starts the loader thread */
+void mgs_loader_destroy(MgsLoader loader);              /* shutdown: joins the thread, drops what is queued */
+int  mgs_loader_push(MgsLoader loader, const char* path); /* pushLoadRequest: append to the queue (any state) */
+/* getStatus: the state of the request at the head (READY when nothing is queued or loading); *queued = requests waiting
+ * behind it, *path_out (optional, >= path_capacity bytes) = its file name */
+int  mgs_loader_status(MgsLoader loader, int* state, uint32_t* queued, char* path_out, size_t path_capacity);
+/* LOADED: hands over the splat set (caller owns it) and resets — the next queued file starts loading.
+ * FAILURE: returns the load's error code (message in mgs_last_error) and resets likewise.  Other states: MGS_ERR_STATE. */
+int  mgs_loader_take(MgsLoader loader, MgsSplatSet* out);
+
 /* ---- scene: replaces SplatSetManagerVk::createSplatSet/createInstance/updateInstanceTransform/
  * processVramUpdates (src/splat_set_manager_vk.h:202,222-249,261).  `device` is the HIP ordinal. */
 int  mgs_scene_create(int device, MgsScene* out);

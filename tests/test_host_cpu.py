@@ -300,3 +300,49 @@ def test_frame_params_defaults_cover_the_new_pipeline_fields():
     assert p.pipeline == capi.PIPELINE_3DGS and p.camera_model == capi.CAMERA_PINHOLE and p.extent_method == capi.EXTENT_CONIC
     assert abs(p.alpha_clamp - 0.99) < 1e-7 and abs(p.kernel_min_response - 0.0113) < 1e-7 and p.fov_rad == 0.0
     assert p.frustum_culling == capi.CULL_AT_DIST and abs(p.frustum_dilation - 0.2) < 1e-7 and p.sh_degree == 3
+
+
+def test_async_loader_queue_follows_the_reference_protocol(tmp_path):
+    """mgs_loader_*: PlyLoaderAsync's READY -> LOADING -> LOADED / FAILURE states with the UI's scene-load queue on top:
+    several files pushed at once load one at a time in order, a bad file fails without stopping the queue"""
+    import time
+    files = []
+    for i, n in enumerate((300, 77, 1500)):
+        sc = synth.make_scene(n, seed=40 + i)
+        p = tmp_path / f"s{i}.ply"
+        synth.write_ply(str(p), sc)
+        files.append((str(p), sc))
+    bad = tmp_path / "broken.ply"
+    bad.write_bytes(b"ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nend_header\n0\n")
+    L = mgs.Loader()
+    assert L.status()[0] == capi.LOADER_READY
+    with pytest.raises(mgs.MgsError) as e:
+        L.take()
+    assert e.value.code == -6  # MGS_ERR_STATE
+    order = [files[0][0], str(bad), files[1][0], files[2][0]]
+    for p in order:
+        L.push(p)
+    got = []
+    for k, path in enumerate(order):
+        t0 = time.time()
+        while True:
+            st, queued, head = L.status()
+            assert head == path and queued == len(order) - 1 - k
+            if st in (capi.LOADER_LOADED, capi.LOADER_FAILURE):
+                break
+            assert st == capi.LOADER_LOADING and time.time() - t0 < 60
+            time.sleep(0.002)
+        if path == str(bad):
+            assert st == capi.LOADER_FAILURE
+            with pytest.raises(mgs.MgsError) as e:
+                L.take()
+            assert e.value.code == -3 and "3DGS" in str(e.value)
+        else:
+            assert st == capi.LOADER_LOADED
+            got.append(L.take().arrays())
+    assert L.status()[:2] == (capi.LOADER_READY, 0)
+    for a, (_, sc) in zip(got, files):
+        for k in FIELDS:
+            assert np.array_equal(a[k], sc[k].reshape(-1)), k
+    L.push(files[0][0])  # destroy with a request in flight / a result not taken: no leak, no hang
+    L.close()

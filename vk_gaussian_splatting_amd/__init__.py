@@ -7,12 +7,12 @@ ctypes mirror of that ABI plus the synthetic-scene generator used by tests and b
 There is NO CPU fallback: importing works anywhere, but creating a Scene without the HIP
 library or without a GPU raises.
 """
-from .capi import (MgsError, SplatSet, Scene, FrameParams, FrameOut, SortOut, lib_path, load_library,
+from .capi import (MgsError, SplatSet, Scene, Loader, FrameParams, FrameOut, SortOut, lib_path, load_library,
                    camera_lookat_perspective, compute_transform,
                    FORMAT_FLOAT32, FORMAT_FLOAT16, FORMAT_UINT8, SORT_GPU_RADIX, SORT_CPU_ASYNC,
                    CULL_NONE, CULL_AT_DIST, CULL_AT_RASTER, TARGET_RGBA16F, TARGET_RGBA32F,
                    ALPHA_COVERAGE, ALPHA_SUM)
 from . import synth
 
-__all__ = ["MgsError", "SplatSet", "Scene", "FrameParams", "FrameOut", "SortOut", "lib_path", "load_library",
+__all__ = ["MgsError", "SplatSet", "Scene", "Loader", "FrameParams", "FrameOut", "SortOut", "lib_path", "load_library",
            "camera_lookat_perspective", "compute_transform", "synth"]

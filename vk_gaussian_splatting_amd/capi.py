@@ -109,6 +109,11 @@ def load_library():
         "mgs_frame_copy_strip": (C.c_int, [vp, vp, C.c_size_t]),
         "mgs_sync": (C.c_int, [vp]),
         "mgs_frame_download_projected": (C.c_int, [vp, P(C.c_uint32), C.c_size_t, P(F), P(C.c_uint32)]),
+        "mgs_loader_create": (C.c_int, [P(vp)]),
+        "mgs_loader_destroy": (None, [vp]),
+        "mgs_loader_push": (C.c_int, [vp, C.c_char_p]),
+        "mgs_loader_status": (C.c_int, [vp, P(C.c_int), P(C.c_uint32), C.c_char_p, C.c_size_t]),
+        "mgs_loader_take": (C.c_int, [vp, P(vp)]),
         "mgs_comm_unique_id": (C.c_int, [vp]),
         "mgs_scene_comm_init": (C.c_int, [vp, C.c_int, C.c_int, vp]),
         "mgs_scene_comm_destroy": (C.c_int, [vp]),
@@ -136,7 +141,8 @@ EXPORTED_SYMBOLS = [
     "mgs_instance_set_transform", "mgs_scene_commit", "mgs_scene_splat_count", "mgs_scene_storage_order", "mgs_scene_download_set",
     "mgs_frame_params_default", "mgs_render", "mgs_frame_stats", "mgs_timings_query", "mgs_frame_download", "mgs_frame_download_surface", "mgs_frame_copy_strip",
     "mgs_frame_download_projected", "mgs_sync", "mgs_comm_unique_id", "mgs_scene_comm_init", "mgs_scene_comm_destroy",
-    "mgs_scene_set_strip_rows", "mgs_render_gathered", "mgs_frame_row_costs", "mgs_sort_keys", "mgs_sort_download", "mgs_radix_sort_u32", "mgs_radix_sort_host",
+    "mgs_scene_set_strip_rows", "mgs_render_gathered", "mgs_frame_row_costs",
+    "mgs_loader_create", "mgs_loader_destroy", "mgs_loader_push", "mgs_loader_status", "mgs_loader_take", "mgs_sort_keys", "mgs_sort_download", "mgs_radix_sort_u32", "mgs_radix_sort_host",
     "mgs_camera_lookat_perspective", "mgs_compute_transform"]
 
 
@@ -203,6 +209,45 @@ class SplatSet:
     def close(self):
         if self._h:
             load_library().mgs_splatset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+LOADER_READY, LOADER_LOADING, LOADER_LOADED, LOADER_FAILURE = 1, 2, 3, 4
+
+
+class Loader:
+    """PlyLoaderAsync + the scene-load queue: push files, poll, take the loaded SplatSets in order"""
+
+    def __init__(self):
+        self._lib = load_library()
+        h = C.c_void_p()
+        _check(self._lib.mgs_loader_create(C.byref(h)))
+        self._h = h
+
+    def push(self, path):
+        _check(self._lib.mgs_loader_push(self._h, os.fsencode(path)))
+
+    def status(self):
+        """(state, requests queued behind the head, head's path)"""
+        st, q = C.c_int(), C.c_uint32()
+        buf = C.create_string_buffer(1024)
+        _check(self._lib.mgs_loader_status(self._h, C.byref(st), C.byref(q), buf, 1024))
+        return st.value, q.value, buf.value.decode(errors="replace")
+
+    def take(self):
+        h = C.c_void_p()
+        _check(self._lib.mgs_loader_take(self._h, C.byref(h)))
+        return SplatSet(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mgs_loader_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -468,6 +468,142 @@ int mgs_splatset_view(MgsSplatSet set, MgsSplatSetView* out)
 
 void mgs_splatset_destroy(MgsSplatSet set) { delete set; }
 
+// ---- asynchronous loader + request queue (PlyLoaderAsync + sceneLoadQueue) -----------------------------------------
+}  // extern "C"
+#include <deque>
+struct MgsLoader_t
+{
+  std::thread             worker;
+  std::mutex              mtx;
+  std::condition_variable cv;
+  std::deque<std::string> queue;     // waiting requests; front() is the head while LOADING / LOADED / FAILURE
+  int                     state = MGS_LOADER_READY;
+  bool                    shutdown = false;
+  MgsSplatSet             result = nullptr;
+  int                     resultCode = MGS_OK;
+  std::string             resultError;
+
+  void run()
+  {
+    std::unique_lock<std::mutex> lk(mtx);
+    for(;;)
+    {
+      cv.wait(lk, [&] { return shutdown || (state == MGS_LOADER_READY && !queue.empty()); });
+      if(shutdown)
+        return;
+      state                  = MGS_LOADER_LOADING;
+      const std::string path = queue.front();
+      lk.unlock();
+      MgsSplatSet set = nullptr;
+      const int   rc  = mgs_splatset_load(path.c_str(), &set);  // the synchronous loader (thread-local error string)
+      const std::string err = rc == MGS_OK ? std::string() : std::string(mgs_last_error());
+      lk.lock();
+      result      = set;
+      resultCode  = rc;
+      resultError = err;
+      state       = rc == MGS_OK ? MGS_LOADER_LOADED : MGS_LOADER_FAILURE;
+      cv.notify_all();
+    }
+  }
+};
+extern "C" {
+
+int mgs_loader_create(MgsLoader* out)
+{
+  if(!out)
+  {
+    setError("mgs_loader_create: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  return guarded("mgs_loader_create", [&] {
+    auto* L   = new MgsLoader_t();
+    L->worker = std::thread([L] { L->run(); });
+    *out      = L;
+    return (int)MGS_OK;
+  });
+}
+
+void mgs_loader_destroy(MgsLoader L)
+{
+  if(!L)
+    return;
+  {
+    std::lock_guard<std::mutex> lk(L->mtx);
+    L->shutdown = true;
+  }
+  L->cv.notify_all();
+  L->worker.join();
+  if(L->result)
+    mgs_splatset_destroy(L->result);
+  delete L;
+}
+
+int mgs_loader_push(MgsLoader L, const char* path)
+{
+  if(!L || !path)
+  {
+    setError("mgs_loader_push: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  return guarded("mgs_loader_push", [&] {
+    {
+      std::lock_guard<std::mutex> lk(L->mtx);
+      L->queue.emplace_back(path);
+    }
+    L->cv.notify_all();
+    return (int)MGS_OK;
+  });
+}
+
+int mgs_loader_status(MgsLoader L, int* state, uint32_t* queued, char* pathOut, size_t cap)
+{
+  if(!L || !state)
+  {
+    setError("mgs_loader_status: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  std::lock_guard<std::mutex> lk(L->mtx);
+  // a request that has been queued but not picked up yet already counts as LOADING for the poller
+  const bool busy = !L->queue.empty();
+  *state          = (L->state == MGS_LOADER_READY && busy) ? MGS_LOADER_LOADING : L->state;
+  if(queued)
+    *queued = busy ? (uint32_t)L->queue.size() - 1u : 0u;
+  if(pathOut && cap)
+  {
+    const std::string& p = busy ? L->queue.front() : std::string();
+    std::snprintf(pathOut, cap, "%s", busy ? p.c_str() : "");
+  }
+  return MGS_OK;
+}
+
+int mgs_loader_take(MgsLoader L, MgsSplatSet* out)
+{
+  if(!L || !out)
+  {
+    setError("mgs_loader_take: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  int rc;
+  {
+    std::lock_guard<std::mutex> lk(L->mtx);
+    if(L->state != MGS_LOADER_LOADED && L->state != MGS_LOADER_FAILURE)
+    {
+      setError("mgs_loader_take: nothing loaded (poll mgs_loader_status)");
+      return MGS_ERR_STATE;
+    }
+    rc = L->resultCode;
+    if(L->state == MGS_LOADER_LOADED)
+      *out = L->result;
+    else
+      setError(L->resultError);
+    L->result = nullptr;
+    L->queue.pop_front();
+    L->state = MGS_LOADER_READY;  // reset(): the next queued file may start
+  }
+  L->cv.notify_all();
+  return rc;
+}
+
 // ------------------------------------------------------------------------------------------------
 static int mgs_scene_create_impl(int device, MgsScene* out);
 int mgs_scene_create(int device, MgsScene* out)
