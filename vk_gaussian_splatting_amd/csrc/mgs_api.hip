@@ -59,7 +59,7 @@ void launchProjectGut(hipStream_t stream, const FrameArgs& args, const FrameArgs
                       const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride);
 void launchCompositeGut(hipStream_t stream, const FrameArgs& A, const FrameArgs* dArgs, const uint2* ranges, const uint32_t* valX,
                         const uint32_t* valY, const SortPlan* planPairs, const GutRec* rec, void* image, int halfOut,
-                        FrameCounters* ctr);
+                        FrameCounters* ctr, int shFormat);
 constexpr uint32_t kPart = 2048;  // == kPrjPart == kSortPart == kBinPart
 }  // namespace mgs
 
@@ -1768,7 +1768,7 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     }
     if(withEvents) HIPCHK(hipEventRecord(fev[4], st));
     if(gut)
-      launchCompositeGut(st, A, s->dArgs.p, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->recGut.p, s->image.p, half, ctr);
+      launchCompositeGut(st, A, s->dArgs.p, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->recGut.p, s->image.p, half, ctr, s->shFormat);
     else
       launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat, ctr,
                       F.surfaceOutputs ? s->surfDepth.p : nullptr, F.surfaceOutputs ? s->surfId.p : nullptr, s->compInst.p,
