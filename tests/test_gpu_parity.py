@@ -1026,6 +1026,38 @@ def test_cpp_caller_renders_the_same_frame(tmp_path):
     scene.close()
 
 
+def test_cpp_multi_gpu_caller_single_rank(tmp_path):
+    """examples/mgs_strips (plain C++: file rendezvous of the RCCL id, mgs_scene_comm_init, cost-balanced strip table,
+    mgs_render_gathered) with WORLD = 1 on this box == the ctypes path, pixel for pixel"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "mgs_strips")
+    if not os.path.exists(exe):
+        assert subprocess.run(["make", "-C", os.path.join(root, "examples")]).returncode == 0
+    sc = synth.make_scene(30000, seed=8)
+    ply = str(tmp_path / "s.ply")
+    synth.write_ply(ply, sc)
+    W, H = 400, 240
+    r = subprocess.run([exe, ply, str(tmp_path / "o.ppm"), "0", "1", str(tmp_path / "rdv.bin"), str(W), str(H)], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "assembled from strips" in r.stdout, r.stdout + r.stderr
+    raw = open(tmp_path / "o.ppm", "rb").read()
+    head = f"P6\n{W} {H}\n255\n".encode()
+    assert raw.startswith(head) and len(raw) == len(head) + W * H * 3
+    ppm = np.frombuffer(raw[len(head):], np.uint8).reshape(H, W, 3)
+    scene = mgs.Scene(0)
+    scene.add_instance(mgs.SplatSet.load(ply))
+    scene.commit()
+    eye = [4.0, 1.5, 0.0]
+    V, P = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, W, H)
+    p = capi.default_params(W, H)
+    capi.set_camera(p, V, P, eye)
+    scene.render(p)
+    img = np.clip(scene.download_frame(p).astype(np.float32)[..., :3], 0, 1)
+    assert np.array_equal((img * 255.0 + 0.5).astype(np.uint8), ppm)
+    scene.close()
+
+
 def test_api_error_behaviour():
     scene = mgs.Scene(0)
     p = capi.default_params(64, 64)

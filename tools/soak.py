@@ -18,6 +18,8 @@ for cyc in range(12):
         p = cam(i)
         if i % 7 == 0: p.strip_row_begin, p.strip_row_end = 5, 30
         if i % 11 == 0: p.surface_outputs = 1
+        elif i % 13 == 0: p.pipeline = capi.PIPELINE_3DGUT          # its record buffer is allocated on first use
+        if i % 17 == 0 and i % 11: p.camera_model = capi.CAMERA_FISHEYE; p.pipeline = capi.PIPELINE_3DGUT
         o = scene.render(p, want_stats=(i % 5 == 0))
     img = scene.download_frame(p); assert np.isfinite(img.astype(np.float32)).all()
     scene.close()
