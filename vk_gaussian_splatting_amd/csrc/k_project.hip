@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
                                                          uint32_t* __restrict__ slotCount, SplatRec* __restrict__ rec,
                                                          uint32_t* __restrict__ rect, const uint32_t* __restrict__ partSkip,
                                                          uint32_t* __restrict__ slotHist, uint32_t histStride,
-                                                         SortPlan* __restrict__ planKeys)
+                                                         SortPlan* __restrict__ planKeys, const float* __restrict__ partR)
 {
   const FrameArgs& A = *Ap;  // frame constants live in device memory (same pointer every frame: graph-replayable)
   // slotHist[d * histStride + partition] = survivors of this partition whose low key byte is d: the radix
@@ -261,7 +261,13 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   uint64_t bal[kPrjItems];
   bool     vis[kPrjItems];
   const bool identityFast = (pflag & 4u) != 0u && I.modelIsIdentity != 0u;
-  const bool insideFast   = (pflag & 2u) != 0u && A.f.cullMode == 1;
+  // strips (multi-GPU): a splat whose centre lies further from this device's rows than the partition's footprint bound R
+  // (k_partition_cull; valid for every splat of the partition) cannot reach them — dropped here, before the projection.
+  // The exact footprint-vs-strip test of phase 2 would reject it anyway: the sorted set is unchanged.
+  const bool  stripPre = partR != nullptr && (A.f.stripRow1 - A.f.stripRow0) < A.f.tilesY;
+  const float stripR   = stripPre ? partR[blockIdx.x] : 3.0e38f;
+  const float stripY0  = (float)(A.f.stripRow0 * kTilePx), stripY1 = (float)min(A.f.stripRow1 * kTilePx, A.f.height);
+  const bool  insideFast = (pflag & 2u) != 0u && A.f.cullMode == 1 && !stripPre;
 #pragma unroll
   for(int it = 0; it < kPrjItems; ++it)
   {
@@ -295,6 +301,13 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
       {  // :71-73 (NaN compares false everywhere, as in the shader)
         const float c = 1.0f + A.f.frustumDilation;
         if(fabsf(nx) > c || fabsf(ny) > c || nz < 0.f - A.f.frustumDilation || nz > 1.0f)
+          v = false;
+      }
+      if(stripPre)
+      {
+        const float R = stripR;
+        const float ypx = (ny + 1.0f) * 0.5f * (float)A.f.height;
+        if(ypx + R < stripY0 || ypx - R > stripY1)
           v = false;
       }
     }
@@ -456,7 +469,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
 // DESIGN.md §3.1), and the partition is skipped when [ymin-R, ymax+R] misses the strip's pixel rows.
 // It is also the frame's first kernel, so it zeroes the per-frame device state (counters, both sort plans, the bin
 // ranges): one launch less than a separate init kernel.
-__global__ __launch_bounds__(256) void k_partition_cull(const FrameArgs* __restrict__ Ap, uint32_t* __restrict__ partSkip,
+__global__ __launch_bounds__(256) void k_partition_cull(const FrameArgs* __restrict__ Ap, uint32_t* __restrict__ partSkip, float* __restrict__ partR,
                                                         uint32_t* __restrict__ zero0, uint32_t n0, uint32_t* __restrict__ zero1,
                                                         uint32_t n1, uint32_t* __restrict__ zero2, uint32_t n2)
 {
@@ -478,6 +491,7 @@ __global__ __launch_bounds__(256) void k_partition_cull(const FrameArgs* __restr
   const float*         bx = I.partBox + 8 * (size_t)(part - I.blockBegin);
   uint32_t             skip = 0, inside = 0;
   const uint32_t       finite = (bx[7] == 0.0f) ? 4u : 0u;
+  float                Rout = 3.0e38f;  // footprint bound of the partition's splats in pixels (strips only; "unknown" = infinite)
   if(bx[7] == 0.0f)
   {
     const float c = 1.0f + A.f.frustumDilation, dl = A.f.frustumDilation;
@@ -529,17 +543,20 @@ __global__ __launch_bounds__(256) void k_partition_cull(const FrameArgs* __restr
       const float y0   = (float)(A.f.stripRow0 * kTilePx), y1 = (float)(min(A.f.stripRow1 * kTilePx, A.f.height));
       if(ymax + R < y0 || ymin - R > y1)
         skip = 1;
+      Rout = R;
     }
   }
+  if(partR != nullptr)
+    partR[part] = Rout;
   partSkip[part] = skip | inside | finite;
 }
 
-void launchPartitionCull(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, uint32_t* partSkip, uint32_t* zero0,
-                         uint32_t n0, uint32_t* zero1, uint32_t n1, uint32_t* zero2, uint32_t n2)
+void launchPartitionCull(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, uint32_t* partSkip, float* partR,
+                         uint32_t* zero0, uint32_t n0, uint32_t* zero1, uint32_t n1, uint32_t* zero2, uint32_t n2)
 {
   if(args.f.totalPartitions == 0)
     return;
-  hipLaunchKernelGGL(k_partition_cull, dim3((args.f.totalPartitions + 255) / 256), dim3(256), 0, stream, dArgs, partSkip, zero0,
+  hipLaunchKernelGGL(k_partition_cull, dim3((args.f.totalPartitions + 255) / 256), dim3(256), 0, stream, dArgs, partSkip, partR, zero0,
                      n0, zero1, n1, zero2, n2);
 }
 
@@ -548,14 +565,14 @@ void launchPartitionCull(hipStream_t stream, const FrameArgs& args, const FrameA
 void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full,
                    FrameCounters* ctr,
                    uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, SplatRec* rec, uint32_t* rect,
-                   const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride, SortPlan* planKeys)
+                   const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride, SortPlan* planKeys, const float* partR)
 {
   const dim3 grid(args.f.totalPartitions), block(kPrjThreads);
   if(args.f.totalPartitions == 0)
     return;
 #define MGS_LAUNCH(FULLV)                                                                                                \
   hipLaunchKernelGGL((k_project<FULLV>), grid, block, 0, stream, dArgs, ctr, keysSlot, idsSlot, slotCount, rec, rect, partSkip, \
-                     slotHist, histStride, planKeys)
+                     slotHist, histStride, planKeys, partR)
   if(full)
     MGS_LAUNCH(true);
   else

@@ -34,9 +34,9 @@ namespace mgs {
 void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full,
                    FrameCounters* ctr,
                    uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, SplatRec* rec, uint32_t* rect,
-                   const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride, SortPlan* planKeys);
-void launchPartitionCull(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, uint32_t* partSkip, uint32_t* zero0,
-                         uint32_t n0, uint32_t* zero1, uint32_t n1, uint32_t* zero2, uint32_t n2);
+                   const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride, SortPlan* planKeys, const float* partR);
+void launchPartitionCull(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, uint32_t* partSkip, float* partR,
+                         uint32_t* zero0, uint32_t n0, uint32_t* zero1, uint32_t n1, uint32_t* zero2, uint32_t n2);
 void launchFrameInit(hipStream_t stream, FrameCounters* ctr, SortPlan* planKeys, SortPlan* planPairs, uint2* ranges,
                      uint32_t nTiles);
 void launchBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
@@ -253,6 +253,7 @@ struct MgsScene_t
   // frame buffers
   DevBuf<uint32_t>      keysSlot, idsSlot, slotCount, keysA, idsA, keysB, idsB, rect, partHist, blockCount;
   DevBuf<uint32_t>      sortedRect, splatOffset, chunkStart, partSkip;
+  DevBuf<float>         partR;       // per partition: footprint bound in pixels (strips), written by k_partition_cull
   DevBuf<uint64_t>      dbinMasks;
   DevBuf<CompositeArgs::Inst> compInst;  // SH table of all instances for the compositor (scenes with > 16 instances)
   DevBuf<FrameArgs>     dArgs;       // this frame's constants (view/proj, instances, knobs): the kernels read them through
@@ -704,7 +705,7 @@ void mgs_scene_destroy(MgsScene s)
   s->keysSlot.release(); s->idsSlot.release(); s->slotCount.release(); s->keysA.release(); s->idsA.release();
   s->keysB.release(); s->idsB.release(); s->rect.release(); s->partHist.release(); s->blockCount.release();
   s->rec.release(); s->recGut.release(); s->pairKey0.release(); s->pairVal0.release(); s->pairKey1.release(); s->pairVal1.release();
-  s->sortedRect.release(); s->splatOffset.release(); s->chunkStart.release(); s->partSkip.release();
+  s->sortedRect.release(); s->splatOffset.release(); s->chunkStart.release(); s->partSkip.release(); s->partR.release();
   s->surfDepth.release(); s->surfId.release(); s->surfNormal.release(); s->dArgs.release(); s->dbinMasks.release(); s->compInst.release();
   for(auto& g : s->graphs) (void)hipGraphExecDestroy(g.second);
   s->graphs.clear();
@@ -1032,6 +1033,7 @@ static int mgs_scene_commit_impl(MgsScene s, int shFormat, int rgbaFormat)
   if((rc = s->idsSlot.ensure(slots))) return rc;
   if((rc = s->slotCount.ensure(parts))) return rc;
   if((rc = s->partSkip.ensure(parts))) return rc;
+  if((rc = s->partR.ensure(parts))) return rc;
   HIPCHK(hipMemset(s->partSkip.p, 0, parts * sizeof(uint32_t)));
   if((rc = s->keysA.ensure(total))) return rc;
   if((rc = s->idsA.ensure(total))) return rc;
@@ -1692,7 +1694,7 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     // the frame's first kernel and zeroes them on the way.
     static_assert(sizeof(SortPlan) % 4 == 0 && sizeof(FrameCounters) % 4 == 0, "word-sized state");
     if(F.partitionCull && s->totalParts > 0)
-      launchPartitionCull(st, A, s->dArgs.p, s->partSkip.p, reinterpret_cast<uint32_t*>(ctr), (uint32_t)(sizeof(FrameCounters) / 4),
+      launchPartitionCull(st, A, s->dArgs.p, s->partSkip.p, s->partR.p, reinterpret_cast<uint32_t*>(ctr), (uint32_t)(sizeof(FrameCounters) / 4),
                           reinterpret_cast<uint32_t*>(planK), (uint32_t)(2 * sizeof(SortPlan) / 4),
                           reinterpret_cast<uint32_t*>(s->ranges.p), 2u * nTiles);
     else
@@ -1706,7 +1708,8 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
                        F.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride);
     else
       launchProject(st, A, s->dArgs.p, true, ctr, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p,
-                    s->rect.p, F.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride, kRemap ? planK : nullptr);
+                    s->rect.p, F.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride, kRemap ? planK : nullptr,
+                    F.partitionCull ? s->partR.p : nullptr);
     if(withEvents) HIPCHK(hipEventRecord(fev[1], st));
     static const bool kFuseRect = [] { const char* e = std::getenv("MGS_FUSE_RECT"); return e ? std::atoi(e) != 0 : false; }();  // measured: +43 us in the scatter for -17 us in the count kernel
     const bool direct0 = directBinningSupported(F.binsX, F.binsY);
@@ -2400,13 +2403,14 @@ int mgs_sort_keys(MgsScene s, const MgsFrameParams* p, MgsSortOut* out)
   HIPCHK(hipMemcpyAsync(s->dArgs.p, &A, offsetof(FrameArgs, inst) + (size_t)A.f.nInstances * sizeof(InstanceConst), hipMemcpyHostToDevice, st));
   HIPCHK(hipEventRecord(s->ev[0], st));
   if(A.f.partitionCull && s->totalParts > 0)
-    launchPartitionCull(st, A, s->dArgs.p, s->partSkip.p, reinterpret_cast<uint32_t*>(s->ctr.p),
+    launchPartitionCull(st, A, s->dArgs.p, s->partSkip.p, s->partR.p, reinterpret_cast<uint32_t*>(s->ctr.p),
                         (uint32_t)(sizeof(FrameCounters) / 4), reinterpret_cast<uint32_t*>(s->plans.p),
                         (uint32_t)(2 * sizeof(SortPlan) / 4), nullptr, 0u);
   else
     launchFrameInit(st, s->ctr.p, &s->plans.p[0], &s->plans.p[1], s->ranges.p, 0);
   launchProject(st, A, s->dArgs.p, false, s->ctr.p, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p, s->rect.p,
-                A.f.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride, kRemap ? &s->plans.p[0] : nullptr);
+                A.f.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride, kRemap ? &s->plans.p[0] : nullptr,
+                A.f.partitionCull ? s->partR.p : nullptr);
   HIPCHK(hipEventRecord(s->ev[1], st));
   keySort(s, st, false, kRemap);
   HIPCHK(hipEventRecord(s->ev[2], st));
