@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 1
+#define MGS_ABI_VERSION 2 /* 2: MgsFrameParams grew the 3DGUT fields; loader, strip-exchange and debug entry points added */
 
 typedef enum MgsStatus {
   MGS_OK              = 0,

@@ -373,7 +373,7 @@ static int guarded(const char* what, Fn&& fn) noexcept
 extern "C" {
 
 const char* mgs_last_error(void) { return lastError(); }
-const char* mgs_version(void) { return "mgs 0.1 (gfx950, ABI 1)"; }
+const char* mgs_version(void) { return "mgs 0.2 (gfx950, ABI 2)"; }
 
 static int mgs_splatset_load_impl(const char* path, MgsSplatSet* out);
 int mgs_splatset_load(const char* path, MgsSplatSet* out)
