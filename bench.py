@@ -49,7 +49,7 @@ def composite_roofline(ms, alg_bytes, world, N, args):
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", PMC_SQ_FILE)))
         if (world == 1 and N == 5_830_000 and args.instances == 1 and ms > 0 and (args.width, args.height) == (1920, 1080)
-                and args.scene == "garden" and not args.alpha_sum and args.pipeline == 0):
+                and args.scene == "garden" and not args.alpha_sum and args.pipeline == 0 and not args.ply):
             busy = pj["k_composite"]["SQ_ACTIVE_INST_VALU"] * 4.0
             out["valu_busy_quad_cycles_per_launch"] = pj["k_composite"]["SQ_ACTIVE_INST_VALU"]
             out["valu_insts_per_launch"] = pj["k_composite"]["SQ_INSTS_VALU"]
@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3, 4],
                     help="shorthand for the BASELINE.json configs: 1 train-sized 1080p, 2 garden-sized 1080p (the default), "
                          "3 garden-sized 3840x2160, 4 eight garden instances (46.6 M splats) 1080p")
+    ap.add_argument("--ply", default=None, help="render this .ply / .spz / .splat (e.g. the real Mip-NeRF360 garden.ply) instead of the "
+                    "synthetic stand-in; same code path, `data` says so")
     ap.add_argument("--scene", default="garden", choices=["garden", "fog", "sparse"],
                     help="garden: syn_garden (SURVEY.md 8d, the benchmark workload); fog: the same splats with opacity logits "
                          "shifted to mean -3 (low opacity: regions saturate late or never, the compositor's hard regime); "
@@ -123,15 +125,24 @@ def main():
 
     W, H, N = args.width, args.height, args.splats
     t0 = time.time()
-    sc = synth.make_scene(N, seed=0xC0FFEE + 2)  # syn_garden; identical on every rank
-    if args.scene == "fog":
+    if args.ply:
+        ss = mgs.SplatSet.load(args.ply)
+        a = ss.arrays()
+        N = args.splats = int(a["count"])
+        sc = {"positions": a["positions"].reshape(-1, 3)}  # the CPU baseline needs the centres only
+    else:
+        sc = synth.make_scene(N, seed=0xC0FFEE + 2)  # syn_garden; identical on every rank
+    if args.ply:
+        pass
+    elif args.scene == "fog":
         sc["opacity"] = (sc["opacity"] - 2.5).astype(np.float32)  # logit mean -0.5 -> -3
     elif args.scene == "sparse":
         r = np.linalg.norm(sc["positions"], axis=1)
         keep = (r >= 4.0) | (np.random.default_rng(7).random(N) < 0.10)
         sc = {k: np.ascontiguousarray(v[keep]) for k, v in sc.items()}
         N = args.splats = int(keep.sum())
-    ss = mgs.SplatSet.from_arrays(**sc)
+    if not args.ply:
+        ss = mgs.SplatSet.from_arrays(**sc)
     K = max(1, args.inflight)
     scenes, streams = [], []
     for _ in range(K):
@@ -291,11 +302,16 @@ def main():
         if K == 1:
             ref_scene.close()
         fence()
+    # one event per frame end (on the frame's own stream): the intervals between consecutive completions give the
+    # p50 / p95 of the frame time as a consumer sees it; 1 us of host work per frame
+    done_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     t1 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+        done_ev[i].record(streams[(args.warmup + i) % K])
     fence()
     elapsed = time.perf_counter() - t1
+    intervals = np.array([done_ev[i].elapsed_time(done_ev[i + 1]) for i in range(args.steps - 1)], np.float64) if args.steps > 2 else np.zeros(1)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -397,7 +413,7 @@ def main():
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
         if (dom_name in pj["kernels"] and world == 1 and N == 5_830_000 and args.instances == 1 and args.scene == "garden"
-                and args.pipeline == 0 and (W, H) == (1920, 1080)):
+                and args.pipeline == 0 and (W, H) == (1920, 1080) and not args.ply):
             traffic = pj["kernels"][dom_name]["traffic_bytes_per_launch_corrected"]
     except Exception:
         pass
@@ -414,10 +430,10 @@ def main():
         "scaling": "strong" if world > 1 else "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic" if not args.ply else f"file:{os.path.basename(args.ply)}",
         "frames_in_flight": K,
         "submission": "per-stage events + plain launches" if args.stage_events else "hipGraph replay (one upload + one graph launch per frame)",
-        "config": {"workload": f"syn_garden N={N} x {args.instances} instance(s) SH deg 3, storage sh/rgba format {args.sh_format}/{args.rgba_format}, "
+        "config": {"workload": f"{'syn_garden' if not args.ply else os.path.basename(args.ply)} N={N} x {args.instances} instance(s) SH deg 3, storage sh/rgba format {args.sh_format}/{args.rgba_format}, "
                                f"{W}x{H}, 64-pose orbit r=4 h=1.5 fov60, GPU radix sort, cull at dist (configs[2])"
                                + ("" if args.scene == "garden" else f", scene variant `{args.scene}`") + (", additive alpha (no early termination)" if args.alpha_sum else "")
                                + (", 3DGUT pipeline" if args.pipeline == 1 else ""),
@@ -430,6 +446,9 @@ def main():
         "visible_splats": {"frustum": Vf, "sorted": Vs, "tile_pairs": D, "shaded": shaded, "list_entries_scanned": scanned},
         "stage_ms": {STAGES[j]: float(stage_ms[j]) for j in range(6)},
         "stage_ms_single_stream": {STAGES[j]: float(calib_ms[j]) for j in range(6)},
+        "frame_interval_ms_percentiles": {"p50": float(np.percentile(intervals, 50)), "p95": float(np.percentile(intervals, 95)),
+                                          "mean": float(intervals.mean()), "max": float(intervals.max()),
+                                          "note": "time between consecutive frame completions in the timed region (HIP events at each frame's end)"},
         "frame_span_ms_percentiles": {"p50": float(np.percentile(st[:, 5], 50)), "p95": float(np.percentile(st[:, 5], 95)),
                                       "min": float(st[:, 5].min()), "max": float(st[:, 5].max())},
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
