@@ -49,7 +49,7 @@ def composite_roofline(ms, alg_bytes, world, N, args):
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", PMC_SQ_FILE)))
         if (world == 1 and N == 5_830_000 and args.instances == 1 and ms > 0 and (args.width, args.height) == (1920, 1080)
-                and args.scene == "garden" and not args.alpha_sum and args.pipeline == 0 and not args.ply):
+                and args.scene == "garden" and not args.alpha_sum and args.pipeline == 0 and not args.ply and not args.stochastic):
             busy = pj["k_composite"]["SQ_ACTIVE_INST_VALU"] * 4.0
             out["valu_busy_quad_cycles_per_launch"] = pj["k_composite"]["SQ_ACTIVE_INST_VALU"]
             out["valu_insts_per_launch"] = pj["k_composite"]["SQ_INSTS_VALU"]
@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--alpha-sum", action="store_true", help="MGS_ALPHA_SUM: the reference's default additive alpha "
                     "(gaussian_splatting.cpp:2083-2084); disables early termination")
     ap.add_argument("--pipeline", type=int, default=0, help="0 3DGS (benchmark), 1 3DGUT")
+    ap.add_argument("--stochastic", action="store_true", help="MGS_SORT_STOCHASTIC (stochastic splats, a new frame_sample_id per frame) "
+                    "instead of the sorted alpha blend; a secondary number, never the headline")
+    ap.add_argument("--dof", type=float, default=0.0, help="3DGUT only: depth of field with this aperture (focus distance 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=3, help="frames in flight per GPU (each on its own HIP stream with "
                     "its own working buffers); >1 overlaps one frame's tails/launch gaps/all-gather with the next frame")
@@ -173,6 +176,11 @@ def main():
         p.collect_timings = 2 if args.stage_events else 0
         p.alpha_mode = capi.ALPHA_SUM if args.alpha_sum else capi.ALPHA_COVERAGE
         p.pipeline = args.pipeline
+        if args.stochastic:
+            p.sort_mode = capi.SORT_STOCHASTIC
+            p.frame_sample_id = i
+        if args.dof > 0.0:
+            p.dof_mode, p.focus_dist, p.aperture, p.frame_sample_id = capi.DOF_FIXED_FOCUS, 3.0, args.dof, i
         poses.append(p)
     tiles_y = multigpu.tile_rows(H)
     bounds = [multigpu.strip_rows(H, world, r)[0] for r in range(world)] + [tiles_y]  # equal strips
@@ -413,7 +421,7 @@ def main():
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
         if (dom_name in pj["kernels"] and world == 1 and N == 5_830_000 and args.instances == 1 and args.scene == "garden"
-                and args.pipeline == 0 and (W, H) == (1920, 1080) and not args.ply):
+                and args.pipeline == 0 and (W, H) == (1920, 1080) and not args.ply and not args.stochastic):
             traffic = pj["kernels"][dom_name]["traffic_bytes_per_launch_corrected"]
     except Exception:
         pass
@@ -436,7 +444,8 @@ def main():
         "config": {"workload": f"{'syn_garden' if not args.ply else os.path.basename(args.ply)} N={N} x {args.instances} instance(s) SH deg 3, storage sh/rgba format {args.sh_format}/{args.rgba_format}, "
                                f"{W}x{H}, 64-pose orbit r=4 h=1.5 fov60, GPU radix sort, cull at dist (configs[2])"
                                + ("" if args.scene == "garden" else f", scene variant `{args.scene}`") + (", additive alpha (no early termination)" if args.alpha_sum else "")
-                               + (", 3DGUT pipeline" if args.pipeline == 1 else ""),
+                               + (", 3DGUT pipeline" if args.pipeline == 1 else "") + (", stochastic splats" if args.stochastic else "")
+                               + (f", depth of field aperture {args.dof}" if args.dof > 0.0 else ""),
                    "partition": "single GPU" if world == 1 else
                    f"{world} tile-row strips of every frame ({'equal' if args.equal_strips else 'cost-balanced'} rows {bounds}) + strip exchange: {gather_mode}"},
         "alternate_frames": alt_out,
@@ -481,7 +490,7 @@ def main():
     }
 
     if (rank == 0 and world == 1 and not args.ply and args.scene == "garden" and args.pipeline == 0 and args.instances == 1
-            and args.splats == 5_830_000 and (W, H) == (1920, 1080) and args.sh_format == 0 and args.rgba_format == 0):
+            and not args.stochastic and args.splats == 5_830_000 and (W, H) == (1920, 1080) and args.sh_format == 0 and args.rgba_format == 0):
         # parity of THIS run's frames against the CPU oracle (SURVEY.md 8d "PSNR / max-abs vs oracle on 4 poses"): the oracle's
         # answers for the benchmark scene are the committed fixture tests/golden/full_size_garden.npz (sorted-stream hashes
         # + 256x256 crops, generator next to it) — data, not code: the oracle itself is not touched here

@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 2 /* 2: MgsFrameParams grew the 3DGUT fields; loader, strip-exchange and debug entry points added */
+#define MGS_ABI_VERSION 3 /* 2: MgsFrameParams grew the 3DGUT fields; loader, strip-exchange and debug entry points added;
+                            3: stochastic splats, depth of field, temporal accumulation (MgsFrameParams 256 -> 288 bytes) */
 
 typedef enum MgsStatus {
   MGS_OK              = 0,
@@ -43,7 +44,14 @@ typedef enum MgsStatus {
  * SplatSetVk::initDataStorage(shFormat, rgbaFormat) (src/splat_set_vk.h:112) */
 enum { MGS_FORMAT_FLOAT32 = 0, MGS_FORMAT_FLOAT16 = 1, MGS_FORMAT_UINT8 = 2 };
 /* sorting methods — shaders/shaderio.h SORTING_* / parameters.h:182 */
-enum { MGS_SORT_GPU_RADIX = 0, MGS_SORT_CPU_ASYNC = 1 };
+enum { MGS_SORT_GPU_RADIX = 0, MGS_SORT_CPU_ASYNC = 1,
+       /* SORTING_STOCHASTIC_SPLAT (shaderio.h:27; threedgs_raster.frag.slang:265-290, threedgut_raster.frag.slang:150-172):
+        * every fragment is accepted with probability alpha and written opaque, the depth test keeps the nearest accepted
+        * one.  The reference skips the sort and lets the depth buffer resolve; here the sorted per-bin lists are walked
+        * nearest first and the first accepted fragment ends the pixel (same winner, ties aside). */
+       MGS_SORT_STOCHASTIC = 3 };
+enum { MGS_DOF_DISABLED = 0, MGS_DOF_FIXED_FOCUS = 1 }; /* shaderio.h:136-138; DOF_AUTO_FOCUS picks the distance under the UI's
+                                                           cursor and then behaves as FIXED_FOCUS: pass that distance */
 /* frustum culling — shaders/shaderio.h:84-86 / parameters.h:184 */
 enum { MGS_CULL_NONE = 0, MGS_CULL_AT_DIST = 1, MGS_CULL_AT_RASTER = 2 };
 /* colour target — src/gaussian_splatting.h:338-340 (RGBA16F default, RGBA32F optional) */
@@ -180,6 +188,18 @@ typedef struct MgsFrameParams {
                                    field of view from proj[5] */
   float   alpha_clamp;          /* 3DGUT: default 0.99 (shaderio.h:271) */
   float   kernel_min_response;  /* 3DGUT: default 0.0113 (parameters.h:216) */
+  /* ---- stochastic paths (ABI 3).  Random numbers: nvshaders/random.h.slang (xxhash32, pcg, rand) of nvpro_core2, which is
+   * not part of the reference tree; restated from the published file (csrc/kernels_common.h). */
+  int32_t dof_mode;             /* 3DGUT only: MGS_DOF_* — thin-lens perturbation of each pixel's ray, one sample per frame
+                                   (threedgut_raster.frag.slang:104-109, cameras.h.slang:85-108) */
+  float   focus_dist;           /* default 1.3   (shaderio.h:278) */
+  float   aperture;             /* default 0.001 (shaderio.h:279) */
+  int32_t frame_sample_id;      /* frameInfo.frameSampleId (shaderio.h:275): seeds the per-pixel random numbers of DoF and of
+                                   MGS_SORT_STOCHASTIC; the caller counts it up while the view stands still
+                                   (gaussian_splatting.cpp:3040-3075) */
+  int32_t temporal_sampling;    /* 0/1 (post.comp.slang:29-43): the frame handed back is the running mean of the samples
+                                   0..frame_sample_id of this scene (sample 0 restarts it); kept in fp32 */
+  int32_t reserved_[3];
 } MgsFrameParams;
 
 void mgs_frame_params_default(MgsFrameParams* p); /* fills the defaults cited above */

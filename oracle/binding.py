@@ -19,7 +19,8 @@ class OrcFrame(C.Structure):
                 ("frustum_culling", C.c_int), ("target_fp16", C.c_int), ("ms_antialiasing", C.c_int),
                 ("size_culling", C.c_int), ("size_culling_min_pixels", C.c_float), ("debug_flags", C.c_int),
                 ("camera_model", C.c_int), ("extent_method", C.c_int), ("fov_rad", C.c_float), ("alpha_clamp", C.c_float),
-                ("kernel_min_response", C.c_float)]
+                ("kernel_min_response", C.c_float), ("stochastic", C.c_int), ("dof_mode", C.c_int), ("focus_dist", C.c_float),
+                ("aperture", C.c_float), ("frame_sample_id", C.c_int)]
 
 
 class OrcInstance(C.Structure):
@@ -166,7 +167,8 @@ def make_instances(prepared_and_transforms):
 def make_frame(view, proj, camera_pos, width, height, splat_scale=1.0, frustum_dilation=0.2,
                alpha_cull=1.0 / 255.0, sh_degree=3, front_to_back=0, frustum_culling=1, target_fp16=0,
                ms_antialiasing=0, debug_flags=0, size_culling=0, size_culling_min_pixels=1.0,
-               camera_model=0, extent_method=1, fov_rad=None, alpha_clamp=0.99, kernel_min_response=0.0113):
+               camera_model=0, extent_method=1, fov_rad=None, alpha_clamp=0.99, kernel_min_response=0.0113,
+               stochastic=0, dof_mode=0, focus_dist=1.3, aperture=0.001, frame_sample_id=0):
     f = OrcFrame()
     v = f32(view).T.reshape(-1)
     p = f32(proj).T.reshape(-1)
@@ -184,7 +186,31 @@ def make_frame(view, proj, camera_pos, width, height, splat_scale=1.0, frustum_d
     # fovRad of the perspective matrix (what cameraManip->getRadFov() returns for the camera that produced proj)
     f.fov_rad = float(fov_rad) if fov_rad is not None else float(2.0 * np.arctan(1.0 / abs(float(p[5]))))
     f.alpha_clamp, f.kernel_min_response = alpha_clamp, kernel_min_response
+    f.stochastic, f.dof_mode, f.focus_dist, f.aperture, f.frame_sample_id = stochastic, dof_mode, focus_dist, aperture, frame_sample_id
     return f
+
+
+def xxhash32(x, y, z):
+    L = lib()
+    L.orc_xxhash32.restype = C.c_uint32
+    return int(L.orc_xxhash32(C.c_uint32(x), C.c_uint32(y), C.c_uint32(z)))
+
+
+def rand(seed):
+    """returns (value in [0,1), next seed)"""
+    L = lib()
+    L.orc_rand.restype = C.c_float
+    s = C.c_uint32(seed)
+    v = float(L.orc_rand(C.byref(s)))
+    return v, int(s.value)
+
+
+def post_accumulate(main_image, aux1, frame_sample_id):
+    """in place on main_image (float32)"""
+    m = np.ascontiguousarray(main_image, np.float32)
+    a = np.ascontiguousarray(aux1, np.float32)
+    lib().orc_post_accumulate(m.ctypes.data_as(F32P), a.ctypes.data_as(F32P), C.c_size_t(m.size), C.c_int(frame_sample_id))
+    return m
 
 
 def key_cull(frame, inst):

@@ -581,7 +581,44 @@ void orc_project(const OrcFrame* f, const OrcInstance* Ip, uint32_t i, OrcProjec
 // `win` (optional) = {x0, y0, x1, y1}: only pixels inside this inclusive window are evaluated, and `img` is then the
 // window's own [y1-y0+1][x1-x0+1][4] buffer.  The per-pixel arithmetic is the same either way; pixels are independent
 // given the draw order, so a windowed render equals the crop of the full one bit for bit.
-static uint64_t raster_one(const OrcFrame* f, const OrcProjected& P, float* img, const int* win = nullptr)
+// ---- nvshaders/random.h.slang (nvpro_core2, absent from the reference tree): restated from the published file ----------
+uint32_t orc_xxhash32(uint32_t x, uint32_t y, uint32_t z)
+{  // xxhash32 over a uint3 (Jarzynski & Olano, "Hash Functions for GPU Rendering"; shadertoy XlGcRh)
+  const uint32_t p0 = 2246822519u, p1 = 3266489917u, p2 = 668265263u, p3 = 374761393u;
+  uint32_t       h  = z + p3 + x * p1;
+  h                 = p2 * ((h << 17) | (h >> (32 - 17)));
+  h += y * p1;
+  h = p2 * ((h << 17) | (h >> (32 - 17)));
+  h = p0 * (h ^ (h >> 15));
+  h = p1 * (h ^ (h >> 13));
+  return h ^ (h >> 16);
+}
+static uint32_t pcg(uint32_t* state)
+{  // pcg-random.org, RXS-M-XS 32
+  const uint32_t prev = *state * 747796405u + 2891336453u;
+  const uint32_t word = ((prev >> ((prev >> 28u) + 4u)) ^ prev) * 277803737u;
+  *state              = prev;
+  return (word >> 22u) ^ word;
+}
+float orc_rand(uint32_t* seed)
+{  // a float in [0,1): the top 23 bits of pcg as the mantissa of a number in [1,2), minus one
+  const uint32_t r = pcg(seed);
+  const uint32_t b = 0x3f800000u | (r >> 9);
+  float          v;
+  std::memcpy(&v, &b, 4);
+  return v - 1.0f;
+}
+
+void orc_post_accumulate(float* main_image, const float* aux1, size_t n, int frame_sample_id)
+{  // post.comp.slang:37-43
+  const float a = 1.0f / (float)(frame_sample_id + 1);
+  for(size_t i = 0; i < n; ++i)
+    main_image[i] = main_image[i] + a * (aux1[i] - main_image[i]);  // lerp(main, aux1, a)
+}
+
+// `depth` (stochastic splats only): the depth attachment, cleared to 1; `gid` = the splat's global id
+static uint64_t raster_one(const OrcFrame* f, const OrcProjected& P, float* img, const int* win = nullptr, float* depth = nullptr,
+                           uint32_t gid = 0)
 {
   const int   W = f->width, H = f->height;
   const float ex = std::fabs(P.basis1[0]) + std::fabs(P.basis2[0]);
@@ -625,6 +662,26 @@ static uint64_t raster_one(const OrcFrame* f, const OrcProjected& P, float* img,
       if(opacity <= 1.0f / 255.0f)                            // :258-262
         continue;
       float* dst = img + ((size_t)(y - oy) * pitch + (x - ox)) * 4;
+      if(f->stochastic && depth)
+      {  // frag.slang:265-290: accept with probability `opacity`, write opaque; depth test LESS_OR_EQUAL + depth write.
+        // primitiveID: the quad (-1,-1),(1,-1),(1,1),(-1,1) is the triangles (0,2,1) and (2,0,3) (mesh.slang:158-159,193):
+        // triangle 0 holds u > v.  The index of the splat inside its mesh workgroup comes from an atomically compacted,
+        // unsorted list in the reference (not reproducible); restated as global id mod RASTER_MESH_WORKGROUP_SIZE (32).
+        uint32_t seed = orc_xxhash32((uint32_t)x, (uint32_t)y, (uint32_t)f->frame_sample_id);
+        seed          = orc_xxhash32(seed, gid, 2u * (gid & 31u) + (u > v ? 0u : 1u));
+        if(!(orc_rand(&seed) < opacity))
+          continue;  // discard
+        float& dz = depth[(size_t)(y - oy) * pitch + (x - ox)];
+        if(!(P.ndc_z <= dz))
+          continue;
+        dz     = P.ndc_z;
+        dst[0] = P.rgba[0];
+        dst[1] = P.rgba[1];
+        dst[2] = P.rgba[2];
+        dst[3] = 1.0f;
+        ++frags;
+        continue;
+      }
       if(f->front_to_back)
       {  // src rgb premultiplied (:303); C = Cs*(1-Ad) + Cd ; A = As*(1-Ad) + Ad
         const float oma = 1.0f - dst[3];
@@ -658,6 +715,9 @@ uint64_t orc_render_order(const OrcFrame* f, const OrcInstance* inst, int n_inst
   for(int k = 0; k < n_inst; ++k)
     offsets[k + 1] = offsets[k] + inst[k].count;
   uint64_t frags = 0, quads = 0;
+  std::vector<float> depth;
+  if(f->stochastic)
+    depth.assign((size_t)f->width * f->height, 1.0f);
   for(uint32_t s = 0; s < v; ++s)
   {
     const uint32_t g = ids[s];
@@ -669,7 +729,7 @@ uint64_t orc_render_order(const OrcFrame* f, const OrcInstance* inst, int n_inst
     if(!P.valid)
       continue;
     ++quads;
-    frags += raster_one(f, P, rgba_out);
+    frags += raster_one(f, P, rgba_out, nullptr, f->stochastic ? depth.data() : nullptr, g);
   }
   if(stats)
   {
@@ -960,6 +1020,26 @@ int orc_gut_fragment(const OrcFrame* f, const OrcInstance* I, const OrcGutProjec
     const float l = std::sqrt((t4[0] * t4[0] + t4[1] * t4[1]) + t4[2] * t4[2]);
     rd[0] = t4[0] / l; rd[1] = t4[1] / l; rd[2] = t4[2] / l;
   }
+  if(f->dof_mode != 0)
+  {  // frag.slang:104-109 + depthOfField, cameras.h.slang:85-108
+    uint32_t    seed = orc_xxhash32((uint32_t)(int)posx, (uint32_t)(int)posy, (uint32_t)f->frame_sample_id);
+    const float fp[3] = {rd[0] * f->focus_dist, rd[1] * f->focus_dist, rd[2] * f->focus_dist};
+    const float r1 = orc_rand(&seed) * 6.28318530717958647692f;  // M_TWO_PI
+    const float r2 = orc_rand(&seed) * f->aperture;
+    const float e1[4] = {1.f, 0.f, 0.f, 0.f}, e2[4] = {0.f, 1.f, 0.f, 0.f};
+    float       right[4], up[4];
+    mat4_mul_vec4(viewInv, e1, right);
+    mat4_mul_vec4(viewInv, e2, up);
+    const float c = std::cos(r1), sn = std::sin(r1), sq = std::sqrt(r2);
+    const float ap[3] = {(c * right[0] + sn * up[0]) * sq, (c * right[1] + sn * up[1]) * sq, (c * right[2] + sn * up[2]) * sq};
+    float       nd[3] = {fp[0] - ap[0], fp[1] - ap[1], fp[2] - ap[2]};
+    const float l = std::sqrt((nd[0] * nd[0] + nd[1] * nd[1]) + nd[2] * nd[2]);
+    for(int c3 = 0; c3 < 3; ++c3)
+    {
+      ro[c3] += ap[c3];
+      rd[c3] = nd[c3] / l;
+    }
+  }
   // model-space ray (:113-118)
   const float ro4[4] = {ro[0], ro[1], ro[2], 1.f};
   float       mo[4];
@@ -1010,6 +1090,9 @@ uint64_t orc_render_gut_order(const OrcFrame* f, const OrcInstance* inst, int n_
   for(int k = 0; k < n_inst; ++k)
     offsets[k + 1] = offsets[k] + inst[k].count;
   uint64_t frags = 0, quads = 0;
+  std::vector<float> gutDepth;
+  if(f->stochastic)
+    gutDepth.assign((size_t)W * H, 1.0f);
   for(uint32_t s = 0; s < v; ++s)
   {
     const uint32_t g = ids[s];
@@ -1041,6 +1124,23 @@ uint64_t orc_render_gut_order(const OrcFrame* f, const OrcInstance* inst, int n_
         if(!orc_gut_fragment(f, &inst[k], &P, x, y, &opacity))
           continue;
         float* dst = rgba_out + ((size_t)y * W + x) * 4;
+        if(f->stochastic)
+        {  // threedgut_raster.frag.slang:150-172 (same seed chain and depth state as the 3DGS fragment shader)
+          uint32_t seed = orc_xxhash32((uint32_t)x, (uint32_t)y, (uint32_t)f->frame_sample_id);
+          seed          = orc_xxhash32(seed, g, 2u * (g & 31u) + (u > w ? 0u : 1u));
+          if(!(orc_rand(&seed) < opacity))
+            continue;
+          float& dz = gutDepth[(size_t)y * W + x];
+          if(!(P.ndc_z <= dz))
+            continue;
+          dz     = P.ndc_z;
+          dst[0] = P.rgba[0];
+          dst[1] = P.rgba[1];
+          dst[2] = P.rgba[2];
+          dst[3] = 1.0f;
+          ++frags;
+          continue;
+        }
         if(f->front_to_back)
         {
           const float oma = 1.0f - dst[3];

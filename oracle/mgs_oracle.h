@@ -68,7 +68,21 @@ typedef struct OrcFrame {
   float fov_rad;              /* frameInfo.fovRad (gaussian_splatting.cpp:1168): fisheye focal + ray generation */
   float alpha_clamp;          /* shaderio.h:271, default 0.99 */
   float kernel_min_response;  /* KERNEL_MIN_RESPONSE, parameters.h:216, default 0.0113 */
+  /* ---- stochastic paths ---- */
+  int   stochastic;           /* STOCHASTIC_SPLAT (sortingMethod == SORTING_STOCHASTIC_SPLAT, shaderio.h:27): the render entry
+                                 points keep a depth buffer (LESS_OR_EQUAL, depth write on: gaussian_splatting.cpp:1386-1396,
+                                 2297-2298) and write accepted fragments opaque (frag.slang:265-290) */
+  int   dof_mode;             /* 3DGUT: DOF_MODE, 0 DOF_DISABLED / 1 DOF_FIXED_FOCUS (shaderio.h:136-138) */
+  float focus_dist, aperture; /* shaderio.h:278-279 */
+  int   frame_sample_id;      /* shaderio.h:275 */
 } OrcFrame;
+
+/* nvshaders/random.h.slang (nvpro_core2; NOT in the reference tree, fetched by its CMake): xxhash32(uint3), pcg, rand —
+ * restated from the published file, unpinned (no vectors of it exist here). */
+uint32_t orc_xxhash32(uint32_t x, uint32_t y, uint32_t z);
+float    orc_rand(uint32_t* seed);
+/* post.comp.slang:29-43: main = lerp(main, aux1, 1/(frame_sample_id+1)) over n floats */
+void     orc_post_accumulate(float* main_image, const float* aux1, size_t n, int frame_sample_id);
 
 typedef struct OrcInstance {
   const float* centers;  /* [count*3] */

@@ -31,7 +31,7 @@ def test_struct_layouts_match_header_sizes():
     # MgsFrameParams: 16+16+3 floats, 2 ints, 3 floats, 12 ints + 6 reserved
 
     import ctypes
-    assert ctypes.sizeof(capi.FrameParams) == 256
+    assert ctypes.sizeof(capi.FrameParams) == 288  # ABI 3: + dof_mode, focus_dist, aperture, frame_sample_id, temporal_sampling, 3 reserved
     assert ctypes.sizeof(capi.FrameOut) == 8 + 8 + 4 + 4 + 8 + 4 + 4 + 8 + 32
     assert ctypes.sizeof(capi.SortOut) == 32
     assert ctypes.sizeof(capi.SplatSetView) == 6 * 8 + 8 + 4 + 4

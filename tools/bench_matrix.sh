@@ -14,6 +14,10 @@ run fog_if1 --scene fog --steps 48 --warmup 8 --inflight 1
 run sparse --scene sparse
 run garden_alphasum --alpha-sum --steps 16 --warmup 4 --inflight 1
 run garden_3dgut --pipeline 1 --steps 32 --warmup 4 --inflight 1
+run garden_stoch --stochastic
+run garden_stoch_if1 --stochastic --inflight 1
+run garden_3dgut_stoch --pipeline 1 --stochastic --steps 32 --warmup 4 --inflight 1
+run garden_3dgut_dof --pipeline 1 --dof 0.02 --steps 32 --warmup 4 --inflight 1
 python - <<'PY'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/matrix_*.json")):

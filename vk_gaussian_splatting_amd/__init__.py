@@ -9,7 +9,7 @@ library or without a GPU raises.
 """
 from .capi import (MgsError, SplatSet, Scene, Loader, FrameParams, FrameOut, SortOut, lib_path, load_library,
                    camera_lookat_perspective, compute_transform,
-                   FORMAT_FLOAT32, FORMAT_FLOAT16, FORMAT_UINT8, SORT_GPU_RADIX, SORT_CPU_ASYNC,
+                   FORMAT_FLOAT32, FORMAT_FLOAT16, FORMAT_UINT8, SORT_GPU_RADIX, SORT_CPU_ASYNC, SORT_STOCHASTIC, DOF_DISABLED, DOF_FIXED_FOCUS,
                    CULL_NONE, CULL_AT_DIST, CULL_AT_RASTER, TARGET_RGBA16F, TARGET_RGBA32F,
                    ALPHA_COVERAGE, ALPHA_SUM)
 from . import synth

@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 FORMAT_FLOAT32, FORMAT_FLOAT16, FORMAT_UINT8 = 0, 1, 2
-SORT_GPU_RADIX, SORT_CPU_ASYNC = 0, 1
+SORT_GPU_RADIX, SORT_CPU_ASYNC, SORT_STOCHASTIC = 0, 1, 3
+DOF_DISABLED, DOF_FIXED_FOCUS = 0, 1
 CULL_NONE, CULL_AT_DIST, CULL_AT_RASTER = 0, 1, 2
 TARGET_RGBA16F, TARGET_RGBA32F, TARGET_RGBA8 = 0, 1, 2
 ALPHA_COVERAGE, ALPHA_SUM = 0, 1
@@ -44,7 +45,9 @@ class FrameParams(C.Structure):
                 ("surface_outputs", C.c_int32), ("depth_iso_threshold", C.c_float), ("cpu_lazy_sort", C.c_int32),
                 ("thin_particle_threshold", C.c_float), ("quantize_normals", C.c_int32),
                 ("pipeline", C.c_int32), ("camera_model", C.c_int32), ("extent_method", C.c_int32), ("fov_rad", C.c_float),
-                ("alpha_clamp", C.c_float), ("kernel_min_response", C.c_float)]
+                ("alpha_clamp", C.c_float), ("kernel_min_response", C.c_float),
+                ("dof_mode", C.c_int32), ("focus_dist", C.c_float), ("aperture", C.c_float),
+                ("frame_sample_id", C.c_int32), ("temporal_sampling", C.c_int32), ("reserved_", C.c_int32 * 3)]
 
 
 class FrameOut(C.Structure):

@@ -83,6 +83,13 @@ struct FrameConst
   float    gutFocal[2];            // pinhole: == focal; fisheye: (1,-1) * viewport / fovRad (gaussian_splatting.cpp:1243)
   float    gutMaxAngle;            // computeMaxAngle (threedgut_camera_models.h.slang:87-118)
   float    viewInv[16], projInv[16];  // glm::inverse (gaussian_splatting.cpp:1166,1200)
+  // stochastic splats (SORTING_STOCHASTIC_SPLAT, frag.slang:265-290) / depth of field (3DGUT, frag.slang:104-109) /
+  // temporal accumulation (post.comp.slang)
+  int32_t  stochastic;             // 1: binary accept/reject per fragment, the nearest accepted fragment is the pixel
+  int32_t  dofMode;                // 0 DOF_DISABLED, 1 DOF_FIXED_FOCUS (shaderio.h:136-138)
+  int32_t  frameSampleId;          // frameInfo.frameSampleId: seeds the per-pixel random numbers
+  int32_t  temporalSampling;       // 1: the frame is folded into the running mean of the samples 0..frameSampleId
+  float    focusDist, aperture;    // shaderio.h:278-279
 };
 
 struct FrameArgs

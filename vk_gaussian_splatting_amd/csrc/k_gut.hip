@@ -14,8 +14,8 @@
 // lists nearest-first like k_composite (one workgroup per 16x16 tile, one pixel per thread, records staged through
 // LDS in list order) and evaluates the particle response per fragment.  This pipeline is a "next" row: correct and
 // reasonably fast, not tuned like the 3DGS compositor.
-// Not built (stated in DESIGN.md): rolling shutter (untested in the reference), depth of field and stochastic splats
-// (their random numbers come from nvshaders/random.h.slang in the absent nvpro_core2), kernel degrees other than 2.
+// Depth of field and stochastic splats are the XT variant of the compositor (random numbers: kernels_common.h).
+// Not built (stated in DESIGN.md): rolling shutter (untested in the reference), kernel degrees other than 2.
 #include "kernels_common.h"
 #include "sh_eval.h"
 #include "sort_plan.h"
@@ -384,13 +384,15 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
 // ---- compositor: one workgroup per 16x16 tile, one pixel per thread -------------------------------------------------------
 constexpr int kGutBatch = 256;  // list entries scanned per round == staging capacity
 
-template <int SHF>
+// XT 1: the variant with depth of field (frag.slang:104-109, cameras.h.slang:85-108) and/or stochastic splats (:150-172)
+template <int SHF, int XT>
 __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restrict__ Ap, const uint2* __restrict__ ranges,
                                                        const uint32_t* __restrict__ valX, const uint32_t* __restrict__ valY,
                                                        const SortPlan* __restrict__ plan, const GutRec* __restrict__ rec,
                                                        void* __restrict__ outImage, int halfOut, FrameCounters* __restrict__ ctr)
 {
   __shared__ float4   s_r[kGutBatch][6];
+  __shared__ uint32_t s_gid[XT ? kGutBatch : 1];
   __shared__ uint32_t s_wc[4];
   __shared__ uint32_t s_live;
   const FrameConst& F = Ap->f;
@@ -436,6 +438,27 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
     dzw = Vi[2] * cx + Vi[6] * cy + Vi[10] * cz;
     const float l = rsqrtf(dxw * dxw + dyw * dyw + dzw * dzw);
     dxw *= l; dyw *= l; dzw *= l;
+  }
+  // depth of field: the ray leaves a random point of the lens and still passes through the focal point of the pinhole ray
+  float    lensX = 0.0f, lensY = 0.0f, lensZ = 0.0f;
+  uint32_t seedPx = 0u;
+  const bool stoch = XT && F.stochastic != 0 && !((F.debugFlags & 4) != 0);
+  if constexpr(XT != 0)
+  {
+    seedPx = rngXxhash32((uint32_t)px, (uint32_t)py, (uint32_t)F.frameSampleId);  // int(position.x), int(position.y), frameSampleId
+    if(F.dofMode != 0)
+    {
+      uint32_t    seed = seedPx;
+      const float r1 = rngRand(seed) * 6.28318530717958647692f, r2 = rngRand(seed) * F.aperture;
+      const float* Vi = F.viewInv;  // camRight = mul(float4(1,0,0,0), viewInverse), camUp = mul(float4(0,1,0,0), viewInverse)
+      const float c = cosf(r1), sn = sinf(r1), sq = sqrtf(r2);
+      lensX = (c * Vi[0] + sn * Vi[4]) * sq;
+      lensY = (c * Vi[1] + sn * Vi[5]) * sq;
+      lensZ = (c * Vi[2] + sn * Vi[6]) * sq;
+      float fx = dxw * F.focusDist - lensX, fy = dyw * F.focusDist - lensY, fz = dzw * F.focusDist - lensZ;
+      const float l = rsqrtf(fx * fx + fy * fy + fz * fz);
+      dxw = fx * l; dyw = fy * l; dzw = fz * l;
+    }
   }
   const bool  early   = F.alphaMode == 0;
   const bool  noGauss = (F.debugFlags & 4) != 0;
@@ -500,6 +523,8 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
       s_r[pos][3] = r3;
       s_r[pos][4] = r4;
       s_r[pos][5] = c5;
+      if constexpr(XT != 0)
+        s_gid[pos] = g;
     }
     if(t == 0)
       s_live = 0u;
@@ -518,12 +543,29 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
       const float gx = b0.x * dxw + b0.y * dyw + b0.z * dzw;
       const float gy = b0.w * dxw + b1.x * dyw + b1.y * dzw;
       const float gz = b1.z * dxw + b1.w * dyw + b2.x * dzw;
-      const float kx = gy * b2.w - gz * b2.z, ky = gz * b2.y - gx * b2.w, kz = gx * b2.z - gy * b2.y;
+      float rox = b2.y, roy = b2.z, roz = b2.w;
+      if constexpr(XT != 0)
+      {  // rayOrigin += randomAperturePos: canonical origin + B * offset
+        rox += b0.x * lensX + b0.y * lensY + b0.z * lensZ;
+        roy += b0.w * lensX + b1.x * lensY + b1.y * lensZ;
+        roz += b1.z * lensX + b1.w * lensY + b2.x * lensZ;
+      }
+      const float kx = gy * roz - gz * roy, ky = gz * rox - gx * roz, kz = gx * roy - gy * rox;
       const float dist2 = (kx * kx + ky * ky + kz * kz) / (gx * gx + gy * gy + gz * gz);
       const float resp  = __expf(-0.5f * dist2);                     // quadratic kernel, :127-131
       const float al    = fminf(F.alphaClamp, resp * c4.w);          // :263
       const bool  hit   = inQuad && (c4.w > F.alphaCull) && (al > (1.0f / 255.0f)) && (resp > F.kernelMinResponse) && T >= tMin;
-      const float op    = hit ? (noGauss ? 1.0f : al) : 0.0f;
+      float       op    = hit ? (noGauss ? 1.0f : al) : 0.0f;
+      if constexpr(XT != 0)
+      {
+        if(stoch)
+        {  // frag.slang:153-158; primitive id as in the 3DGS compositor (k_raster.hip): 2 * (id mod 32) + triangle
+          const uint32_t gid = s_gid[j];
+          const float    qu = ddx * a0.z + ddy * a0.w, qv = ddx * a1.x + ddy * a1.y;
+          uint32_t       h  = rngXxhash32(seedPx, gid, 2u * (gid & 31u) + (qu > qv ? 0u : 1u));
+          op                = (hit && rngRand(h) < op) ? 1.0f : 0.0f;
+        }
+      }
       const float wgt   = op * T;
       cr += wgt * c4.x;
       cg += wgt * c4.y;
@@ -587,15 +629,25 @@ void launchCompositeGut(hipStream_t stream, const FrameArgs& A, const FrameArgs*
   const int tiles = A.f.tilesX * (A.f.stripRow1 - A.f.stripRow0);
   if(tiles <= 0)
     return;
-#define MGS_LAUNCH(SHF)                                                                                                          \
-  hipLaunchKernelGGL((k_composite_gut<SHF>), dim3(tiles), dim3(256), 0, stream, dArgs, ranges, valX, valY, planPairs, rec, image, \
+  const bool extras = A.f.dofMode != 0 || A.f.stochastic != 0;
+#define MGS_LAUNCH(SHF, XT)                                                                                                          \
+  hipLaunchKernelGGL((k_composite_gut<SHF, XT>), dim3(tiles), dim3(256), 0, stream, dArgs, ranges, valX, valY, planPairs, rec, image, \
                      halfOut, ctr)
+#define MGS_LAUNCH_X(SHF)  \
+  do                       \
+  {                        \
+    if(extras)             \
+      MGS_LAUNCH(SHF, 1);  \
+    else                   \
+      MGS_LAUNCH(SHF, 0);  \
+  } while(0)
   if(shFormat == 0)
-    MGS_LAUNCH(0);
+    MGS_LAUNCH_X(0);
   else if(shFormat == 1)
-    MGS_LAUNCH(1);
+    MGS_LAUNCH_X(1);
   else
-    MGS_LAUNCH(2);
+    MGS_LAUNCH_X(2);
+#undef MGS_LAUNCH_X
 #undef MGS_LAUNCH
 }
 

@@ -621,7 +621,9 @@ constexpr int kCmpCap     = MGS_CMP_CAP;                // LDS batch capacity (r
 constexpr int kCmpGo      = MGS_CMP_GO;                // blend as soon as this many records are staged (<= kCmpCap-256)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// MODE bit 0: additive alpha (no early-out), bit 1: DISABLE_OPACITY_GAUSSIAN, bit 2: surface side outputs; SHF: SH storage format
+// MODE bit 0: additive alpha (no early-out), bit 1: DISABLE_OPACITY_GAUSSIAN, bit 2: surface side outputs,
+// bit 3: stochastic splats (frag.slang:265-290: a fragment is accepted with probability alpha and written opaque; the
+// depth test keeps the nearest accepted one == the first accepted one of the nearest-first list); SHF: SH storage format
 // World-space normal of one splat as the mesh shader emits it with NEED_SURFACE_INFO (threedgs_raster.mesh.slang:209-235):
 // particle = (centre, exp(scale), normalised quaternion) (threedgrt.h.slang:42-48); max-density-plane normal
 // n = Sigma^-1 (camera - centre) with the thin-particle cases (threedgrt.h.slang:358-419); to world space by the
@@ -763,6 +765,16 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
   constexpr bool early   = (MODE & 1) == 0;
   constexpr bool noGauss = (MODE & 2) != 0;
   constexpr bool surf    = (MODE & 4) != 0;  // FTB side outputs: picked depth + the splat that set it (frag.slang:320-349)
+  constexpr bool stoch   = (MODE & 8) != 0;
+  // frag.slang:271: seed = xxhash32(uint3(fragCoord.xy, frameSampleId)); the sample id changes every frame: read through
+  // the per-frame constants, not the by-value arguments a captured graph freezes
+  uint32_t seedPx0 = 0u, seedPx1 = 0u;
+  if constexpr(stoch)
+  {
+    const uint32_t sid = (uint32_t)Ap->f.frameSampleId;
+    seedPx0            = rngXxhash32((uint32_t)px, (uint32_t)py, sid);
+    seedPx1            = rngXxhash32((uint32_t)px + 8u, (uint32_t)py, sid);
+  }
   v2f            pickZ   = {0.0f, 0.0f};
   uint32_t       pickId0 = 0xFFFFFFFFu, pickId1 = 0xFFFFFFFFu;
   v2f            nx = {0.f, 0.f}, ny = {0.f, 0.f}, nz = {0.f, 0.f};  // integrated normal (surface outputs)
@@ -997,6 +1009,17 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
           v2f ah;  // frag.slang:242-245,258-262, predicated
           ah.x = (q.x <= kQMax && al.x > (1.0f / 255.0f) && T.x >= tMin) ? al.x : 0.0f;
           ah.y = (q.y <= kQMax && al.y > (1.0f / 255.0f) && T.y >= tMin) ? al.y : 0.0f;
+          if constexpr(stoch)
+          {  // frag.slang:272-276: seed = xxhash32(uint3(seed, splatId, primitiveID)); accept iff rand(seed) < opacity.
+            // primitiveID = 2 * (index of the splat in its mesh workgroup of 32) + triangle; the quad (-1,-1),(1,-1),(1,1),(-1,1)
+            // is split along (-1,-1)-(1,1): triangle 0 = (0,2,1) holds u > v (mesh.slang:158-159,193).  The reference's index
+            // comes from an unsorted, atomically compacted list (not reproducible); ours is the global id modulo 32.
+            const uint32_t gid = s_g[j], prim = 2u * (gid & 31u);
+            uint32_t       h0 = rngXxhash32(seedPx0, gid, prim + (s1.x > u1.x ? 0u : 1u));
+            uint32_t       h1 = rngXxhash32(seedPx1, gid, prim + (s1.y > u1.y ? 0u : 1u));
+            ah.x = (ah.x > 0.0f && rngRand(h0) < ah.x) ? 1.0f : 0.0f;
+            ah.y = (ah.y > 0.0f && rngRand(h1) < ah.y) ? 1.0f : 0.0f;
+          }
           const v2f wgt = ah * T;
           cr += wgt * c1.x;
           cg += wgt * c1.y;
@@ -1143,7 +1166,11 @@ void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges
   // a strip have empty regions that exit at once)
   const int nBins   = F.binsX * F.binsY;
   const int per     = ((nBins + 7) / 8) * (1 << (F.binShiftX - 1 + F.binShiftY));  // workgroups per XCD
-  const int mode = (F.alphaMode != 0 ? 1 : 0) | ((F.debugFlags & 4) ? 2 : 0) | (F.surfaceOutputs ? 4 : 0);
+  int mode = (F.alphaMode != 0 ? 1 : 0) | ((F.debugFlags & 4) ? 2 : 0) | (F.surfaceOutputs ? 4 : 0);
+  // stochastic splats: opaque writes, so the alpha mode is irrelevant; with the opacity gaussian disabled every fragment is
+  // accepted (alpha 1) and the plain path already yields the nearest fragment
+  if(F.stochastic && !(F.debugFlags & 4))
+    mode = 8 | (F.surfaceOutputs ? 4 : 0);
   CompositeArgs C;
   std::memset(&C, 0, sizeof(C));
   C.width = F.width; C.height = F.height; C.tilesX = F.tilesX;
@@ -1180,7 +1207,9 @@ void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges
     case 4: MGS_CMP_FMT(4); break;
     case 5: MGS_CMP_FMT(5); break;
     case 6: MGS_CMP_FMT(6); break;
-    default: MGS_CMP_FMT(7); break;
+    case 7: MGS_CMP_FMT(7); break;
+    case 8: MGS_CMP_FMT(8); break;
+    default: MGS_CMP_FMT(12); break;
   }
 #undef MGS_CMP_FMT
 #undef MGS_CMP

@@ -145,4 +145,34 @@ __device__ __forceinline__ float divExact(float a, float b)
   return a / b;
 }
 
+// ---- random numbers of the stochastic paths --------------------------------------------------------------------
+// The reference takes xxhash32 / pcg / rand from nvshaders/random.h.slang of nvpro_core2, a dependency that is not in
+// the reference tree (CMake fetches it).  Restated from the published file: xxhash32 over a uint3 (Jarzynski & Olano,
+// "Hash Functions for GPU Rendering", the shadertoy XlGcRh variant), the PCG output function (pcg-random.org, RXS-M-XS
+// 32), and rand() = the top 23 bits of pcg as the mantissa of a float in [1,2) minus 1.  Unpinned: there are no vectors
+// of that file here; the oracle restates the same three functions and the tests check oracle == device bit for bit.
+__device__ __host__ __forceinline__ uint32_t rngXxhash32(uint32_t px, uint32_t py, uint32_t pz)
+{
+  const uint32_t p0 = 2246822519u, p1 = 3266489917u, p2 = 668265263u, p3 = 374761393u;
+  uint32_t       h  = pz + p3 + px * p1;
+  h                 = p2 * ((h << 17) | (h >> 15));
+  h += py * p1;
+  h = p2 * ((h << 17) | (h >> 15));
+  h = p0 * (h ^ (h >> 15));
+  h = p1 * (h ^ (h >> 13));
+  return h ^ (h >> 16);
+}
+__device__ __host__ __forceinline__ uint32_t rngPcg(uint32_t& state)
+{
+  const uint32_t prev = state * 747796405u + 2891336453u;
+  const uint32_t word = ((prev >> ((prev >> 28u) + 4u)) ^ prev) * 277803737u;
+  state               = prev;
+  return (word >> 22u) ^ word;
+}
+__device__ __forceinline__ float rngRand(uint32_t& seed)
+{
+  const uint32_t r = rngPcg(seed);
+  return __uint_as_float(0x3f800000u | (r >> 9)) - 1.0f;
+}
+
 }  // namespace mgs

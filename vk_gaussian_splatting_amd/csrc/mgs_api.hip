@@ -269,6 +269,7 @@ struct MgsScene_t
   DevBuf<float>         surfDepth;   // FTB side outputs of the last frame rendered with surface_outputs
   DevBuf<uint32_t>      surfId;
   DevBuf<float4>        surfNormal;
+  DevBuf<float4>        accum;       // temporal accumulation (post.comp.slang): running mean of the frame samples, fp32
   bool                  haveSurface = false;
   DevBuf<SplatRec>      rec;
   DevBuf<GutRec>        recGut;  // 3DGUT records (96 B per splat), allocated by the first 3DGUT frame
@@ -373,7 +374,7 @@ static int guarded(const char* what, Fn&& fn) noexcept
 extern "C" {
 
 const char* mgs_last_error(void) { return lastError(); }
-const char* mgs_version(void) { return "mgs 0.2 (gfx950, ABI 2)"; }
+const char* mgs_version(void) { return "mgs 0.3 (gfx950, ABI 3)"; }
 
 static int mgs_splatset_load_impl(const char* path, MgsSplatSet* out);
 int mgs_splatset_load(const char* path, MgsSplatSet* out)
@@ -706,7 +707,7 @@ void mgs_scene_destroy(MgsScene s)
   s->keysB.release(); s->idsB.release(); s->rect.release(); s->partHist.release(); s->blockCount.release();
   s->rec.release(); s->recGut.release(); s->pairKey0.release(); s->pairVal0.release(); s->pairKey1.release(); s->pairVal1.release();
   s->sortedRect.release(); s->splatOffset.release(); s->chunkStart.release(); s->partSkip.release(); s->partR.release();
-  s->surfDepth.release(); s->surfId.release(); s->surfNormal.release(); s->dArgs.release(); s->dbinMasks.release(); s->compInst.release();
+  s->surfDepth.release(); s->surfId.release(); s->surfNormal.release(); s->accum.release(); s->dArgs.release(); s->dbinMasks.release(); s->compInst.release();
   for(auto& g : s->graphs) (void)hipGraphExecDestroy(g.second);
   s->graphs.clear();
   s->ranges.release(); s->image.release(); s->ctr.release(); s->plans.release(); s->cpuDistDev.release();
@@ -1242,6 +1243,11 @@ void mgs_frame_params_default(MgsFrameParams* p)
   p->kernel_min_response     = 0.0113f;  // parameters.h:216
   p->surface_outputs         = 0;
   p->depth_iso_threshold     = 0.7f;  // parameters.h:200
+  p->dof_mode                = MGS_DOF_DISABLED;
+  p->focus_dist              = 1.3f;    // shaderio.h:278
+  p->aperture                = 0.001f;  // shaderio.h:279
+  p->frame_sample_id         = 0;
+  p->temporal_sampling       = 0;
 }
 
 // storage global id <-> caller global id.  Instances are concatenated in creation order in both spaces;
@@ -1365,6 +1371,14 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
   F.fovRad            = p->fov_rad > 0.0f ? p->fov_rad : 2.0f * std::atan(1.0f / std::fabs(p->proj[5]));
   F.alphaClamp        = p->alpha_clamp;
   F.kernelMinResponse = p->kernel_min_response;
+  F.stochastic        = p->sort_mode == MGS_SORT_STOCHASTIC ? 1 : 0;
+  if(F.stochastic)
+    F.alphaMode = MGS_ALPHA_COVERAGE;  // opaque writes: the pixel's alpha is "a fragment was accepted"
+  F.dofMode          = p->pipeline == MGS_PIPELINE_3DGUT ? p->dof_mode : 0;
+  F.focusDist        = p->focus_dist;
+  F.aperture         = p->aperture;
+  F.frameSampleId    = p->frame_sample_id;
+  F.temporalSampling = p->temporal_sampling ? 1 : 0;
   if(p->camera_model == MGS_CAMERA_FISHEYE)
   {  // gaussian_splatting.cpp:1243
     F.gutFocal[0] = (float)p->width / F.fovRad;
@@ -1577,6 +1591,60 @@ __global__ void k_fill_u32(uint32_t* p, uint32_t v, uint32_t n)
   for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     p[i] = v;
 }
+// post.comp.slang:29-43: main = lerp(main, aux1, 1 / (frameSampleId + 1)) — aux1 is the frame just rendered, main the
+// accumulated image.  Here the accumulator is a separate fp32 image and the result is written back over the frame in the
+// target's format, so the caller reads the running mean where it reads every frame.
+__global__ void k_post_accumulate(const FrameArgs* __restrict__ Ap, float4* __restrict__ acc, void* __restrict__ image, int halfOut)
+{
+  const FrameConst& F  = Ap->f;
+  const int         y0 = F.stripRow0 * kTilePx, y1 = min(F.stripRow1 * kTilePx, F.height);
+  const size_t      n  = (size_t)(y1 - y0) * (size_t)F.width;
+  const float       a  = 1.0f / (float)(F.frameSampleId + 1);
+  for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+  {
+    const size_t o = (size_t)y0 * F.width + i;
+    float4       c;
+    if(halfOut == 1)
+    {
+      const uint2   pk = reinterpret_cast<const uint2*>(image)[o];
+      const float2  lo = __half22float2(*reinterpret_cast<const __half2*>(&pk.x)), hi = __half22float2(*reinterpret_cast<const __half2*>(&pk.y));
+      c = make_float4(lo.x, lo.y, hi.x, hi.y);
+    }
+    else if(halfOut == 2)
+    {
+      const uint32_t pk = reinterpret_cast<const uint32_t*>(image)[o];
+      c = make_float4((float)(pk & 255u) / 255.0f, (float)((pk >> 8) & 255u) / 255.0f, (float)((pk >> 16) & 255u) / 255.0f, (float)(pk >> 24) / 255.0f);
+    }
+    else
+      c = reinterpret_cast<const float4*>(image)[o];
+    float4 m = acc[o];
+    if(F.frameSampleId <= 0)
+      m = c;  // lerp(main, aux1, 1) without touching what the accumulator held (it may be uninitialised)
+    else
+    {  // lerp(x, y, s) = x + s * (y - x)
+      m.x = m.x + a * (c.x - m.x);
+      m.y = m.y + a * (c.y - m.y);
+      m.z = m.z + a * (c.z - m.z);
+      m.w = m.w + a * (c.w - m.w);
+    }
+    acc[o] = m;
+    if(halfOut == 1)
+    {
+      const __half2 lo = __floats2half2_rn(m.x, m.y), hi = __floats2half2_rn(m.z, m.w);
+      uint2         pk;
+      pk.x = *reinterpret_cast<const uint32_t*>(&lo);
+      pk.y = *reinterpret_cast<const uint32_t*>(&hi);
+      reinterpret_cast<uint2*>(image)[o] = pk;
+    }
+    else if(halfOut == 2)
+    {
+      auto q8 = [](float v) { return (uint32_t)(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f + 0.5f); };
+      reinterpret_cast<uint32_t*>(image)[o] = q8(m.x) | (q8(m.y) << 8) | (q8(m.z) << 16) | (q8(m.w) << 24);
+    }
+    else
+      reinterpret_cast<float4*>(image)[o] = m;
+  }
+}
 __global__ void k_iota_u32(uint32_t* p, uint32_t n)
 {
   for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
@@ -1641,7 +1709,22 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
       if((rc = s->recGut.ensure(s->totalSplats))) return rc;
     }
   }
-  const void* before[5] = {s->ranges.p, s->image.p, s->surfDepth.p, s->surfId.p, s->surfNormal.p};
+  else if(p->dof_mode != MGS_DOF_DISABLED)
+  {
+    setError("frame: depth of field is a feature of the 3DGUT pipeline (per-pixel rays); the 3DGS pipeline has none");
+    return MGS_ERR_UNSUPPORTED;
+  }
+  if(p->sort_mode != MGS_SORT_GPU_RADIX && p->sort_mode != MGS_SORT_CPU_ASYNC && p->sort_mode != MGS_SORT_STOCHASTIC)
+  {
+    setError("frame: sort_mode must be MGS_SORT_GPU_RADIX, MGS_SORT_CPU_ASYNC or MGS_SORT_STOCHASTIC");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(p->dof_mode < MGS_DOF_DISABLED || p->dof_mode > MGS_DOF_FIXED_FOCUS || p->frame_sample_id < 0)
+  {
+    setError("frame: dof_mode / frame_sample_id out of range");
+    return MGS_ERR_INVALID_ARG;
+  }
+  const void* before[6] = {s->ranges.p, s->image.p, s->surfDepth.p, s->surfId.p, s->surfNormal.p, s->accum.p};
   if((rc = s->ranges.ensure(std::max<uint32_t>(nTiles, 256u)))) return rc;
   if(s->image.n < s->imageBytes)
   {
@@ -1654,6 +1737,8 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     if((rc = s->surfId.ensure((size_t)F.width * F.height))) return rc;
     if((rc = s->surfNormal.ensure((size_t)F.width * F.height))) return rc;
   }
+  if(F.temporalSampling)
+    if((rc = s->accum.ensure((size_t)F.width * F.height))) return rc;
   {
     static const bool kDirectBin0 = [] { const char* e = std::getenv("MGS_DIRECT_BIN"); return e ? std::atoi(e) != 0 : true; }();
     if(!(kDirectBin0 && directBinningSupported(F.binsX, F.binsY)) && s->pairKey0.n < s->pairCapacity)
@@ -1668,7 +1753,7 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
   }
   s->haveSurface    = F.surfaceOutputs != 0;
   {
-    const void* after[5] = {s->ranges.p, s->image.p, s->surfDepth.p, s->surfId.p, s->surfNormal.p};
+    const void* after[6] = {s->ranges.p, s->image.p, s->surfDepth.p, s->surfId.p, s->surfNormal.p, s->accum.p};
     if(std::memcmp(before, after, sizeof(before)) != 0 && !s->graphs.empty())
     {  // a buffer moved: captured frames point at the old one
       HIPCHK(hipStreamSynchronize(s->stream));
@@ -1776,6 +1861,8 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
       launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat, ctr,
                       F.surfaceOutputs ? s->surfDepth.p : nullptr, F.surfaceOutputs ? s->surfId.p : nullptr, s->compInst.p,
                       s->dArgs.p, F.surfaceOutputs ? s->surfNormal.p : nullptr);
+    if(F.temporalSampling)
+      hipLaunchKernelGGL(k_post_accumulate, dim3(2048), dim3(256), 0, st, s->dArgs.p, s->accum.p, s->image.p, half);
     if(withEvents) HIPCHK(hipEventRecord(fev[5], st));
     return MGS_OK;
   };
@@ -1794,7 +1881,7 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     // everything the compositor receives by value (CompositeArgs) must be part of the key
     const int32_t kv[16] = {F.width, F.height, F.stripRow0, F.stripRow1, F.binShiftX, F.binShiftY, F.partitionCull, F.alphaMode,
                             F.debugFlags & (2 | 4 | 256), F.surfaceOutputs, half, F.nInstances, F.shDegree, isoBits,
-                            F.pipeline, 0};
+                            F.pipeline, F.stochastic | (F.dofMode << 1) | (F.temporalSampling << 2)};
     std::memcpy(key.v, kv, sizeof(kv));
     key.p[0] = s->image.p;
     key.p[1] = s->surfDepth.p;

@@ -51,7 +51,9 @@ class Project:
         p.frustum_culling = int(r.get("frustumCulling", capi.CULL_AT_DIST))
         p.size_culling = int(r.get("sizeCulling", 0))
         p.size_culling_min_pixels = float(r.get("sizeCullingMinPixels", 1.0))
-        p.sort_mode = capi.SORT_GPU_RADIX if int(r.get("sortingMethod", 0)) == 0 else capi.SORT_CPU_ASYNC
+        # shaderio.h:24-27: 0 GPU radix, 1/2 CPU async (mono / multi), 3 stochastic splat
+        sm = int(r.get("sortingMethod", 0))
+        p.sort_mode = {0: capi.SORT_GPU_RADIX, 3: capi.SORT_STOCHASTIC}.get(sm, capi.SORT_CPU_ASYNC)
         p.cpu_lazy_sort = int(bool(r.get("cpuLazySort", True)))
         p.thin_particle_threshold = float(r.get("thinParticleThreshold", 1e-6))
         p.debug_flags = ((capi.DEBUG_POINT_CLOUD if r.get("pointCloudModeEnabled", False) else 0)
