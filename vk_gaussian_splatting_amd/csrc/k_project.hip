@@ -22,9 +22,14 @@
 
 namespace mgs {
 
-constexpr int kPrjThreads = 256;
-constexpr int kPrjItems   = 8;
+#ifndef MGS_PRJ_THREADS
+#define MGS_PRJ_THREADS 256
+#endif
+constexpr int kPrjThreads = MGS_PRJ_THREADS;
+constexpr int kPrjWaves   = kPrjThreads / 64;
+constexpr int kPrjItems   = 2048 / kPrjThreads;
 constexpr int kPrjPart    = kPrjThreads * kPrjItems;  // 2048 splats per workgroup
+static_assert(kPrjItems * kPrjWaves == 32 && kPrjPart == 2048, "the round x wave table of scanRoundWaveCounts has 32 entries");
 
 struct Projected
 {
@@ -186,8 +191,8 @@ __device__ __forceinline__ void top16Post(uint32_t mn, uint32_t mx, uint32_t* s_
   }
   if(laneId() == 0)
   {
-    s_red[threadIdx.x >> 6]       = mn;
-    s_red[4 + (threadIdx.x >> 6)] = mx;
+    s_red[threadIdx.x >> 6]               = mn;
+    s_red[kPrjWaves + (threadIdx.x >> 6)] = mx;
   }
 }
 // returns true when the caller's threads must mark their own keys
@@ -195,7 +200,13 @@ __device__ __forceinline__ bool top16Mark(SortPlan* plan, uint32_t count, const 
 {
   if(plan == nullptr || count == 0u)
     return false;
-  const uint32_t lo = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3])), hi = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+  uint32_t lo = s_red[0], hi = s_red[kPrjWaves];
+#pragma unroll
+  for(int i = 1; i < kPrjWaves; ++i)
+  {
+    lo = min(lo, s_red[i]);
+    hi = max(hi, s_red[kPrjWaves + i]);
+  }
   if(hi - lo > 24u)
     return true;
   if(threadIdx.x == 0)
@@ -225,13 +236,15 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   {  // k_partition_cull proved that no splat of this partition can survive the cull / reach the strip
     if(threadIdx.x == 0)
       slotCount[blockIdx.x] = 0u;
-    slotHist[(size_t)threadIdx.x * histStride + blockIdx.x] = 0u;
+    if(threadIdx.x < 256)
+      slotHist[(size_t)threadIdx.x * histStride + blockIdx.x] = 0u;
     return;
   }
   __shared__ uint32_t s_hist[256];
-  __shared__ float4   s_rec[FULL ? 4 : 1][FULL ? 64 * 3 : 1];  // per wave: 64 records at a 48-byte pitch
-  __shared__ uint32_t s_gid[FULL ? 4 : 1][64];
-  s_hist[threadIdx.x] = 0u;  // ordered before its first use by the barriers of phase 1
+  __shared__ float4   s_rec[FULL ? kPrjWaves : 1][FULL ? 64 * 3 : 1];  // per wave: 64 records at a 48-byte pitch
+  __shared__ uint32_t s_gid[FULL ? kPrjWaves : 1][64];
+  if(threadIdx.x < 256)
+    s_hist[threadIdx.x] = 0u;  // ordered before its first use by the barriers of phase 1
   __shared__ uint16_t s_li[kPrjPart];   // bit 15: survived phase 2
   __shared__ uint32_t s_key[kPrjPart];
   __shared__ uint32_t s_cnt[32];
@@ -318,14 +331,14 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
     key[it] = A.f.frontToBack ? encodeKey(nz) : encodeKey(-nz);  // :163-167
     bal[it] = __ballot(v);
     if(lane == 0)
-      s_cnt[it * 4 + w] = (uint32_t)__popcll(bal[it]);
+      s_cnt[it * kPrjWaves + w] = (uint32_t)__popcll(bal[it]);
   }
   const uint32_t M = scanRoundWaveCounts(s_cnt, s_base);
 #pragma unroll
   for(int it = 0; it < kPrjItems; ++it)
     if(vis[it])
     {
-      const uint32_t pos = s_base[it * 4 + w] + lanesBelow(bal[it]);
+      const uint32_t pos = s_base[it * kPrjWaves + w] + lanesBelow(bal[it]);
       s_li[pos]          = (uint16_t)(it * kPrjThreads + t);
       s_key[pos]         = key[it];
     }
@@ -354,7 +367,8 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
         atomicAdd(&ctr->sortedCount, M);
     }
     __syncthreads();
-    slotHist[(size_t)t * histStride + part] = s_hist[t];
+    if(t < 256)
+      slotHist[(size_t)t * histStride + part] = s_hist[t];
     if(top16Mark(planKeys, M, s_cnt))
       for(uint32_t j = t; j < M; j += kPrjThreads)
         sortMarkTop16(planKeys, s_key[j] >> 16);
@@ -423,7 +437,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
       vis[r]           = (j < M) && (s_li[j] & 0x8000u);
       bal[r]           = __ballot(vis[r]);
       if(lane == 0)
-        s_cnt[r * 4 + w] = (uint32_t)__popcll(bal[r]);
+        s_cnt[r * kPrjWaves + w] = (uint32_t)__popcll(bal[r]);
     }
     const uint32_t outCount = scanRoundWaveCounts(s_cnt, s_base);
     uint32_t       tmn = 0xFFFFu, tmx = 0u;
@@ -432,7 +446,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
       if(vis[r])
       {
         const uint32_t j         = r * kPrjThreads + t;
-        const uint32_t pos       = s_base[r * 4 + w] + lanesBelow(bal[r]);
+        const uint32_t pos       = s_base[r * kPrjWaves + w] + lanesBelow(bal[r]);
         keysSlot[slotBase + pos] = s_key[j];
         idsSlot[slotBase + pos]  = I.globalOffset + local0 + (s_li[j] & 0x7FFFu);
         atomicAdd(&s_hist[s_key[j] & 255u], 1u);
@@ -447,7 +461,8 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
         atomicAdd(&ctr->sortedCount, outCount);
     }
     __syncthreads();
-    slotHist[(size_t)t * histStride + part] = s_hist[t];
+    if(t < 256)
+      slotHist[(size_t)t * histStride + part] = s_hist[t];
     if(top16Mark(planKeys, outCount, s_cnt))
     {
 #pragma unroll
