@@ -198,7 +198,8 @@ typedef struct MgsFrameParams {
                                    MGS_SORT_STOCHASTIC; the caller counts it up while the view stands still
                                    (gaussian_splatting.cpp:3040-3075) */
   int32_t temporal_sampling;    /* 0/1 (post.comp.slang:29-43): the frame handed back is the running mean of the samples
-                                   0..frame_sample_id of this scene (sample 0 restarts it); kept in fp32 */
+                                   0..frame_sample_id of this scene (sample 0 restarts it: pass 0 whenever the view, the size
+                                   or the scene changed, as updateFrameSampleId does); kept in fp32 */
   int32_t reserved_[3];
 } MgsFrameParams;
 
