@@ -200,7 +200,9 @@ typedef struct MgsFrameParams {
   int32_t temporal_sampling;    /* 0/1 (post.comp.slang:29-43): the frame handed back is the running mean of the samples
                                    0..frame_sample_id of this scene (sample 0 restarts it: pass 0 whenever the view, the size
                                    or the scene changed, as updateFrameSampleId does); kept in fp32 */
-  int32_t reserved_[3];
+  int32_t kernel_degree;        /* 3DGUT: KERNEL_DEGREE (shaderio.h:112-119, default 2 = quadratic, parameters.h:215): the generalised
+                                   Gaussian of particleRayMaxKernelResponse (threedgrt.h.slang:83-127); 0,1,2,3,4,5,8 */
+  int32_t reserved_[2];
 } MgsFrameParams;
 
 void mgs_frame_params_default(MgsFrameParams* p); /* fills the defaults cited above */

@@ -1072,7 +1072,18 @@ int orc_gut_fragment(const OrcFrame* f, const OrcInstance* I, const OrcGutProjec
   // particleRayMinSquaredDistance, :77-81
   const float cr[3] = {prd[1] * pro[2] - prd[2] * pro[1], prd[2] * pro[0] - prd[0] * pro[2], prd[0] * pro[1] - prd[1] * pro[0]};
   const float dist2 = (cr[0] * cr[0] + cr[1] * cr[1]) + cr[2] * cr[2];
-  const float maxResponse = std::exp(-0.5f * dist2);  // quadratic kernel (KERNEL_DEGREE 2), :127-131
+  // particleRayMaxKernelResponse<KERNEL_DEGREE>(rayDist), threedgrt.h.slang:83-127 (rayDist is the squared distance)
+  float maxResponse;
+  switch(f->kernel_degree)
+  {
+    case 8: { const float sq = dist2 * dist2; maxResponse = std::exp(-0.000685871056241f * sq * sq); break; }
+    case 5: maxResponse = std::exp(-0.0185185185185f * dist2 * dist2 * std::sqrt(dist2)); break;
+    case 4: maxResponse = std::exp(-0.0555555555556f * dist2 * dist2); break;
+    case 3: maxResponse = std::exp(-0.166666666667f * dist2 * std::sqrt(dist2)); break;
+    case 1: maxResponse = std::exp(-1.5f * std::sqrt(dist2)); break;
+    case 0: maxResponse = std::max(1.0f + -0.329630334487f * std::sqrt(dist2), 0.0f); break;
+    default: maxResponse = std::exp(-0.5f * dist2); break;  // quadratic
+  }
   const float alpha       = std::min(f->alpha_clamp, maxResponse * density);
   const bool  accept      = ((double)alpha > (double)(1.0f / 255.0f)) && (maxResponse > f->kernel_min_response);
   if(!accept)

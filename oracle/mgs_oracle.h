@@ -75,6 +75,7 @@ typedef struct OrcFrame {
   int   dof_mode;             /* 3DGUT: DOF_MODE, 0 DOF_DISABLED / 1 DOF_FIXED_FOCUS (shaderio.h:136-138) */
   float focus_dist, aperture; /* shaderio.h:278-279 */
   int   frame_sample_id;      /* shaderio.h:275 */
+  int   kernel_degree;        /* 3DGUT: KERNEL_DEGREE (shaderio.h:112-119); 2 = quadratic (default, parameters.h:215) */
 } OrcFrame;
 
 /* nvshaders/random.h.slang (nvpro_core2; NOT in the reference tree, fetched by its CMake): xxhash32(uint3), pcg, rand —

@@ -193,7 +193,7 @@ def gut_project(centers, scales_log, rotations_wxyz, rgba, M, V, P, W, H, extent
     return dict(valid=valid, center_px=center, cov=cov, half_x=hx, half_y=hy, axes=R, scale=s, position=c)
 
 
-def gut_opacity(g, i, density, M, V, P, W, H, px, py, alpha_clamp=0.99, min_response=0.0113):
+def gut_opacity(g, i, density, M, V, P, W, H, px, py, alpha_clamp=0.99, min_response=0.0113, degree=2):
     """opacity of splat i at pixel (px, py) or None: ray of the fragment (SV_Position + 0.5, as the reference writes it),
     canonical ray, quadratic kernel"""
     S_V, S_P, S_M = slang(V), slang(P), slang(M)
@@ -212,6 +212,10 @@ def gut_opacity(g, i, density, M, V, P, W, H, px, py, alpha_clamp=0.99, min_resp
     r = (md @ A.T) / g["scale"][i]
     r /= np.linalg.norm(r)
     cr = np.cross(r, ro)
-    resp = np.exp(-0.5 * (cr @ cr))
+    d2 = cr @ cr
+    if degree == 0:      # generalised Gaussian of degree n in the distance: exp(-4.5 / 3^n * dist^n); n = 0 is the linear kernel
+        resp = max(1.0 - 0.329630334487 * np.sqrt(d2), 0.0)
+    else:
+        resp = np.exp(-4.5 / 3.0 ** degree * np.sqrt(d2) ** degree)
     alpha = min(alpha_clamp, resp * density)
     return alpha if (alpha > 1.0 / 255.0 and resp > min_response) else None

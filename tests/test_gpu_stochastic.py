@@ -183,3 +183,21 @@ def test_dof_needs_the_gut_pipeline_and_bad_modes_are_rejected(stage):
     p, *_ = params(0, frame_sample_id=-1)
     with pytest.raises(mgs.MgsError):
         scene.render(p)
+
+
+@pytest.mark.parametrize("degree", [0, 1, 3, 4, 5, 8])
+def test_gut_kernel_degrees_match_oracle(stage, ob, degree):
+    """KERNEL_DEGREE (shaderio.h:112-119): the generalised Gaussians of particleRayMaxKernelResponse in the 3DGUT compositor"""
+    scene, sc, sc_p = stage
+    p, V, P, eye = params(8, pipeline=capi.PIPELINE_3DGUT, kernel_degree=degree)
+    out = scene.render(p, want_stats=True)
+    img = scene.download_frame(p).astype(np.float32)
+    oimg, st = oracle_storage_frame(ob, sc_p, V, P, eye, True, kernel_degree=degree)
+    oimg = oimg.astype(np.float16).astype(np.float32)
+    psnr = ob.psnr_rgb(img, oimg)
+    err = np.abs(img[..., :3] - oimg[..., :3])
+    print(f"3DGUT kernel degree {degree}: PSNR {psnr:.2f} dB, max abs {err.max():.4f}")
+    assert out.error_flags == 0 and psnr >= 50.0 and err.max() <= 3e-2
+    p.kernel_degree = 7
+    with pytest.raises(mgs.MgsError):
+        scene.render(p)

@@ -31,7 +31,7 @@ def test_struct_layouts_match_header_sizes():
     # MgsFrameParams: 16+16+3 floats, 2 ints, 3 floats, 12 ints + 6 reserved
 
     import ctypes
-    assert ctypes.sizeof(capi.FrameParams) == 288  # ABI 3: + dof_mode, focus_dist, aperture, frame_sample_id, temporal_sampling, 3 reserved
+    assert ctypes.sizeof(capi.FrameParams) == 288  # ABI 3: + dof_mode, focus_dist, aperture, frame_sample_id, temporal_sampling, kernel_degree, 2 reserved
     assert ctypes.sizeof(capi.FrameOut) == 8 + 8 + 4 + 4 + 8 + 4 + 4 + 8 + 32
     assert ctypes.sizeof(capi.SortOut) == 32
     assert ctypes.sizeof(capi.SplatSetView) == 6 * 8 + 8 + 4 + 4
@@ -299,6 +299,8 @@ def test_frame_params_defaults_cover_the_new_pipeline_fields():
     p = capi.default_params(640, 480)
     assert p.pipeline == capi.PIPELINE_3DGS and p.camera_model == capi.CAMERA_PINHOLE and p.extent_method == capi.EXTENT_CONIC
     assert abs(p.alpha_clamp - 0.99) < 1e-7 and abs(p.kernel_min_response - 0.0113) < 1e-7 and p.fov_rad == 0.0
+    assert p.kernel_degree == 2 and p.dof_mode == 0 and abs(p.focus_dist - 1.3) < 1e-7 and abs(p.aperture - 0.001) < 1e-9
+    assert p.frame_sample_id == 0 and p.temporal_sampling == 0
     assert p.frustum_culling == capi.CULL_AT_DIST and abs(p.frustum_dilation - 0.2) < 1e-7 and p.sh_degree == 3
 
 

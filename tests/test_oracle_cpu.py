@@ -665,3 +665,36 @@ def test_gut_depth_of_field_oracle_properties(ob):
         main = ob.post_accumulate(main, img, k)
     grad = lambda im: float(np.abs(np.diff(im[..., :3], axis=1)).mean())
     assert grad(main) < 0.9 * grad(sharp)
+
+
+@pytest.mark.parametrize("degree", [0, 1, 3, 4, 5, 8])
+def test_gut_kernel_degrees_against_the_closed_form(ob, degree):
+    """particleRayMaxKernelResponse<KERNEL_DEGREE> (threedgrt.h.slang:83-127): the oracle's table of constants against the
+    formula its comment states — exp(-4.5 / 3^n * d^n) of the distance d — in float64"""
+    import np_reference as npr
+    n = 600
+    sc = synth.make_scene(n, seed=23)
+    ps = ob.PreparedSet(sc)
+    inst = ob.make_instances([(ps, None)])
+    W, H = 256, 160
+    eye = np.array([3.0, 1.0, 1.5], np.float32)
+    V, P = lookat(eye, [0, 0, 0], [0, 1, 0]), persp(55, W / H, 0.1, 2000)
+    fr = ob.make_frame(V, P, eye, W, H, kernel_degree=degree)
+    g = npr.gut_project(ps.positions, sc["scale"], sc["rotation"], ps.rgba, np.eye(4), V, P, W, H)
+    rng = np.random.default_rng(degree)
+    frag = 0
+    for i in range(n):
+        q = ob.project_gut(fr, inst, 0, i)
+        if not (q.valid and g["valid"][i]):
+            continue
+        for _ in range(2):
+            px = int(np.clip(q.center_px[0] + rng.integers(-4, 5), 0, W - 1))
+            py = int(np.clip(q.center_px[1] + rng.integers(-4, 5), 0, H - 1))
+            a = ob.gut_fragment(fr, inst, 0, q, px, py)
+            b = npr.gut_opacity(g, i, float(q.rgba[3]), np.eye(4), V, P, W, H, px, py, degree=degree)
+            if a is None or b is None:
+                assert (a is None and (b is None or b < 8e-3)) or (b is None and a < 8e-3), (i, a, b)
+            else:
+                assert np.isclose(a, b, rtol=3e-3, atol=3e-4), (i, px, py, a, b)
+                frag += 1
+    assert frag > 150

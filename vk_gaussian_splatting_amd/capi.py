@@ -47,7 +47,8 @@ class FrameParams(C.Structure):
                 ("pipeline", C.c_int32), ("camera_model", C.c_int32), ("extent_method", C.c_int32), ("fov_rad", C.c_float),
                 ("alpha_clamp", C.c_float), ("kernel_min_response", C.c_float),
                 ("dof_mode", C.c_int32), ("focus_dist", C.c_float), ("aperture", C.c_float),
-                ("frame_sample_id", C.c_int32), ("temporal_sampling", C.c_int32), ("reserved_", C.c_int32 * 3)]
+                ("frame_sample_id", C.c_int32), ("temporal_sampling", C.c_int32), ("kernel_degree", C.c_int32),
+                ("reserved_", C.c_int32 * 2)]
 
 
 class FrameOut(C.Structure):

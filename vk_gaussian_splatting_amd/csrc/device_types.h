@@ -90,6 +90,7 @@ struct FrameConst
   int32_t  frameSampleId;          // frameInfo.frameSampleId: seeds the per-pixel random numbers
   int32_t  temporalSampling;       // 1: the frame is folded into the running mean of the samples 0..frameSampleId
   float    focusDist, aperture;    // shaderio.h:278-279
+  int32_t  kernelDegree;           // KERNEL_DEGREE (3DGUT particle response), 2 = quadratic
 };
 
 struct FrameArgs

@@ -15,7 +15,7 @@
 // LDS in list order) and evaluates the particle response per fragment.  This pipeline is a "next" row: correct and
 // reasonably fast, not tuned like the 3DGS compositor.
 // Depth of field and stochastic splats are the XT variant of the compositor (random numbers: kernels_common.h).
-// Not built (stated in DESIGN.md): rolling shutter (untested in the reference), kernel degrees other than 2.
+// Kernel degrees other than 2 run in the XT variant too.  Not built (stated in DESIGN.md): rolling shutter (untested in the reference).
 #include "kernels_common.h"
 #include "sh_eval.h"
 #include "sort_plan.h"
@@ -384,7 +384,8 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
 // ---- compositor: one workgroup per 16x16 tile, one pixel per thread -------------------------------------------------------
 constexpr int kGutBatch = 256;  // list entries scanned per round == staging capacity
 
-// XT 1: the variant with depth of field (frag.slang:104-109, cameras.h.slang:85-108) and/or stochastic splats (:150-172)
+// XT 1: the variant with depth of field (frag.slang:104-109, cameras.h.slang:85-108), stochastic splats (:150-172) and/or
+// a particle kernel other than the quadratic one
 template <int SHF, int XT>
 __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restrict__ Ap, const uint2* __restrict__ ranges,
                                                        const uint32_t* __restrict__ valX, const uint32_t* __restrict__ valY,
@@ -552,7 +553,20 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
       }
       const float kx = gy * roz - gz * roy, ky = gz * rox - gx * roz, kz = gx * roy - gy * rox;
       const float dist2 = (kx * kx + ky * ky + kz * kz) / (gx * gx + gy * gy + gz * gz);
-      const float resp  = __expf(-0.5f * dist2);                     // quadratic kernel, :127-131
+      float resp = __expf(-0.5f * dist2);                            // quadratic kernel, :127-131
+      if constexpr(XT != 0)
+      {  // particleRayMaxKernelResponse<KERNEL_DEGREE>, threedgrt.h.slang:83-127 (its argument is the squared distance)
+        switch(F.kernelDegree)
+        {
+          case 8: resp = __expf(-0.000685871056241f * (dist2 * dist2) * (dist2 * dist2)); break;
+          case 5: resp = __expf(-0.0185185185185f * dist2 * dist2 * sqrtf(dist2)); break;
+          case 4: resp = __expf(-0.0555555555556f * dist2 * dist2); break;
+          case 3: resp = __expf(-0.166666666667f * dist2 * sqrtf(dist2)); break;
+          case 1: resp = __expf(-1.5f * sqrtf(dist2)); break;
+          case 0: resp = fmaxf(1.0f + -0.329630334487f * sqrtf(dist2), 0.0f); break;
+          default: break;
+        }
+      }
       const float al    = fminf(F.alphaClamp, resp * c4.w);          // :263
       const bool  hit   = inQuad && (c4.w > F.alphaCull) && (al > (1.0f / 255.0f)) && (resp > F.kernelMinResponse) && T >= tMin;
       float       op    = hit ? (noGauss ? 1.0f : al) : 0.0f;
@@ -629,7 +643,7 @@ void launchCompositeGut(hipStream_t stream, const FrameArgs& A, const FrameArgs*
   const int tiles = A.f.tilesX * (A.f.stripRow1 - A.f.stripRow0);
   if(tiles <= 0)
     return;
-  const bool extras = A.f.dofMode != 0 || A.f.stochastic != 0;
+  const bool extras = A.f.dofMode != 0 || A.f.stochastic != 0 || A.f.kernelDegree != 2;
 #define MGS_LAUNCH(SHF, XT)                                                                                                          \
   hipLaunchKernelGGL((k_composite_gut<SHF, XT>), dim3(tiles), dim3(256), 0, stream, dArgs, ranges, valX, valY, planPairs, rec, image, \
                      halfOut, ctr)

@@ -1248,6 +1248,7 @@ void mgs_frame_params_default(MgsFrameParams* p)
   p->aperture                = 0.001f;  // shaderio.h:279
   p->frame_sample_id         = 0;
   p->temporal_sampling       = 0;
+  p->kernel_degree           = 2;       // parameters.h:215
 }
 
 // storage global id <-> caller global id.  Instances are concatenated in creation order in both spaces;
@@ -1379,6 +1380,7 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
   F.aperture         = p->aperture;
   F.frameSampleId    = p->frame_sample_id;
   F.temporalSampling = p->temporal_sampling ? 1 : 0;
+  F.kernelDegree     = p->kernel_degree;
   if(p->camera_model == MGS_CAMERA_FISHEYE)
   {  // gaussian_splatting.cpp:1243
     F.gutFocal[0] = (float)p->width / F.fovRad;
@@ -1704,6 +1706,11 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
       setError("frame: camera_model / extent_method out of range");
       return MGS_ERR_INVALID_ARG;
     }
+    if(p->kernel_degree != 8 && (p->kernel_degree < 0 || p->kernel_degree > 5))
+    {
+      setError("frame: kernel_degree must be one of 0, 1, 2, 3, 4, 5, 8 (shaderio.h:112-119)");
+      return MGS_ERR_INVALID_ARG;
+    }
     if(s->recGut.n < s->totalSplats)
     {  // first 3DGUT frame of this scene: its record buffer (captured frames do not reference it yet)
       if((rc = s->recGut.ensure(s->totalSplats))) return rc;
@@ -1881,7 +1888,7 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     // everything the compositor receives by value (CompositeArgs) must be part of the key
     const int32_t kv[16] = {F.width, F.height, F.stripRow0, F.stripRow1, F.binShiftX, F.binShiftY, F.partitionCull, F.alphaMode,
                             F.debugFlags & (2 | 4 | 256), F.surfaceOutputs, half, F.nInstances, F.shDegree, isoBits,
-                            F.pipeline, F.stochastic | (F.dofMode << 1) | (F.temporalSampling << 2)};
+                            F.pipeline, F.stochastic | (F.dofMode << 1) | (F.temporalSampling << 2) | ((F.pipeline == 1 && F.kernelDegree != 2) ? 8 : 0)};
     std::memcpy(key.v, kv, sizeof(kv));
     key.p[0] = s->image.p;
     key.p[1] = s->surfDepth.p;
