@@ -113,6 +113,9 @@ struct CompositeArgs
   int32_t nInstances;
   int32_t shDegree;
   int32_t looseMask;          // A/B knob (MGS_LOOSE_MASK)
+#ifdef MGS_CMP_TRACE
+  uint64_t* trace;            // debug build only (tools/cmp_trace.py): per-workgroup time stamps and counts
+#endif
   float   depthIsoThreshold;
   int32_t shOnly;             // SHOW_SH_ONLY (mesh.slang:205-207): base colour 0.5
   struct Inst

@@ -9,6 +9,8 @@
 // accumulate front-to-back with transmittance, which is the same sum in exact arithmetic:
 //   C = sum_i c_i a_i prod_{j nearer than i} (1 - a_j).
 #include <cstring>
+#include <cstdio>
+#include <vector>
 
 #include "kernels_common.h"
 #include "sh_eval.h"
@@ -714,7 +716,16 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
                                                    const FrameArgs* __restrict__ Ap, float4* __restrict__ outNormal)
 {
   uint32_t statStaged = 0, statScanned = 0;
-  __shared__ float4   s_a[kCmpCap];  // cx, cy, ex, ey
+#ifdef MGS_CMP_TRACE  // debug build (tools/cmp_trace.py): per-workgroup wall-clock stamps, 100 MHz
+  const uint64_t traceT0 = wall_clock64();
+  uint64_t       traceA = 0, traceS = 0, traceB = 0, traceLast;  // time spent in stage A / shading / blending
+  uint32_t       traceIters = 0, traceRounds = 0;
+  traceLast = traceT0;
+#define MGS_TRACE_PHASE(acc) { const uint64_t now_ = wall_clock64(); acc += now_ - traceLast; traceLast = now_; }
+#else
+#define MGS_TRACE_PHASE(acc)
+#endif
+  __shared__ float4   s_a[kCmpCap];  // cx, cy, fragment cutoff, ey
   __shared__ float4   s_b[kCmpCap];  // p1, p2 (scaled by sqrt(log2 e))
   __shared__ float4   s_c[kCmpCap];  // r, g, b, a
   __shared__ uint32_t s_g[kCmpCap];  // global id: what the deferred shading needs
@@ -808,6 +819,9 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
     // The ids of the NEXT round are fetched before this round's barrier (one dependent trip instead of two).
     while(hi > range.x && fill < (uint32_t)kCmpGo)
     {
+#ifdef MGS_CMP_TRACE
+      ++traceRounds;
+#endif
       const uint32_t avail = hi - range.x;
       uint32_t       g[kCmpEntries];
       float4         a[kCmpEntries], pb[kCmpEntries];  // (cx, cy, ex, ey), (p1, p2)
@@ -872,7 +886,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
           {
             const uint32_t pos = base + wb + lanesBelow(bal[k]);
             const float4   sb  = make_float4(pb[k].x * kSqrtLog2e, pb[k].y * kSqrtLog2e, pb[k].z * kSqrtLog2e, pb[k].w * kSqrtLog2e);
-            s_a[pos]           = a[k];
+            s_a[pos]           = make_float4(a[k].x, a[k].y, 0.0f, a[k].w);  // .z: the fragment cutoff, below
             s_b[pos]           = sb;
             s_c[pos]           = make_float4(0.f, 0.f, 0.f, al[k]);  // rgb: shading phase
             s_g[pos]           = g[k];
@@ -885,7 +899,13 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
             const bool  xl = a[k].x - a[k].z <= bcx - 0.5f, xr = a[k].x + a[k].z >= bcx + 0.5f;
             const bool  yt = a[k].y - a[k].w <= bcy - 0.5f, yb = a[k].y + a[k].w >= bcy + 0.5f;
             const float rc = al[k];
-            const float qLim = noGauss ? kQMax : fminf(kQMax, __log2f(fmaxf(rc * 255.0f, 1.0f))) * 1.001f + 1e-3f;
+            // Fragment rule of frag.slang:242-262 — discard A > 8 (q > kQMax here), discard alpha <= 1/255 — as ONE compare per
+            // pixel: alpha = a 2^-q > 1/255  <=>  q < log2(255 a).  (Two compares + the saturation test per pixel were a
+            // quarter of the blend loop's instructions.)  A fragment whose alpha is within rounding of 1/255 may fall on
+            // the other side than with the exp-then-compare order: a contribution of <= 0.4 % of one splat's colour.
+            const float qCut = noGauss ? kQMax : fminf(kQMax, __log2f(fmaxf(rc * 255.0f, 1.0f)));
+            s_a[pos].z       = qCut;
+            const float qLim = qCut * 1.001f + 1e-3f;
             const float rs = 7.5f * fabsf(sb.x) + 3.5f * fabsf(sb.y), ru = 7.5f * fabsf(sb.z) + 3.5f * fabsf(sb.w);
             uint32_t    qm = 0;
 #pragma unroll
@@ -912,6 +932,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
         break;  // batch full: blend, then rescan the unconsumed sub-groups
     }
     __syncthreads();
+    MGS_TRACE_PHASE(traceA)
     // ---- shading: the SH sum of the staged splats (mesh.slang:243), one thread per record ---------------------
     // Deferred from the projection: only splats that reach an unsaturated region are ever shaded (a quarter of
     // the frustum survivors on the garden-sized bench), and their 192-byte SH records are the bulk of a splat.
@@ -981,6 +1002,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
       }
     }
     __syncthreads();
+    MGS_TRACE_PHASE(traceS)
     // ---- stage B: blend the batch ------------------------------------------------------------------------
     // 64 records at a time: a ballot over the quarter masks gives this wave's hit set; the hits are walked
     // with scalar bit tricks (no per-record branch) and the per-pixel discards are predicated.
@@ -1006,9 +1028,16 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
             const v2f e = {__builtin_amdgcn_exp2f(-q.x), __builtin_amdgcn_exp2f(-q.y)};
             al          = e * c1.w;
           }
-          v2f ah;  // frag.slang:242-245,258-262, predicated
+          v2f ah;  // frag.slang:242-245,258-262, predicated (cutoff per record, see stage A)
+#ifdef MGS_CMP_EXACT_PRED
           ah.x = (q.x <= kQMax && al.x > (1.0f / 255.0f) && T.x >= tMin) ? al.x : 0.0f;
           ah.y = (q.y <= kQMax && al.y > (1.0f / 255.0f) && T.y >= tMin) ? al.y : 0.0f;
+#else
+          // no test of T: a saturated pixel of a live wave keeps taking fragments (each weighs < 1e-4) until the WAVE retires,
+          // which is checked per record and depends only on the sequence of records — the same in a strip and in the full frame
+          ah.x = (q.x <= a1.z) ? al.x : 0.0f;
+          ah.y = (q.y <= a1.z) ? al.y : 0.0f;
+#endif
           if constexpr(stoch)
           {  // frag.slang:272-276: seed = xxhash32(uint3(seed, splatId, primitiveID)); accept iff rand(seed) < opacity.
             // primitiveID = 2 * (index of the splat in its mesh workgroup of 32) + triangle; the quad (-1,-1),(1,-1),(1,1),(-1,1)
@@ -1060,11 +1089,23 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
       }
     }
     fill = 0;
+#ifdef MGS_CMP_TRACE
+    ++traceIters;
+#endif
     const int allDone = __syncthreads_and(waveDone ? 1 : 0);
+    MGS_TRACE_PHASE(traceB)
     if(allDone || hi <= range.x)
       break;
   }
 
+#ifdef MGS_CMP_TRACE
+  if(t == 0 && F.trace)
+  {
+    uint64_t* o = F.trace + (size_t)blockIdx.x * 10;
+    o[0] = traceT0; o[1] = wall_clock64(); o[2] = statScanned; o[3] = statStaged; o[4] = traceIters; o[5] = traceRounds;
+    o[6] = traceA; o[7] = traceS; o[8] = traceB; o[9] = (uint64_t)range.y - range.x;
+  }
+#endif
   if(t == 0)
   {  // frame statistics (mgs_frame_stats): two fire-and-forget adds per workgroup
     atomicAdd(&ctr->stagedSlots[blockIdx.x & 7], statStaged);
@@ -1188,6 +1229,18 @@ void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges
     C.inst[i].shDegree     = A.inst[i].shDegree;
   }
   C.instTable = static_cast<const CompositeArgs::Inst*>(instTable);
+#ifdef MGS_CMP_TRACE
+  static uint64_t* traceBuf = nullptr;
+  const char*      tracePath = std::getenv("MGS_CMP_TRACE_FILE");
+  const size_t     traceN = (size_t)per * 8 * 10;
+  if(tracePath)
+  {
+    if(!traceBuf)
+      (void)hipMalloc(&traceBuf, (size_t)1 << 24);
+    (void)hipMemsetAsync(traceBuf, 0, traceN * 8, stream);
+    C.trace = traceBuf;
+  }
+#endif
 #define MGS_CMP(M, S)                                                                                                  \
   hipLaunchKernelGGL((k_composite<M, S>), dim3(per * 8), dim3(256), 0, stream, C, ranges, valX, valY, planPairs, rec, image, \
                      halfOut, ctr, outDepth, outSplatId, dArgs, outNormal)
@@ -1213,6 +1266,19 @@ void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges
   }
 #undef MGS_CMP_FMT
 #undef MGS_CMP
+#ifdef MGS_CMP_TRACE
+  if(tracePath)
+  {
+    (void)hipStreamSynchronize(stream);
+    std::vector<uint64_t> h(traceN);
+    (void)hipMemcpy(h.data(), traceBuf, traceN * 8, hipMemcpyDeviceToHost);
+    if(FILE* fp = std::fopen(tracePath, "wb"))
+    {
+      std::fwrite(h.data(), 8, traceN, fp);
+      std::fclose(fp);
+    }
+  }
+#endif
 }
 
 }  // namespace mgs
