@@ -725,7 +725,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
 #else
 #define MGS_TRACE_PHASE(acc)
 #endif
-  __shared__ float4   s_a[kCmpCap];  // cx, cy, fragment cutoff, ey
+  __shared__ float4   s_a[kCmpCap];  // k1, k2 (centre terms of d.p1, d.p2), fragment cutoff, -
   __shared__ float4   s_b[kCmpCap];  // p1, p2 (scaled by sqrt(log2 e))
   __shared__ float4   s_c[kCmpCap];  // r, g, b, a
   __shared__ uint32_t s_g[kCmpCap];  // global id: what the deferred shading needs
@@ -772,6 +772,8 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
   const v2f      pcx = {(float)px + 0.5f, (float)px + 8.5f};
   const float    pcy = (float)py + 0.5f;
   const float    bcx = (float)(tx * kTilePx) + 16.0f, bcy = (float)(ty * kTilePx) + 8.0f;  // region centre
+  const v2f      lx  = {pcx.x - bcx, pcx.y - bcx};  // pixel centre relative to the region centre (exact: half-integers)
+  const float    ly  = pcy - bcy;
   const bool     in0 = px < F.width && py < F.height, in1 = px + 8 < F.width && py < F.height;
   constexpr bool early   = (MODE & 1) == 0;
   constexpr bool noGauss = (MODE & 2) != 0;
@@ -886,7 +888,11 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
           {
             const uint32_t pos = base + wb + lanesBelow(bal[k]);
             const float4   sb  = make_float4(pb[k].x * kSqrtLog2e, pb[k].y * kSqrtLog2e, pb[k].z * kSqrtLog2e, pb[k].w * kSqrtLog2e);
-            s_a[pos]           = make_float4(a[k].x, a[k].y, 0.0f, a[k].w);  // .z: the fragment cutoff, below
+            // (s, u) = (d.p1, d.p2) with d = pixel - centre, rewritten around the region centre: s = lx*p1x + (ly*p1y + k1),
+            // k1 = -((cx - bcx)*p1x + (cy - bcy)*p1y), lx/ly = the pixel relative to the region centre (|.| <= 15.5):
+            // two instructions per pixel pair instead of three, and small operands (no 1000-px coordinates in the products)
+            const float rx = a[k].x - bcx, ry = a[k].y - bcy;
+            s_a[pos]       = make_float4(-(rx * sb.x + ry * sb.y), -(rx * sb.z + ry * sb.w), 0.0f, 0.0f);  // .z: the fragment cutoff, below
             s_b[pos]           = sb;
             s_c[pos]           = make_float4(0.f, 0.f, 0.f, al[k]);  // rgb: shading phase
             s_g[pos]           = g[k];
@@ -1018,9 +1024,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
           const uint32_t j = j0 + (uint32_t)__builtin_ctzll(hits);
           hits &= hits - 1ull;
           const float4 a1 = s_a[j], b1 = s_b[j], c1 = s_c[j];
-          const v2f    dx = pcx - a1.x;
-          const float  dy = pcy - a1.y;
-          const v2f    s1 = dx * b1.x + dy * b1.y, u1 = dx * b1.z + dy * b1.w;
+          const v2f    s1 = lx * b1.x + (ly * b1.y + a1.x), u1 = lx * b1.z + (ly * b1.w + a1.y);
           const v2f    q  = s1 * s1 + u1 * u1;  // == (A/2) * log2 e of frag.slang:236
           v2f          al = {1.0f, 1.0f};
           if(!noGauss)  // frag.slang:248-254
