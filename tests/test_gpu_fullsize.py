@@ -189,7 +189,10 @@ def test_projected_records_match_oracle_per_splat(ob, case):
     # the HIP side contracts into FMAs and uses rsqrt; the oracle is unfused IEEE: both are fp32 evaluations of
     # half^2 - det, which cancels for nearly round footprints — the worst splat of 43 K sits at ~1e-4 relative
     assert cerr <= 2e-3 and aerr <= 1e-5
-    assert eerr <= 1e-3 and np.percentile(eall, 99) <= 5e-5
+    # ... and where the reference's floor max(0.1, half^2 - det) applies (threedgs.h.slang:88) the two eigenvalues are
+    # half +- 0.316 along a direction that rounding decides: a relative 0.63 / half of the extent matrix (1.3e-3 for the
+    # worst splat, a 20-px round one, with the 1-ulp rcp / sqrt of the front end; 1e-4 with correctly rounded ones)
+    assert eerr <= 3e-3 and np.percentile(eall, 99) <= 5e-5 and np.percentile(eall, 99.9) <= 2e-4
     # a vector's direction error is the extent-matrix error divided by the relative eigenvalue gap: bounded per splat,
     # tight in the bulk
     gap = (l1 ** 2 - l2 ** 2) / l1 ** 2

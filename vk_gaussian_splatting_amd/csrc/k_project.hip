@@ -17,6 +17,9 @@
 //   * splats that can never produce a fragment (alpha cull, lambda2<=0, clipped by z, footprint
 //     outside the strip) are dropped BEFORE the sort.
 //   * the 180-byte SH record (62 % of a splat's bytes) is not read here: shading is deferred.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 #include "kernels_common.h"
 #include "sort_plan.h"
 
@@ -60,6 +63,12 @@ __device__ __forceinline__ SplatFetch fetchSplat(const InstanceConst& I, uint32_
   return f;
 }
 
+// The raster front end (phase 2) is floating-point work with a tolerance (centre / basis <= 1e-5 relative), not the
+// bit-exact key: its reciprocals and square roots are the 1-ulp hardware instructions instead of hipcc's correctly rounded
+// expansions (10 instructions each; five divisions and seven roots per splat were a fifth of this kernel's instructions).
+__device__ __forceinline__ float fastRcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fastSqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 __device__ __forceinline__ bool projectSplat(const FrameConst& F, const InstanceConst& I, int instIdx, const SplatFetch& in,
                                              Projected& out)
 {
@@ -85,14 +94,14 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
     const float c = (1.0f + F.frustumDilation) * cw;
     ok            = ok && !(fabsf(cx) > c || fabsf(cy) > c || cz < (0.0f - F.frustumDilation) * cw || cz > cw);
   }
-  const float rw   = 1.0f / cw;
+  const float rw   = fastRcp(cw);
   const float ndcx = cx * rw, ndcy = cy * rw, ndcz = cz * rw;
   // fixed-function z clip of the emitted quad (all vertices at z = ndc.z, w = 1; no depth clamp)
   ok = ok && (ndcz >= 0.0f && ndcz <= 1.0f);
 
   // ---- covariance projection, threedgs.h.slang:26-56 ---------------------------------------------------------
   const float s00 = cA.x, s01 = cA.y, s02 = cA.z, s11 = cA.w, s12 = cB.x, s22 = cB.y;
-  const float rz = 1.0f / tz, rz2 = rz * rz;
+  const float rz = fastRcp(tz), rz2 = rz * rz;
   const float j00 = F.focal[0] * rz, j02 = -(F.focal[0] * tx) * rz2;
   const float j11 = F.focal[1] * rz, j12 = -(F.focal[1] * ty) * rz2;
   // W(r,c) = MV(r,c);  T = J * W (rows 0 and 1 only)
@@ -116,11 +125,11 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   if(F.msAA)
   {
     const float detBlur = a * d - b * b;
-    col.w *= sqrtf(fmaxf(detOrig / detBlur, 0.0f));
+    col.w *= fastSqrt(fmaxf(detOrig * fastRcp(detBlur), 0.0f));
   }
   const float D     = a * d - b * b;
   const float half  = 0.5f * (a + d);
-  const float term2 = sqrtf(fmaxf(0.1f, half * half - D));
+  const float term2 = fastSqrt(fmaxf(0.1f, half * half - D));
   float ev1 = half + term2, ev2 = half - term2;
   ok        = ok && !(ev2 <= 0.0f);
   if(F.debugFlags & 1)  // POINT_CLOUD_MODE, threedgs.h.slang:108-110
@@ -130,8 +139,8 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   e1x *= el;
   e1y *= el;
   const float kSqrt8 = 2.8284271247461903f;
-  const float l1     = F.splatScale * fminf(kSqrt8 * sqrtf(ev1), 2048.0f);
-  const float l2     = F.splatScale * fminf(kSqrt8 * sqrtf(fmaxf(ev2, 0.f)), 2048.0f);
+  const float l1     = F.splatScale * fminf(kSqrt8 * fastSqrt(ev1), 2048.0f);
+  const float l2     = F.splatScale * fminf(kSqrt8 * fastSqrt(fmaxf(ev2, 0.f)), 2048.0f);
   ok                 = ok && (l1 > 0.f && l2 > 0.f);
   const float b1x = e1x * l1, b1y = e1y * l1;   // basisVector1 (pixels)
   const float b2x = e1y * l2, b2y = -e1x * l2;  // basisVector2 = (e1.y, -e1.x) * l2
@@ -141,9 +150,9 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   const float a255    = col.w * 255.0f;
   ok                  = ok && (noGauss || a255 > 1.0f);
   const float qmax    = noGauss ? 4.0f : fminf(4.0f, __logf(fmaxf(a255, 1.0f)) + 1e-3f);
-  const float shrink = sqrtf(qmax * 0.25f) * 1.0005f;
-  const float ex = shrink * sqrtf(b1x * b1x + b2x * b2x) + 0.01f;
-  const float ey = shrink * sqrtf(b1y * b1y + b2y * b2y) + 0.01f;
+  const float shrink = fastSqrt(qmax * 0.25f) * 1.0005f;
+  const float ex = shrink * fastSqrt(b1x * b1x + b2x * b2x) + 0.01f;
+  const float ey = shrink * fastSqrt(b1y * b1y + b2y * b2y) + 0.01f;
 
   const float pcx = (ndcx + 1.0f) * 0.5f * (float)F.width;
   const float pcy = (ndcy + 1.0f) * 0.5f * (float)F.height;
@@ -161,7 +170,7 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
 
   // base colour, view direction and the SH sum (mesh.slang:205-207,240-243) are the compositor's business: it
   // shades the records it stages (kernels_common.h: viewDirection, k_raster.hip: shading phase)
-  const float n1 = 2.0f / (b1x * b1x + b1y * b1y), n2 = 2.0f / (b2x * b2x + b2y * b2y);
+  const float n1 = 2.0f * fastRcp(b1x * b1x + b1y * b1y), n2 = 2.0f * fastRcp(b2x * b2x + b2y * b2y);
   out.rec.cx  = pcx;
   out.rec.cy  = pcy;
   out.rec.p1x = b1x * n1;
@@ -219,6 +228,12 @@ __device__ __forceinline__ bool top16Mark(SortPlan* plan, uint32_t count, const 
 // Output: survivors of partition p, ascending id, in keysSlot/idsSlot[p*2048 ...], count in slotCount[p].
 // No barrier sits inside a loop that waits on memory: all 8 centre loads of a thread are issued up front,
 // and the heavy per-survivor loop runs barrier-free (waves drift apart and overlap each other's loads).
+#ifdef MGS_PRJ_TRACE  // debug build (tools/prj_trace.py): per-workgroup wall-clock stamps (100 MHz) of the phases
+__device__ uint64_t* g_prjTrace = nullptr;
+#define MGS_PRJ_STAMP(i) if(threadIdx.x == 0) trc[i] = wall_clock64();
+#else
+#define MGS_PRJ_STAMP(i)
+#endif
 template <bool FULL>
 __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __restrict__ Ap, FrameCounters* __restrict__ ctr,
                                                          uint32_t* __restrict__ keysSlot, uint32_t* __restrict__ idsSlot,
@@ -228,6 +243,11 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
                                                          SortPlan* __restrict__ planKeys, const float* __restrict__ partR)
 {
   const FrameArgs& A = *Ap;  // frame constants live in device memory (same pointer every frame: graph-replayable)
+#ifdef MGS_PRJ_TRACE
+  __shared__ uint64_t trc[8];
+  if(threadIdx.x < 8) trc[threadIdx.x] = 0;
+  MGS_PRJ_STAMP(0)
+#endif
   // slotHist[d * histStride + partition] = survivors of this partition whose low key byte is d: the radix
   // sort's pass-0 partition histogram, produced here while the keys are still on chip.
   // partition flags of k_partition_cull: bit 0 skip, bit 1 every centre passes the frustum test, bit 2 all centres finite
@@ -242,7 +262,6 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   }
   __shared__ uint32_t s_hist[256];
   __shared__ float4   s_rec[FULL ? kPrjWaves : 1][FULL ? 64 * 3 : 1];  // per wave: 64 records at a 48-byte pitch
-  __shared__ uint32_t s_gid[FULL ? kPrjWaves : 1][64];
   if(threadIdx.x < 256)
     s_hist[threadIdx.x] = 0u;  // ordered before its first use by the barriers of phase 1
   __shared__ uint16_t s_li[kPrjPart];   // bit 15: survived phase 2
@@ -273,6 +292,10 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   uint32_t key[kPrjItems];
   uint64_t bal[kPrjItems];
   bool     vis[kPrjItems];
+#ifdef MGS_PRJ_TRACE
+  if(px[0] + py[1] + pz[2] == 12345.678f) trc[7] = 1;  // consume the loads: the stamp below follows their arrival
+  MGS_PRJ_STAMP(1)
+#endif
   const bool identityFast = (pflag & 4u) != 0u && I.modelIsIdentity != 0u;
   // strips (multi-GPU): a splat whose centre lies further from this device's rows than the partition's footprint bound R
   // (k_partition_cull; valid for every splat of the partition) cannot reach them — dropped here, before the projection.
@@ -333,6 +356,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
     if(lane == 0)
       s_cnt[it * kPrjWaves + w] = (uint32_t)__popcll(bal[it]);
   }
+  MGS_PRJ_STAMP(2)
   const uint32_t M = scanRoundWaveCounts(s_cnt, s_base);
 #pragma unroll
   for(int it = 0; it < kPrjItems; ++it)
@@ -346,6 +370,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   if(t == 0 && M)
     atomicAdd(&ctr->frustumCount, M);
 
+  MGS_PRJ_STAMP(3)
   const size_t slotBase = (size_t)part * kPrjPart;
   if constexpr(!FULL)
   {
@@ -414,13 +439,15 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
           s_li[j] |= 0x8000u;  // own entry only: no race
         }
       }
-      s_gid[w][lane] = gidOk;
+      // the id rides in the pitch's third (padding) quad: a separate 1 KB array was what kept the workgroup above 26 KB of LDS
+      // and the CU at 5 resident workgroups instead of 6
+      reinterpret_cast<uint32_t*>(&s_rec[w][lane * 3 + 2])[0] = gidOk;
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for(int i = 0; i < 2; ++i)
       {
         const int      rr = 32 * i + (lane >> 1), part = lane & 1;
-        const uint32_t g  = s_gid[w][rr];
+        const uint32_t g  = reinterpret_cast<const uint32_t*>(&s_rec[w][rr * 3 + 2])[0];
         if(g != 0xFFFFFFFFu)
           reinterpret_cast<float4*>(rec + g)[part] = s_rec[w][rr * 3 + part];
       }
@@ -430,6 +457,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
     }
     // ---- second ordered compaction straight into the partition's slot region ---------------------------
     __syncthreads();
+    MGS_PRJ_STAMP(4)
 #pragma unroll
     for(int r = 0; r < kPrjItems; ++r)
     {
@@ -470,6 +498,16 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
         if(vis[r])
           sortMarkTop16(planKeys, s_key[r * kPrjThreads + t] >> 16);
     }
+#ifdef MGS_PRJ_TRACE
+    MGS_PRJ_STAMP(5)
+    if(threadIdx.x == 0 && g_prjTrace)
+    {
+      uint64_t* o = g_prjTrace + (size_t)blockIdx.x * 8;
+      for(int i = 0; i < 6; ++i) o[i] = trc[i];
+      o[6] = M;
+      o[7] = outCount;
+    }
+#endif
   }
 }
 
@@ -585,6 +623,20 @@ void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* d
   const dim3 grid(args.f.totalPartitions), block(kPrjThreads);
   if(args.f.totalPartitions == 0)
     return;
+#ifdef MGS_PRJ_TRACE
+  static uint64_t* traceBuf = nullptr;
+  const char*      tracePath = std::getenv("MGS_PRJ_TRACE_FILE");
+  const size_t     traceN = (size_t)args.f.totalPartitions * 8;
+  if(tracePath && full)
+  {
+    if(!traceBuf)
+    {
+      (void)hipMalloc(&traceBuf, (size_t)1 << 24);
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prjTrace), &traceBuf, sizeof(traceBuf));
+    }
+    (void)hipMemsetAsync(traceBuf, 0, traceN * 8, stream);
+  }
+#endif
 #define MGS_LAUNCH(FULLV)                                                                                                \
   hipLaunchKernelGGL((k_project<FULLV>), grid, block, 0, stream, dArgs, ctr, keysSlot, idsSlot, slotCount, rec, rect, partSkip, \
                      slotHist, histStride, planKeys, partR)
@@ -593,6 +645,19 @@ void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* d
   else
     MGS_LAUNCH(false);
 #undef MGS_LAUNCH
+#ifdef MGS_PRJ_TRACE
+  if(tracePath && full)
+  {
+    (void)hipStreamSynchronize(stream);
+    std::vector<uint64_t> h(traceN);
+    (void)hipMemcpy(h.data(), traceBuf, traceN * 8, hipMemcpyDeviceToHost);
+    if(FILE* fp = std::fopen(tracePath, "wb"))
+    {
+      std::fwrite(h.data(), 8, traceN, fp);
+      std::fclose(fp);
+    }
+  }
+#endif
 }
 
 }  // namespace mgs
