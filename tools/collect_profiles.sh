@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes behind profiles/${TAG}_* (run on the GPU box via gpurun; results land in gpurun_out/).
-export TAG=${TAG:-r2_d}; export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-/root/repo}; cd /tmp; rm -rf /tmp/pf /tmp/pw /tmp/psq /tmp/ps1 /tmp/ps3
+export TAG=${TAG:-r2_h}; export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-/root/repo}; cd /tmp; rm -rf /tmp/pf /tmp/pw /tmp/psq /tmp/ps1 /tmp/ps3
 CMD="python $R/bench.py --steps 24 --warmup 4 --no-cpu-baseline --inflight 1"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -- $CMD > /tmp/l1 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -- $CMD > /tmp/l2 2>&1
@@ -17,7 +17,7 @@ import json, os
 d = json.load(open('gpurun_out/pmc_sq_all.json'))
 out = {}
 for k, v in d.items():
-    name = 'k_composite' if 'k_composite' in k else ('k_project' if 'k_project' in k else None)
+    name = 'k_composite' if 'k_composite' in k else ('k_project' if 'k_project<true>' in k else None)
     if name:
         out[name] = {c: x['mean'] for c, x in v.items()}
         out[name]['kernel'] = k
