@@ -27,8 +27,9 @@ out = {"command": sys.argv[4], "frames_profiled": frames,
        "correction": "per frame: 2*FETCH_SIZE (gfx950 tallies 16 B/lane streaming reads at half) + WRITE_SIZE, KB*1024",
        "kernels": {}, "all": {"FETCH_SIZE": fetch, "WRITE_SIZE": write}}
 for stage, pats in STAGE.items():
-    f = sum(v["total_KB"] for k, v in fetch.items() if any(p in k for p in pats)) / frames
-    w = sum(v["total_KB"] for k, v in write.items() if any(p in k for p in pats)) / frames
+    # k_project<false> is the sort-only hook (bench.py's parity leg, mgs_sort_download): not part of a frame
+    f = sum(v["total_KB"] for k, v in fetch.items() if any(p in k for p in pats) and "<false>" not in k) / frames
+    w = sum(v["total_KB"] for k, v in write.items() if any(p in k for p in pats) and "<false>" not in k) / frames
     out["kernels"][stage] = {"FETCH_SIZE_KB_per_frame": f, "WRITE_SIZE_KB_per_frame": w,
                              "traffic_bytes_per_launch_corrected": (2 * f + w) * 1024, "traffic_bytes_uncorrected": (f + w) * 1024}
     print(stage, "fetch %.1f MB write %.1f MB -> corrected %.1f MB" % (f / 1024, w / 1024, (2 * f + w) / 1024))
