@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
   {
     uint64_t* o = F.trace + (size_t)blockIdx.x * 10;
     o[0] = traceT0; o[1] = wall_clock64(); o[2] = statScanned; o[3] = statStaged; o[4] = traceIters; o[5] = traceRounds;
-    o[6] = traceA; o[7] = traceS; o[8] = traceB; o[9] = (uint64_t)range.y - range.x;
+    o[6] = traceA; o[7] = traceS; o[8] = traceB; o[9] = ((uint64_t)range.y - range.x) | ((uint64_t)(ty * colsX + cx2) << 32);
   }
 #endif
   if(t == 0)
