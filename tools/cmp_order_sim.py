@@ -58,3 +58,34 @@ for pose in range(0, 8):
     print(line, flush=True)
     prev[pose] = cost
 print("lower bound (sum / 1536):", round(float(dur.sum()) / 1536, 1), " longest workgroup:", round(float(dur.max()), 1))
+
+# ---- same-frame predictors of a region's cost (no history): centre counts / opacity mass per region from the splat data ----
+def region_stats(pose):
+    eye = synth.orbit_pose(pose)
+    V, P = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, W, H)
+    pos = sc["positions"].astype(np.float64)
+    h = np.concatenate([pos, np.ones((pos.shape[0], 1))], axis=1)
+    clip = h @ (np.asarray(P, np.float64) @ np.asarray(V, np.float64)).T
+    w = clip[:, 3]
+    ok = w > 1e-6
+    ndc = clip[ok, :3] / w[ok, None]
+    inside = (np.abs(ndc[:, 0]) < 1) & (np.abs(ndc[:, 1]) < 1) & (ndc[:, 2] > 0) & (ndc[:, 2] < 1)
+    px = (ndc[inside, 0] + 1) * 0.5 * W
+    py = (ndc[inside, 1] + 1) * 0.5 * H
+    alpha = 1.0 / (1.0 + np.exp(-sc["opacity"].reshape(-1).astype(np.float64)))[ok][inside]
+    colsX = (W // 16 + 1) // 2
+    rid = (py // 16).astype(np.int64) * colsX + (px // 32).astype(np.int64)
+    n = ((H + 15) // 16) * colsX
+    return np.bincount(rid, minlength=n), np.bincount(rid, weights=alpha, minlength=n)
+
+
+print("--- same-frame predictors")
+for pose in (0, 5):
+    reg, dur, span = trace(pose)
+    cnt, mass = region_stats(pose)
+    c, m = cnt[reg].astype(np.float64), mass[reg]
+    for name, key in (("few centres first", -c), ("little opacity mass first", -m), ("1/(1+count)", 1.0 / (1.0 + c)),
+                      ("1/(8+mass)", 1.0 / (8.0 + m))):
+        o = np.argsort(-key, kind="stable")
+        print(f"pose {pose}: {name:28s} simulated span {simulate(dur[o]):.1f} us (corr with duration {np.corrcoef(key, dur)[0, 1]:.2f}); "
+              f"launch order {simulate(dur):.1f}, own durations {simulate(np.sort(dur)[::-1]):.1f}")
