@@ -26,6 +26,12 @@ constexpr int kGutThreads = 256;
 constexpr int kGutItems   = 8;
 constexpr int kGutPart    = kGutThreads * kGutItems;  // == the project kernel's partition: same slots, same sort input
 
+// This pipeline's arithmetic has a tolerance (>= 50 dB vs the oracle), no bit-exact part except the keys of phase 1: reciprocals
+// and square roots are the 1-ulp hardware instructions, not hipcc's correctly rounded expansions (10 instructions each; the
+// front end had ~30 divisions per splat, the compositor one per fragment).
+__device__ __forceinline__ float gRcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float gSqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 // threedgut_camera_projections.h.slang:32-44
 __device__ __forceinline__ float gutStableNorm2(float x, float y)
 {
@@ -33,8 +39,8 @@ __device__ __forceinline__ float gutStableNorm2(float x, float y)
   const float mn = fminf(ax, ay), mx = fmaxf(ax, ay);
   if(mx <= 0.0f)
     return 0.0f;
-  const float r = mn / mx;
-  return mx * sqrtf(1.0f + r * r);
+  const float r = mn * gRcp(mx);
+  return mx * gSqrt(1.0f + r * r);
 }
 
 // projectPointWithShutter (global shutter) + projectPoint for the perfect pinhole / fisheye models.  `cam` is the
@@ -48,7 +54,7 @@ __device__ __forceinline__ bool gutProjectCam(const FrameConst& F, float cx, flo
     const float rho       = fmaxf(gutStableNorm2(cx, cy), 1e-7f);
     const float thetaFull = atan2f(rho, cz);
     const float theta     = fminf(thetaFull, F.gutMaxAngle);
-    const float delta     = theta / rho;
+    const float delta     = theta * gRcp(rho);
     ox                    = F.gutFocal[0] * cx * delta + resx * 0.5f;
     oy                    = F.gutFocal[1] * cy * delta + resy * 0.5f;
     ok                    = theta < F.gutMaxAngle;
@@ -60,8 +66,9 @@ __device__ __forceinline__ bool gutProjectCam(const FrameConst& F, float cx, flo
       ox = oy = 0.0f;
       return false;
     }
-    ox = (cx / cz) * F.gutFocal[0] + resx * 0.5f;
-    oy = (cy / cz) * F.gutFocal[1] + resy * 0.5f;
+    const float rcz = gRcp(cz);
+    ox = (cx * rcz) * F.gutFocal[0] + resx * 0.5f;
+    oy = (cy * rcz) * F.gutFocal[1] + resy * 0.5f;
     ok = true;
   }
   const float mx = resx * 0.1f, my = resy * 0.1f;  // withinResolution, GUT_IN_IMAGE_MARGIN_FACTOR
@@ -75,10 +82,10 @@ __device__ __forceinline__ bool projectSplatGut(const FrameConst& F, const Insta
   // evaluated by the compositor for the records it stages (deferred shading, as in the 3DGS path: 0.96 M staged
   // (tile, splat) pairs against 4.1 M sorted splats on the garden-sized frame; the SH records were half of this kernel's time)
   const float  px = I.centers[3 * (size_t)li], py = I.centers[3 * (size_t)li + 1], pz = I.centers[3 * (size_t)li + 2];
-  const float  s0 = expf(I.scales[3 * (size_t)li]), s1 = expf(I.scales[3 * (size_t)li + 1]), s2 = expf(I.scales[3 * (size_t)li + 2]);
+  const float  s0 = __expf(I.scales[3 * (size_t)li]), s1 = __expf(I.scales[3 * (size_t)li + 1]), s2 = __expf(I.scales[3 * (size_t)li + 2]);
   const float4 rq = *reinterpret_cast<const float4*>(I.rotations + 4 * (size_t)li);  // (w,x,y,z)
-  const float  ql = sqrtf(rq.x * rq.x + rq.y * rq.y + rq.z * rq.z + rq.w * rq.w);
-  const float  w = rq.x / ql, x = rq.y / ql, y = rq.z / ql, z = rq.w / ql;
+  const float  ql = rsqrtf(rq.x * rq.x + rq.y * rq.y + rq.z * rq.z + rq.w * rq.w);
+  const float  w = rq.x * ql, x = rq.y * ql, y = rq.z * ql, z = rq.w * ql;
   const float  xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
   // quatToMat3 (quaternions.h.slang:39-58): row a = a-th principal axis
   const float R[3][3] = {{1.0f - 2.0f * (yy + zz), 2.0f * (xy + wz), 2.0f * (xz - wy)},
@@ -141,22 +148,22 @@ __device__ __forceinline__ bool projectSplatGut(const FrameConst& F, const Insta
       return false;
     float wop = alpha;
     if(F.msAA)
-      wop = alpha * sqrtf(fmaxf(0.000025f, (c0 * c2 - c1 * c1) / det));
+      wop = alpha * gSqrt(fmaxf(0.000025f, (c0 * c2 - c1 * c1) * gRcp(det)));
     if(wop < 0.01f)
       return false;
-    const float maxPower = logf(wop / 0.01f);
-    const float factor   = fminf(3.33f, sqrtf(2.0f * maxPower));
+    const float maxPower = __logf(wop * 100.0f);
+    const float factor   = fminf(3.33f, gSqrt(2.0f * maxPower));
     const float mid      = 0.5f * (ddx + ddz);
-    const float lambda   = mid + sqrtf(fmaxf(0.01f, mid * mid - det));
-    const float radius   = factor * sqrtf(lambda);
+    const float lambda   = mid + gSqrt(fmaxf(0.01f, mid * mid - det));
+    const float radius   = factor * gSqrt(lambda);
     if(!(radius > 0.0f))
       return false;
     if(F.msAA)
       alpha = wop;
-    h1x = fminf(factor * sqrtf(ddx), radius);
+    h1x = fminf(factor * gSqrt(ddx), radius);
     h1y = 0.0f;
     h2x = 0.0f;
-    h2y = fminf(factor * sqrtf(ddz), radius);
+    h2y = fminf(factor * gSqrt(ddz), radius);
   }
   else
   {  // threedgsProjectedExtentBasis(cov, 3.33, splatScale, ...), threedgs.h.slang:60-121
@@ -166,19 +173,19 @@ __device__ __forceinline__ bool projectSplatGut(const FrameConst& F, const Insta
     a += 0.3f;
     d += 0.3f;
     if(F.msAA)
-      alpha *= sqrtf(fmaxf(detOrig / (a * d - b * b), 0.0f));
+      alpha *= gSqrt(fmaxf(detOrig * gRcp(a * d - b * b), 0.0f));
     const float D = a * d - b * b, half = 0.5f * (a + d);
-    const float term2 = sqrtf(fmaxf(0.1f, half * half - D));
+    const float term2 = gSqrt(fmaxf(0.1f, half * half - D));
     float ev1 = half + term2, ev2 = half - term2;
     if(ev2 <= 0.0f)
       return false;
     if(F.debugFlags & 1)
       ev1 = ev2 = 0.2f;
     float       e1x = (fabsf(b) < 0.001f) ? 1.0f : b, e1y = ev1 - a;
-    const float el  = sqrtf(e1x * e1x + e1y * e1y);
-    e1x /= el;
-    e1y /= el;
-    const float l1 = F.splatScale * fminf(3.33f * sqrtf(ev1), 2048.0f), l2 = F.splatScale * fminf(3.33f * sqrtf(ev2), 2048.0f);
+    const float el  = rsqrtf(e1x * e1x + e1y * e1y);
+    e1x *= el;
+    e1y *= el;
+    const float l1 = F.splatScale * fminf(3.33f * gSqrt(ev1), 2048.0f), l2 = F.splatScale * fminf(3.33f * gSqrt(ev2), 2048.0f);
     h1x = e1x * l1;
     h1y = e1y * l1;
     h2x = e1y * l2;
@@ -194,7 +201,7 @@ __device__ __forceinline__ bool projectSplatGut(const FrameConst& F, const Insta
   const float  tw = MV[3] * px + MV[7] * py + MV[11] * pz + MV[15];
   const float  cz = P[2] * tx + P[6] * ty + P[10] * tz + P[14] * tw;
   const float  cw = P[3] * tx + P[7] * ty + P[11] * tz + P[15] * tw;
-  const float  ndcz = cz / cw;
+  const float  ndcz = cz * gRcp(cw);
   if(!(ndcz >= 0.0f && ndcz <= 1.0f))
     return false;
   const float n1 = h1x * h1x + h1y * h1y, n2 = h2x * h2x + h2y * h2y;
@@ -214,20 +221,22 @@ __device__ __forceinline__ bool projectSplatGut(const FrameConst& F, const Insta
 
   out.cx  = ccx;
   out.cy  = ccy;
-  out.q1x = h1x / n1;
-  out.q1y = h1y / n1;
-  out.q2x = h2x / n2;
-  out.q2y = h2y / n2;
+  const float rn1 = gRcp(n1), rn2 = gRcp(n2);
+  out.q1x = h1x * rn1;
+  out.q1y = h1y * rn1;
+  out.q2x = h2x * rn2;
+  out.q2y = h2y * rn2;
   out.bex = bex + 0.01f;
   out.bey = bey + 0.01f;
   // canonical frame: A = S^-1 R^T, i.e. A[k][r] = R[k][r] / s_k with R's rows the axes;  B = A N, ro = A (M^-1 o - p)
   const float* Mi = I.modelInv;
   float        A[3][3];
+  const float  rsc[3] = {gRcp(sc[0]), gRcp(sc[1]), gRcp(sc[2])};
 #pragma unroll
   for(int k = 0; k < 3; ++k)
 #pragma unroll
     for(int r = 0; r < 3; ++r)
-      A[k][r] = R[k][r] / sc[k];
+      A[k][r] = R[k][r] * rsc[k];
 #pragma unroll
   for(int k = 0; k < 3; ++k)
 #pragma unroll
@@ -552,7 +561,7 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
         roz += b1.z * lensX + b1.w * lensY + b2.x * lensZ;
       }
       const float kx = gy * roz - gz * roy, ky = gz * rox - gx * roz, kz = gx * roy - gy * rox;
-      const float dist2 = (kx * kx + ky * ky + kz * kz) / (gx * gx + gy * gy + gz * gz);
+      const float dist2 = (kx * kx + ky * ky + kz * kz) * gRcp(gx * gx + gy * gy + gz * gz);
       float resp = __expf(-0.5f * dist2);                            // quadratic kernel, :127-131
       if constexpr(XT != 0)
       {  // particleRayMaxKernelResponse<KERNEL_DEGREE>, threedgrt.h.slang:83-127 (its argument is the squared distance)
