@@ -5,7 +5,7 @@ C=vk_gaussian_splatting_amd/csrc
 cp $C/libmgs.so /tmp/libmgs_base.so
 for tag in base "$@"; do
   if [ "$tag" = base ]; then cp /tmp/libmgs_base.so $C/libmgs.so; else cp $C/libmgs_$tag.so $C/libmgs.so; fi
-  python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "keys or full_size or strips or matches_oracle or knobs" 2>&1 | tail -2 > gpurun_out/ab_${tag}_tests.log
+  python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "keys or full_size or strips or matches_oracle or knobs or binning" 2>&1 | tail -2 > gpurun_out/ab_${tag}_tests.log
   python bench.py --no-cpu-baseline --inflight 1 2>&1 | grep '^{' | tail -1 > gpurun_out/ab_${tag}_if1.json
   python bench.py --no-cpu-baseline 2>&1 | grep '^{' | tail -1 > gpurun_out/ab_${tag}_if3.json
 done
