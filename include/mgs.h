@@ -169,7 +169,8 @@ typedef struct MgsFrameParams {
   int32_t size_culling;         /* 0/1, default 0 (parameters.h:185): drop splats whose projected extent is below ...  */
   float   size_culling_min_pixels; /* ... this many pixels, default 1.0 (shaderio.h:266, dist.comp.slang:93-134)      */
   int32_t surface_outputs;      /* 0/1, default 0: also produce the FTB side outputs of NEED_SURFACE_INFO
-                                   (threedgs_raster.frag.slang:320-349): picked depth + the splat that set it */
+                                   (threedgs_raster.frag.slang:320-349; 3DGUT pipeline: threedgut_raster.frag.slang:195-228):
+                                   picked depth + the splat that set it + the integrated normal */
   float   depth_iso_threshold;  /* default 0.7 (parameters.h:200): depth = ndc z of the first fragment after which
                                    the pixel's transmittance is below this */
   int32_t cpu_lazy_sort;        /* CPU_ASYNC only, default 1 (parameters.h:183): start a new sort only if the viewpoint changed */

@@ -308,6 +308,21 @@ def render_surface(frame, inst, order_front_to_back, depth_iso_threshold=0.7, th
     return (depth, ids, nrm) if normals else (depth, ids)
 
 
+def render_surface_gut(frame, inst, order_front_to_back, depth_iso_threshold=0.7, thin_particle_threshold=1e-6, normals=False):
+    """3DGUT pipeline: (depth, splat_id[, normal]) as render_surface"""
+    o = np.ascontiguousarray(order_front_to_back, np.uint32)
+    depth = np.zeros((frame.height, frame.width), np.float32)
+    ids = np.zeros((frame.height, frame.width), np.uint32)
+    nrm = np.zeros((frame.height, frame.width, 4), np.float32) if normals else None
+    fn = lib().orc_render_surface_gut
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    fn(C.cast(C.byref(frame), C.c_void_p), C.cast(inst, C.c_void_p), len(inst), o.ctypes.data, o.size,
+       float(depth_iso_threshold), float(thin_particle_threshold), depth.ctypes.data, ids.ctypes.data,
+       nrm.ctypes.data if normals else None)
+    return (depth, ids, nrm) if normals else (depth, ids)
+
+
 def splat_normal(frame, inst, k, local_idx, thin_particle_threshold=1e-6, quantize=False):
     out = np.zeros(3, np.float32)
     fn = lib().orc_splat_normal

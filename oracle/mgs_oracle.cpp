@@ -1395,6 +1395,75 @@ void orc_render_surface(const OrcFrame* f, const OrcInstance* inst, int n_inst, 
   }
 }
 
+// 3DGUT with NEED_SURFACE_INFO, FTB (threedgut_raster.frag.slang:127-131,195-228; particleProcessHitGutWithNormal,
+// threedgrt.h.slang:281-345): ids nearest first.  The max-density-plane normal depends on the ray ORIGIN only (per splat
+// without depth of field) except for particles with two degenerate axes, whose normal is minus the pixel's ray; it is
+// not quantised (computed in the fragment shader).
+void orc_render_surface_gut(const OrcFrame* f, const OrcInstance* inst, int n_inst, const uint32_t* ids, uint32_t v,
+                            float depth_iso_threshold, float thin_particle_threshold, float* depth_out, uint32_t* id_out,
+                            float* normal_out)
+{
+  const int          W = f->width, H = f->height;
+  const size_t       np = (size_t)W * H;
+  std::vector<float> trans(np, 1.0f);
+  std::fill(depth_out, depth_out + np, 0.0f);
+  std::fill(id_out, id_out + np, 0xFFFFFFFFu);
+  if(normal_out)
+    std::fill(normal_out, normal_out + 4 * np, 0.0f);
+  std::vector<uint32_t> offsets(n_inst + 1, 0);
+  for(int k = 0; k < n_inst; ++k)
+    offsets[k + 1] = offsets[k] + inst[k].count;
+  for(uint32_t s = 0; s < v; ++s)
+  {
+    const uint32_t g = ids[s];
+    int            k = 0;
+    while(k + 1 < n_inst && g >= offsets[k + 1])
+      ++k;
+    OrcGutProjected P;
+    orc_project_gut(f, &inst[k], g - offsets[k], &P);
+    if(!P.valid)
+      continue;
+    const float ex = std::fabs(P.half1[0]) + std::fabs(P.half2[0]), ey = std::fabs(P.half1[1]) + std::fabs(P.half2[1]);
+    const float fx0 = P.center_px[0] - ex - 0.5f, fx1 = P.center_px[0] + ex - 0.5f;
+    const float fy0 = P.center_px[1] - ey - 0.5f, fy1 = P.center_px[1] + ey - 0.5f;
+    if(!(fx1 >= 0.f && fy1 >= 0.f && fx0 <= (float)(W - 1) && fy0 <= (float)(H - 1)))
+      continue;
+    const int   x0 = (int)std::max(0.0f, std::floor(fx0)), x1 = (int)std::min((float)(W - 1), std::ceil(fx1));
+    const int   y0 = (int)std::max(0.0f, std::floor(fy0)), y1 = (int)std::min((float)(H - 1), std::ceil(fy1));
+    const float n1 = P.half1[0] * P.half1[0] + P.half1[1] * P.half1[1], n2 = P.half2[0] * P.half2[0] + P.half2[1] * P.half2[1];
+    float       nrm[3] = {0.f, 0.f, 0.f};
+    if(normal_out)
+      orc_splat_normal(f, &inst[k], g - offsets[k], thin_particle_threshold, 0, nrm);
+    for(int y = y0; y <= y1; ++y)
+      for(int x = x0; x <= x1; ++x)
+      {
+        const float dx = ((float)x + 0.5f) - P.center_px[0], dy = ((float)y + 0.5f) - P.center_px[1];
+        const float u = (dx * P.half1[0] + dy * P.half1[1]) / n1, w = (dx * P.half2[0] + dy * P.half2[1]) / n2;
+        if(std::fabs(u) > 1.0f || std::fabs(w) > 1.0f)
+          continue;
+        float opacity;
+        if(!orc_gut_fragment(f, &inst[k], &P, x, y, &opacity))
+          continue;
+        const size_t i = (size_t)y * W + x;
+        if(normal_out)
+        {
+          float*      d  = &normal_out[4 * i];
+          const float om = 1.0f - d[3];
+          d[0] += nrm[0] * opacity * om;
+          d[1] += nrm[1] * opacity * om;
+          d[2] += nrm[2] * opacity * om;
+          d[3] += opacity * om;
+        }
+        trans[i] *= (1.0f - opacity);
+        if(depth_out[i] == 0.0f && trans[i] < depth_iso_threshold)
+        {
+          depth_out[i] = P.ndc_z;
+          id_out[i]    = g;
+        }
+      }
+  }
+}
+
 uint64_t orc_render(const OrcFrame* f, const OrcInstance* inst, int n_inst, float* rgba_out, uint64_t* stats)
 {
   size_t total = 0;

@@ -167,6 +167,11 @@ void     orc_oct_decode(uint32_t packed, float out[3]);
  * quaternions.h.slang:33-76.  quantize != 0 applies the QUANTIZE_NORMALS round trip (frag.slang:200). */
 void orc_splat_normal(const OrcFrame* f, const OrcInstance* inst, uint32_t local_idx, float thin_particle_threshold,
                       int quantize, float out[3]);
+/* 3DGUT pipeline with NEED_SURFACE_INFO, front to back: picked depth, the splat that set it, integrated normal [4/pixel] (may be NULL) */
+void     orc_render_surface_gut(const OrcFrame* f, const OrcInstance* inst, int n_inst, const uint32_t* ids_front_to_back, uint32_t v,
+                                float depth_iso_threshold, float thin_particle_threshold, float* depth_out, uint32_t* id_out,
+                                float* normal_out);
+
 /* FTB surface side outputs, threedgs_raster.frag.slang:320-349 ; `ids` front-to-back.
  * depth_out/id_out: picked depth + the splat that set it.  normal_out (may be NULL): [H][W][4], the integrated
  * normal attachment = "under" blend of float4(normal * opacity, opacity) (gaussian_splatting.cpp:2090-2107),

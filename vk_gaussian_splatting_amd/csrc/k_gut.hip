@@ -15,9 +15,11 @@
 // LDS in list order) and evaluates the particle response per fragment.  This pipeline is a "next" row: correct and
 // reasonably fast, not tuned like the 3DGS compositor.
 // Depth of field and stochastic splats are the XT variant of the compositor (random numbers: kernels_common.h).
-// Kernel degrees other than 2 run in the XT variant too.  Not built (stated in DESIGN.md): rolling shutter (untested in the reference).
+// Kernel degrees other than 2 and the surface side outputs run in the XT variant too.  Not built (stated in DESIGN.md):
+// rolling shutter (untested in the reference).
 #include "kernels_common.h"
 #include "sh_eval.h"
+#include "surface_normal.h"
 #include "sort_plan.h"
 
 namespace mgs {
@@ -394,15 +396,19 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
 constexpr int kGutBatch = 256;  // list entries scanned per round == staging capacity
 
 // XT 1: the variant with depth of field (frag.slang:104-109, cameras.h.slang:85-108), stochastic splats (:150-172) and/or
-// a particle kernel other than the quadratic one
+// a particle kernel other than the quadratic one, and/or the surface side outputs (picked depth, splat id, integrated normal)
 template <int SHF, int XT>
 __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restrict__ Ap, const uint2* __restrict__ ranges,
                                                        const uint32_t* __restrict__ valX, const uint32_t* __restrict__ valY,
                                                        const SortPlan* __restrict__ plan, const GutRec* __restrict__ rec,
-                                                       void* __restrict__ outImage, int halfOut, FrameCounters* __restrict__ ctr)
+                                                       void* __restrict__ outImage, int halfOut, FrameCounters* __restrict__ ctr,
+                                                       float* __restrict__ outDepth, uint32_t* __restrict__ outSplatId,
+                                                       float4* __restrict__ outNormal)
 {
   __shared__ float4   s_r[kGutBatch][6];
   __shared__ uint32_t s_gid[XT ? kGutBatch : 1];
+  __shared__ float4   s_n[XT ? kGutBatch : 1];  // surface outputs: world normal of the record (.w = 1: minus the pixel's ray)
+  __shared__ float    s_z[XT ? kGutBatch : 1];  //                  fragCoord.z of the record's quad
   __shared__ uint32_t s_wc[4];
   __shared__ uint32_t s_live;
   const FrameConst& F = Ap->f;
@@ -477,6 +483,9 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
   const int      bin   = (ty >> F.binShiftY) * F.binsX + (tx >> F.binShiftX);
   const uint2    range = ranges[bin];
   float T = (inside && rayOk) ? 1.0f : 0.0f, cr = 0.f, cg = 0.f, cb = 0.f, asum = 0.f;
+  const bool surf = XT && F.surfaceOutputs != 0;
+  float      nx = 0.f, ny = 0.f, nz = 0.f, pickZ = 0.f;
+  uint32_t   pickId = 0xFFFFFFFFu;
   uint32_t hi = range.y;
   uint32_t statScanned = 0, statStaged = 0;
   while(hi > range.x)
@@ -534,7 +543,26 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
       s_r[pos][4] = r4;
       s_r[pos][5] = c5;
       if constexpr(XT != 0)
+      {
         s_gid[pos] = g;
+        if(F.surfaceOutputs)
+        {  // frag.slang:127-131 -> particleProcessHitGutWithNormal (threedgrt.h.slang:281-345): the max-density-plane normal is a
+          // per-splat quantity (ray ORIGIN only) except for particles with two degenerate axes; no octahedral round trip here
+          // (the normal is computed in the fragment shader, not carried through an interstage variable).  fragCoord.z: the
+          // quad sits at the pinhole depth of the centre (mesh.slang:221-226)
+          s_n[pos] = splatWorldNormal(F, I, li, false);
+          const float  cpx = I.centers[3 * (size_t)li], cpy = I.centers[3 * (size_t)li + 1], cpz = I.centers[3 * (size_t)li + 2];
+          const float* MV = I.modelView;
+          const float* P  = F.proj;
+          const float  tx = MV[0] * cpx + MV[4] * cpy + MV[8] * cpz + MV[12];
+          const float  ty = MV[1] * cpx + MV[5] * cpy + MV[9] * cpz + MV[13];
+          const float  tz = MV[2] * cpx + MV[6] * cpy + MV[10] * cpz + MV[14];
+          const float  tw = MV[3] * cpx + MV[7] * cpy + MV[11] * cpz + MV[15];
+          const float  cz = P[2] * tx + P[6] * ty + P[10] * tz + P[14] * tw;
+          const float  cw = P[3] * tx + P[7] * ty + P[11] * tz + P[15] * tw;
+          s_z[pos]        = cz * gRcp(cw);
+        }
+      }
     }
     if(t == 0)
       s_live = 0u;
@@ -595,6 +623,23 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
       cb += wgt * c4.z;
       asum += op;
       T -= wgt;
+      if constexpr(XT != 0)
+      {
+        if(surf)
+        {  // frag.slang:195-228: normal attachment "under"-blended with (normal * opacity, opacity); picked depth = the
+          // fragment after which the transmittance is below the threshold, and the splat that set it
+          const float4 n1 = s_n[j];
+          const bool   ray = n1.w != 0.0f;  // degenerate particle: -rayDirection (model -> world: minus the pixel's world ray)
+          nx += wgt * (ray ? -dxw : n1.x);
+          ny += wgt * (ray ? -dyw : n1.y);
+          nz += wgt * (ray ? -dzw : n1.z);
+          if(op > 0.0f && pickZ == 0.0f && T < F.depthIsoThreshold)
+          {
+            pickZ  = s_z[j];
+            pickId = s_gid[j];
+          }
+        }
+      }
     }
     if(early)
     {
@@ -616,6 +661,15 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
     return;
   const float alphaOut = F.alphaMode == 1 ? asum : 1.0f - ((inside && rayOk) ? T : 1.0f);
   const size_t pix = (size_t)py * F.width + px;
+  if constexpr(XT != 0)
+  {
+    if(surf)
+    {
+      outDepth[pix]   = pickZ;
+      outSplatId[pix] = pickId;
+      outNormal[pix]  = make_float4(nx, ny, nz, 1.0f - ((inside && rayOk) ? T : 1.0f));
+    }
+  }
   if(halfOut == 1)
   {
     const __half2 lo = __floats2half2_rn(cr, cg), hi2 = __floats2half2_rn(cb, alphaOut);
@@ -647,15 +701,15 @@ void launchProjectGut(hipStream_t stream, const FrameArgs& args, const FrameArgs
 
 void launchCompositeGut(hipStream_t stream, const FrameArgs& A, const FrameArgs* dArgs, const uint2* ranges, const uint32_t* valX,
                         const uint32_t* valY, const SortPlan* planPairs, const GutRec* rec, void* image, int halfOut,
-                        FrameCounters* ctr, int shFormat)
+                        FrameCounters* ctr, int shFormat, float* outDepth, uint32_t* outSplatId, float4* outNormal)
 {
   const int tiles = A.f.tilesX * (A.f.stripRow1 - A.f.stripRow0);
   if(tiles <= 0)
     return;
-  const bool extras = A.f.dofMode != 0 || A.f.stochastic != 0 || A.f.kernelDegree != 2;
+  const bool extras = A.f.dofMode != 0 || A.f.stochastic != 0 || A.f.kernelDegree != 2 || A.f.surfaceOutputs != 0;
 #define MGS_LAUNCH(SHF, XT)                                                                                                          \
   hipLaunchKernelGGL((k_composite_gut<SHF, XT>), dim3(tiles), dim3(256), 0, stream, dArgs, ranges, valX, valY, planPairs, rec, image, \
-                     halfOut, ctr)
+                     halfOut, ctr, outDepth, outSplatId, outNormal)
 #define MGS_LAUNCH_X(SHF)  \
   do                       \
   {                        \

@@ -14,6 +14,7 @@
 
 #include "kernels_common.h"
 #include "sh_eval.h"
+#include "surface_normal.h"
 #include "sort_plan.h"
 
 namespace mgs {
@@ -633,83 +634,6 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // MODE bit 0: additive alpha (no early-out), bit 1: DISABLE_OPACITY_GAUSSIAN, bit 2: surface side outputs,
 // bit 3: stochastic splats (frag.slang:265-290: a fragment is accepted with probability alpha and written opaque; the
 // depth test keeps the nearest accepted one == the first accepted one of the nearest-first list); SHF: SH storage format
-// World-space normal of one splat as the mesh shader emits it with NEED_SURFACE_INFO (threedgs_raster.mesh.slang:209-235):
-// particle = (centre, exp(scale), normalised quaternion) (threedgrt.h.slang:42-48); max-density-plane normal
-// n = Sigma^-1 (camera - centre) with the thin-particle cases (threedgrt.h.slang:358-419); to world space by the
-// instance's 3x3; optionally through the 2x16-bit octahedral code (octahedral_normal.h.slang:27-87).
-__device__ inline float4 splatWorldNormal(const FrameConst& F, const InstanceConst& I, uint32_t li)
-{
-  const float  px = I.centers[3 * (size_t)li], py = I.centers[3 * (size_t)li + 1], pz = I.centers[3 * (size_t)li + 2];
-  const float  s0 = expf(I.scales[3 * (size_t)li]), s1 = expf(I.scales[3 * (size_t)li + 1]),
-              s2 = expf(I.scales[3 * (size_t)li + 2]);
-  const float4 rq = *reinterpret_cast<const float4*>(I.rotations + 4 * (size_t)li);  // (w,x,y,z)
-  const float  ql = sqrtf(rq.x * rq.x + rq.y * rq.y + rq.z * rq.z + rq.w * rq.w);
-  const float  w = rq.x / ql, x = rq.y / ql, y = rq.z / ql, z = rq.w / ql;
-  const float  xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
-  // quatToMat3Transpose (quaternions.h.slang:56-73), rows as written; mul(v, M) = row vector times matrix
-  const float m[9] = {1.0f - 2.0f * (yy + zz), 2.0f * (xy - wz), 2.0f * (xz + wy),
-                      2.0f * (xy + wz), 1.0f - 2.0f * (xx + zz), 2.0f * (yz - wx),
-                      2.0f * (xz - wy), 2.0f * (yz + wx), 1.0f - 2.0f * (xx + yy)};
-  const float l0 = I.camModel[0] - px, l1 = I.camModel[1] - py, l2 = I.camModel[2] - pz;  // modelRayOrigin - position
-  const float th = F.thinParticleThreshold;
-  const bool  t0 = s0 < th, t1 = s1 < th, t2 = s2 < th;
-  const int   smallCount = (t0 ? 1 : 0) + (t1 ? 1 : 0) + (t2 ? 1 : 0);
-  float       n0, n1, n2;
-  if(smallCount == 0)
-  {
-    const float c0 = (l0 * m[0] + l1 * m[3] + l2 * m[6]) * (1.0f / (s0 * s0));
-    const float c1 = (l0 * m[1] + l1 * m[4] + l2 * m[7]) * (1.0f / (s1 * s1));
-    const float c2 = (l0 * m[2] + l1 * m[5] + l2 * m[8]) * (1.0f / (s2 * s2));
-    const float g0 = c0 * m[0] + c1 * m[1] + c2 * m[2];
-    const float g1 = c0 * m[3] + c1 * m[4] + c2 * m[5];
-    const float g2 = c0 * m[6] + c1 * m[7] + c2 * m[8];
-    const float rl = 1.0f / sqrtf(g0 * g0 + g1 * g1 + g2 * g2);
-    n0 = g0 * rl; n1 = g1 * rl; n2 = g2 * rl;
-    if(n0 * l0 + n1 * l1 + n2 * l2 < 0.0f) { n0 = -n0; n1 = -n1; n2 = -n2; }
-  }
-  else if(smallCount == 1)
-  {
-    const int a = t0 ? 0 : (t1 ? 1 : 2);
-    n0 = m[a]; n1 = m[3 + a]; n2 = m[6 + a];
-    if(n0 * l0 + n1 * l1 + n2 * l2 < 0.0f) { n0 = -n0; n1 = -n1; n2 = -n2; }
-  }
-  else
-  {
-    const float l = sqrtf(l0 * l0 + l1 * l1 + l2 * l2);
-    n0 = l0 / l; n1 = l1 / l; n2 = l2 / l;
-  }
-  const float* M = I.model;  // glm column-major
-  float        w0 = M[0] * n0 + M[4] * n1 + M[8] * n2;
-  float        w1 = M[1] * n0 + M[5] * n1 + M[9] * n2;
-  float        w2 = M[2] * n0 + M[6] * n1 + M[10] * n2;
-  const float  wl = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);
-  w0 /= wl; w1 /= wl; w2 /= wl;
-  if(F.quantizeNormals)
-  {
-    const float inv = 1.0f / (fabsf(w0) + fabsf(w1) + fabsf(w2));
-    float       e0 = w0 * inv, e1 = w1 * inv;
-    if(w2 < 0.0f)
-    {
-      const float a0 = (1.0f - fabsf(e1)) * (e0 >= 0.0f ? 1.0f : -1.0f);
-      const float a1 = (1.0f - fabsf(e0)) * (e1 >= 0.0f ? 1.0f : -1.0f);
-      e0 = a0; e1 = a1;
-    }
-    const uint32_t qx = (uint32_t)fminf(fmaxf((e0 * 0.5f + 0.5f) * 65535.0f, 0.0f), 65535.0f);
-    const uint32_t qy = (uint32_t)fminf(fmaxf((e1 * 0.5f + 0.5f) * 65535.0f, 0.0f), 65535.0f);
-    const float    fx = (float)qx / 65535.0f * 2.0f - 1.0f, fy = (float)qy / 65535.0f * 2.0f - 1.0f;
-    float          d0 = fx, d1 = fy, d2 = 1.0f - fabsf(fx) - fabsf(fy);
-    if(d2 < 0.0f)
-    {
-      const float a0 = (1.0f - fabsf(d1)) * (d0 >= 0.0f ? 1.0f : -1.0f);
-      const float a1 = (1.0f - fabsf(d0)) * (d1 >= 0.0f ? 1.0f : -1.0f);
-      d0 = a0; d1 = a1;
-    }
-    const float dl = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
-    w0 = d0 / dl; w1 = d1 / dl; w2 = d2 / dl;
-  }
-  return make_float4(w0, w1, w2, 0.0f);
-}
-
 constexpr bool surf_lds(int mode) { return (mode & 4) != 0; }
 #ifndef MGS_CMP_WAVES
 #define MGS_CMP_WAVES 6
@@ -1001,7 +925,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
       if constexpr(surf)
       {
         const InstanceConst& IC = Ap->inst[instIdx];
-        s_n[j] = splatWorldNormal(Ap->f, IC, li);
+        s_n[j] = splatWorldNormal(Ap->f, IC, li, Ap->f.quantizeNormals != 0);
         // fragCoord.z of the splat's quad: clip.z / clip.w of the centre (mesh.slang:175-178,276-289)
         const float* MV = IC.modelView;
         const float* P  = Ap->f.proj;

@@ -59,7 +59,7 @@ void launchProjectGut(hipStream_t stream, const FrameArgs& args, const FrameArgs
                       const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride);
 void launchCompositeGut(hipStream_t stream, const FrameArgs& A, const FrameArgs* dArgs, const uint2* ranges, const uint32_t* valX,
                         const uint32_t* valY, const SortPlan* planPairs, const GutRec* rec, void* image, int halfOut,
-                        FrameCounters* ctr, int shFormat);
+                        FrameCounters* ctr, int shFormat, float* outDepth, uint32_t* outSplatId, float4* outNormal);
 constexpr uint32_t kPart = 2048;  // == kPrjPart == kSortPart == kBinPart
 }  // namespace mgs
 
@@ -1695,11 +1695,6 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
   }
   if(gut)
   {
-    if(p->surface_outputs)
-    {
-      setError("frame: surface_outputs are not built for the 3DGUT pipeline");
-      return MGS_ERR_UNSUPPORTED;
-    }
     if(p->camera_model < MGS_CAMERA_PINHOLE || p->camera_model > MGS_CAMERA_FISHEYE || p->extent_method < MGS_EXTENT_EIGEN
        || p->extent_method > MGS_EXTENT_CONIC)
     {
@@ -1863,7 +1858,9 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     }
     if(withEvents) HIPCHK(hipEventRecord(fev[4], st));
     if(gut)
-      launchCompositeGut(st, A, s->dArgs.p, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->recGut.p, s->image.p, half, ctr, s->shFormat);
+      launchCompositeGut(st, A, s->dArgs.p, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->recGut.p, s->image.p, half, ctr, s->shFormat,
+                         F.surfaceOutputs ? s->surfDepth.p : nullptr, F.surfaceOutputs ? s->surfId.p : nullptr,
+                         F.surfaceOutputs ? s->surfNormal.p : nullptr);
     else
       launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat, ctr,
                       F.surfaceOutputs ? s->surfDepth.p : nullptr, F.surfaceOutputs ? s->surfId.p : nullptr, s->compInst.p,
