@@ -360,3 +360,50 @@ def test_file_readers_survive_mutated_files_under_sanitizers():
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     lines = [l for l in r.stdout.splitlines() if "mutated files" in l]
     assert len(lines) >= 9 and all("no crash / sanitizer report" in l for l in lines)
+
+
+def test_camera_set_presets_and_project_camera_fields(tmp_path):
+    """class CameraSet (src/camera_set.h:65-190): home preset, duplicate presets collapse (operator== ignores the DoF fields),
+    the last preset cannot be erased; the .vkgs camera carries model / dofMode (old files: dofEnabled) / focusDist / aperture
+    (vkgs_project_reader.cpp:569-584) and "pipeline" 4 selects 3DGUT (shaderio.h:61-66)"""
+    import json
+    from vk_gaussian_splatting_amd import cameras, project
+    cs = cameras.CameraSet()
+    a = cameras.Camera(eye=np.array([1, 2, 3], np.float32))
+    b = cameras.Camera(eye=np.array([1, 2, 3], np.float32), dof_mode=1, aperture=0.05)   # same view, other lens
+    c = cameras.Camera(eye=np.array([0, 2, 3], np.float32), model=1)
+    cs.set_home_preset(a)
+    assert len(cs) == 1 and cs.create_preset(b) == 0 and len(cs) == 1      # equal to the home preset: no duplicate
+    assert cs.create_preset(c) == 1 and len(cs) == 2
+    assert cs.load_preset(1) and cs.camera is c and not cs.load_preset(5)
+    assert cs.store_current_camera() == 1
+    assert cs.set_preset(0, c) and not cs.set_preset(9, c)
+    assert cs.erase_preset(0) and len(cs) == 1 and not cs.erase_preset(0)   # the last one stays
+    cs.set_home_preset(a)
+    assert cs.get_preset(0) is a
+    cs.reset()
+    assert len(cs) == 0 and np.allclose(cs.camera.eye, [1.7, 1.5, 1.7])
+    R = [[1, 0, 0], [0, 1, 0], [0, 0, 1]]
+    items = [dict(id=i, img_name=f"{i}.jpg", width=8, height=8, position=[float(i % 2), 0.0, 1.0], rotation=R, fy=1.0, fx=1.0) for i in range(4)]
+    (tmp_path / "cameras.json").write_text(json.dumps(items))
+    assert cs.import_inria(str(tmp_path / "cameras.json")) == 4 and len(cs) == 2   # two distinct poses among the four
+
+    doc = {"version": 5, "renderer": {"pipeline": 4, "sortingMethod": 3, "kernelDegree": 3, "kernelMinResponse": 0.02, "temporalSampling": True},
+           "camera": {"model": 1, "eye": [2, 1, 2], "ctr": [0, 0, 0], "up": [0, 1, 0], "fov": 120.0, "clip": [0.1, 100.0],
+                      "dofEnabled": True, "focusDist": 2.5, "aperture": 0.01},
+           "cameras": [{"eye": [1, 1, 1], "dofEnabled": True, "dofMode": 0}]}
+    (tmp_path / "gut.vkgs").write_text(json.dumps(doc))
+    pr = project.load_project(str(tmp_path / "gut.vkgs"))
+    assert pr.camera.model == 1 and pr.camera.dof_mode == 1 and pr.camera.focus_dist == 2.5 and pr.camera.aperture == 0.01
+    assert pr.cameras[0].dof_mode == 0                                             # "dofMode" overrides the legacy key
+    p = pr.frame_params(320, 200)
+    assert (p.pipeline, p.camera_model, p.sort_mode, p.kernel_degree, p.dof_mode, p.temporal_sampling) == \
+           (capi.PIPELINE_3DGUT, capi.CAMERA_FISHEYE, capi.SORT_STOCHASTIC, 3, capi.DOF_FIXED_FOCUS, 1)
+    assert abs(p.kernel_min_response - 0.02) < 1e-7 and abs(p.focus_dist - 2.5) < 1e-7 and abs(p.aperture - 0.01) < 1e-7
+    project.save_project(pr, str(tmp_path / "gut2.vkgs"))
+    back = json.loads((tmp_path / "gut2.vkgs").read_text())["camera"]
+    assert back["model"] == 1 and back["dofMode"] == 1 and back["focusDist"] == 2.5 and abs(back["aperture"] - 0.01) < 1e-9
+    doc["renderer"]["pipeline"] = 1
+    (tmp_path / "gs.vkgs").write_text(json.dumps(doc))
+    p = project.load_project(str(tmp_path / "gs.vkgs")).frame_params(320, 200)
+    assert p.pipeline == capi.PIPELINE_3DGS and p.dof_mode == capi.DOF_DISABLED

@@ -20,9 +20,28 @@ class Camera:
     up: np.ndarray = field(default_factory=lambda: np.array([0.0, 1.0, 0.0], np.float32))
     fov: float = 60.0
     clip: tuple = (0.1, 2000.0)
+    model: int = 0        # CAMERA_PINHOLE 0 / CAMERA_FISHEYE 1 (camera_set.h:46)
+    dof_mode: int = 0     # DOF_DISABLED (camera_set.h:55-57)
+    focus_dist: float = 1.3
+    aperture: float = 0.001
     name: str = ""
     width: int = 0
     height: int = 0
+
+    def same_view(self, o):
+        """Camera::operator== (camera_set.h:59-62): model, eye, ctr, up, fov, clip — the depth-of-field fields do not count"""
+        return (self.model == o.model and np.array_equal(np.asarray(self.eye, np.float32), np.asarray(o.eye, np.float32))
+                and np.array_equal(np.asarray(self.ctr, np.float32), np.asarray(o.ctr, np.float32))
+                and np.array_equal(np.asarray(self.up, np.float32), np.asarray(o.up, np.float32))
+                and float(self.fov) == float(o.fov) and tuple(map(float, self.clip)) == tuple(map(float, o.clip)))
+
+    def apply(self, params):
+        """the camera's share of MgsFrameParams beyond the matrices: sensor model and depth of field (3DGUT pipeline)"""
+        params.camera_model = int(self.model)
+        params.dof_mode = 1 if int(self.dof_mode) != 0 else 0   # DOF_AUTO_FOCUS (2) = fixed focus at a picked distance
+        params.focus_dist = float(self.focus_dist)
+        params.aperture = float(self.aperture)
+        return params
 
     def matrices(self, width, height, flip_y=False):
         """(view, proj) through the C ABI helper mgs_camera_lookat_perspective"""
@@ -50,3 +69,70 @@ def import_cameras_inria(path):
         out.append(Camera(eye=eye, ctr=eye + at, up=up, name=str(item.get("img_name", "")),
                           width=int(item.get("width", 0)), height=int(item.get("height", 0))))
     return out
+
+
+class CameraSet:
+    """class CameraSet (src/camera_set.h:65-190) without the manipulator: the active camera and the list of presets, with the
+    reference's rules — preset 0 is the home preset, createPreset returns the index of an equal preset instead of adding a
+    duplicate, the last preset cannot be erased."""
+
+    def __init__(self):
+        self.camera = Camera()
+        self.presets = []
+
+    def reset(self):
+        self.camera = Camera()
+        self.presets = []
+
+    def set_camera(self, camera):
+        self.camera = camera
+
+    def set_home_preset(self, camera):
+        if not self.presets:
+            self.presets.append(camera)
+        else:
+            self.presets[0] = camera
+
+    def __len__(self):
+        return len(self.presets)
+
+    def clear_presets(self):
+        self.presets = []
+
+    def create_preset(self, camera):
+        for i, p in enumerate(self.presets):
+            if p.same_view(camera):
+                return i
+        self.presets.append(camera)
+        return len(self.presets) - 1
+
+    def store_current_camera(self):
+        return self.create_preset(self.camera)
+
+    def load_preset(self, index):
+        if index < 0 or index >= len(self.presets):
+            return False
+        self.camera = self.presets[index]
+        return True
+
+    def erase_preset(self, index):
+        if len(self.presets) <= 1 or index < 0 or index >= len(self.presets):
+            return False
+        del self.presets[index]
+        return True
+
+    def get_preset(self, index):
+        return self.presets[index]
+
+    def set_preset(self, index, camera):
+        if index < 0 or index >= len(self.presets):
+            return False
+        self.presets[index] = camera
+        return True
+
+    def import_inria(self, path):
+        """importCamerasINRIA: every camera of the file becomes a preset (duplicates collapse); returns how many were read"""
+        cams = import_cameras_inria(path)
+        for c in cams:
+            self.create_preset(c)
+        return len(cams)

@@ -54,6 +54,15 @@ class Project:
         # shaderio.h:24-27: 0 GPU radix, 1/2 CPU async (mono / multi), 3 stochastic splat
         sm = int(r.get("sortingMethod", 0))
         p.sort_mode = {0: capi.SORT_GPU_RADIX, 3: capi.SORT_STOCHASTIC}.get(sm, capi.SORT_CPU_ASYNC)
+        # "pipeline" (shaderio.h:61-66): 4 / 5 = the 3DGUT mesh pipeline (5 = hybrid with ray-traced secondary rays: its raster part);
+        # everything else renders through the 3DGS raster path here
+        p.pipeline = capi.PIPELINE_3DGUT if int(r.get("pipeline", 1)) in (4, 5) else capi.PIPELINE_3DGS
+        p.kernel_degree = int(r.get("kernelDegree", 2))
+        p.kernel_min_response = float(r.get("kernelMinResponse", 0.0113))
+        p.temporal_sampling = int(bool(r.get("temporalSampling", False)))
+        self.camera.apply(p)
+        if p.pipeline != capi.PIPELINE_3DGUT:
+            p.dof_mode = capi.DOF_DISABLED   # the 3DGS raster pipeline has no per-pixel rays
         p.cpu_lazy_sort = int(bool(r.get("cpuLazySort", True)))
         p.thin_particle_threshold = float(r.get("thinParticleThreshold", 1e-6))
         p.debug_flags = ((capi.DEBUG_POINT_CLOUD if r.get("pointCloudModeEnabled", False) else 0)
@@ -82,13 +91,19 @@ def _cam_from(item):
     if "up" in item: c.up = np.asarray(item["up"], np.float32)
     if "fov" in item: c.fov = float(item["fov"])
     if "clip" in item: c.clip = (float(item["clip"][0]), float(item["clip"][1]))
+    if "model" in item: c.model = int(item["model"])
+    # old files carry "dofEnabled" (bool), newer ones "dofMode", which wins (vkgs_project_reader.cpp:579-582)
+    if "dofEnabled" in item: c.dof_mode = int(bool(item["dofEnabled"]))
+    if "dofMode" in item: c.dof_mode = int(item["dofMode"])
+    if "focusDist" in item: c.focus_dist = float(item["focusDist"])
+    if "aperture" in item: c.aperture = float(item["aperture"])
     return c
 
 
 def _cam_to(c):
-    return {"model": 0, "ctr": [float(x) for x in c.ctr], "eye": [float(x) for x in c.eye], "up": [float(x) for x in c.up],
-            "fov": float(c.fov), "clip": [float(c.clip[0]), float(c.clip[1])], "dofMode": 0, "focusDist": 1.3,
-            "aperture": 0.001}
+    return {"model": int(c.model), "ctr": [float(x) for x in c.ctr], "eye": [float(x) for x in c.eye], "up": [float(x) for x in c.up],
+            "fov": float(c.fov), "clip": [float(c.clip[0]), float(c.clip[1])], "dofMode": int(c.dof_mode),
+            "focusDist": float(c.focus_dist), "aperture": float(c.aperture)}
 
 
 def load_project(path):
