@@ -193,7 +193,7 @@ def gut_project(centers, scales_log, rotations_wxyz, rgba, M, V, P, W, H, extent
     return dict(valid=valid, center_px=center, cov=cov, half_x=hx, half_y=hy, axes=R, scale=s, position=c)
 
 
-def gut_opacity(g, i, density, M, V, P, W, H, px, py, alpha_clamp=0.99, min_response=0.0113, degree=2):
+def gut_opacity(g, i, density, M, V, P, W, H, px, py, alpha_clamp=0.99, min_response=0.0113, degree=2, lens=None):
     """opacity of splat i at pixel (px, py) or None: ray of the fragment (SV_Position + 0.5, as the reference writes it),
     canonical ray, quadratic kernel"""
     S_V, S_P, S_M = slang(V), slang(P), slang(M)
@@ -204,6 +204,15 @@ def gut_opacity(g, i, density, M, V, P, W, H, px, py, alpha_clamp=0.99, min_resp
     target = np.array([d[0], d[1], 1.0, 1.0]) @ pi
     rd = (np.array([target[0], target[1], target[2], 0.0]) @ vi)[:3]
     rd /= np.linalg.norm(rd)
+    if lens is not None:
+        # depthOfField (cameras.h.slang:85-108): lens = (r1, r2, focus distance) with r1 = rand * 2 pi, r2 = rand * aperture
+        r1, r2, focus = lens
+        right = (np.array([1.0, 0, 0, 0]) @ vi)[:3]
+        up = (np.array([0, 1.0, 0, 0]) @ vi)[:3]
+        ap = (np.cos(r1) * right + np.sin(r1) * up) * np.sqrt(r2)
+        nd = rd * focus - ap
+        origin = origin + ap
+        rd = nd / np.linalg.norm(nd)
     mo = (np.append(origin, 1.0) @ mi)[:3]
     md = rd @ mi[:3, :3]
     md /= np.linalg.norm(md)

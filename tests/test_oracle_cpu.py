@@ -698,3 +698,38 @@ def test_gut_kernel_degrees_against_the_closed_form(ob, degree):
                 assert np.isclose(a, b, rtol=3e-3, atol=3e-4), (i, px, py, a, b)
                 frag += 1
     assert frag > 150
+
+
+def test_gut_depth_of_field_against_independent_numpy_fp64(ob):
+    """depthOfField (cameras.h.slang:85-108) in the oracle's 3DGUT fragment vs the float64 restatement, the lens sample drawn with
+    the integer-only restatement of the random numbers: seed = xxhash32(px, py, sample), r1 = rand * 2 pi, r2 = rand * aperture"""
+    import np_reference as npr
+    n = 800
+    sc = synth.make_scene(n, seed=29)
+    ps = ob.PreparedSet(sc)
+    inst = ob.make_instances([(ps, None)])
+    W, H = 256, 160
+    eye = np.array([3.0, 1.0, 1.5], np.float32)
+    V, P = lookat(eye, [0, 0, 0], [0, 1, 0]), persp(55, W / H, 0.1, 2000)
+    focus, aperture, sample = 2.5, 0.03, 11
+    fr = ob.make_frame(V, P, eye, W, H, dof_mode=1, focus_dist=focus, aperture=aperture, frame_sample_id=sample)
+    g = npr.gut_project(ps.positions, sc["scale"], sc["rotation"], ps.rgba, np.eye(4), V, P, W, H)
+    rng = np.random.default_rng(4)
+    frag = 0
+    for i in range(n):
+        q = ob.project_gut(fr, inst, 0, i)
+        if not (q.valid and g["valid"][i]):
+            continue
+        px = int(np.clip(q.center_px[0] + rng.integers(-3, 4), 0, W - 1))
+        py = int(np.clip(q.center_px[1] + rng.integers(-3, 4), 0, H - 1))
+        seed = _np_xxhash32(px, py, sample)
+        u1, seed = _np_rand(seed)
+        u2, seed = _np_rand(seed)
+        a = ob.gut_fragment(fr, inst, 0, q, px, py)
+        b = npr.gut_opacity(g, i, float(q.rgba[3]), np.eye(4), V, P, W, H, px, py, lens=(u1 * 2.0 * np.pi, u2 * aperture, focus))
+        if a is None or b is None:
+            assert (a is None and (b is None or b < 8e-3)) or (b is None and a < 8e-3), (i, a, b)
+        else:
+            assert np.isclose(a, b, rtol=3e-3, atol=3e-4), (i, px, py, a, b)
+            frag += 1
+    assert frag > 60
