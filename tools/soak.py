@@ -20,6 +20,9 @@ for cyc in range(12):
         if i % 11 == 0: p.surface_outputs = 1
         elif i % 13 == 0: p.pipeline = capi.PIPELINE_3DGUT          # its record buffer is allocated on first use
         if i % 17 == 0 and i % 11: p.camera_model = capi.CAMERA_FISHEYE; p.pipeline = capi.PIPELINE_3DGUT
+        if i % 9 == 4: p.sort_mode = capi.SORT_STOCHASTIC; p.frame_sample_id = i; p.temporal_sampling = i % 2
+        if i % 19 == 3: p.pipeline = capi.PIPELINE_3DGUT; p.dof_mode = capi.DOF_FIXED_FOCUS; p.aperture = 0.02; p.frame_sample_id = i
+        if i % 23 == 5: p.pipeline = capi.PIPELINE_3DGUT; p.kernel_degree = 4; p.surface_outputs = 1
         o = scene.render(p, want_stats=(i % 5 == 0))
     img = scene.download_frame(p); assert np.isfinite(img.astype(np.float32)).all()
     scene.close()
@@ -32,7 +35,7 @@ sc = synth.make_scene(1_000_000, seed=99)
 scene = mgs.Scene(0); scene.add_instance(mgs.SplatSet.from_arrays(**sc)); scene.commit()
 t0 = time.time(); n = 0
 ref = None
-while time.time() - t0 < 20.0:
+while time.time() - t0 < float(os.environ.get('SOAK_SECONDS', '20')):
     for i in range(64):
         scene.render(cam(i)); n += 1
     img = scene.download_frame(cam(63))
