@@ -1870,7 +1870,7 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     if(withEvents) HIPCHK(hipEventRecord(fev[5], st));
     return MGS_OK;
   };
-  // The frame is 18 dependent launches; on the submitting thread that is ~0.15 ms of API calls.  A frame whose
+  // The frame is 17 dependent launches (18 with temporal accumulation); on the submitting thread that is ~0.15 ms of API calls.  A frame whose
   // launch sequence does not depend on host-side data (GPU sort, no per-stage events) is captured ONCE per
   // (resolution, strip, mode) into a hipGraph and replayed: the kernels read everything that changes from frame to
   // frame through dArgs.  MGS_GRAPH=0 forces plain launches.
