@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <cmath>
 #include <vector>
 
 #include "mgs.h"
@@ -59,13 +60,20 @@ int main(int argc, char** argv)
 {
   if(argc < 3)
   {
-    std::fprintf(stderr, "usage: %s scene.ply|.spz|.splat out.ppm [W H] [ex ey ez] [instances]\n%s\n", argv[0], mgs_version());
+    std::fprintf(stderr,
+                 "usage: %s scene.ply|.spz|.splat out.ppm [W H] [ex ey ez] [instances] [mode]\n"
+                 "  mode: 3dgs (default) | 3dgut | fisheye | stochastic[:samples] | dof[:samples]  (the last two accumulate `samples` frames)\n%s\n",
+                 argv[0], mgs_version());
     return 2;
   }
   const int   W = argc > 4 ? std::atoi(argv[3]) : 1920, H = argc > 4 ? std::atoi(argv[4]) : 1080;
   const float eye[3]    = {argc > 7 ? (float)std::atof(argv[5]) : 1.7f, argc > 7 ? (float)std::atof(argv[6]) : 1.5f,
                            argc > 7 ? (float)std::atof(argv[7]) : 1.7f};
   const int   instances = argc > 8 ? std::max(1, std::atoi(argv[8])) : 1;
+  const std::string mode = argc > 9 ? argv[9] : "3dgs";
+  const size_t      colon = mode.find(':');
+  const std::string kind  = mode.substr(0, colon);
+  const int         samples = colon == std::string::npos ? 1 : std::max(1, std::atoi(mode.c_str() + colon + 1));
 
   MgsSplatSet set = nullptr;
   CHECK(mgs_splatset_load(argv[1], &set));
@@ -90,8 +98,30 @@ int main(int argc, char** argv)
   p.width           = W;
   p.height          = H;
   p.collect_timings = 1;
+  // the other pipelines and modes of the C ABI: the 3DGUT raster pipeline (pinhole / fisheye), stochastic splats and depth of
+  // field, the latter two averaged over `samples` frames by the library (temporal_sampling = post.comp.slang)
+  if(kind == "3dgut" || kind == "fisheye" || kind == "dof")
+    p.pipeline = MGS_PIPELINE_3DGUT;
+  if(kind == "fisheye")
+  {
+    p.camera_model = MGS_CAMERA_FISHEYE;
+    p.fov_rad      = 2.6f;
+  }
+  if(kind == "stochastic")
+    p.sort_mode = MGS_SORT_STOCHASTIC;
+  if(kind == "dof")
+  {
+    p.dof_mode   = MGS_DOF_FIXED_FOCUS;
+    p.focus_dist = std::sqrt(eye[0] * eye[0] + eye[1] * eye[1] + eye[2] * eye[2]);
+    p.aperture   = 0.02f;
+  }
+  p.temporal_sampling = samples > 1 ? 1 : 0;
   MgsFrameOut out;
-  CHECK(mgs_render(scene, &p, &out));
+  for(int k = 0; k < samples; ++k)
+  {
+    p.frame_sample_id = k;
+    CHECK(mgs_render(scene, &p, &out));
+  }
   std::vector<uint16_t> img((size_t)W * H * 4);
   CHECK(mgs_frame_download(scene, img.data(), img.size() * sizeof(uint16_t)));
   std::printf("%llu splats, %u in frustum, %u sorted, %llu bin-list entries, %u shaded pairs, %.3f ms on the GPU\n",

@@ -1023,6 +1023,23 @@ def test_cpp_caller_renders_the_same_frame(tmp_path):
     scene.render(p)
     img = np.clip(scene.download_frame(p).astype(np.float32)[..., :3], 0, 1)
     assert np.array_equal((img * 255.0 + 0.5).astype(np.uint8), ppm)
+    # the other modes through the same plain C++ caller: 3DGUT, and stochastic splats averaged over 16 samples by the library
+    for mode, kw in (("3dgut", dict(pipeline=capi.PIPELINE_3DGUT)),
+                     ("stochastic:16", dict(sort_mode=capi.SORT_STOCHASTIC, temporal_sampling=1))):
+        r = subprocess.run([exe, ply, str(tmp_path / "m.ppm"), str(W), str(H), "1.7", "1.5", "1.7", "2", mode], capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        raw = open(tmp_path / "m.ppm", "rb").read()
+        got = np.frombuffer(raw[len(head):], np.uint8).reshape(H, W, 3)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        for sid in range(16 if "stochastic" in mode else 1):
+            p.frame_sample_id = sid
+            scene.render(p)
+        want = (np.clip(scene.download_frame(p).astype(np.float32)[..., :3], 0, 1) * 255.0 + 0.5).astype(np.uint8)
+        assert np.array_equal(got, want), mode
+        p = capi.default_params(W, H)
+        capi.set_camera(p, V, P, eye)
     scene.close()
 
 
