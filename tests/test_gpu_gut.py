@@ -69,7 +69,13 @@ def test_gut_frame_matches_oracle(scene_gut, ob, name, kw, fkw):
     assert out.error_flags == 0 and out.frustum_count == st["visible"]
     # the oracle counts every emitted quad; the build drops the ones that cover no pixel centre or lie off screen before the sort
     assert int(st["quads"]) * 0.85 <= int(out.sorted_count) <= int(st["quads"]) + 3
-    assert psnr >= PSNR_MIN and err.max() <= ABS_TOL
+    if kw.get("debug_flags", 0) & 4:
+        # opacity gaussian disabled: every accepted fragment is opaque, so a fragment on an acceptance threshold (response >
+        # 0.0113, alpha > 1/255, quad edge) that falls on the other side changes the whole pixel — the stochastic tests' bar
+        same = np.all(err <= 2e-3, axis=-1).mean()
+        assert psnr >= PSNR_MIN and same >= 0.999, (psnr, same)
+    else:
+        assert psnr >= PSNR_MIN and err.max() <= ABS_TOL
 
 
 def test_gut_two_instances_and_strips(ob):

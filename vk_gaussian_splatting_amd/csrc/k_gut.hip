@@ -17,6 +17,7 @@
 // Depth of field and stochastic splats are the XT variant of the compositor (random numbers: kernels_common.h).
 // Kernel degrees other than 2 and the surface side outputs run in the XT variant too.  Not built (stated in DESIGN.md):
 // rolling shutter (untested in the reference).
+#include <cstdlib>
 #include "kernels_common.h"
 #include "sh_eval.h"
 #include "surface_normal.h"
@@ -392,6 +393,43 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
   slotHist[(size_t)t * histStride + part] = s_hist[t];
 }
 
+// world-space ray direction of the pixel whose centre is (pcx, pcy) (threedgut_raster.frag.slang:101-111); false: outside the
+// fisheye's field of view (the fragment is discarded)
+__device__ __forceinline__ bool gutPixelRay(const FrameConst& F, float pcx, float pcy, float& dxw, float& dyw, float& dzw)
+{
+  const float* Vi = F.viewInv;
+  float        cx, cy, cz;
+  bool         rayOk = true;
+  if(F.cameraModel == 1)
+  {  // generateFisheyeRay(position.xy, viewport, fovRad, principal 0, viewInverse), cameras.h.slang:46-82
+    const float u = (pcx / ((float)F.width - 1.0f)) * 2.0f - 1.0f, v = (pcy / ((float)F.height - 1.0f)) * 2.0f - 1.0f;
+    const float r = sqrtf(u * u + v * v);
+    rayOk         = !(r > 1.0f);
+    float phiCos  = fabsf(r) > 1e-9f ? u / r : 0.0f;
+    phiCos        = fminf(fmaxf(phiCos, -1.0f), 1.0f);
+    float phi     = acosf(phiCos);
+    phi           = v < 0.0f ? -phi : phi;
+    const float theta = r * F.fovRad * 0.5f;
+    cx = cosf(phi) * sinf(theta);
+    cy = -sinf(phi) * sinf(theta);
+    cz = -cosf(theta);
+  }
+  else
+  {  // generatePinholeRay(position.xy, float2(0.5), ...): the 0.5 is added to SV_Position, as the reference writes it
+    const float ux = ((pcx + 0.5f) / (float)F.width) * 2.0f - 1.0f, uy = ((pcy + 0.5f) / (float)F.height) * 2.0f - 1.0f;
+    const float* Pi = F.projInv;
+    cx = Pi[0] * ux + Pi[4] * uy + Pi[8] + Pi[12];
+    cy = Pi[1] * ux + Pi[5] * uy + Pi[9] + Pi[13];
+    cz = Pi[2] * ux + Pi[6] * uy + Pi[10] + Pi[14];
+  }
+  dxw = Vi[0] * cx + Vi[4] * cy + Vi[8] * cz;
+  dyw = Vi[1] * cx + Vi[5] * cy + Vi[9] * cz;
+  dzw = Vi[2] * cx + Vi[6] * cy + Vi[10] * cz;
+  const float l = rsqrtf(dxw * dxw + dyw * dyw + dzw * dzw);
+  dxw *= l; dyw *= l; dzw *= l;
+  return rayOk;
+}
+
 // ---- compositor: one workgroup per 16x16 tile, one pixel per thread -------------------------------------------------------
 constexpr int kGutBatch = 256;  // list entries scanned per round == staging capacity
 
@@ -423,38 +461,7 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
   const float bcx = (float)(tx * kTilePx) + 8.0f, bcy = (float)(ty * kTilePx) + 8.0f;
   // ray of this pixel in world space (frag.slang:101-111)
   float dxw, dyw, dzw;
-  bool  rayOk = true;
-  {
-    const float* Vi = F.viewInv;
-    float        cx, cy, cz;
-    if(F.cameraModel == 1)
-    {  // generateFisheyeRay(position.xy, viewport, fovRad, principal 0, viewInverse), cameras.h.slang:46-82
-      const float u = (pcx / ((float)F.width - 1.0f)) * 2.0f - 1.0f, v = (pcy / ((float)F.height - 1.0f)) * 2.0f - 1.0f;
-      const float r = sqrtf(u * u + v * v);
-      rayOk         = !(r > 1.0f);
-      float phiCos  = fabsf(r) > 1e-9f ? u / r : 0.0f;
-      phiCos        = fminf(fmaxf(phiCos, -1.0f), 1.0f);
-      float phi     = acosf(phiCos);
-      phi           = v < 0.0f ? -phi : phi;
-      const float theta = r * F.fovRad * 0.5f;
-      cx = cosf(phi) * sinf(theta);
-      cy = -sinf(phi) * sinf(theta);
-      cz = -cosf(theta);
-    }
-    else
-    {  // generatePinholeRay(position.xy, float2(0.5), ...): the 0.5 is added to SV_Position, as the reference writes it
-      const float ux = ((pcx + 0.5f) / (float)F.width) * 2.0f - 1.0f, uy = ((pcy + 0.5f) / (float)F.height) * 2.0f - 1.0f;
-      const float* Pi = F.projInv;
-      cx = Pi[0] * ux + Pi[4] * uy + Pi[8] + Pi[12];
-      cy = Pi[1] * ux + Pi[5] * uy + Pi[9] + Pi[13];
-      cz = Pi[2] * ux + Pi[6] * uy + Pi[10] + Pi[14];
-    }
-    dxw = Vi[0] * cx + Vi[4] * cy + Vi[8] * cz;
-    dyw = Vi[1] * cx + Vi[5] * cy + Vi[9] * cz;
-    dzw = Vi[2] * cx + Vi[6] * cy + Vi[10] * cz;
-    const float l = rsqrtf(dxw * dxw + dyw * dyw + dzw * dzw);
-    dxw *= l; dyw *= l; dzw *= l;
-  }
+  const bool rayOk = gutPixelRay(F, pcx, pcy, dxw, dyw, dzw);
   // depth of field: the ray leaves a random point of the lens and still passes through the focal point of the pinhole ray
   float    lensX = 0.0f, lensY = 0.0f, lensZ = 0.0f;
   uint32_t seedPx = 0u;
@@ -687,6 +694,224 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
   }
 }
 
+
+// ---- packed compositor (plain mode: quadratic kernel, coverage alpha, no depth of field / stochastic / surface outputs) -------------
+// The geometry of the 3DGS compositor (k_raster.hip): one workgroup per 32x16-pixel region, one wave per 16x8 quarter, TWO pixels
+// per lane (x and x + 8) so that the per-fragment arithmetic runs on gfx950's packed-fp32 instructions with the particle's
+// parameters broadcast — the one-pixel-per-lane kernel above spends ~45 instructions per (record, pixel), this one ~50 per
+// (record, pixel PAIR) — and a region twice as large halves the list entries scanned per pixel.  Records are culled against the
+// region, compacted in list order into an LDS batch together with a 4-bit mask of the quarters their quad's box touches, shaded
+// there (deferred SH), and each wave walks only the records of its quarter.  Saturation is a per-fragment predicate (T >= 1e-4),
+// so the frame does not depend on batch boundaries (strips == full frame).
+typedef float gv2f __attribute__((ext_vector_type(2)));
+constexpr int kGut2Cap = 256;  // LDS batch capacity == entries scanned per round
+
+template <int SHF>
+__global__ __launch_bounds__(256) void k_composite_gut2(const FrameArgs* __restrict__ Ap, const uint2* __restrict__ ranges,
+                                                        const uint32_t* __restrict__ valX, const uint32_t* __restrict__ valY,
+                                                        const SortPlan* __restrict__ plan, const GutRec* __restrict__ rec,
+                                                        void* __restrict__ outImage, int halfOut, FrameCounters* __restrict__ ctr)
+{
+  __shared__ float4   s_r[kGut2Cap][6];
+  __shared__ uint8_t  s_m[kGut2Cap];
+  __shared__ uint32_t s_wc[4];
+  const FrameConst& F = Ap->f;
+  const int t = threadIdx.x, lane = laneId(), w = t >> 6;
+  // region order as in k_composite (k_raster.hip): all regions of a bin on one XCD (workgroup b runs on XCD b % 8; they read
+  // the same list), consecutive bins on different XCDs, bins taken longest list first (ranked by the binning stage)
+  const int colsX    = (F.tilesX + 1) >> 1;
+  const int bw       = 1 << (F.binShiftX - 1), bh = 1 << F.binShiftY;  // bin size in regions
+  const int binRow0  = F.stripRow0 >> F.binShiftY;
+  const int binRows  = ((F.stripRow1 - 1) >> F.binShiftY) - binRow0 + 1;
+  const int perBin   = bw * bh;
+  const int seq      = (int)(blockIdx.x >> 3);
+  const int ord      = (seq / perBin) * 8 + (int)(blockIdx.x & 7);  // bin ordinal
+  const int inBin    = seq % perBin;
+  const bool ordered = plan->ghist[2][0] != 0u;
+  int cx2, ty;
+  if(ordered)
+  {
+    if(ord >= F.binsX * F.binsY)
+      return;
+    const int b = (int)plan->ghist[1][ord];
+    cx2         = (b % F.binsX) * bw + inBin % bw;
+    ty          = (b / F.binsX) * bh + inBin / bw;
+  }
+  else
+  {
+    if(ord >= binRows * F.binsX)
+      return;
+    cx2 = (ord % F.binsX) * bw + inBin % bw;
+    ty  = (binRow0 + ord / F.binsX) * bh + inBin / bw;
+  }
+  if(cx2 >= colsX || ty < F.stripRow0 || ty >= F.stripRow1)
+    return;
+  const int tx  = cx2 * 2;
+  const int qx0 = tx * kTilePx + (w & 1) * 16, qy0 = ty * kTilePx + (w >> 1) * 8;
+  const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);  // second pixel: px + 8
+  const bool in0 = px < F.width && py < F.height, in1 = px + 8 < F.width && py < F.height;
+  const gv2f  pcx = {(float)px + 0.5f, (float)px + 8.5f};
+  const float pcy = (float)py + 0.5f;
+  const float bcx = (float)(tx * kTilePx) + 16.0f, bcy = (float)(ty * kTilePx) + 8.0f;  // region centre
+  gv2f dxw, dyw, dzw;
+  bool ok0, ok1;
+  {
+    float a, b, c;
+    ok0 = gutPixelRay(F, pcx.x, pcy, a, b, c);
+    dxw.x = a; dyw.x = b; dzw.x = c;
+    ok1 = gutPixelRay(F, pcx.y, pcy, a, b, c);
+    dxw.y = a; dyw.y = b; dzw.y = c;
+  }
+  const bool  noGauss = (F.debugFlags & 4) != 0;
+  constexpr float tMin = 1.0e-4f;
+  const uint32_t* vals = plan->finalSel ? valY : valX;
+  const int      bin   = (ty >> F.binShiftY) * F.binsX + (tx >> F.binShiftX);
+  const uint2    range = ranges[bin];
+  gv2f T = {(in0 && ok0) ? 1.0f : 0.0f, (in1 && ok1) ? 1.0f : 0.0f}, cr = {0.f, 0.f}, cg = {0.f, 0.f}, cb = {0.f, 0.f};
+  uint32_t hi = range.y;
+  uint32_t statScanned = 0, statStaged = 0;
+  while(hi > range.x)
+  {
+    // ---- stage: the next 256 nearest entries, culled against the region, compacted in list order ----
+    const uint32_t avail = hi - range.x;
+    const bool     have  = (uint32_t)t < avail;
+    const uint32_t g     = have ? vals[hi - 1u - (uint32_t)t] : 0u;
+    float4         r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 0.f, -1.f, -1.f);
+    if(have)
+    {
+      const float4* rp = reinterpret_cast<const float4*>(rec + g);
+      r0 = rp[0];
+      r1 = rp[1];
+    }
+    // pixel centres of the region span bcx +- 15.5, bcy +- 7.5
+    const bool     ok  = have && fabsf(r0.x - bcx) <= r1.z + 15.5f && fabsf(r0.y - bcy) <= r1.w + 7.5f;
+    const uint64_t bal = __ballot(ok);
+    if(lane == 0)
+      s_wc[w] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t base = 0;
+    if(w > 0) base += s_wc[0];
+    if(w > 1) base += s_wc[1];
+    if(w > 2) base += s_wc[2];
+    const uint32_t fill = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+    if(ok)
+    {
+      const uint32_t pos = base + lanesBelow(bal);
+      const float4*  rp  = reinterpret_cast<const float4*>(rec + g);
+      const float4   r2 = rp[2], r3 = rp[3], r4 = rp[4];
+      float4         c5 = rp[5];
+      // deferred shading (mesh.slang:142-148): base colour + SH in the splat's model coordinates, once per staged record
+      int k = 0;
+      for(int i = 1; i < F.nInstances; ++i)
+        if(g >= Ap->inst[i].globalOffset)
+          k = i;
+      const InstanceConst& I  = Ap->inst[k];
+      const uint32_t       li = g - I.globalOffset;
+      const float4         col = reinterpret_cast<const float4*>(I.rgbaF32)[li];
+      float dx = I.centers[3 * (size_t)li] - I.camModel[0], dy = I.centers[3 * (size_t)li + 1] - I.camModel[1],
+            dz = I.centers[3 * (size_t)li + 2] - I.camModel[2];
+      const float dl = rsqrtf(dx * dx + dy * dy + dz * dz);
+      dx *= dl; dy *= dl; dz *= dl;
+      const bool shOnly = (F.debugFlags & 2) != 0;
+      c5.x = shOnly ? 0.5f : col.x;
+      c5.y = shOnly ? 0.5f : col.y;
+      c5.z = shOnly ? 0.5f : col.z;
+      const int deg = (I.sh == nullptr) ? 0 : min(I.shDegree, F.shDegree);
+      if(deg > 0)
+        addShRadiance<SHF>(I.sh, li, deg, dx, dy, dz, c5.x, c5.y, c5.z);
+      if(!(c5.w > F.alphaCull))
+        c5.w = 0.0f;  // particleProcessHitGut rejects the whole particle (density <= alphaCullThreshold): no fragment can pass
+      // acceptance of particleProcessHitGut (threedgrt.h.slang:259-267) as ONE compare per pixel: alpha = min(clamp, response *
+      // density) > 1/255 and response > kernelMinResponse  <=>  response > max(kMin, 1 / (255 density))  <=>  (quadratic
+      // kernel) dist^2 < -2 ln(that): a per-record cutoff, staged in the slot of the box extents (used above only)
+      const float rcut  = fmaxf(F.kernelMinResponse, 1.0f / (255.0f * fmaxf(c5.w, 1e-30f)));
+      const float d2cut = (c5.w > 0.0f && rcut < 1.0f) ? -2.0f * __logf(rcut) : -1.0f;
+      s_r[pos][0] = r0;
+      s_r[pos][1] = make_float4(r1.x, r1.y, d2cut, 0.0f);
+      s_r[pos][2] = r2;
+      s_r[pos][3] = r3;
+      s_r[pos][4] = r4;
+      s_r[pos][5] = c5;
+      // quarters (16 x 8 pixels; centres x in [bcx-15.5,bcx-0.5] / [bcx+0.5,bcx+15.5], y in [bcy-7.5,bcy-0.5] / [bcy+0.5,bcy+7.5])
+      // the box of the quad touches
+      const bool xl = r0.x - r1.z <= bcx - 0.5f, xr = r0.x + r1.z >= bcx + 0.5f;
+      const bool yt = r0.y - r1.w <= bcy - 0.5f, yb = r0.y + r1.w >= bcy + 0.5f;
+      s_m[pos] = (uint8_t)(((xl && yt) ? 1u : 0u) | ((xr && yt) ? 2u : 0u) | ((xl && yb) ? 4u : 0u) | ((xr && yb) ? 8u : 0u));
+    }
+    __syncthreads();
+    statScanned += min(avail, (uint32_t)kGut2Cap);
+    statStaged += fill;
+    hi -= min(avail, (uint32_t)kGut2Cap);
+    // ---- blend front to back: 64 records at a time, this wave's hit set from the quarter masks ----
+    for(uint32_t j0 = 0; j0 < fill; j0 += 64)
+    {
+      const uint32_t jl   = j0 + (uint32_t)lane;
+      const bool     mine = jl < fill && ((s_m[jl] >> w) & 1u);
+      uint64_t       hits = __ballot(mine);
+      while(hits != 0ull)
+      {
+        const uint32_t j = j0 + (uint32_t)__builtin_ctzll(hits);
+        hits &= hits - 1ull;
+        const float4 a0 = s_r[j][0], a1 = s_r[j][1], b0 = s_r[j][2], b1 = s_r[j][3], b2 = s_r[j][4], c4 = s_r[j][5];
+        const gv2f   ddx = pcx - a0.x;
+        const float  ddy = pcy - a0.y;
+        const gv2f   qu = ddx * a0.z + ddy * a0.w, qv = ddx * a1.x + ddy * a1.y;
+        // canonical ray direction ~ B d, origin ro; dist^2 = |g x ro|^2 / |g|^2  (threedgrt.h.slang:57-81)
+        const gv2f gx = dxw * b0.x + (dyw * b0.y + dzw * b0.z);
+        const gv2f gy = dxw * b0.w + (dyw * b1.x + dzw * b1.y);
+        const gv2f gz = dxw * b1.z + (dyw * b1.w + dzw * b2.x);
+        const gv2f kx = gy * b2.w - gz * b2.z, ky = gz * b2.y - gx * b2.w, kz = gx * b2.z - gy * b2.y;
+        const gv2f kk = kx * kx + (ky * ky + kz * kz), gg = gx * gx + (gy * gy + gz * gz);
+        const gv2f dist2 = {kk.x * gRcp(gg.x), kk.y * gRcp(gg.y)};
+        const gv2f resp  = {__expf(-0.5f * dist2.x), __expf(-0.5f * dist2.y)};  // quadratic kernel, :127-131
+        const gv2f raw   = resp * c4.w;
+        const gv2f al    = {fminf(F.alphaClamp, raw.x), fminf(F.alphaClamp, raw.y)};  // :263
+        const bool h0 = fmaxf(fabsf(qu.x), fabsf(qv.x)) <= 1.0f && dist2.x < a1.z && T.x >= tMin;
+        const bool h1 = fmaxf(fabsf(qu.y), fabsf(qv.y)) <= 1.0f && dist2.y < a1.z && T.y >= tMin;
+        const gv2f op  = {h0 ? (noGauss ? 1.0f : al.x) : 0.0f, h1 ? (noGauss ? 1.0f : al.y) : 0.0f};
+        const gv2f wgt = op * T;
+        cr += wgt * c4.x;
+        cg += wgt * c4.y;
+        cb += wgt * c4.z;
+        T -= wgt;
+      }
+    }
+    // all four waves saturated: stop fetching (the predicate above already keeps saturated pixels unchanged)
+    if(__syncthreads_and((T.x >= tMin || T.y >= tMin) ? 0 : 1))
+      break;
+  }
+  if(t == 0)
+  {
+    atomicAdd(&ctr->scannedSlots[blockIdx.x & 7], statScanned);
+    atomicAdd(&ctr->stagedSlots[blockIdx.x & 7], statStaged);
+  }
+#pragma unroll
+  for(int h = 0; h < 2; ++h)
+  {
+    if(!(h ? in1 : in0))
+      continue;
+    const bool  rok = h ? ok1 : ok0;
+    const float r = h ? cr.y : cr.x, g = h ? cg.y : cg.x, b = h ? cb.y : cb.x;
+    const float alphaOut = 1.0f - (rok ? (h ? T.y : T.x) : 1.0f);
+    const size_t pix = (size_t)py * F.width + (size_t)(px + 8 * h);
+    if(halfOut == 1)
+    {
+      const __half2 lo = __floats2half2_rn(r, g), hi2 = __floats2half2_rn(b, alphaOut);
+      uint2         o;
+      o.x = *reinterpret_cast<const uint32_t*>(&lo);
+      o.y = *reinterpret_cast<const uint32_t*>(&hi2);
+      reinterpret_cast<uint2*>(outImage)[pix] = o;
+    }
+    else if(halfOut == 0)
+      reinterpret_cast<float4*>(outImage)[pix] = make_float4(r, g, b, alphaOut);
+    else
+    {
+      auto q = [](float v) { return (uint32_t)(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f + 0.5f); };
+      reinterpret_cast<uint32_t*>(outImage)[pix] = q(r) | (q(g) << 8) | (q(b) << 16) | (q(alphaOut) << 24);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 void launchProjectGut(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, int shFormat, FrameCounters* ctr,
                       uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, GutRec* rec, uint32_t* rect,
@@ -707,6 +932,25 @@ void launchCompositeGut(hipStream_t stream, const FrameArgs& A, const FrameArgs*
   if(tiles <= 0)
     return;
   const bool extras = A.f.dofMode != 0 || A.f.stochastic != 0 || A.f.kernelDegree != 2 || A.f.surfaceOutputs != 0;
+  static const bool kPacked = [] { const char* e = std::getenv("MGS_GUT_PACKED"); return e ? std::atoi(e) != 0 : true; }();
+  if(kPacked && !extras && A.f.alphaMode == 0)
+  {  // the plain mode runs on the packed two-pixels-per-lane compositor
+    // all bins of the frame are enumerated (the bin order of the binning stage is over the whole frame; regions outside a
+    // strip exit at once)
+    const int nBins   = A.f.binsX * A.f.binsY;
+    const int regions = ((nBins + 7) / 8) * (1 << (A.f.binShiftX - 1 + A.f.binShiftY)) * 8;
+#define MGS_LAUNCH2(SHF)                                                                                                                  \
+  hipLaunchKernelGGL((k_composite_gut2<SHF>), dim3(regions), dim3(256), 0, stream, dArgs, ranges, valX, valY, planPairs, rec, image, halfOut, \
+                     ctr)
+    if(shFormat == 0)
+      MGS_LAUNCH2(0);
+    else if(shFormat == 1)
+      MGS_LAUNCH2(1);
+    else
+      MGS_LAUNCH2(2);
+#undef MGS_LAUNCH2
+    return;
+  }
 #define MGS_LAUNCH(SHF, XT)                                                                                                          \
   hipLaunchKernelGGL((k_composite_gut<SHF, XT>), dim3(tiles), dim3(256), 0, stream, dArgs, ranges, valX, valY, planPairs, rec, image, \
                      halfOut, ctr, outDepth, outSplatId, outNormal)
