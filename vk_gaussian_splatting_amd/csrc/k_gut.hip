@@ -99,29 +99,27 @@ __device__ __forceinline__ bool projectSplatGut(const FrameConst& F, const Insta
   if(alpha < F.alphaCull)     // :150-155
     return false;
   // threedgutParticleProjection, threedgut.h.slang:26-110 (GUT_D 3, alpha 1, beta 2, kappa 0 -> lambda 0, delta sqrt 3)
-  const float* M = I.model;
-  const float* V = F.view;
-  auto project = [&](float mx, float my, float mz, float& ox, float& oy) {
-    const float wx_ = M[0] * mx + M[4] * my + M[8] * mz + M[12];
-    const float wy_ = M[1] * mx + M[5] * my + M[9] * mz + M[13];
-    const float wz_ = M[2] * mx + M[6] * my + M[10] * mz + M[14];
-    const float vx = V[0] * wx_ + V[4] * wy_ + V[8] * wz_ + V[12];
-    const float vy = V[1] * wx_ + V[5] * wy_ + V[9] * wz_ + V[13];
-    const float vz = V[2] * wx_ + V[6] * wy_ + V[10] * wz_ + V[14];
-    return gutProjectCam(F, vx, vy, -vz, ox, oy);
-  };
+  // the sigma points p +- delta_a through V*M: the map is affine, so the mean goes through the model-view matrix once and each
+  // axis offset through its 3x3 (7 x 18 FMAs -> 9 + 3 x 9 + adds); only the camera model is evaluated per point
+  const float* MV = I.modelView;
+  const float  vcx = MV[0] * px + MV[4] * py + MV[8] * pz + MV[12];
+  const float  vcy = MV[1] * px + MV[5] * py + MV[9] * pz + MV[13];
+  const float  vcz = MV[2] * px + MV[6] * py + MV[10] * pz + MV[14];
   float spx[7], spy[7];
-  int   nValid = project(px, py, pz, spx[0], spy[0]) ? 1 : 0;
+  int   nValid = gutProjectCam(F, vcx, vcy, -vcz, spx[0], spy[0]) ? 1 : 0;
   constexpr float kDelta = 1.73205080757f, kWI = 1.0f / 6.0f;
   float ccx = 0.0f, ccy = 0.0f;  // weight of the mean: lambda / (D + lambda) = 0
 #pragma unroll
   for(int a = 0; a < 3; ++a)
   {
     const float ex = kDelta * sc[a] * R[a][0], ey = kDelta * sc[a] * R[a][1], ez = kDelta * sc[a] * R[a][2];
-    nValid += project(px + ex, py + ey, pz + ez, spx[a + 1], spy[a + 1]) ? 1 : 0;
+    const float dvx = MV[0] * ex + MV[4] * ey + MV[8] * ez;
+    const float dvy = MV[1] * ex + MV[5] * ey + MV[9] * ez;
+    const float dvz = MV[2] * ex + MV[6] * ey + MV[10] * ez;
+    nValid += gutProjectCam(F, vcx + dvx, vcy + dvy, -(vcz + dvz), spx[a + 1], spy[a + 1]) ? 1 : 0;
     ccx += kWI * spx[a + 1];
     ccy += kWI * spy[a + 1];
-    nValid += project(px - ex, py - ey, pz - ez, spx[a + 4], spy[a + 4]) ? 1 : 0;
+    nValid += gutProjectCam(F, vcx - dvx, vcy - dvy, -(vcz - dvz), spx[a + 4], spy[a + 4]) ? 1 : 0;
     ccx += kWI * spx[a + 4];
     ccy += kWI * spy[a + 4];
   }
@@ -196,11 +194,8 @@ __device__ __forceinline__ bool projectSplatGut(const FrameConst& F, const Insta
   }
   // depth of the quad from the pinhole projection matrix (":205-214": a coarse approximation for fisheye) and the
   // fixed-function clip of a quad emitted at z = ndc.z, w = 1
-  const float* MV = I.modelView;
   const float* P  = F.proj;
-  const float  tx = MV[0] * px + MV[4] * py + MV[8] * pz + MV[12];
-  const float  ty = MV[1] * px + MV[5] * py + MV[9] * pz + MV[13];
-  const float  tz = MV[2] * px + MV[6] * py + MV[10] * pz + MV[14];
+  const float  tx = vcx, ty = vcy, tz = vcz;  // the mean in view space, computed above
   const float  tw = MV[3] * px + MV[7] * py + MV[11] * pz + MV[15];
   const float  cz = P[2] * tx + P[6] * ty + P[10] * tz + P[14] * tw;
   const float  cw = P[3] * tx + P[7] * ty + P[11] * tz + P[15] * tw;
