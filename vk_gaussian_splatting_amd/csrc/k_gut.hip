@@ -428,7 +428,7 @@ __device__ __forceinline__ bool gutPixelRay(const FrameConst& F, float pcx, floa
 // ---- compositor: one workgroup per 16x16 tile, one pixel per thread -------------------------------------------------------
 constexpr int kGutBatch = 256;  // list entries scanned per round == staging capacity
 
-// XT 1: the variant with depth of field (frag.slang:104-109, cameras.h.slang:85-108), stochastic splats (:150-172) and/or
+// XT 1 (2: + the non-quadratic particle kernels, the surface side outputs and their LDS): the variant with depth of field (frag.slang:104-109, cameras.h.slang:85-108), stochastic splats (:150-172) and/or
 // a particle kernel other than the quadratic one, and/or the surface side outputs (picked depth, splat id, integrated normal)
 template <int SHF, int XT>
 __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restrict__ Ap, const uint2* __restrict__ ranges,
@@ -440,8 +440,8 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
 {
   __shared__ float4   s_r[kGutBatch][6];
   __shared__ uint32_t s_gid[XT ? kGutBatch : 1];
-  __shared__ float4   s_n[XT ? kGutBatch : 1];  // surface outputs: world normal of the record (.w = 1: minus the pixel's ray)
-  __shared__ float    s_z[XT ? kGutBatch : 1];  //                  fragCoord.z of the record's quad
+  __shared__ float4   s_n[XT == 2 ? kGutBatch : 1];  // surface outputs (XT 2): world normal of the record (.w = 1: minus the pixel's ray)
+  __shared__ float    s_z[XT == 2 ? kGutBatch : 1];  //                         fragCoord.z of the record's quad
   __shared__ uint32_t s_wc[4];
   __shared__ uint32_t s_live;
   const FrameConst& F = Ap->f;
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
   const int      bin   = (ty >> F.binShiftY) * F.binsX + (tx >> F.binShiftX);
   const uint2    range = ranges[bin];
   float T = (inside && rayOk) ? 1.0f : 0.0f, cr = 0.f, cg = 0.f, cb = 0.f, asum = 0.f;
-  const bool surf = XT && F.surfaceOutputs != 0;
+  const bool surf = XT == 2 && F.surfaceOutputs != 0;
   float      nx = 0.f, ny = 0.f, nz = 0.f, pickZ = 0.f;
   uint32_t   pickId = 0xFFFFFFFFu;
   uint32_t hi = range.y;
@@ -538,8 +538,12 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
       const int deg = (I.sh == nullptr) ? 0 : min(I.shDegree, F.shDegree);
       if(deg > 0)
         addShRadiance<SHF>(I.sh, li, deg, dx, dy, dz, c5.x, c5.y, c5.z);
+      // acceptance (threedgrt.h.slang:259-267) with two compares less per fragment: density > alphaCull, alpha = min(clamp,
+      // response * density) > 1/255 and response > kMin  <=>  response > max(kMin, 1 / (255 density)) — a per-record cutoff
+      // that takes the slot of the box extents (needed above only)
+      const float rcut = (c5.w > F.alphaCull) ? fmaxf(F.kernelMinResponse, 1.0f / (255.0f * fmaxf(c5.w, 1e-30f))) : 3.0e38f;
       s_r[pos][0] = r0;
-      s_r[pos][1] = r1;
+      s_r[pos][1] = make_float4(r1.x, r1.y, rcut, 0.0f);
       s_r[pos][2] = r2;
       s_r[pos][3] = r3;
       s_r[pos][4] = r4;
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
       if constexpr(XT != 0)
       {
         s_gid[pos] = g;
-        if(F.surfaceOutputs)
+        if constexpr(XT == 2)
         {  // frag.slang:127-131 -> particleProcessHitGutWithNormal (threedgrt.h.slang:281-345): the max-density-plane normal is a
           // per-splat quantity (ray ORIGIN only) except for particles with two degenerate axes; no octahedral round trip here
           // (the normal is computed in the fragment shader, not carried through an interstage variable).  fragCoord.z: the
@@ -593,7 +597,7 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
       const float kx = gy * roz - gz * roy, ky = gz * rox - gx * roz, kz = gx * roy - gy * rox;
       const float dist2 = (kx * kx + ky * ky + kz * kz) * gRcp(gx * gx + gy * gy + gz * gz);
       float resp = __expf(-0.5f * dist2);                            // quadratic kernel, :127-131
-      if constexpr(XT != 0)
+      if constexpr(XT >= 2)
       {  // particleRayMaxKernelResponse<KERNEL_DEGREE>, threedgrt.h.slang:83-127 (its argument is the squared distance)
         switch(F.kernelDegree)
         {
@@ -607,7 +611,7 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
         }
       }
       const float al    = fminf(F.alphaClamp, resp * c4.w);          // :263
-      const bool  hit   = inQuad && (c4.w > F.alphaCull) && (al > (1.0f / 255.0f)) && (resp > F.kernelMinResponse) && T >= tMin;
+      const bool  hit   = inQuad && resp > a1.z && T >= tMin;
       float       op    = hit ? (noGauss ? 1.0f : al) : 0.0f;
       if constexpr(XT != 0)
       {
@@ -625,7 +629,7 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
       cb += wgt * c4.z;
       asum += op;
       T -= wgt;
-      if constexpr(XT != 0)
+      if constexpr(XT == 2)
       {
         if(surf)
         {  // frag.slang:195-228: normal attachment "under"-blended with (normal * opacity, opacity); picked depth = the
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
     return;
   const float alphaOut = F.alphaMode == 1 ? asum : 1.0f - ((inside && rayOk) ? T : 1.0f);
   const size_t pix = (size_t)py * F.width + px;
-  if constexpr(XT != 0)
+  if constexpr(XT == 2)
   {
     if(surf)
     {
@@ -949,13 +953,15 @@ void launchCompositeGut(hipStream_t stream, const FrameArgs& A, const FrameArgs*
 #define MGS_LAUNCH(SHF, XT)                                                                                                          \
   hipLaunchKernelGGL((k_composite_gut<SHF, XT>), dim3(tiles), dim3(256), 0, stream, dArgs, ranges, valX, valY, planPairs, rec, image, \
                      halfOut, ctr, outDepth, outSplatId, outNormal)
-#define MGS_LAUNCH_X(SHF)  \
-  do                       \
-  {                        \
-    if(extras)             \
-      MGS_LAUNCH(SHF, 1);  \
-    else                   \
-      MGS_LAUNCH(SHF, 0);  \
+#define MGS_LAUNCH_X(SHF)            \
+  do                                 \
+  {                                  \
+    if(A.f.surfaceOutputs != 0 || A.f.kernelDegree != 2) \
+      MGS_LAUNCH(SHF, 2);            \
+    else if(extras)                  \
+      MGS_LAUNCH(SHF, 1);            \
+    else                             \
+      MGS_LAUNCH(SHF, 0);            \
   } while(0)
   if(shFormat == 0)
     MGS_LAUNCH_X(0);
