@@ -705,7 +705,8 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
 typedef float gv2f __attribute__((ext_vector_type(2)));
 constexpr int kGut2Cap = 256;  // LDS batch capacity == entries scanned per round
 
-template <int SHF>
+// XT 1: + depth of field (a lens offset per pixel) and stochastic splats (quadratic kernel only)
+template <int SHF, int XT>
 __global__ __launch_bounds__(256) void k_composite_gut2(const FrameArgs* __restrict__ Ap, const uint2* __restrict__ ranges,
                                                         const uint32_t* __restrict__ valX, const uint32_t* __restrict__ valY,
                                                         const SortPlan* __restrict__ plan, const GutRec* __restrict__ rec,
@@ -713,6 +714,7 @@ __global__ __launch_bounds__(256) void k_composite_gut2(const FrameArgs* __restr
 {
   __shared__ float4   s_r[kGut2Cap][6];
   __shared__ uint8_t  s_m[kGut2Cap];
+  __shared__ uint32_t s_gid[XT ? kGut2Cap : 1];
   __shared__ uint32_t s_wc[4];
   const FrameConst& F = Ap->f;
   const int t = threadIdx.x, lane = laneId(), w = t >> 6;
@@ -761,6 +763,32 @@ __global__ __launch_bounds__(256) void k_composite_gut2(const FrameArgs* __restr
     ok1 = gutPixelRay(F, pcx.y, pcy, a, b, c);
     dxw.y = a; dyw.y = b; dzw.y = c;
   }
+  // depth of field (frag.slang:104-109, cameras.h.slang:85-108): one lens sample per pixel and frame
+  gv2f     lensX = {0.f, 0.f}, lensY = {0.f, 0.f}, lensZ = {0.f, 0.f};
+  uint32_t seed0 = 0u, seed1 = 0u;
+  if constexpr(XT != 0)
+  {
+    seed0 = rngXxhash32((uint32_t)px, (uint32_t)py, (uint32_t)F.frameSampleId);
+    seed1 = rngXxhash32((uint32_t)px + 8u, (uint32_t)py, (uint32_t)F.frameSampleId);
+    if(F.dofMode != 0)
+    {
+      const float* Vi = F.viewInv;
+#pragma unroll
+      for(int h = 0; h < 2; ++h)
+      {
+        uint32_t    sd = h ? seed1 : seed0;
+        const float r1 = rngRand(sd) * 6.28318530717958647692f, r2 = rngRand(sd) * F.aperture;
+        const float c = cosf(r1), sn = sinf(r1), sq = gSqrt(r2);
+        const float lx = (c * Vi[0] + sn * Vi[4]) * sq, ly = (c * Vi[1] + sn * Vi[5]) * sq, lz = (c * Vi[2] + sn * Vi[6]) * sq;
+        const float dx0 = h ? dxw.y : dxw.x, dy0 = h ? dyw.y : dyw.x, dz0 = h ? dzw.y : dzw.x;
+        const float fx = dx0 * F.focusDist - lx, fy = dy0 * F.focusDist - ly, fz = dz0 * F.focusDist - lz;
+        const float l  = rsqrtf(fx * fx + fy * fy + fz * fz);
+        if(h) { lensX.y = lx; lensY.y = ly; lensZ.y = lz; dxw.y = fx * l; dyw.y = fy * l; dzw.y = fz * l; }
+        else  { lensX.x = lx; lensY.x = ly; lensZ.x = lz; dxw.x = fx * l; dyw.x = fy * l; dzw.x = fz * l; }
+      }
+    }
+  }
+  const bool  stoch   = XT && F.stochastic != 0 && !((F.debugFlags & 4) != 0);
   const bool  noGauss = (F.debugFlags & 4) != 0;
   constexpr float tMin = 1.0e-4f;
   const uint32_t* vals = plan->finalSel ? valY : valX;
@@ -831,6 +859,8 @@ __global__ __launch_bounds__(256) void k_composite_gut2(const FrameArgs* __restr
       s_r[pos][3] = r3;
       s_r[pos][4] = r4;
       s_r[pos][5] = c5;
+      if constexpr(XT != 0)
+        s_gid[pos] = g;
       // quarters (16 x 8 pixels; centres x in [bcx-15.5,bcx-0.5] / [bcx+0.5,bcx+15.5], y in [bcy-7.5,bcy-0.5] / [bcy+0.5,bcy+7.5])
       // the box of the quad touches
       const bool xl = r0.x - r1.z <= bcx - 0.5f, xr = r0.x + r1.z >= bcx + 0.5f;
@@ -859,7 +889,14 @@ __global__ __launch_bounds__(256) void k_composite_gut2(const FrameArgs* __restr
         const gv2f gx = dxw * b0.x + (dyw * b0.y + dzw * b0.z);
         const gv2f gy = dxw * b0.w + (dyw * b1.x + dzw * b1.y);
         const gv2f gz = dxw * b1.z + (dyw * b1.w + dzw * b2.x);
-        const gv2f kx = gy * b2.w - gz * b2.z, ky = gz * b2.y - gx * b2.w, kz = gx * b2.z - gy * b2.y;
+        gv2f rox = {b2.y, b2.y}, roy = {b2.z, b2.z}, roz = {b2.w, b2.w};
+        if constexpr(XT != 0)
+        {  // rayOrigin += randomAperturePos: canonical origin + B * offset
+          rox += lensX * b0.x + (lensY * b0.y + lensZ * b0.z);
+          roy += lensX * b0.w + (lensY * b1.x + lensZ * b1.y);
+          roz += lensX * b1.z + (lensY * b1.w + lensZ * b2.x);
+        }
+        const gv2f kx = gy * roz - gz * roy, ky = gz * rox - gx * roz, kz = gx * roy - gy * rox;
         const gv2f kk = kx * kx + (ky * ky + kz * kz), gg = gx * gx + (gy * gy + gz * gz);
         const gv2f dist2 = {kk.x * gRcp(gg.x), kk.y * gRcp(gg.y)};
         const gv2f resp  = {__expf(-0.5f * dist2.x), __expf(-0.5f * dist2.y)};  // quadratic kernel, :127-131
@@ -867,7 +904,18 @@ __global__ __launch_bounds__(256) void k_composite_gut2(const FrameArgs* __restr
         const gv2f al    = {fminf(F.alphaClamp, raw.x), fminf(F.alphaClamp, raw.y)};  // :263
         const bool h0 = fmaxf(fabsf(qu.x), fabsf(qv.x)) <= 1.0f && dist2.x < a1.z && T.x >= tMin;
         const bool h1 = fmaxf(fabsf(qu.y), fabsf(qv.y)) <= 1.0f && dist2.y < a1.z && T.y >= tMin;
-        const gv2f op  = {h0 ? (noGauss ? 1.0f : al.x) : 0.0f, h1 ? (noGauss ? 1.0f : al.y) : 0.0f};
+        gv2f op  = {h0 ? (noGauss ? 1.0f : al.x) : 0.0f, h1 ? (noGauss ? 1.0f : al.y) : 0.0f};
+        if constexpr(XT != 0)
+        {
+          if(stoch)
+          {  // frag.slang:153-158; primitive id as in the other compositors: 2 * (id mod 32) + triangle (0: u > v)
+            const uint32_t gid = s_gid[j], prim = 2u * (gid & 31u);
+            uint32_t       q0 = rngXxhash32(seed0, gid, prim + (qu.x > qv.x ? 0u : 1u));
+            uint32_t       q1 = rngXxhash32(seed1, gid, prim + (qu.y > qv.y ? 0u : 1u));
+            op.x = (h0 && rngRand(q0) < op.x) ? 1.0f : 0.0f;
+            op.y = (h1 && rngRand(q1) < op.y) ? 1.0f : 0.0f;
+          }
+        }
         const gv2f wgt = op * T;
         cr += wgt * c4.x;
         cg += wgt * c4.y;
@@ -932,21 +980,32 @@ void launchCompositeGut(hipStream_t stream, const FrameArgs& A, const FrameArgs*
     return;
   const bool extras = A.f.dofMode != 0 || A.f.stochastic != 0 || A.f.kernelDegree != 2 || A.f.surfaceOutputs != 0;
   static const bool kPacked = [] { const char* e = std::getenv("MGS_GUT_PACKED"); return e ? std::atoi(e) != 0 : true; }();
-  if(kPacked && !extras && A.f.alphaMode == 0)
-  {  // the plain mode runs on the packed two-pixels-per-lane compositor
+  const bool packedOk = A.f.kernelDegree == 2 && A.f.surfaceOutputs == 0 && (A.f.alphaMode == 0 || A.f.stochastic != 0);
+  if(kPacked && packedOk)
+  {  // the quadratic-kernel modes without side outputs run on the packed two-pixels-per-lane compositor
     // all bins of the frame are enumerated (the bin order of the binning stage is over the whole frame; regions outside a
     // strip exit at once)
     const int nBins   = A.f.binsX * A.f.binsY;
     const int regions = ((nBins + 7) / 8) * (1 << (A.f.binShiftX - 1 + A.f.binShiftY)) * 8;
-#define MGS_LAUNCH2(SHF)                                                                                                                  \
-  hipLaunchKernelGGL((k_composite_gut2<SHF>), dim3(regions), dim3(256), 0, stream, dArgs, ranges, valX, valY, planPairs, rec, image, halfOut, \
-                     ctr)
+    const bool xt = A.f.dofMode != 0 || A.f.stochastic != 0;
+#define MGS_LAUNCH2X(SHF, XTV)                                                                                                            \
+  hipLaunchKernelGGL((k_composite_gut2<SHF, XTV>), dim3(regions), dim3(256), 0, stream, dArgs, ranges, valX, valY, planPairs, rec, image, \
+                     halfOut, ctr)
+#define MGS_LAUNCH2(SHF)   \
+  do                       \
+  {                        \
+    if(xt)                 \
+      MGS_LAUNCH2X(SHF, 1); \
+    else                   \
+      MGS_LAUNCH2X(SHF, 0); \
+  } while(0)
     if(shFormat == 0)
       MGS_LAUNCH2(0);
     else if(shFormat == 1)
       MGS_LAUNCH2(1);
     else
       MGS_LAUNCH2(2);
+#undef MGS_LAUNCH2X
 #undef MGS_LAUNCH2
     return;
   }
