@@ -260,7 +260,7 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
                                                              uint32_t* __restrict__ keysSlot, uint32_t* __restrict__ idsSlot,
                                                              uint32_t* __restrict__ slotCount, GutRec* __restrict__ rec,
                                                              uint32_t* __restrict__ rect, const uint32_t* __restrict__ partSkip,
-                                                             uint32_t* __restrict__ slotHist, uint32_t histStride)
+                                                             uint32_t* __restrict__ slotHist, uint32_t histStride, SortPlan* __restrict__ planKeys)
 {
   const FrameArgs& A = *Ap;
   if(partSkip != nullptr && (partSkip[blockIdx.x] & 1u) != 0u)
@@ -368,6 +368,7 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
       s_cnt[r * 4 + w] = (uint32_t)__popcll(bal[r]);
   }
   const uint32_t outCount = scanRoundWaveCounts(s_cnt, s_base);
+  uint32_t       tmn = 0xFFFFu, tmx = 0u;
 #pragma unroll
   for(int r = 0; r < kGutItems; ++r)
     if(vis[r])
@@ -377,7 +378,10 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
       keysSlot[slotBase + pos] = s_key[j];
       idsSlot[slotBase + pos]  = I.globalOffset + local0 + (s_li[j] & 0x7FFFu);
       atomicAdd(&s_hist[s_key[j] & 255u], 1u);
+      tmn = min(tmn, s_key[j] >> 16);
+      tmx = max(tmx, s_key[j] >> 16);
     }
+  sortTop16Post<4>(tmn, tmx, s_cnt);  // pass elision of the key sort (sort_plan.h), as in k_project
   if(t == 0)
   {
     slotCount[part] = outCount;
@@ -386,6 +390,13 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
   }
   __syncthreads();
   slotHist[(size_t)t * histStride + part] = s_hist[t];
+  if(sortTop16Mark<4>(planKeys, outCount, s_cnt))
+  {
+#pragma unroll
+    for(int r = 0; r < kGutItems; ++r)
+      if(vis[r])
+        sortMarkTop16(planKeys, s_key[r * kGutThreads + t] >> 16);
+  }
 }
 
 // world-space ray direction of the pixel whose centre is (pcx, pcy) (threedgut_raster.frag.slang:101-111); false: outside the
@@ -962,13 +973,13 @@ __global__ __launch_bounds__(256) void k_composite_gut2(const FrameArgs* __restr
 // ---------------------------------------------------------------------------------------------
 void launchProjectGut(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, int shFormat, FrameCounters* ctr,
                       uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, GutRec* rec, uint32_t* rect,
-                      const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride)
+                      const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride, SortPlan* planKeys)
 {
   (void)shFormat;
   if(args.f.totalPartitions == 0)
     return;
   hipLaunchKernelGGL(k_project_gut, dim3(args.f.totalPartitions), dim3(kGutThreads), 0, stream, dArgs, ctr, keysSlot, idsSlot, slotCount,
-                     rec, rect, partSkip, slotHist, histStride);
+                     rec, rect, partSkip, slotHist, histStride, planKeys);
 }
 
 void launchCompositeGut(hipStream_t stream, const FrameArgs& A, const FrameArgs* dArgs, const uint2* ranges, const uint32_t* valX,

@@ -185,49 +185,10 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   return true;
 }
 
-// Pass elision of the key sort (sort_plan.h): the workgroup marks which values of key >> 16 it hands to the sort.  A
-// partition is a compact cell of space, so its keys span one to three values: thread 0 marks the range; a partition that
-// spans many (a cell around the camera) has every thread mark its own keys.  Split in two so that it needs no barrier of
-// its own and the marking's memory latency overlaps the kernel's last stores: post the per-wave min / max before the
-// kernel's final barrier, mark after it.
-__device__ __forceinline__ void top16Post(uint32_t mn, uint32_t mx, uint32_t* s_red /*8 free words*/)
-{
-#pragma unroll
-  for(int o = 32; o > 0; o >>= 1)
-  {
-    mn = min(mn, (uint32_t)__shfl_xor(mn, o, 64));
-    mx = max(mx, (uint32_t)__shfl_xor(mx, o, 64));
-  }
-  if(laneId() == 0)
-  {
-    s_red[threadIdx.x >> 6]               = mn;
-    s_red[kPrjWaves + (threadIdx.x >> 6)] = mx;
-  }
-}
-// returns true when the caller's threads must mark their own keys
-__device__ __forceinline__ bool top16Mark(SortPlan* plan, uint32_t count, const uint32_t* s_red)
-{
-  if(plan == nullptr || count == 0u)
-    return false;
-  uint32_t lo = s_red[0], hi = s_red[kPrjWaves];
-#pragma unroll
-  for(int i = 1; i < kPrjWaves; ++i)
-  {
-    lo = min(lo, s_red[i]);
-    hi = max(hi, s_red[kPrjWaves + i]);
-  }
-  if(hi - lo > 24u)
-    return true;
-  if(threadIdx.x == 0)
-    for(uint32_t v = lo; v <= hi; ++v)
-      sortMarkTop16(plan, v);
-  return false;
-}
+// pass elision of the key sort: sortTop16Post / sortTop16Mark (sort_plan.h)
+__device__ __forceinline__ void top16Post(uint32_t mn, uint32_t mx, uint32_t* s_red) { sortTop16Post<kPrjWaves>(mn, mx, s_red); }
+__device__ __forceinline__ bool top16Mark(SortPlan* plan, uint32_t count, const uint32_t* s_red) { return sortTop16Mark<kPrjWaves>(plan, count, s_red); }
 
-// One workgroup = one partition of 2048 consecutive splats of one instance.
-// Output: survivors of partition p, ascending id, in keysSlot/idsSlot[p*2048 ...], count in slotCount[p].
-// No barrier sits inside a loop that waits on memory: all 8 centre loads of a thread are issued up front,
-// and the heavy per-survivor loop runs barrier-free (waves drift apart and overlap each other's loads).
 #ifdef MGS_PRJ_TRACE  // debug build (tools/prj_trace.py): per-workgroup wall-clock stamps (100 MHz) of the phases
 __device__ uint64_t* g_prjTrace = nullptr;
 #define MGS_PRJ_STAMP(i) if(threadIdx.x == 0) trc[i] = wall_clock64();

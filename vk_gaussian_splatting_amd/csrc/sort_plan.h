@@ -34,6 +34,46 @@ __device__ __forceinline__ void sortMarkTop16(SortPlan* plan, uint32_t v)
     atomicOr(&plan->topBitmap[v >> 5], 1u << (v & 31u));
 }
 
+// Pass elision of the key sort: the producer's workgroup marks which values of key >> 16 it hands to the sort.  A partition is
+// a compact cell of space, so its keys span one to three values: thread 0 marks the range; a partition that spans many (a cell
+// around the camera) has every thread mark its own keys.  Split in two so that it needs no barrier of its own and the marking's
+// memory latency overlaps the kernel's last stores: post the per-wave min / max before the kernel's final barrier, mark after it.
+template <int WAVES>
+__device__ __forceinline__ void sortTop16Post(uint32_t mn, uint32_t mx, uint32_t* s_red /* 2 * WAVES free words */)
+{
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1)
+  {
+    mn = min(mn, (uint32_t)__shfl_xor(mn, o, 64));
+    mx = max(mx, (uint32_t)__shfl_xor(mx, o, 64));
+  }
+  if((threadIdx.x & 63u) == 0u)
+  {
+    s_red[threadIdx.x >> 6]           = mn;
+    s_red[WAVES + (threadIdx.x >> 6)] = mx;
+  }
+}
+// returns true when the caller's threads must mark their own keys
+template <int WAVES>
+__device__ __forceinline__ bool sortTop16Mark(SortPlan* plan, uint32_t count, const uint32_t* s_red)
+{
+  if(plan == nullptr || count == 0u)
+    return false;
+  uint32_t lo = s_red[0], hi = s_red[WAVES];
+#pragma unroll
+  for(int i = 1; i < WAVES; ++i)
+  {
+    lo = min(lo, s_red[i]);
+    hi = max(hi, s_red[WAVES + i]);
+  }
+  if(hi - lo > 24u)
+    return true;
+  if(threadIdx.x == 0)
+    for(uint32_t v = lo; v <= hi; ++v)
+      sortMarkTop16(plan, v);
+  return false;
+}
+
 // scratch of the sample sort (k_ssort.hip); all device pointers, owned by the caller
 struct SampleSortBuffers
 {
