@@ -334,9 +334,16 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
     atomicAdd(&ctr->frustumCount, Mv);
   // ---- 3DGUT front end over the survivors ----
   const size_t slotBase = (size_t)part * kGutPart;
+  // The 96-byte records leave through LDS (as k_project's do): every lane builds one record, then the wave stores its 64 records
+  // six lanes per record, so that a store instruction covers whole sectors wherever neighbouring ids both survive (a wave's
+  // survivors are mostly consecutive ids: 6 KB contiguous).  Written lane-per-record, each of the six instructions put 16 bytes
+  // into 64 different sectors.  Pitch 7 quads: conflict-free 16-byte LDS accesses.
+  __shared__ float4   s_grec[4][64 * 7];
+  __shared__ uint32_t s_ggid[4][64];
   for(uint32_t j0 = 0; j0 < Mv; j0 += kGutThreads)
   {
-    const uint32_t j = j0 + t;
+    const uint32_t j     = j0 + t;
+    uint32_t       gidOk = 0xFFFFFFFFu;
     if(j < Mv)
     {
       const uint32_t li = local0 + s_li[j];
@@ -344,18 +351,29 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
       uint32_t       rc;
       if(projectSplatGut(A.f, I, li, r, rc))
       {
-        const uint32_t gid = I.globalOffset + li;
-        float4*        dst = reinterpret_cast<float4*>(rec + gid);
-        dst[0]             = make_float4(r.cx, r.cy, r.q1x, r.q1y);
-        dst[1]             = make_float4(r.q2x, r.q2y, r.bex, r.bey);
-        dst[2]             = make_float4(r.B[0], r.B[1], r.B[2], r.B[3]);
-        dst[3]             = make_float4(r.B[4], r.B[5], r.B[6], r.B[7]);
-        dst[4]             = make_float4(r.B[8], r.ro[0], r.ro[1], r.ro[2]);
-        dst[5]             = make_float4(r.r, r.g, r.b, r.a);
-        rect[gid]          = rc;
+        gidOk       = I.globalOffset + li;
+        float4* dst = &s_grec[w][lane * 7];
+        dst[0]      = make_float4(r.cx, r.cy, r.q1x, r.q1y);
+        dst[1]      = make_float4(r.q2x, r.q2y, r.bex, r.bey);
+        dst[2]      = make_float4(r.B[0], r.B[1], r.B[2], r.B[3]);
+        dst[3]      = make_float4(r.B[4], r.B[5], r.B[6], r.B[7]);
+        dst[4]      = make_float4(r.B[8], r.ro[0], r.ro[1], r.ro[2]);
+        dst[5]      = make_float4(r.r, r.g, r.b, r.a);
+        rect[gidOk] = rc;
         s_li[j] |= 0x8000u;
       }
     }
+    s_ggid[w][lane] = gidOk;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for(int i = 0; i < 6; ++i)
+    {
+      const uint32_t idx = (uint32_t)(i * 64 + lane), rr = idx / 6u, pt = idx - rr * 6u;
+      const uint32_t g   = s_ggid[w][rr];
+      if(g != 0xFFFFFFFFu)
+        reinterpret_cast<float4*>(rec + g)[pt] = s_grec[w][rr * 7 + pt];
+    }
+    __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
 #pragma unroll
