@@ -31,13 +31,16 @@ def one(seed):
     V, P = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], float(rng.uniform(35, 80)), 0.1, 2000.0, W, H)
     gut = bool(rng.integers(0, 2))
     sample = int(rng.integers(0, 200))
-    mode = rng.choice(["stoch", "dof", "both"]) if gut else "stoch"
+    mode = rng.choice(["stoch", "dof", "both", "plain"]) if gut else "stoch"   # plain: the 3DGUT frame itself (packed compositor)
     p = capi.default_params(W, H)
     capi.set_camera(p, V, P, eye)
     p.pipeline = capi.PIPELINE_3DGUT if gut else capi.PIPELINE_3DGS
     p.target_format = capi.TARGET_RGBA32F
     p.frame_sample_id = sample
     fkw = dict(frame_sample_id=sample)
+    if gut and mode == "plain" and rng.integers(0, 2):
+        p.ms_antialiasing = 1
+        fkw["ms_antialiasing"] = 1
     if gut:
         p.camera_model = int(rng.integers(0, 2))
         p.extent_method = int(rng.integers(0, 2))
