@@ -47,7 +47,9 @@ prev = {}
 for pose in range(0, 8):
     reg, dur, span = trace(pose)
     cost = dict(zip(reg.tolist(), dur.tolist()))
-    line = f"pose {pose}: measured span {span:.1f} us; simulated: launch order {simulate(dur):.1f}, longest-first (own durations) {simulate(np.sort(dur)[::-1]):.1f}"
+    rs = np.random.default_rng(pose)
+    line = (f"pose {pose}: measured span {span:.1f} us; simulated: launch order {simulate(dur):.1f}, reversed {simulate(dur[::-1]):.1f}, "
+            f"random {np.mean([simulate(rs.permutation(dur)) for _ in range(5)]):.1f}, longest-first (own durations) {simulate(np.sort(dur)[::-1]):.1f}")
     for lag in (1, 3):
         if pose - lag in prev:
             pc = prev[pose - lag]
