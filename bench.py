@@ -147,24 +147,26 @@ def main():
     if not args.ply:
         ss = mgs.SplatSet.from_arrays(**sc)
     K = max(1, args.inflight)
+    # ONE resident scene, committed once; frames in flight are frame contexts over it (own stream + working set + graphs),
+    # like the reference's single copy of the splat buffers under its frames in flight (gaussian_splatting.cpp:1092-1111)
     scenes, streams = [], []
-    for _ in range(K):
-        sc_k = mgs.Scene(local)
-        for q in range(args.instances):
-            if args.instances == 1:
-                sc_k.add_instance(ss)
-            else:
-                cols = (args.instances + 1) // 2
-                M = np.eye(4, dtype=np.float32)
-                M[0, 3] = ((q % cols) - (cols - 1) / 2.0) * 12.0
-                M[2, 3] = ((q // cols) - 0.5) * 12.0
-                sc_k.add_instance(ss, M)
-        sc_k.commit(args.sh_format, args.rgba_format)
+    scene = mgs.Scene(local)
+    for q in range(args.instances):
+        if args.instances == 1:
+            scene.add_instance(ss)
+        else:
+            cols = (args.instances + 1) // 2
+            M = np.eye(4, dtype=np.float32)
+            M[0, 3] = ((q % cols) - (cols - 1) / 2.0) * 12.0
+            M[2, 3] = ((q // cols) - 0.5) * 12.0
+            scene.add_instance(ss, M)
+    scene.commit(args.sh_format, args.rgba_format)
+    for c in range(K):
+        sc_k = scene if c == 0 else scene.frame_context()
         st_k = torch.cuda.Stream()        # a real (non-null) stream shared by this context's renderer and RCCL
         sc_k.set_stream(st_k.cuda_stream)
         scenes.append(sc_k)
         streams.append(st_k)
-    scene = scenes[0]
     setup_s = time.time() - t0
 
     poses = []
@@ -540,7 +542,7 @@ def main():
                                "ms": best}
     if rank == 0:
         print(json.dumps(out, allow_nan=False))
-    for sc_k in scenes:
+    for sc_k in reversed(scenes):
         sc_k.close()
     if world > 1:
         dist.destroy_process_group()

@@ -133,6 +133,26 @@ int  mgs_instance_set_transform(MgsScene scene, int instance_id, const float tra
  * Idempotent; call again after changing formats (the reference's --updateData). */
 int  mgs_scene_commit(MgsScene scene, int sh_format, int rgba_format);
 uint64_t mgs_scene_splat_count(MgsScene scene); /* getTotalGlobalSplatCount, gaussian_splatting.cpp:369 */
+/* ---- frame contexts: frames in flight over ONE resident scene.
+ * The reference keeps a single copy of the splat buffers however many frames its application loop has in flight; that is why
+ * processUpdateRequests waits for the device before it touches them (src/gaussian_splatting.cpp:1092-1111).  A frame context
+ * is the per-frame-in-flight state of that loop: its own HIP stream, working buffers (slots, sort ping-pong, projected records,
+ * bin lists, frame image, counters) and captured frame graphs, reading the scene's committed buffers.  The returned handle is
+ * accepted by every frame-level entry point below (mgs_render, mgs_sort_keys, mgs_frame_*, mgs_timings_query, mgs_sync,
+ * mgs_scene_set_stream, the multi-GPU exchange); the scene-editing entry points (mgs_instance_add, mgs_instance_set_transform,
+ * mgs_scene_commit) return MGS_ERR_STATE on it — edit the scene.  Transforms set on the scene reach every context's next
+ * frame; mgs_scene_commit waits for the frames in flight on all contexts, and each context re-sizes its working set on its
+ * next frame.  Threading: one thread per handle at a time; do not edit or commit the scene while another thread renders one
+ * of its contexts.  Contexts may outlive the scene handle (the data is freed with the last handle). */
+int  mgs_frame_context_create(MgsScene scene, MgsScene* context_out);
+void mgs_frame_context_destroy(MgsScene context);
+/* capacity of this handle's per-bin splat lists in entries (4 B each); 0 restores the default of 32 per global splat.  Takes
+ * effect before the next frame.  A frame whose lists do not fit is incomplete: mgs_frame_stats returns MGS_ERR_OVERFLOW and
+ * sets bit 0 of error_flags (the analogue of the reference's fixed-size sorting buffers, splat_set_manager_vk.cpp:2304-2360,
+ * which are sized for the splat count and cannot overflow because a quad is not a list entry). */
+int  mgs_scene_set_list_capacity(MgsScene scene_or_context, uint64_t entries);
+/* device bytes held by the committed scene data (shared by all its contexts) and by this handle's working set */
+int  mgs_scene_memory_usage(MgsScene scene_or_context, uint64_t* scene_bytes, uint64_t* working_bytes);
 /* The device keeps every splat set in a spatially coherent STORAGE ORDER (Morton order of the centres;
  * build-defined, the reference keeps file order).  Every id that crosses this ABI is in the caller's
  * order; this returns the permutation storage index -> caller's index of an instance's splat set.
@@ -261,10 +281,15 @@ int mgs_scene_comm_destroy(MgsScene scene);
  * frame (16-pixel rows).  NULL restores the default: equal strips of ceil(rows / world_size).  Cost-balanced tables
  * come from mgs_frame_row_costs of earlier frames ("optionally cost-balanced from last frame's D"). */
 int mgs_scene_set_strip_rows(MgsScene scene, const int32_t* row_bounds, int count);
-/* mgs_render of this rank's strip + the exchange.  params->strip_row_* are ignored (the table decides). */
+/* mgs_render of this rank's strip + the exchange.  params->strip_row_* are ignored (the table decides).  A rank whose strip is
+ * empty (equal consecutive bounds, more ranks than tile rows) renders nothing and only receives.  A rank whose own render fails
+ * still joins the exchange (its rows are stale) and returns the render's error afterwards, so the peers never block; if it
+ * cannot even hold a frame buffer it aborts its communicator, which fails the peers' collective instead of hanging it. */
 int mgs_render_gathered(MgsScene scene, const MgsFrameParams* params, MgsFrameOut* out);
 /* per 16-pixel tile row of the last full frame: bin-list entries attributed to that row (a bin's entries spread
- * evenly over its tile rows) — the cost proxy the strip balancing uses.  Waits for the frame. */
+ * evenly over its tile rows) — the cost proxy the strip balancing uses.  Waits for the frame.  Calibrate on full-frame
+ * mgs_render calls: after mgs_render_gathered the lists cover this rank's rows only, every rank would derive a different
+ * table and the exchange sizes would disagree — MGS_ERR_STATE. */
 int mgs_frame_row_costs(MgsScene scene, uint32_t* cost_per_tile_row, size_t rows);
 
 /* test/debug hook (no reference counterpart: these are the mesh shader's per-quad outputs,

@@ -351,7 +351,83 @@ uint32_t orc_encode_key(float v)
   return bits;
 }
 
-// shaders/dist.comp.slang:40-171 (pinhole; size culling off = reference default parameters.h)
+// ---- CAMERA_TYPE == CAMERA_FISHEYE branch of the dist stage (dist.comp.slang:75-90) ----
+// atan2 is implementation-defined in the reference (SPIR-V Atan2).  The cull decision selects the sorted set, which the
+// tests compare bit for bit, so oracle and kernels share ONE definition: the single-precision arctangent of the Cephes
+// library (range reduction at tan(pi/8) and tan(3pi/8), degree-9 odd polynomial, about 2 ulp), every operation rounded
+// separately (this file is compiled with -ffp-contract=off).  y > 0 (rho >= 1e-7).
+float orc_atan2_det(float y, float x)
+{
+  const float ax = std::fabs(x);
+  const float t  = y / ax;
+  float base = 0.0f, u = t;
+  if(t > 2.414213562373095f)
+  {
+    base = 1.5707963267948966f;
+    u    = -1.0f / t;
+  }
+  else if(t > 0.4142135623730950f)
+  {
+    base = 0.7853981633974483f;
+    u    = (t - 1.0f) / (t + 1.0f);
+  }
+  const float z = u * u;
+  const float p = ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z) * u + u;
+  const float a = base + p;
+  return (x < 0.0f) ? (3.14159274101257f - a) : a;
+}
+
+namespace {
+// frameInfo.focal as the dist stage reads it (gaussian_splatting.cpp:1239-1251)
+void distStageFocal(const OrcFrame* f, float focal[2])
+{
+  if(f->camera_model == 1 && f->pipeline_3dgut)
+  {
+    focal[0] = (float)f->width / f->fov_rad;
+    focal[1] = -(float)f->height / f->fov_rad;
+  }
+  else
+  {
+    focal[0] = f->proj[0] * 0.5f * (float)f->width;
+    focal[1] = f->proj[5] * 0.5f * (float)f->height;
+  }
+}
+}  // namespace
+
+// dist.comp.slang:78-86: initPerfectFisheyeCamera(viewport, focal) (threedgut_camera_models.h.slang:120-136: principal point at
+// the viewport centre, zero radial coefficients, maxAngle = computeMaxAngle :87-118) and projectPointFisheye
+// (threedgut_camera_projections.h.slang:149-171) on float3(1,1,-1) * viewPos with GUT_IN_IMAGE_MARGIN_FACTOR = 0.1.
+// min / max are written as selects so that a NaN anywhere fails the validity test (the reference's min/max on NaN are
+// undefined in SPIR-V; the kernels use the same selects).
+int orc_fisheye_cull_valid(const OrcFrame* f, const float view_pos[3])
+{
+  float focal[2];
+  distStageFocal(f, focal);
+  const float resx = (float)f->width, resy = (float)f->height;
+  const float mdx = resx - resx / 2.0f, mdy = resy - resy / 2.0f;  // computeMaxDistanceToBorder, principal point at the centre
+  const float maxR     = std::sqrt(mdx * mdx + mdy * mdy);
+  const float maxAngle = std::max(2.0f * maxR / focal[0], 2.0f * maxR / focal[1]) / 2.0f;
+  const float px = view_pos[0], py = view_pos[1], pz = -view_pos[2];
+  const float ax = std::fabs(px), ay = std::fabs(py);  // stableNorm2 :32-44
+  const float mn = (ax < ay) ? ax : ay, mx = (ax < ay) ? ay : ax;
+  float       nrm = 0.0f;
+  if(mx > 0.0f)
+  {
+    const float r = mn / mx;
+    nrm           = mx * std::sqrt(1.0f + r * r);
+  }
+  const float rho       = (nrm > 1e-7f) ? nrm : 1e-7f;
+  const float thetaFull = orc_atan2_det(rho, pz);
+  const float theta     = (thetaFull < maxAngle) ? thetaFull : maxAngle;
+  const float theta2    = theta * theta;
+  const float delta     = (theta * (0.0f * theta2 + 1.0f)) / rho;
+  const float ox = (focal[0] * px) * delta + resx / 2.0f;
+  const float oy = (focal[1] * py) * delta + resy / 2.0f;
+  const float tx = resx * 0.1f, ty = resy * 0.1f;  // withinResolution :78-83
+  return (theta < maxAngle) && (ox > -tx) && (oy > -ty) && (ox < resx + tx) && (oy < resy + ty);
+}
+
+// shaders/dist.comp.slang:40-171 (both CAMERA_TYPE branches of the dist-stage cull, size culling)
 // Global ids are the concatenation of instances in creation order
 // (src/splat_set_manager_vk.cpp:2319-2357).  Survivor order: ascending global id — a
 // deterministic refinement of the reference's atomic append order (dist.comp.slang:137-139).
@@ -371,12 +447,19 @@ uint32_t orc_key_cull(const OrcFrame* f, const OrcInstance* inst, int n_inst, ui
       mat4_mul_vec4(f->proj, view, clip);    // mul(viewPos, projectionMatrix)         :60
       const float ndc[3] = {clip[0] / clip[3], clip[1] / clip[3], clip[2] / clip[3]};  // :61
       const float depth  = ndc[2];
-      if(f->frustum_culling == 1)
+      if(f->frustum_culling == 1 && f->camera_model != 1)
       {
         const float c = 1.0f + f->frustum_dilation;  // :71-73
         if(std::fabs(ndc[0]) > c || std::fabs(ndc[1]) > c || ndc[2] < 0.f - f->frustum_dilation || ndc[2] > 1.0f)
           continue;
         // NaN compares false in every test above, exactly as in the shader: a NaN splat survives.
+      }
+      else if(f->frustum_culling == 1)
+      {  // :75-90, CAMERA_FISHEYE
+        if(!orc_fisheye_cull_valid(f, view))
+          continue;
+        if(ndc[2] < 0.f - f->frustum_dilation || ndc[2] > 1.0f)
+          continue;
       }
       if(f->size_culling && I.scales)
       {  // dist.comp.slang:93-134
@@ -393,8 +476,9 @@ uint32_t orc_key_cull(const OrcFrame* f, const OrcInstance* inst, int n_inst, ui
         const float viewDist = std::fabs(view[2]);
         if(viewDist > 0.0001f)
         {
-          const float focal0   = f->proj[0] * 0.5f * (float)f->width, focal1 = f->proj[5] * 0.5f * (float)f->height;
-          const float maxFocal = std::max(std::fabs(focal0), std::fabs(focal1));
+          float focal[2];
+          distStageFocal(f, focal);  // frameInfo.focal :125
+          const float maxFocal = std::max(std::fabs(focal[0]), std::fabs(focal[1]));
           const float projectedPixels = (extent * maxFocal) / viewDist;
           if(projectedPixels < f->size_culling_min_pixels)
             continue;

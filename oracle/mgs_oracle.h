@@ -76,7 +76,16 @@ typedef struct OrcFrame {
   float focus_dist, aperture; /* shaderio.h:278-279 */
   int   frame_sample_id;      /* shaderio.h:275 */
   int   kernel_degree;        /* 3DGUT: KERNEL_DEGREE (shaderio.h:112-119); 2 = quadratic (default, parameters.h:215) */
+  int   pipeline_3dgut;       /* 1: the frame runs a 3DGUT pipeline.  Only consumer: frameInfo.focal as the DIST stage sees it —
+                                 the fisheye focal for a fisheye camera on a 3DGUT pipeline, the pinhole focal otherwise
+                                 (gaussian_splatting.cpp:1239-1251).  The orc_gut_* entry points imply 1. */
 } OrcFrame;
+
+/* atan2 as both the oracle and the kernels evaluate it in the fisheye dist-stage cull (dist.comp.slang:75-90): the reference's
+ * is implementation-defined (SPIR-V Atan2), so a fixed unfused-fp32 polynomial stands in; y > 0 */
+float orc_atan2_det(float y, float x);
+/* projectPointFisheye validity of dist.comp.slang:78-86 for a view-space position (before the (1,1,-1) flip) */
+int   orc_fisheye_cull_valid(const OrcFrame* f, const float view_pos[3]);
 
 /* nvshaders/random.h.slang (nvpro_core2; NOT in the reference tree, fetched by its CMake): xxhash32(uint3), pcg, rand —
  * restated from the published file, unpinned (no vectors of it exist here). */

@@ -9,6 +9,7 @@ Test infrastructure only.  Follows:
   shaders/threedgs_particle_storage.h.slang:103-159   SH radiance
   shaders/threedgs_raster.frag.slang:236-309     per-fragment alpha, discards, blend source
   src/gaussian_splatting.cpp:2066-2087           'over' blend state, cleared RGBA target
+  shaders/dist.comp.slang:55-91                  dist-stage cull, both CAMERA_TYPE branches (dist_cull below)
 """
 import numpy as np
 
@@ -228,3 +229,44 @@ def gut_opacity(g, i, density, M, V, P, W, H, px, py, alpha_clamp=0.99, min_resp
         resp = np.exp(-4.5 / 3.0 ** degree * np.sqrt(d2) ** degree)
     alpha = min(alpha_clamp, resp * density)
     return alpha if (alpha > 1.0 / 255.0 and resp > min_response) else None
+
+
+# ---- dist stage: which splats survive (dist.comp.slang:55-91), float64, the shader's row-vector form ------------------
+def dist_cull(centers, M, V, P, W, H, dilation=0.2, fisheye=False, focal=None):
+    """returns (survives[n] bool, margin[n]): margin = distance of the decision from its nearest threshold, relative, so that a
+    caller comparing against an fp32 implementation can set borderline splats aside.
+    pinhole: :65-73.  fisheye: :75-90 = initPerfectFisheyeCamera(viewport, frameInfo.focal) (threedgut_camera_models.h.slang:
+    87-136) + projectPointFisheye (threedgut_camera_projections.h.slang:149-171) on (1,1,-1) * viewPos, tolerance 0.1, then the
+    z test.  `focal` = frameInfo.focal (gaussian_splatting.cpp:1239-1251); default: the pinhole focal."""
+    c = np.asarray(centers, np.float64).reshape(-1, 3)
+    h = np.concatenate([c, np.ones((c.shape[0], 1))], 1)
+    view = (h @ slang(M)) @ slang(V)        # mul(mul(splatPos, transform), viewMatrix)   :58
+    clip = view @ slang(P)                  #                                             :60
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ndc = clip / clip[:, 3:4]           #                                             :61
+    zin = ~((ndc[:, 2] < 0.0 - dilation) | (ndc[:, 2] > 1.0))
+    zmargin = np.minimum(np.abs(ndc[:, 2] + dilation), np.abs(ndc[:, 2] - 1.0))
+    if not fisheye:
+        lim = 1.0 + dilation
+        ok = ~((np.abs(ndc[:, 0]) > lim) | (np.abs(ndc[:, 1]) > lim)) & zin
+        margin = np.minimum(np.minimum(np.abs(np.abs(ndc[:, 0]) - lim), np.abs(np.abs(ndc[:, 1]) - lim)), zmargin)
+        return ok, margin
+    f = np.asarray(focal if focal is not None else [P[0][0] * 0.5 * W, P[1][1] * 0.5 * H], np.float64)
+    res = np.array([W, H], np.float64)
+    pp = res / 2.0
+    # computeMaxAngle: max distance from the principal point to a border per axis (centre: half the size), radius = length
+    max_r = np.linalg.norm(np.where(pp > 0.5 * res, pp, res - pp))
+    max_angle = max(2.0 * max_r / f[0], 2.0 * max_r / f[1]) / 2.0
+    pos = view[:, :3] * np.array([1.0, 1.0, -1.0])
+    rho = np.maximum(np.hypot(pos[:, 0], pos[:, 1]), 1e-7)
+    theta_full = np.arctan2(rho, pos[:, 2])
+    theta = np.minimum(theta_full, max_angle)
+    delta = theta / rho                     # radial coefficients are all zero
+    px = f * pos[:, :2] * delta[:, None] + pp
+    tol = res * 0.1
+    within = (px[:, 0] > -tol[0]) & (px[:, 1] > -tol[1]) & (px[:, 0] < res[0] + tol[0]) & (px[:, 1] < res[1] + tol[1])
+    ok = (theta < max_angle) & within & zin
+    edge = np.minimum(np.minimum(np.abs(px[:, 0] + tol[0]), np.abs(px[:, 0] - res[0] - tol[0])) / res[0],
+                      np.minimum(np.abs(px[:, 1] + tol[1]), np.abs(px[:, 1] - res[1] - tol[1])) / res[1])
+    margin = np.minimum(np.minimum(np.abs(theta_full - max_angle), edge), zmargin)
+    return ok, margin

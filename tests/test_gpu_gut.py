@@ -40,7 +40,9 @@ def oracle_frame(ob, scene, sc, p, V, P, eye, W, H, transforms=(None,), **fkw):
     perm = scene.storage_order(0, n)
     ps_p = ob.PreparedSet({k: v[perm] for k, v in sc.items()})
     inst_p = ob.make_instances([(ps_p, m) for m in transforms])
-    ok, oi = ob.key_cull(ob.make_frame(V, P, eye, W, H), inst_p)
+    # the dist stage of a 3DGUT frame: CAMERA_TYPE selects the cull (dist.comp.slang:64-91), frameInfo.focal is the fisheye focal
+    cull_kw = dict(camera_model=fkw.get("camera_model", 0), pipeline_3dgut=1)
+    ok, oi = ob.key_cull(ob.make_frame(V, P, eye, W, H, **cull_kw), inst_p)
     oks, ois = ob.sort_stable(ok, oi)
     order = ((ois // n) * n + perm[ois % n]).astype(np.uint32)  # ties in the library's storage order
     inst = ob.make_instances([(ob.PreparedSet(sc), m) for m in transforms])
@@ -177,3 +179,55 @@ def test_gut_surface_outputs_match_oracle(scene_gut, ob):
     scene.render(p)
     d2, i2 = scene.download_surface(p)
     assert np.array_equal(i2[80:224], ids[80:224]) and np.array_equal(d2[80:224], depth[80:224])
+
+
+@pytest.mark.parametrize("pipeline", [capi.PIPELINE_3DGUT, capi.PIPELINE_3DGS])
+@pytest.mark.parametrize("fov,eye", [(100.0, None), (150.0, (0.45, 0.15, 0.3)), (170.0, (0.0, 0.2, -0.4))])
+def test_fisheye_dist_stage_cull_bit_exact(scene_gut, ob, pipeline, fov, eye):
+    """CAMERA_TYPE == CAMERA_FISHEYE in the dist stage (dist.comp.slang:75-90): survivors are chosen by projectPointFisheye's
+    validity (cone of maxAngle + image rectangle with the 0.1 margin) and the z test, not by the NDC box.  Wide fields of view
+    and cameras inside the cloud, where the two culls differ by thousands of splats: keys and ids bit-exact vs the oracle
+    (which shares the fixed-polynomial atan2), the frame >= 50 dB.  On a 3DGS pipeline frameInfo.focal stays the pinhole focal
+    (gaussian_splatting.cpp:1239-1251) and the raster is the pinhole one: only the sorted set changes."""
+    scene, sc = scene_gut
+    n = sc["positions"].shape[0]
+    W, H = 640, 480
+    e = np.asarray(eye if eye is not None else synth.orbit_pose(7), np.float32)
+    ctr = [0, 0, 0] if eye is None else [e[0] + 0.3, e[1] - 0.1, e[2] + 1.0]
+    V, P = mgs.camera_lookat_perspective(e, ctr, [0, 1, 0], fov, 0.1, 2000.0, W, H)
+    p = capi.default_params(W, H)
+    capi.set_camera(p, V, P, e)
+    p.pipeline, p.camera_model = pipeline, capi.CAMERA_FISHEYE
+    gut = pipeline == capi.PIPELINE_3DGUT
+    perm = scene.storage_order(0, n)
+    inst_p = ob.make_instances([(ob.PreparedSet({k: v[perm] for k, v in sc.items()}), None)])
+    fish = ob.make_frame(V, P, e, W, H, camera_model=1, pipeline_3dgut=int(gut))
+    ok, oi = ob.key_cull(fish, inst_p)
+    oks, ois = ob.sort_stable(ok, oi)
+    so = scene.sort_keys(p)
+    gk, gi = scene.sort_download(so.count)
+    assert so.count == oks.size and np.array_equal(gk, oks) and np.array_equal(gi, perm[ois])
+    # the pinhole box keeps a different set
+    pk, pi = ob.key_cull(ob.make_frame(V, P, e, W, H), inst_p)
+    only_fish, only_pin = np.setdiff1d(oi, pi).size, np.setdiff1d(pi, oi).size
+    print(f"fisheye cull fov {fov} pipeline {pipeline}: {oi.size} survivors, {only_fish} not in the pinhole set, {only_pin} only in it")
+    assert only_fish + only_pin > 100
+    out = scene.render(p, want_stats=True)
+    assert out.error_flags == 0 and out.frustum_count == oks.size
+    img = scene.download_frame(p).astype(np.float32)
+    inst = ob.make_instances([(ob.PreparedSet(sc), None)])
+    order = perm[ois].astype(np.uint32)
+    if gut:
+        oimg, st = ob.render_gut(ob.make_frame(V, P, e, W, H, target_fp16=1, camera_model=1, pipeline_3dgut=1), inst, order)
+    else:
+        oimg, st = ob.render(ob.make_frame(V, P, e, W, H, target_fp16=1, camera_model=1), inst, order=order)
+    psnr = ob.psnr_rgb(img, oimg)
+    print(f"  frame PSNR {psnr:.2f} dB, sorted {out.sorted_count}, oracle quads {st['quads']}")
+    assert psnr >= PSNR_MIN
+    # strips == full frame with the fisheye cull (partition culling must stay conservative for it)
+    full16 = scene.download_frame(p).view(np.uint16).copy()
+    for b, en in ((0, 9), (9, 30)):
+        p.strip_row_begin, p.strip_row_end = b, en
+        scene.render(p)
+        part = scene.download_frame(p).view(np.uint16)
+        assert np.array_equal(part[b * 16:min(en * 16, H)], full16[b * 16:min(en * 16, H)]), (b, en)

@@ -637,6 +637,74 @@ def test_surface_outputs_of_strips_are_bit_identical_to_full_frame(scene_small):
     p.surface_outputs = 0
 
 
+def test_frame_contexts_share_one_committed_scene(ob):
+    """frames in flight = frame contexts over ONE committed scene (mgs_frame_context_create; the reference keeps one copy of the
+    splat buffers under all its frames in flight, gaussian_splatting.cpp:1092-1111): same frames bit for bit, device memory =
+    scene + one working set per context, the scene's edits and commits reach the contexts, contexts are read-only"""
+    sc = synth.make_scene(40000, seed=31)
+    ss = mgs.SplatSet.from_arrays(**sc)
+    scene = mgs.Scene(0)
+    scene.add_instance(ss)
+    M1, _ = mgs.compute_transform([1.0, 1.0, 1.0], [0.0, 40.0, 0.0], [2.5, 0.0, 0.5])
+    scene.add_instance(ss, M1)
+    scene.commit()
+    ctxs = [scene.frame_context() for _ in range(2)]
+    W, H = 640, 400
+    want = []
+    for pose in (2, 19, 44):
+        p, *_ = camera(pose, W, H)
+        scene.render(p)
+        want.append(scene.download_frame(p).view(np.uint16).copy())
+    # three frames in flight: each handle renders a different pose on its own stream, nothing synchronised in between
+    handles = [scene] + ctxs
+    params = [camera(pose, W, H)[0] for pose in (2, 19, 44)]
+    for rep in range(3):
+        for h, p in zip(handles, params):
+            h.render(p)
+    for h, p, w in zip(handles, params, want):
+        assert np.array_equal(h.download_frame(p).view(np.uint16), w)
+    # and every context renders every pose identically
+    for h in ctxs:
+        for p, w in zip(params, want):
+            h.render(p)
+            assert np.array_equal(h.download_frame(p).view(np.uint16), w)
+    sb, wb = scene.memory_usage()
+    for h in ctxs:
+        sb_c, wb_c = h.memory_usage()
+        assert sb_c == sb and 0 < wb_c <= wb     # the scene bytes are the same buffers; a working set each
+    per_splat = sb / 40000
+    print(f"scene {sb / 1e6:.1f} MB ({per_splat:.0f} B/splat, shared), working set {wb / 1e6:.1f} MB per handle")
+    assert 250 <= per_splat <= 320              # ONE copy of a 280 B/splat set for two instances and three handles
+    # contexts are read-only views of the scene
+    for fn in (lambda: ctxs[0].commit(), lambda: ctxs[0].add_instance(ss), lambda: ctxs[0].set_transform(0, np.eye(4, dtype=np.float32))):
+        with pytest.raises(capi.MgsError) as e:
+            fn()
+        assert e.value.code == capi.ERR_STATE
+    # a transform set on the scene reaches the contexts' next frame
+    M2, _ = mgs.compute_transform([1.2, 1.0, 0.8], [10.0, 0.0, 0.0], [-1.0, 0.3, 0.0])
+    scene.set_transform(1, M2)
+    scene.render(params[0])
+    moved = scene.download_frame(params[0]).view(np.uint16).copy()
+    assert not np.array_equal(moved, want[0])
+    ctxs[1].render(params[0])
+    assert np.array_equal(ctxs[1].download_frame(params[0]).view(np.uint16), moved)
+    # a re-commit (other storage formats) is followed by the contexts on their next frame
+    scene.commit(capi.FORMAT_UINT8, capi.FORMAT_FLOAT16)
+    scene.render(params[1])
+    q = scene.download_frame(params[1]).view(np.uint16).copy()
+    ctxs[0].render(params[1])
+    assert np.array_equal(ctxs[0].download_frame(params[1]).view(np.uint16), q)
+    # the sort hook works on a context too, and a context outlives the scene handle
+    so = ctxs[0].sort_keys(params[2])
+    scene.close()
+    so2 = ctxs[1].sort_keys(params[2])
+    assert so.count == so2.count > 0
+    ctxs[1].render(params[1])
+    assert np.array_equal(ctxs[1].download_frame(params[1]).view(np.uint16), q)
+    for h in ctxs:
+        h.close()
+
+
 def test_determinism_and_empty_view(scene_small):
     scene, _ = scene_small
     p, *_ = camera(2, 320, 240)
@@ -1135,3 +1203,89 @@ def test_full_size_properties(n):
     part = scene.download_frame(p).view(np.uint16)
     assert np.array_equal(part[480:608], full[480:608])
     scene.close()
+
+
+def test_full_size_eight_instances_unified_sort():
+    """BASELINE configs[4] at its full size: 8 instances of the 5.83 M set on the bench's 2 x 4 grid = 46.64 M global splats,
+    1920x1080, one unified depth order.  Size-independent properties: sortedness, permutation, ids of several instances
+    interleaved in the order, ties in ascending storage id inside an instance and in instance order across, idempotent sort,
+    error_flags == 0 (the u32 list offsets reach 32 N = 1.49 G entries here), strip == full frame on a band."""
+    n, k = 5_830_000, 8
+    sc = synth.make_scene(n, seed=0xC0FFEE + 2)
+    ss = mgs.SplatSet.from_arrays(**sc)
+    scene = mgs.Scene(0)
+    Ms = []
+    for q in range(k):
+        M = np.eye(4, dtype=np.float32)
+        M[0, 3] = ((q % 4) - 1.5) * 12.0
+        M[2, 3] = ((q // 4) - 0.5) * 12.0
+        Ms.append(M)
+        scene.add_instance(ss, M)
+    scene.commit()
+    assert scene.splat_count == n * k == 46_640_000
+    W, H = 1920, 1080
+    eye = np.array([20.0, 9.0, 22.0], np.float32)      # outside the grid: most instances in view, depth ranges overlapping
+    V, P = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, W, H)
+    p = capi.default_params(W, H)
+    capi.set_camera(p, V, P, eye)
+    so = scene.sort_keys(p)
+    keys, ids = scene.sort_download(so.count)
+    assert so.count > 20_000_000
+    assert np.all(keys[1:] >= keys[:-1])
+    assert ids.max() < n * k and np.unique(ids).size == ids.size
+    inst = ids // n
+    present = np.unique(inst)
+    assert present.size >= 6
+    changes = int((inst[1:] != inst[:-1]).sum())
+    print(f"x8 full size: V {so.count}, {present.size} instances in view, instance changes along the order {changes}, passes {so.passes}")
+    assert changes > 100_000                                               # one unified order, not instance after instance
+    same = keys[1:] == keys[:-1]
+    inv = np.empty(n, np.uint32); inv[scene.storage_order(0, n)] = np.arange(n, dtype=np.uint32)
+    gst = inst.astype(np.uint64) * n + inv[ids % n]                        # global STORAGE id
+    assert np.all(gst[1:][same] > gst[:-1][same])                          # ties: stable in global storage order
+    # survivors == fp64 restatement of the cull per instance, up to borderline rounding
+    pos = np.c_[sc["positions"].astype(np.float64), np.ones(n)]
+    total = 0
+    for M in Ms:
+        clip = pos @ (P.astype(np.float64) @ V.astype(np.float64) @ M.astype(np.float64)).T
+        ndc = clip[:, :3] / clip[:, 3:4]
+        total += int(((np.abs(ndc[:, 0]) <= 1.2) & (np.abs(ndc[:, 1]) <= 1.2) & (ndc[:, 2] >= -0.2) & (ndc[:, 2] <= 1.0)).sum())
+    assert abs(total - int(so.count)) <= 400
+    k2, i2, _ = scene.radix_sort_host(keys, ids)                           # idempotence at 40 M keys
+    assert np.array_equal(k2, keys) and np.array_equal(i2, ids)
+    del k2, i2, gst, inst
+    out = scene.render(p, want_stats=True)
+    print(f"  frame: sorted {out.sorted_count}, list entries {out.tile_pairs}, error_flags {out.error_flags}")
+    assert out.error_flags == 0 and out.sorted_count <= out.frustum_count == so.count
+    full = scene.download_frame(p).view(np.uint16).copy()
+    assert np.isfinite(full.view(np.float16).astype(np.float32)).all() and full.view(np.float16)[..., 3].max() > 0.5
+    p.strip_row_begin, p.strip_row_end = 30, 38
+    scene.render(p)
+    part = scene.download_frame(p).view(np.uint16)
+    assert np.array_equal(part[480:608], full[480:608])
+    # the bench's own orbit pose too (camera inside the grid)
+    p2, *_ = camera(0, W, H)
+    o2 = scene.render(p2, want_stats=True)
+    assert o2.error_flags == 0 and o2.sorted_count > 1_000_000
+    scene.close()
+
+
+def test_list_capacity_overflow_is_reported(scene_small):
+    """a frame whose per-bin lists do not fit the capacity is flagged, never silently truncated: MGS_ERR_OVERFLOW from
+    mgs_frame_stats, bit 0 of error_flags; with the capacity restored the same frame is whole again"""
+    scene, sc = scene_small
+    p, *_ = camera(12, 640, 480)
+    out = scene.render(p, want_stats=True)
+    good = scene.download_frame(p).view(np.uint16).copy()
+    need = int(out.tile_pairs)
+    assert out.error_flags == 0 and need > 20000
+    ctx = scene.frame_context()
+    ctx.set_list_capacity(need // 3)
+    ctx.render(p)
+    with pytest.raises(capi.MgsError) as e:
+        ctx.frame_stats()
+    assert e.value.code == capi.ERR_OVERFLOW
+    ctx.set_list_capacity(0)
+    o2 = ctx.render(p, want_stats=True)
+    assert o2.error_flags == 0 and np.array_equal(ctx.download_frame(p).view(np.uint16), good)
+    ctx.close()

@@ -733,3 +733,57 @@ def test_gut_depth_of_field_against_independent_numpy_fp64(ob):
             assert np.isclose(a, b, rtol=3e-3, atol=3e-4), (i, px, py, a, b)
             frag += 1
     assert frag > 60
+
+
+# ---- CAMERA_FISHEYE branch of the dist stage (dist.comp.slang:75-90) --------------------------------------------------------
+def test_deterministic_atan2_is_an_accurate_atan2(ob):
+    """the fixed polynomial that stands in for the reference's implementation-defined atan2 in the fisheye cull: within 4e-7
+    (3 ulp at pi/2) of the float64 arctangent over every quadrant the cull can reach (y = rho > 0), incl. x = 0, +-inf"""
+    import ctypes as C
+    L = ob.lib()
+    L.orc_atan2_det.restype = C.c_float
+    L.orc_atan2_det.argtypes = [C.c_float, C.c_float]
+    rng = np.random.default_rng(5)
+    ys = np.concatenate([10.0 ** rng.uniform(-7, 4, 4000), [1e-7, 1.0, 3.0]]).astype(np.float32)
+    xs = np.concatenate([rng.standard_normal(2000) * 10.0 ** rng.uniform(-6, 4, 2000), 10.0 ** rng.uniform(-7, 4, 2000) * rng.choice([-1, 1], 2000),
+                         [0.0, -0.0, 1.0]]).astype(np.float32)
+    got = np.array([L.orc_atan2_det(float(y), float(x)) for y, x in zip(ys, xs)], np.float64)
+    want = np.arctan2(ys.astype(np.float64), xs.astype(np.float64))
+    assert np.abs(got - want).max() <= 4e-7, np.abs(got - want).max()
+    assert abs(L.orc_atan2_det(1.0, float("inf")) - 0.0) <= 1e-7 and abs(L.orc_atan2_det(1.0, float("-inf")) - np.pi) <= 4e-7
+    assert abs(L.orc_atan2_det(2.0, 0.0) - np.pi / 2) <= 2e-7
+    assert np.isnan(L.orc_atan2_det(float("nan"), 1.0)) and np.isnan(L.orc_atan2_det(1.0, float("nan")))
+
+
+@pytest.mark.parametrize("fov,gut,inside", [(60.0, 1, False), (100.0, 0, False), (150.0, 1, True), (170.0, 0, True), (175.0, 1, True)])
+def test_fisheye_dist_cull_against_independent_numpy_fp64(ob, fov, gut, inside):
+    """orc_key_cull with camera_model = fisheye vs np_reference.dist_cull (float64, row-vector form, numpy's arctan2): the same
+    survivors except for splats within 1e-5 of a threshold; frameInfo.focal is the fisheye focal only on a 3DGUT pipeline; the
+    set differs from the pinhole box's; non-finite centres are culled"""
+    import np_reference as npr
+    from vk_gaussian_splatting_amd import synth
+    import vk_gaussian_splatting_amd as mgs
+    sc = synth.make_scene(30000, seed=77)
+    sc["positions"][:5] = [[np.nan, 0, 0], [0, np.inf, 0], [0, 0, -np.inf], [np.nan] * 3, [1e30, 1e30, 1e30]]
+    W, H = 640, 360
+    eye = np.array([0.3, 0.1, -0.2] if inside else [3.0, 1.2, 2.5], np.float32)
+    ctr = [eye[0] + 0.2, eye[1], eye[2] + 1.0] if inside else [0, 0, 0]
+    V, P = mgs.camera_lookat_perspective(eye, ctr, [0, 1, 0], fov, 0.1, 2000.0, W, H)
+    M, _ = mgs.compute_transform([1.1, 0.9, 1.0], [5.0, -20.0, 12.0], [0.2, -0.1, 0.3])
+    ps = ob.PreparedSet(sc)
+    inst = ob.make_instances([(ps, M)])
+    fr = ob.make_frame(V, P, eye, W, H, camera_model=1, pipeline_3dgut=gut)
+    _, ids = ob.key_cull(fr, inst)
+    fov_rad = 2.0 * np.arctan(1.0 / abs(float(np.float32(P[1][1]))))
+    focal = [W / np.float32(fov_rad), -H / np.float32(fov_rad)] if gut else None
+    with np.errstate(invalid="ignore", over="ignore"):
+        ok, margin = npr.dist_cull(sc["positions"], M, V, P, W, H, 0.2, fisheye=True, focal=focal)
+    got = np.zeros(ok.size, bool)
+    got[ids] = True
+    sure = np.nan_to_num(margin, nan=1.0) > 1e-5
+    assert np.array_equal(got[sure], ok[sure]), int((got[sure] != ok[sure]).sum())
+    assert not got[:5].any()                      # non-finite / absurd centres never survive the fisheye validity test
+    assert (~sure).sum() < 30 and 100 < ids.size < ok.size
+    pin_ok, _ = npr.dist_cull(sc["positions"], M, V, P, W, H, 0.2)
+    print(f"fisheye cull fov {fov} gut {gut}: {ids.size} survive, pinhole box keeps {int(pin_ok.sum())}, differ on {int((pin_ok != got).sum())}")
+    assert (pin_ok != got).sum() > 50

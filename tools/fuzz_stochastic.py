@@ -55,7 +55,7 @@ def one(seed):
     assert out.error_flags == 0
     img = scene.download_frame(p).astype(np.float32)
     inst = ob.make_instances([(ob.PreparedSet(sc_p), M)])
-    ok, oi = ob.key_cull(ob.make_frame(V, P, eye, W, H), inst)
+    ok, oi = ob.key_cull(ob.make_frame(V, P, eye, W, H, camera_model=fkw.get("camera_model", 0), pipeline_3dgut=int(gut)), inst)
     _, ois = ob.sort_stable(ok, oi)
     oimg, st = (ob.render_gut if gut else ob.render)(ob.make_frame(V, P, eye, W, H, **fkw), inst, ois)
     if "stochastic" in fkw:

@@ -20,6 +20,10 @@ EXTENT_EIGEN, EXTENT_CONIC = 0, 1
 STAGE_NAMES = ["project", "sort", "bin", "pairsort", "composite", "total"]
 
 
+# status codes of include/mgs.h
+OK, ERR_INVALID_ARG, ERR_IO, ERR_FORMAT, ERR_DEVICE, ERR_OOM, ERR_STATE, ERR_OVERFLOW, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7, -8
+
+
 class MgsError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"mgs error {code}: {msg}")
@@ -102,6 +106,10 @@ def load_library():
         "mgs_instance_set_transform": (C.c_int, [vp, C.c_int, P(F)]),
         "mgs_scene_commit": (C.c_int, [vp, C.c_int, C.c_int]),
         "mgs_scene_splat_count": (C.c_uint64, [vp]),
+        "mgs_frame_context_create": (C.c_int, [vp, P(vp)]),
+        "mgs_frame_context_destroy": (None, [vp]),
+        "mgs_scene_memory_usage": (C.c_int, [vp, P(C.c_uint64), P(C.c_uint64)]),
+        "mgs_scene_set_list_capacity": (C.c_int, [vp, C.c_uint64]),
         "mgs_scene_download_set": (C.c_int, [vp, C.c_int, C.c_int, P(F), C.c_size_t]),
         "mgs_scene_storage_order": (C.c_int, [vp, C.c_int, P(C.c_uint32), C.c_size_t]),
         "mgs_frame_params_default": (None, [P(FrameParams)]),
@@ -143,6 +151,7 @@ EXPORTED_SYMBOLS = [
     "mgs_last_error", "mgs_version", "mgs_splatset_load", "mgs_splatset_from_arrays", "mgs_splatset_view",
     "mgs_splatset_destroy", "mgs_scene_create", "mgs_scene_destroy", "mgs_scene_set_stream", "mgs_instance_add",
     "mgs_instance_set_transform", "mgs_scene_commit", "mgs_scene_splat_count", "mgs_scene_storage_order", "mgs_scene_download_set",
+    "mgs_frame_context_create", "mgs_frame_context_destroy", "mgs_scene_memory_usage", "mgs_scene_set_list_capacity",
     "mgs_frame_params_default", "mgs_render", "mgs_frame_stats", "mgs_timings_query", "mgs_frame_download", "mgs_frame_download_surface", "mgs_frame_copy_strip",
     "mgs_frame_download_projected", "mgs_sync", "mgs_comm_unique_id", "mgs_scene_comm_init", "mgs_scene_comm_destroy",
     "mgs_scene_set_strip_rows", "mgs_render_gathered", "mgs_frame_row_costs",
@@ -308,13 +317,29 @@ def compute_transform(scale, rotation_deg, translation):
 class Scene:
     """Device scene (SplatSetManagerVk + renderer buffers) on one MI355X."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _context_of=None):
         lib = load_library()
         self._lib = lib
         h = C.c_void_p()
-        _check(lib.mgs_scene_create(device, C.byref(h)))
+        if _context_of is None:
+            _check(lib.mgs_scene_create(device, C.byref(h)))
+        else:
+            _check(lib.mgs_frame_context_create(_context_of._h, C.byref(h)))
         self._h = h
-        self._sets = []
+        self._sets = [] if _context_of is None else _context_of._sets
+
+    def frame_context(self):
+        """a frame in flight over this scene's committed data: own stream, working buffers and graphs (mgs_frame_context_create)"""
+        return Scene(_context_of=self)
+
+    def set_list_capacity(self, entries):
+        _check(self._lib.mgs_scene_set_list_capacity(self._h, int(entries)))
+
+    def memory_usage(self):
+        """(scene_bytes, working_bytes): the committed data shared by all contexts, and this handle's working set"""
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(self._lib.mgs_scene_memory_usage(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def set_stream(self, stream_ptr):
         _check(self._lib.mgs_scene_set_stream(self._h, C.c_void_p(stream_ptr)))

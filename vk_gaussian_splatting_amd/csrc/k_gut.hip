@@ -306,12 +306,8 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
     mulMat4Exact(A.f.proj, vp[0], vp[1], vp[2], vp[3], cp);   // :60
     const float nx = divExact(cp[0], cp[3]), ny = divExact(cp[1], cp[3]), nz = divExact(cp[2], cp[3]);  // :61
     bool        v  = li < I.count;
-    if(A.f.cullMode == 1)
-    {
-      const float c = 1.0f + A.f.frustumDilation;
-      if(fabsf(nx) > c || fabsf(ny) > c || nz < 0.f - A.f.frustumDilation || nz > 1.0f)
-        v = false;
-    }
+    if(A.f.cullMode == 1 && distStageCulled(A.f, nx, ny, nz, vp[0], vp[1], vp[2]))  // dist.comp.slang:64-91
+      v = false;
     if(A.f.sizeCulling && v)
       v = !sizeCulled(I.maxScale[min(li, I.count - 1u)], A.f.splatScale, I.modelAxisMax, vp[2], A.f.maxFocal, A.f.sizeCullingMinPixels);
     vis[it] = v;

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   // strips (multi-GPU): a splat whose centre lies further from this device's rows than the partition's footprint bound R
   // (k_partition_cull; valid for every splat of the partition) cannot reach them — dropped here, before the projection.
   // The exact footprint-vs-strip test of phase 2 would reject it anyway: the sorted set is unchanged.
-  const bool  stripPre = partR != nullptr && (A.f.stripRow1 - A.f.stripRow0) < A.f.tilesY;
+  const bool  stripPre = FULL && partR != nullptr && (A.f.stripRow1 - A.f.stripRow0) < A.f.tilesY;
   const float stripR   = stripPre ? partR[blockIdx.x] : 3.0e38f;
   const float stripY0  = (float)(A.f.stripRow0 * kTilePx), stripY1 = (float)min(A.f.stripRow1 * kTilePx, A.f.height);
   const bool  insideFast = (pflag & 2u) != 0u && A.f.cullMode == 1 && !stripPre;
@@ -294,12 +294,8 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
       mulMat4Exact(A.f.proj, vp[0], vp[1], vp[2], vp[3], cp);   // :60
       const float nx = divExact(cp[0], cp[3]), ny = divExact(cp[1], cp[3]);  // :61
       nz             = divExact(cp[2], cp[3]);
-      if(A.f.cullMode == 1)
-      {  // :71-73 (NaN compares false everywhere, as in the shader)
-        const float c = 1.0f + A.f.frustumDilation;
-        if(fabsf(nx) > c || fabsf(ny) > c || nz < 0.f - A.f.frustumDilation || nz > 1.0f)
-          v = false;
-      }
+      if(A.f.cullMode == 1 && distStageCulled(A.f, nx, ny, nz, vp[0], vp[1], vp[2]))  // :64-91, pinhole box or fisheye validity
+        v = false;
       if(stripPre)
       {
         const float R = stripR;
@@ -543,10 +539,32 @@ __global__ __launch_bounds__(256) void k_partition_cull(const FrameArgs* __restr
       rx    = fmaxf(rx, fabsf(tx / tz));
       ry    = fmaxf(ry, fabsf(ty / tz));
     }
-    if(allWpos && (outXp || outXn || outYp || outYn || outZf || outZn))
+    // CAMERA_FISHEYE (dist.comp.slang:75-90): the x/y box is replaced by the fisheye validity test (cone of maxAngle around the
+    // view axis + the image rectangle); the z test stays.  Conservative form: the z conditions as above, and the bounding
+    // sphere of the box against the cone.  "Every centre passes" is never claimed for fisheye frames.
+    const bool fisheye = A.f.cameraModel == 1;
+    if(allWpos && (outZf || outZn || (!fisheye && (outXp || outXn || outYp || outYn))))
       skip = 1;
-    inside = (allIn && !skip) ? 2u : 0u;
-    const bool strip = (A.f.stripRow1 - A.f.stripRow0) < A.f.tilesY;
+    if(fisheye && !skip)
+    {
+      const float  mx = 0.5f * (bx[0] + bx[3]), my = 0.5f * (bx[1] + bx[4]), mz = 0.5f * (bx[2] + bx[5]);
+      const float  hx = 0.5f * (bx[3] - bx[0]), hy = 0.5f * (bx[4] - bx[1]), hz = 0.5f * (bx[5] - bx[2]);
+      const float* MV = I.modelView;
+      const float  sx = MV[0] * mx + MV[4] * my + MV[8] * mz + MV[12];
+      const float  sy = MV[1] * mx + MV[5] * my + MV[9] * mz + MV[13];
+      const float  sz = MV[2] * mx + MV[6] * my + MV[10] * mz + MV[14];
+      const float  rad  = sqrtf(hx * hx + hy * hy + hz * hz) * I.modelScale * 1.001f + 1e-6f;
+      const float  dist = sqrtf(sx * sx + sy * sy + sz * sz);
+      if(dist > rad * 1.001f)
+      {
+        const float thetaC = atan2f(sqrtf(sx * sx + sy * sy), -sz);
+        if(thetaC - asinf(rad / dist) > A.f.gutMaxAngle * 1.001f + 1e-3f)
+          skip = 1;
+      }
+    }
+    inside = (allIn && !skip && !fisheye) ? 2u : 0u;
+    // the strip bound R is the 3DGS (pinhole EWA) footprint: not valid for a 3DGUT fisheye frame
+    const bool strip = (A.f.stripRow1 - A.f.stripRow0) < A.f.tilesY && !(fisheye && A.f.pipeline == 1);
     if(!skip && strip && allWpos && zvmin > 1e-4f)
     {
       const float S    = I.modelScale;  // largest singular value of the model 3x3 (host, per frame)

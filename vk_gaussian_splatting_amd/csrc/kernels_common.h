@@ -145,6 +145,74 @@ __device__ __forceinline__ float divExact(float a, float b)
   return a / b;
 }
 
+// ---- fisheye dist-stage cull (CAMERA_TYPE == CAMERA_FISHEYE) -------------------------------------------------------
+// shaders/dist.comp.slang:75-90 culls with projectPointFisheye (threedgut_camera_projections.h.slang:149-171) of the perfect
+// fisheye model (initPerfectFisheyeCamera, threedgut_camera_models.h.slang:120-136: zero radial coefficients, principal point
+// at the viewport centre, maxAngle of computeMaxAngle) on (1,1,-1) * viewPos, margin GUT_IN_IMAGE_MARGIN_FACTOR = 0.1, and
+// then the z test of the pinhole branch.  The decision selects the sorted set, so it must equal the oracle's bit for bit:
+// the arithmetic is unfused, divisions and roots are IEEE, and atan2 — whose result is implementation-defined in the
+// reference (SPIR-V Atan2) — is the fixed polynomial below, restated identically in oracle/mgs_oracle.cpp.
+// Non-finite positions are culled (every comparison on a NaN is written so that it fails the validity test).
+__device__ __forceinline__ float atan2Det(float y /* > 0 */, float x)
+{
+#pragma clang fp contract(off)
+  const float ax = fabsf(x);
+  const float t  = y / ax;  // [0, +inf]
+  float base = 0.0f, u = t;
+  if(t > 2.414213562373095f)
+  {
+    base = 1.5707963267948966f;
+    u    = -1.0f / t;
+  }
+  else if(t > 0.4142135623730950f)
+  {
+    base = 0.7853981633974483f;
+    u    = (t - 1.0f) / (t + 1.0f);
+  }
+  const float z = u * u;
+  const float p = ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z) * u + u;
+  const float a = base + p;
+  return (x < 0.0f) ? (3.14159274101257f - a) : a;
+}
+
+__device__ __forceinline__ bool fisheyeCullValid(const FrameConst& F, float vx, float vy, float vz)
+{
+#pragma clang fp contract(off)
+  const float px = vx, py = vy, pz = -vz;  // float3(1,1,-1) * viewPos.xyz, dist.comp.slang:83
+  // stableNorm2, threedgut_camera_projections.h.slang:32-44
+  const float ax = fabsf(px), ay = fabsf(py);
+  const float mn = (ax < ay) ? ax : ay, mx = (ax < ay) ? ay : ax;
+  float       nrm = 0.0f;
+  if(mx > 0.0f)
+  {
+    const float r = mn / mx;
+    nrm           = mx * sqrtf(1.0f + r * r);  // IEEE (hipcc default: correctly rounded divide / sqrt)
+  }
+  const float rho       = (nrm > 1e-7f) ? nrm : 1e-7f;                              // max(., eps)            :152
+  const float thetaFull = atan2Det(rho, pz);                                        //                        :153
+  const float theta     = (thetaFull < F.gutMaxAngle) ? thetaFull : F.gutMaxAngle;  // min(., maxAngle)       :160
+  const float theta2    = theta * theta;
+  const float delta     = (theta * (0.0f * theta2 + 1.0f)) / rho;                   // radial coefficients 0  :164
+  const float resx = (float)F.width, resy = (float)F.height;
+  const float ox = (F.gutFocal[0] * px) * delta + resx / 2.0f;                       //                        :165
+  const float oy = (F.gutFocal[1] * py) * delta + resy / 2.0f;
+  const float tx = resx * 0.1f, ty = resy * 0.1f;                                    // withinResolution       :78-83
+  return (theta < F.gutMaxAngle) && (ox > -tx) && (oy > -ty) && (ox < resx + tx) && (oy < resy + ty);
+}
+
+// the dist-stage frustum test (dist.comp.slang:64-91) on ndc = clip / w and the view-space position
+__device__ __forceinline__ bool distStageCulled(const FrameConst& F, float nx, float ny, float nz, float vx, float vy, float vz)
+{
+  if(F.cameraModel == 1)
+  {
+    if(!fisheyeCullValid(F, vx, vy, vz))
+      return true;
+    return nz < 0.f - F.frustumDilation || nz > 1.0f;  // :88
+  }
+  const float c = 1.0f + F.frustumDilation;  // :71-73 (NaN compares false everywhere, as in the shader)
+  return fabsf(nx) > c || fabsf(ny) > c || nz < 0.f - F.frustumDilation || nz > 1.0f;
+}
+
 // ---- random numbers of the stochastic paths --------------------------------------------------------------------
 // The reference takes xxhash32 / pcg / rand from nvshaders/random.h.slang of nvpro_core2, a dependency that is not in
 // the reference tree (CMake fetches it).  Restated from the published file: xxhash32 over a uint3 (Jarzynski & Olano,

@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types only: the library itself is resolved with dlopen on first use
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -239,23 +240,40 @@ struct CpuSorter
 
 }  // namespace
 
-struct MgsScene_t
+// What a commit produces: the resident splat buffers and the instance list.  ONE copy per scene, shared read-only by the scene
+// handle and every frame context created from it — the reference likewise keeps one copy of the splat buffers however many
+// frames are in flight, which is why processUpdateRequests waits for the device before it touches them
+// (src/gaussian_splatting.cpp:1092-1111); mgs_scene_commit does the same over all contexts' streams.
+struct SceneData
 {
-  int         device = 0;
-  hipStream_t stream = nullptr, ownStream = nullptr;
-
+  int                    device = 0;
   std::vector<DeviceSet> sets;
   std::vector<Instance>  instances;
   bool                   committed = false;
   int                    shFormat = 0, rgbaFormat = 0;
   uint32_t               totalSplats = 0, totalParts = 0;
+  DevBuf<CompositeArgs::Inst> compInst;  // SH table of all instances for the compositor (scenes with > 16 instances)
+  uint64_t               epoch = 0;      // bumped by every commit: a context re-sizes its working set when it lags
+  std::mutex             mtx;            // guards `handles`
+  std::vector<MgsScene_t*> handles;      // the owning scene and its live frame contexts
+  ~SceneData();
+};
+
+struct MgsScene_t
+{
+  int         device = 0;
+  hipStream_t stream = nullptr, ownStream = nullptr;
+
+  std::shared_ptr<SceneData> d;   // shared with the frame contexts (mgs_frame_context_create)
+  uint64_t    listCapacityOverride = 0;  // mgs_scene_set_list_capacity: entries of the per-bin lists (0 = 32 per splat)
+  bool        isContext = false;  // a frame context: own stream, working buffers and graphs; the scene data is the parent's
+  uint64_t    wsEpoch   = ~0ull;  // d->epoch the working set below was sized for
 
   // frame buffers
   DevBuf<uint32_t>      keysSlot, idsSlot, slotCount, keysA, idsA, keysB, idsB, rect, partHist, blockCount;
   DevBuf<uint32_t>      sortedRect, splatOffset, chunkStart, partSkip;
   DevBuf<float>         partR;       // per partition: footprint bound in pixels (strips), written by k_partition_cull
   DevBuf<uint64_t>      dbinMasks;
-  DevBuf<CompositeArgs::Inst> compInst;  // SH table of all instances for the compositor (scenes with > 16 instances)
   DevBuf<FrameArgs>     dArgs;       // this frame's constants (view/proj, instances, knobs): the kernels read them through
                                      // this pointer, so a captured frame graph replays with nothing but a 5 KB upload
   struct GraphKey
@@ -293,6 +311,7 @@ struct MgsScene_t
   // last frame
   MgsFrameParams lastParams{};
   bool           haveFrame = false, lastTimed = false, lastWasSortOnly = false;
+  bool           lastListsPartial = false;  // the last frame came from mgs_render_gathered: its bin lists cover this rank's rows only
   size_t         imageBytes = 0, imageRowBytes = 0;
   MgsSortOut     lastSort{};
 
@@ -633,6 +652,9 @@ static int mgs_scene_create_impl(int device, MgsScene* out)
   HIPCHK(hipSetDevice(device));
   auto* s   = new MgsScene_t();
   s->device = device;
+  s->d      = std::make_shared<SceneData>();
+  s->d->device = device;
+  s->d->handles.push_back(s);
   if(hipStreamCreateWithFlags(&s->ownStream, hipStreamNonBlocking) != hipSuccess)
   {
     s->ownStream = nullptr;
@@ -692,6 +714,14 @@ static void freeSet(DeviceSet& d)
   d.shFormat = d.rgbaFormat = -1;  // a freed (or half-built) set never matches a requested format: commit rebuilds it
 }
 
+SceneData::~SceneData()
+{  // the last handle (scene or context) is gone: every stream that read these buffers was synchronised by its handle's destroy
+  (void)hipSetDevice(device);
+  for(auto& d : sets)
+    freeSet(d);
+  compInst.release();
+}
+
 void mgs_scene_destroy(MgsScene s)
 {
   if(!s)
@@ -701,13 +731,17 @@ void mgs_scene_destroy(MgsScene s)
     (void)mgs_scene_comm_destroy(s);
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->stream);  // like vkDeviceWaitIdle before destruction (gaussian_splatting.cpp:1096)
-  for(auto& d : s->sets)
-    freeSet(d);
+  if(s->d)
+  {
+    std::lock_guard<std::mutex> lk(s->d->mtx);
+    auto& h = s->d->handles;
+    h.erase(std::remove(h.begin(), h.end(), s), h.end());
+  }
   s->keysSlot.release(); s->idsSlot.release(); s->slotCount.release(); s->keysA.release(); s->idsA.release();
   s->keysB.release(); s->idsB.release(); s->rect.release(); s->partHist.release(); s->blockCount.release();
   s->rec.release(); s->recGut.release(); s->pairKey0.release(); s->pairVal0.release(); s->pairKey1.release(); s->pairVal1.release();
   s->sortedRect.release(); s->splatOffset.release(); s->chunkStart.release(); s->partSkip.release(); s->partR.release();
-  s->surfDepth.release(); s->surfId.release(); s->surfNormal.release(); s->accum.release(); s->dArgs.release(); s->dbinMasks.release(); s->compInst.release();
+  s->surfDepth.release(); s->surfId.release(); s->surfNormal.release(); s->accum.release(); s->dArgs.release(); s->dbinMasks.release();
   for(auto& g : s->graphs) (void)hipGraphExecDestroy(g.second);
   s->graphs.clear();
   s->ranges.release(); s->image.release(); s->ctr.release(); s->plans.release(); s->cpuDistDev.release();
@@ -739,6 +773,87 @@ int mgs_scene_set_stream(MgsScene s, void* stream)
   return MGS_OK;
 }
 
+// ---- frame contexts -----------------------------------------------------------------------------------------------------
+// The reference keeps ONE copy of the splat buffers however many frames its application loop has in flight
+// (src/gaussian_splatting.cpp:1092-1111: updates wait for the device before they touch the buffers all frames share).  A frame
+// context is that: its own HIP stream, working buffers, counters and captured frame graphs over the scene's committed data.
+static int mgs_frame_context_create_impl(MgsScene parent, MgsScene* out)
+{
+  if(!parent || !out)
+  {
+    setError("mgs_frame_context_create: null argument");
+    return MGS_ERR_INVALID_ARG;
+  }
+  MgsScene c  = nullptr;
+  const int rc = mgs_scene_create(parent->device, &c);
+  if(rc != MGS_OK)
+    return rc;
+  {
+    std::lock_guard<std::mutex> lk(parent->d->mtx);
+    c->d         = parent->d;  // drops the context's own (empty) SceneData
+    c->isContext = true;
+    c->d->handles.push_back(c);
+  }
+  *out = c;
+  return MGS_OK;
+}
+int mgs_frame_context_create(MgsScene parent, MgsScene* out)
+{
+  return guarded("mgs_frame_context_create", [&] { return mgs_frame_context_create_impl(parent, out); });
+}
+void mgs_frame_context_destroy(MgsScene ctx) { mgs_scene_destroy(ctx); }
+
+int mgs_scene_set_list_capacity(MgsScene s, uint64_t entries)
+{
+  if(!s)
+  {
+    setError("mgs_scene_set_list_capacity: null scene");
+    return MGS_ERR_INVALID_ARG;
+  }
+  s->listCapacityOverride = entries;
+  s->wsEpoch              = ~0ull;  // the working set is re-sized before the next frame (or by the next commit)
+  return MGS_OK;
+}
+
+static uint64_t setBytes(const DeviceSet& d)
+{
+  if(!d.centers)
+    return 0;
+  const uint64_t n   = d.count;
+  const uint64_t fmt[3] = {4, 2, 1};
+  uint64_t       b   = n * (12 + 24 + 4 + 4 + 12 + 16) + ((n + kPart - 1) / kPart) * 32;  // centres, cov6, alpha, maxScale, scales, rotations, partBox
+  b += n * 4 * fmt[d.rgbaFormat] + (d.rgbaFormat != MGS_FORMAT_FLOAT32 ? n * 16 : 0);
+  b += d.sh ? n * (uint64_t)d.shPitch * fmt[d.shFormat] : 0;
+  return b;
+}
+int mgs_scene_memory_usage(MgsScene s, uint64_t* sceneBytes, uint64_t* workingBytes)
+{
+  if(!s)
+  {
+    setError("mgs_scene_memory_usage: null scene");
+    return MGS_ERR_INVALID_ARG;
+  }
+  if(sceneBytes)
+  {
+    uint64_t b = s->d->compInst.n * sizeof(CompositeArgs::Inst);
+    for(const auto& d : s->d->sets)
+      b += setBytes(d);
+    *sceneBytes = b;
+  }
+  if(workingBytes)
+  {
+    uint64_t b = 0;
+    auto add = [&](auto& buf) { b += (uint64_t)buf.n * sizeof(*buf.p); };
+    add(s->keysSlot); add(s->idsSlot); add(s->slotCount); add(s->keysA); add(s->idsA); add(s->keysB); add(s->idsB); add(s->rect);
+    add(s->partHist); add(s->blockCount); add(s->sortedRect); add(s->splatOffset); add(s->chunkStart); add(s->partSkip); add(s->partR);
+    add(s->dbinMasks); add(s->dArgs); add(s->surfDepth); add(s->surfId); add(s->surfNormal); add(s->accum); add(s->rec); add(s->recGut);
+    add(s->pairKey0); add(s->pairVal0); add(s->pairKey1); add(s->pairVal1); add(s->ranges); add(s->image); add(s->ctr); add(s->plans);
+    add(s->rsKeys); add(s->rsVals); add(s->rsHist); add(s->rsCount); add(s->rsKeysY); add(s->rsValsY); add(s->rsPlan); add(s->cpuDistDev);
+    *workingBytes = b;
+  }
+  return MGS_OK;
+}
+
 static int mgs_instance_add_impl(MgsScene s, MgsSplatSet set, const float m[16], int* id);
 int mgs_instance_add(MgsScene s, MgsSplatSet set, const float m[16], int* id)
 {
@@ -751,25 +866,30 @@ static int mgs_instance_add_impl(MgsScene s, MgsSplatSet set, const float m[16],
     setError("mgs_instance_add: null argument");
     return MGS_ERR_INVALID_ARG;
   }
-  if((int)s->instances.size() >= kMaxInstances)
+  if(s->isContext)
+  {
+    setError("mgs_instance_add: a frame context is read-only; edit the scene it was created from");
+    return MGS_ERR_STATE;
+  }
+  if((int)s->d->instances.size() >= kMaxInstances)
   {
     setError("mgs_instance_add: at most " + std::to_string(kMaxInstances) + " instances per scene in this build");
     return MGS_ERR_UNSUPPORTED;
   }
   int idx = -1;
-  for(size_t i = 0; i < s->sets.size(); ++i)
-    if(s->sets[i].host == set->data)
+  for(size_t i = 0; i < s->d->sets.size(); ++i)
+    if(s->d->sets[i].host == set->data)
       idx = (int)i;
   if(idx < 0)
   {
     DeviceSet d;
     d.host = set->data;
-    s->sets.push_back(d);
-    idx = (int)s->sets.size() - 1;
+    s->d->sets.push_back(d);
+    idx = (int)s->d->sets.size() - 1;
   }
   uint64_t total = 0;
-  for(const auto& I : s->instances)
-    total += s->sets[I.set].host->size();
+  for(const auto& I : s->d->instances)
+    total += s->d->sets[I.set].host->size();
   total += set->data->size();
   if(total > 0xFFFFFFFFull)
   {
@@ -779,22 +899,27 @@ static int mgs_instance_add_impl(MgsScene s, MgsSplatSet set, const float m[16],
   Instance I;
   I.set = idx;
   std::memcpy(I.M, m, sizeof(I.M));
-  s->instances.push_back(I);
-  s->committed = false;
+  s->d->instances.push_back(I);
+  s->d->committed = false;
   if(id)
-    *id = (int)s->instances.size() - 1;
+    *id = (int)s->d->instances.size() - 1;
   return MGS_OK;
 }
 
 int mgs_instance_set_transform(MgsScene s, int id, const float m[16])
 {
-  if(!s || !m || id < 0 || id >= (int)s->instances.size())
+  if(!s || !m || id < 0 || id >= (int)s->d->instances.size())
   {
     setError("mgs_instance_set_transform: bad argument");
     return MGS_ERR_INVALID_ARG;
   }
-  std::memcpy(s->instances[id].M, m, sizeof(float) * 16);
-  return MGS_OK;  // transforms travel with every frame; no re-commit needed
+  if(s->isContext)
+  {
+    setError("mgs_instance_set_transform: a frame context is read-only; edit the scene it was created from");
+    return MGS_ERR_STATE;
+  }
+  std::memcpy(s->d->instances[id].M, m, sizeof(float) * 16);
+  return MGS_OK;  // transforms travel with every frame (of every context); no re-commit needed
 }
 
 uint64_t mgs_scene_splat_count(MgsScene s)
@@ -802,8 +927,8 @@ uint64_t mgs_scene_splat_count(MgsScene s)
   if(!s)
     return 0;
   uint64_t total = 0;
-  for(const auto& I : s->instances)
-    total += s->sets[I.set].host->size();
+  for(const auto& I : s->d->instances)
+    total += s->d->sets[I.set].host->size();
   return total;
 }
 
@@ -841,6 +966,12 @@ static int uploadFormatted(const std::vector<float>& src, int format, bool isSh,
   return MGS_OK;
 }
 
+static int sizeWorkingSet(MgsScene s);
+// a frame context that has not seen the scene's latest commit re-sizes its working set before it renders
+static int ensureWorkingSet(MgsScene s)
+{
+  return s->wsEpoch == s->d->epoch ? MGS_OK : sizeWorkingSet(s);
+}
 static int mgs_scene_commit_impl(MgsScene s, int shFormat, int rgbaFormat);
 int mgs_scene_commit(MgsScene s, int shFormat, int rgbaFormat)
 {
@@ -858,17 +989,27 @@ static int mgs_scene_commit_impl(MgsScene s, int shFormat, int rgbaFormat)
     setError("mgs_scene_commit: formats must be MGS_FORMAT_FLOAT32/FLOAT16/UINT8");
     return MGS_ERR_INVALID_ARG;
   }
-  if(s->instances.empty())
+  if(s->isContext)
+  {
+    setError("mgs_scene_commit: a frame context shares its scene's data; commit the scene it was created from");
+    return MGS_ERR_STATE;
+  }
+  if(s->d->instances.empty())
   {
     setError("mgs_scene_commit: scene has no instances");
     return MGS_ERR_STATE;
   }
   HIPCHK(hipSetDevice(s->device));
-  HIPCHK(hipStreamSynchronize(s->stream));
-  for(auto& g : s->graphs)  // captured frames hold the old buffers and grid sizes
+  {  // every frame in flight on any context reads the buffers this call may free: wait for all of them, like the reference's
+     // vkDeviceWaitIdle before it touches the splat buffers (gaussian_splatting.cpp:1092-1111)
+    std::lock_guard<std::mutex> lk(s->d->mtx);
+    for(MgsScene_t* h : s->d->handles)
+      HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  for(auto& g : s->graphs)  // captured frames hold the old buffers and grid sizes (contexts drop theirs when they see the new epoch)
     (void)hipGraphExecDestroy(g.second);
   s->graphs.clear();
-  for(auto& d : s->sets)
+  for(auto& d : s->d->sets)
   {
     if(d.centers && d.shFormat == shFormat && d.rgbaFormat == rgbaFormat)
       continue;  // idempotent
@@ -1013,21 +1154,52 @@ static int mgs_scene_commit_impl(MgsScene s, int shFormat, int rgbaFormat)
     d.shFormat   = shFormat;
     d.rgbaFormat = rgbaFormat;
   }
-  s->shFormat   = shFormat;
-  s->rgbaFormat = rgbaFormat;
+  s->d->shFormat   = shFormat;
+  s->d->rgbaFormat = rgbaFormat;
 
   // global id space + partitions (a5: rebuildGlobalIndexTables, splat_set_manager_vk.cpp:2304-2360,
   // here a closed-form prefix instead of an 8-byte-per-splat table)
   uint64_t total = 0, parts = 0;
-  for(const auto& I : s->instances)
+  for(const auto& I : s->d->instances)
   {
-    const uint32_t c = s->sets[I.set].count;
+    const uint32_t c = s->d->sets[I.set].count;
     total += c;
     parts += (c + kPart - 1) / kPart;
   }
-  s->totalSplats = (uint32_t)total;
-  s->totalParts  = (uint32_t)parts;
+  s->d->totalSplats = (uint32_t)total;
+  s->d->totalParts  = (uint32_t)parts;
+  int rc = MGS_OK;
+  {  // the compositor's SH table of all instances (it carries the first 16 by value)
+    std::vector<CompositeArgs::Inst> tab(s->d->instances.size());
+    uint32_t                         off = 0;
+    for(size_t k = 0; k < s->d->instances.size(); ++k)
+    {
+      const DeviceSet& d  = s->d->sets[s->d->instances[k].set];
+      tab[k].sh           = d.sh;
+      tab[k].rgba         = reinterpret_cast<const float4*>(d.rgbaF32);
+      tab[k].centers      = d.centers;
+      tab[k].globalOffset = off;
+      tab[k].shDegree     = d.shDegree;
+      off += d.count;
+    }
+    if((rc = s->d->compInst.ensure(tab.size()))) return rc;
+    HIPCHK(hipMemcpy(s->d->compInst.p, tab.data(), tab.size() * sizeof(tab[0]), hipMemcpyHostToDevice));
+  }
+  s->d->committed = true;
+  s->d->epoch += 1;
+  return sizeWorkingSet(s);
+}
 
+// The per-handle working set (slots, sort ping-pong, records, lists, counters): sized for the committed scene.  A scene sizes
+// its own at commit; a frame context when it first renders after a commit (wsEpoch lags d->epoch).
+static int sizeWorkingSet(MgsScene s)
+{
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  for(auto& g : s->graphs)
+    (void)hipGraphExecDestroy(g.second);
+  s->graphs.clear();
+  const uint64_t total = s->d->totalSplats, parts = s->d->totalParts;
   int rc = MGS_OK;
   const size_t slots = (size_t)parts * kPart;
   if((rc = s->keysSlot.ensure(slots))) return rc;
@@ -1054,6 +1226,8 @@ static int mgs_scene_commit_impl(MgsScene s, int shFormat, int rgbaFormat)
   uint64_t cap = std::max<uint64_t>(32ull * total, 64ull << 20);  // 16 B per pair: 3 GB for a garden-sized scene
   if(const char* e = std::getenv("MGS_PAIR_CAPACITY"))
     cap = std::strtoull(e, nullptr, 10);
+  if(s->listCapacityOverride)
+    cap = s->listCapacityOverride;
   cap = std::min<uint64_t>(std::max<uint64_t>(cap, kPart), 0xFFFFF000ull);
   s->pairCapacity = (uint32_t)cap;
   if((rc = s->pairVal1.ensure(cap))) return rc;  // the per-bin lists
@@ -1064,28 +1238,12 @@ static int mgs_scene_commit_impl(MgsScene s, int shFormat, int rgbaFormat)
   s->pStride              = (uint32_t)maxParts;
   if((rc = s->partHist.ensure(256ull * maxParts))) return rc;
   if((rc = s->blockCount.ensure(std::max<uint64_t>((total + kPart - 1) / kPart, 1)))) return rc;
-  {  // the compositor's SH table of all instances (it carries the first 16 by value)
-    std::vector<CompositeArgs::Inst> tab(s->instances.size());
-    uint32_t                         off = 0;
-    for(size_t k = 0; k < s->instances.size(); ++k)
-    {
-      const DeviceSet& d  = s->sets[s->instances[k].set];
-      tab[k].sh           = d.sh;
-      tab[k].rgba         = reinterpret_cast<const float4*>(d.rgbaF32);
-      tab[k].centers      = d.centers;
-      tab[k].globalOffset = off;
-      tab[k].shDegree     = d.shDegree;
-      off += d.count;
-    }
-    if((rc = s->compInst.ensure(tab.size()))) return rc;
-    HIPCHK(hipMemcpy(s->compInst.p, tab.data(), tab.size() * sizeof(tab[0]), hipMemcpyHostToDevice));
-  }
   HIPCHK(hipMemset(s->ctr.p, 0, sizeof(FrameCounters)));
   HIPCHK(hipMemset(s->plans.p, 0, 2 * sizeof(SortPlan)));
   // hipMemset on device memory is asynchronous on the NULL stream, and the render stream is non-blocking:
   // without this the memsets above can land in the middle of the first frame (caught by the test suite)
   HIPCHK(hipDeviceSynchronize());
-  s->committed = true;
+  s->wsEpoch = s->d->epoch;
   {  // a changed scene invalidates the CPU sorter's last result (lazy sorting must not reuse it)
     std::lock_guard<std::mutex> lk(s->cpu.mtx);
     s->cpu.haveLast   = false;
@@ -1097,17 +1255,17 @@ static int mgs_scene_commit_impl(MgsScene s, int shFormat, int rgbaFormat)
 
 int mgs_scene_storage_order(MgsScene s, int instance, uint32_t* newToOld, size_t count)
 {
-  if(!s || !newToOld || instance < 0 || instance >= (int)s->instances.size())
+  if(!s || !newToOld || instance < 0 || instance >= (int)s->d->instances.size())
   {
     setError("mgs_scene_storage_order: bad argument");
     return MGS_ERR_INVALID_ARG;
   }
-  if(!s->committed)
+  if(!s->d->committed)
   {
     setError("mgs_scene_storage_order: scene not committed");
     return MGS_ERR_STATE;
   }
-  const DeviceSet& d = s->sets[s->instances[instance].set];
+  const DeviceSet& d = s->d->sets[s->d->instances[instance].set];
   if(count < d.count)
   {
     setError("mgs_scene_storage_order: destination too small");
@@ -1119,18 +1277,18 @@ int mgs_scene_storage_order(MgsScene s, int instance, uint32_t* newToOld, size_t
 
 int mgs_scene_download_set(MgsScene s, int instance, int which, float* dst, size_t count)
 {
-  if(!s || !dst || instance < 0 || instance >= (int)s->instances.size())
+  if(!s || !dst || instance < 0 || instance >= (int)s->d->instances.size())
   {
     setError("mgs_scene_download_set: bad argument");
     return MGS_ERR_INVALID_ARG;
   }
-  if(!s->committed)
+  if(!s->d->committed)
   {
     setError("mgs_scene_download_set: scene not committed");
     return MGS_ERR_STATE;
   }
   HIPCHK(hipSetDevice(s->device));
-  const DeviceSet& d = s->sets[s->instances[instance].set];
+  const DeviceSet& d = s->d->sets[s->d->instances[instance].set];
   const size_t     n = d.count;
   size_t           need;
   const void*      src;
@@ -1257,36 +1415,36 @@ static void mapIdsToCaller(MgsScene s, uint32_t* ids, size_t n)
 {
   std::vector<uint32_t> offs;
   uint32_t              o = 0;
-  for(const auto& I : s->instances)
+  for(const auto& I : s->d->instances)
   {
     offs.push_back(o);
-    o += s->sets[I.set].count;
+    o += s->d->sets[I.set].count;
   }
   offs.push_back(o);
   parallelBatches(n, [&](size_t i) {
     const uint32_t g = ids[i];
     size_t         k = 0;
-    while(k + 1 < s->instances.size() && g >= offs[k + 1])
+    while(k + 1 < s->d->instances.size() && g >= offs[k + 1])
       ++k;
-    ids[i] = offs[k] + s->sets[s->instances[k].set].newToOld[g - offs[k]];
+    ids[i] = offs[k] + s->d->sets[s->d->instances[k].set].newToOld[g - offs[k]];
   });
 }
 static void mapIdsToStorage(MgsScene s, uint32_t* ids, size_t n)
 {
   std::vector<uint32_t> offs;
   uint32_t              o = 0;
-  for(const auto& I : s->instances)
+  for(const auto& I : s->d->instances)
   {
     offs.push_back(o);
-    o += s->sets[I.set].count;
+    o += s->d->sets[I.set].count;
   }
   offs.push_back(o);
   parallelBatches(n, [&](size_t i) {
     const uint32_t g = ids[i];
     size_t         k = 0;
-    while(k + 1 < s->instances.size() && g >= offs[k + 1])
+    while(k + 1 < s->d->instances.size() && g >= offs[k + 1])
       ++k;
-    ids[i] = offs[k] + s->sets[s->instances[k].set].oldToNew[g - offs[k]];
+    ids[i] = offs[k] + s->d->sets[s->d->instances[k].set].oldToNew[g - offs[k]];
   });
 }
 
@@ -1381,8 +1539,9 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
   F.frameSampleId    = p->frame_sample_id;
   F.temporalSampling = p->temporal_sampling ? 1 : 0;
   F.kernelDegree     = p->kernel_degree;
-  if(p->camera_model == MGS_CAMERA_FISHEYE)
-  {  // gaussian_splatting.cpp:1243
+  if(p->camera_model == MGS_CAMERA_FISHEYE && p->pipeline == MGS_PIPELINE_3DGUT)
+  {  // gaussian_splatting.cpp:1239-1244: frameInfo.focal is the fisheye focal only for the 3DGUT pipelines; a fisheye camera on
+     // the 3DGS pipelines keeps the pinhole focal (and dist.comp's fisheye cull then runs on that)
     F.gutFocal[0] = (float)p->width / F.fovRad;
     F.gutFocal[1] = -(float)p->height / F.fovRad;
   }
@@ -1398,18 +1557,18 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
   }
   mat4Inverse(p->view, F.viewInv);
   mat4Inverse(p->proj, F.projInv);
-  F.maxFocal        = std::max(std::fabs(F.focal[0]), std::fabs(F.focal[1]));
+  F.maxFocal        = std::max(std::fabs(F.gutFocal[0]), std::fabs(F.gutFocal[1]));  // frameInfo.focal (dist.comp.slang:125)
   F.targetFormat    = p->target_format;
-  F.nInstances      = (int)s->instances.size();
-  F.totalSplats     = s->totalSplats;
-  F.totalPartitions = s->totalParts;
+  F.nInstances      = (int)s->d->instances.size();
+  F.totalSplats     = s->d->totalSplats;
+  F.totalPartitions = s->d->totalParts;
   static const bool kPartCull = [] { const char* e = std::getenv("MGS_PARTITION_CULL"); return e ? std::atoi(e) != 0 : true; }();
   F.partitionCull   = (kPartCull && F.cullMode == MGS_CULL_AT_DIST) ? 1 : 0;
   uint32_t offset = 0, block = 0;
   for(int k = 0; k < F.nInstances; ++k)
   {
-    const Instance&  I = s->instances[k];
-    const DeviceSet& d = s->sets[I.set];
+    const Instance&  I = s->d->instances[k];
+    const DeviceSet& d = s->d->sets[I.set];
     InstanceConst&   C = A.inst[k];
     C.centers = d.centers;
     C.cov6    = d.cov6;
@@ -1498,12 +1657,12 @@ static void keySort(MgsScene s, hipStream_t st, bool fuseRectGather, bool allowR
   L.keysY = s->keysB.p;
   L.valsY = s->idsB.p;
   L.slotCount    = s->slotCount.p;
-  L.partsSlotted = s->totalParts;
+  L.partsSlotted = s->d->totalParts;
   L.nPtr         = &s->ctr.p->sortedCount;
   L.plan         = &s->plans.p[0];
   L.partHist     = s->partHist.p;
   L.pStride      = s->pStride;
-  L.maxElems     = s->totalSplats;
+  L.maxElems     = s->d->totalSplats;
   L.beginBit     = 0;
   L.endBit       = 32;
   // default: four LSD passes (k_sort.hip).  MGS_SORT=sample selects the two-round-trip sample sort (k_ssort.hip):
@@ -1534,13 +1693,13 @@ static int cpuSortStep(MgsScene s, const MgsFrameParams* p, bool blocking)
     c.job.frontToBack = false;
     c.job.inst.clear();
     uint32_t offset = 0;
-    for(const auto& I : s->instances)
+    for(const auto& I : s->d->instances)
     {
       CpuSorter::Job::Inst ji;
-      ji.set = s->sets[I.set].host;
+      ji.set = s->d->sets[I.set].host;
       std::memcpy(ji.M, I.M, sizeof(ji.M));
       ji.offset = offset;
-      ji.count  = s->sets[I.set].count;
+      ji.count  = s->d->sets[I.set].count;
       offset += ji.count;
       c.job.inst.push_back(ji);
     }
@@ -1665,11 +1824,13 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     setError("mgs_render: null argument");
     return MGS_ERR_INVALID_ARG;
   }
-  if(!s->committed)
+  if(!s->d->committed)
   {
     setError("mgs_render: call mgs_scene_commit first");
     return MGS_ERR_STATE;
   }
+  if(int wrc = ensureWorkingSet(s))
+    return wrc;
   HIPCHK(hipSetDevice(s->device));
   FrameArgs A;
   int       rc = buildFrameArgs(s, p, A);
@@ -1693,12 +1854,29 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     setError("frame: pipeline must be MGS_PIPELINE_3DGS or MGS_PIPELINE_3DGUT");
     return MGS_ERR_INVALID_ARG;
   }
+  if(p->camera_model < MGS_CAMERA_PINHOLE || p->camera_model > MGS_CAMERA_FISHEYE)
+  {  // CAMERA_TYPE also selects the dist-stage cull of the 3DGS pipelines (dist.comp.slang:64-91)
+    setError("frame: camera_model out of range");
+    return MGS_ERR_INVALID_ARG;
+  }
   if(gut)
   {
-    if(p->camera_model < MGS_CAMERA_PINHOLE || p->camera_model > MGS_CAMERA_FISHEYE || p->extent_method < MGS_EXTENT_EIGEN
-       || p->extent_method > MGS_EXTENT_CONIC)
+    if(p->extent_method < MGS_EXTENT_EIGEN || p->extent_method > MGS_EXTENT_CONIC)
     {
-      setError("frame: camera_model / extent_method out of range");
+      setError("frame: extent_method out of range");
+      return MGS_ERR_INVALID_ARG;
+    }
+    // the float knobs of the particle response and the lens: values outside these ranges make every ray NaN (negative or
+    // non-finite aperture, focus distance <= 0) or reject / accept every hit differently from the reference (alphaClamp <=
+    // 1/255 rejects everything in threedgrt.h.slang:181-184, which the per-record cutoff of the packed compositor would not)
+    if(!(p->alpha_clamp > 1.0f / 255.0f && p->alpha_clamp <= 1.0f) || !(p->kernel_min_response >= 0.0f && p->kernel_min_response < 1.0f))
+    {
+      setError("frame: alpha_clamp must be in (1/255, 1] and kernel_min_response in [0, 1)");
+      return MGS_ERR_INVALID_ARG;
+    }
+    if(p->dof_mode != MGS_DOF_DISABLED && (!(p->aperture >= 0.0f) || !std::isfinite(p->aperture) || !(p->focus_dist > 0.0f) || !std::isfinite(p->focus_dist)))
+    {
+      setError("frame: depth of field needs a finite aperture >= 0 and a finite focus_dist > 0");
       return MGS_ERR_INVALID_ARG;
     }
     if(p->kernel_degree != 8 && (p->kernel_degree < 0 || p->kernel_degree > 5))
@@ -1706,9 +1884,9 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
       setError("frame: kernel_degree must be one of 0, 1, 2, 3, 4, 5, 8 (shaderio.h:112-119)");
       return MGS_ERR_INVALID_ARG;
     }
-    if(s->recGut.n < s->totalSplats)
+    if(s->recGut.n < s->d->totalSplats)
     {  // first 3DGUT frame of this scene: its record buffer (captured frames do not reference it yet)
-      if((rc = s->recGut.ensure(s->totalSplats))) return rc;
+      if((rc = s->recGut.ensure(s->d->totalSplats))) return rc;
     }
   }
   else if(p->dof_mode != MGS_DOF_DISABLED)
@@ -1750,7 +1928,7 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
       if((rc = s->pairVal0.ensure(cap))) return rc;
       if((rc = s->pairKey1.ensure(cap))) return rc;
       if((rc = s->chunkStart.ensure(cap / kPart + 4))) return rc;
-      if((rc = s->splatOffset.ensure(s->totalSplats))) return rc;
+      if((rc = s->splatOffset.ensure(s->d->totalSplats))) return rc;
     }
   }
   s->haveSurface    = F.surfaceOutputs != 0;
@@ -1780,7 +1958,7 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     // per-frame device state: counters, both sort plans (adjacent), bin ranges.  The partition cull, when it runs, is
     // the frame's first kernel and zeroes them on the way.
     static_assert(sizeof(SortPlan) % 4 == 0 && sizeof(FrameCounters) % 4 == 0, "word-sized state");
-    if(F.partitionCull && s->totalParts > 0)
+    if(F.partitionCull && s->d->totalParts > 0)
       launchPartitionCull(st, A, s->dArgs.p, s->partSkip.p, s->partR.p, reinterpret_cast<uint32_t*>(ctr), (uint32_t)(sizeof(FrameCounters) / 4),
                           reinterpret_cast<uint32_t*>(planK), (uint32_t)(2 * sizeof(SortPlan) / 4),
                           reinterpret_cast<uint32_t*>(s->ranges.p), 2u * nTiles);
@@ -1789,9 +1967,9 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     if(withEvents) HIPCHK(hipEventRecord(fev[6], st));  // MGS_STAGE_CULL ends here; it is part of MGS_STAGE_PROJECT too
     const bool cpuMode = (p->sort_mode == MGS_SORT_CPU_ASYNC);
     if(cpuMode)  // rejected splats must look empty to the binning stage: rect with x0 > x1
-      hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, st, s->rect.p, 1u, s->totalSplats);
+      hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, st, s->rect.p, 1u, s->d->totalSplats);
     if(gut)
-      launchProjectGut(st, A, s->dArgs.p, s->shFormat, ctr, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->recGut.p, s->rect.p,
+      launchProjectGut(st, A, s->dArgs.p, s->d->shFormat, ctr, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->recGut.p, s->rect.p,
                        F.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride, kRemap ? planK : nullptr);
     else
       launchProject(st, A, s->dArgs.p, true, ctr, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p,
@@ -1807,15 +1985,15 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
       rc = cpuSortStep(s, p, p->cpu_sort_blocking != 0);
       if(rc != MGS_OK)
         return rc;
-      if(s->cpuHaveIndices && s->cpuIndices.size() == s->totalSplats)
+      if(s->cpuHaveIndices && s->cpuIndices.size() == s->d->totalSplats)
       {
         s->cpuStorageIds = s->cpuIndices;  // the sorter works in the caller's id space
         mapIdsToStorage(s, s->cpuStorageIds.data(), s->cpuStorageIds.size());
-        HIPCHK(hipMemcpyAsync(s->idsA.p, s->cpuStorageIds.data(), (size_t)s->totalSplats * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(s->idsA.p, s->cpuStorageIds.data(), (size_t)s->d->totalSplats * 4, hipMemcpyHostToDevice, st));
       }
       else  // no result yet: the reference draws with whatever the index buffer holds; we use identity order
-        hipLaunchKernelGGL(k_iota_u32, dim3(1024), dim3(256), 0, st, s->idsA.p, s->totalSplats);
-      hipLaunchKernelGGL(k_set_plan_n, dim3(1), dim3(1), 0, st, planK, ctr, s->totalSplats);
+        hipLaunchKernelGGL(k_iota_u32, dim3(1024), dim3(256), 0, st, s->idsA.p, s->d->totalSplats);
+      hipLaunchKernelGGL(k_set_plan_n, dim3(1), dim3(1), 0, st, planK, ctr, s->d->totalSplats);
     }
     if(withEvents) HIPCHK(hipEventRecord(fev[2], st));
     // coarse bins (the default): stable multi-split straight into the per-bin lists, no records, no pair sort
@@ -1823,14 +2001,14 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     const bool direct = kDirectBin && directBinningSupported(F.binsX, F.binsY);
     if(direct)
     {
-      launchDirectBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, s->sortedRect.p, s->dbinMasks.p, s->totalSplats,
+      launchDirectBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, s->sortedRect.p, s->dbinMasks.p, s->d->totalSplats,
                           s->partHist.p, s->pStride, &planP->ghist[0][0], s->pairVal1.p, s->ranges.p, ctr, s->pairCapacity,
                           F.binsX, F.binsY);
       if(withEvents) HIPCHK(hipEventRecord(fev[3], st));
     }
     else
     {
-      launchBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, s->blockCount.p, (s->totalSplats + kPart - 1) / kPart, ctr,
+      launchBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, s->blockCount.p, (s->d->totalSplats + kPart - 1) / kPart, ctr,
                     s->sortedRect.p, s->splatOffset.p, s->chunkStart.p, s->pairKey0.p, s->pairVal0.p, s->pairCapacity, F.binsX, true);
       if(withEvents) HIPCHK(hipEventRecord(fev[3], st));
       {
@@ -1858,12 +2036,12 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     }
     if(withEvents) HIPCHK(hipEventRecord(fev[4], st));
     if(gut)
-      launchCompositeGut(st, A, s->dArgs.p, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->recGut.p, s->image.p, half, ctr, s->shFormat,
+      launchCompositeGut(st, A, s->dArgs.p, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->recGut.p, s->image.p, half, ctr, s->d->shFormat,
                          F.surfaceOutputs ? s->surfDepth.p : nullptr, F.surfaceOutputs ? s->surfId.p : nullptr,
                          F.surfaceOutputs ? s->surfNormal.p : nullptr);
     else
-      launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->shFormat, ctr,
-                      F.surfaceOutputs ? s->surfDepth.p : nullptr, F.surfaceOutputs ? s->surfId.p : nullptr, s->compInst.p,
+      launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->d->shFormat, ctr,
+                      F.surfaceOutputs ? s->surfDepth.p : nullptr, F.surfaceOutputs ? s->surfId.p : nullptr, s->d->compInst.p,
                       s->dArgs.p, F.surfaceOutputs ? s->surfNormal.p : nullptr);
     if(F.temporalSampling)
       hipLaunchKernelGGL(k_post_accumulate, dim3(2048), dim3(256), 0, st, s->dArgs.p, s->accum.p, s->image.p, half);
@@ -1933,6 +2111,7 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
   s->haveFrame       = true;
   s->lastTimed       = timed;
   s->lastWasSortOnly = false;
+  s->lastListsPartial = false;
   if(timed)
     ++s->frameIndex;
   if(out)
@@ -2122,6 +2301,7 @@ struct Rccl
   ncclResult_t (*GetUniqueId)(ncclUniqueId*)                                                             = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int)                                      = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t)                                                                = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t)                                                                  = nullptr;
   ncclResult_t (*GroupStart)()                                                                           = nullptr;
   ncclResult_t (*GroupEnd)()                                                                             = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)    = nullptr;
@@ -2142,6 +2322,7 @@ Rccl& rccl()
     r.GetUniqueId    = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
     r.CommInitRank   = (decltype(r.CommInitRank))sym("ncclCommInitRank");
     r.CommDestroy    = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.CommAbort      = (decltype(r.CommAbort))sym("ncclCommAbort");
     r.GroupStart     = (decltype(r.GroupStart))sym("ncclGroupStart");
     r.GroupEnd       = (decltype(r.GroupEnd))sym("ncclGroupEnd");
     r.Broadcast      = (decltype(r.Broadcast))sym("ncclBroadcast");
@@ -2269,6 +2450,32 @@ static void stripOfRank(MgsScene s, int tilesY, int r, int& b, int& e)
   e             = std::min(b + per, tilesY);
 }
 
+// the frame buffer of a rank that does not render this frame (empty strip) or whose render failed: the exchange still
+// receives everybody else's rows into it
+static int ensureFrameBufferFor(MgsScene s, const MgsFrameParams* p)
+{
+  if(p->width <= 0 || p->height <= 0 || p->target_format < MGS_TARGET_RGBA16F || p->target_format > MGS_TARGET_RGBA8)
+  {
+    setError("frame: bad size / target_format");
+    return MGS_ERR_INVALID_ARG;
+  }
+  const size_t pixB = p->target_format == MGS_TARGET_RGBA16F ? 8 : (p->target_format == MGS_TARGET_RGBA8 ? 4 : 16);
+  s->imageRowBytes  = (size_t)p->width * pixB;
+  s->imageBytes     = s->imageRowBytes * (size_t)p->height;
+  if(s->image.n < s->imageBytes)
+  {
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for(auto& g : s->graphs)  // captured frames hold the old image pointer
+      (void)hipGraphExecDestroy(g.second);
+    s->graphs.clear();
+    int rc = s->image.ensure(s->imageBytes);
+    if(rc != MGS_OK)
+      return rc;
+    HIPCHK(hipMemsetAsync(s->image.p, 0, s->imageBytes, s->stream));
+  }
+  return MGS_OK;
+}
+
 static int mgs_render_gathered_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
 {
   if(!s || !p)
@@ -2285,30 +2492,37 @@ static int mgs_render_gathered_impl(MgsScene s, const MgsFrameParams* p, MgsFram
   MgsFrameParams q = *p;
   int b, e;
   stripOfRank(s, tilesY, s->commRank, b, e);
-  int rc = MGS_OK;
+  // A rank must reach the exchange whatever happens to its own strip: the peers block in the collective otherwise.  A failed
+  // (or absent) local render still joins with a frame buffer of the right size — its rows are stale, the error is returned
+  // after the exchange.  Only if no buffer can be had at all is the communicator aborted, which fails the peers' collective
+  // instead of hanging it.
+  int         localRc = MGS_OK;
+  std::string localErr;
   if(e > b)
   {
     q.strip_row_begin = b;
     q.strip_row_end   = e;
-    rc                = mgs_render(s, &q, out);
-    if(rc != MGS_OK)
-      return rc;
+    localRc           = mgs_render(s, &q, out);
   }
-  else
-  {  // more ranks than tile rows: this rank owns nothing but still takes part in the exchange
-    q.strip_row_begin = 0;
-    q.strip_row_end   = 0;
-    if(!s->haveFrame || s->lastParams.width != p->width || s->lastParams.height != p->height
-       || s->lastParams.target_format != p->target_format)
-    {  // make sure the frame buffer exists at this size
-      rc = mgs_render(s, &q, out);
-      if(rc != MGS_OK)
-        return rc;
-    }
+  else if(out)
+    std::memset(out, 0, sizeof(*out));  // more ranks than tile rows (or an empty strip in the table): nothing to render
+  if(localRc != MGS_OK)
+    localErr = lastError();
+  HIPCHK(hipSetDevice(s->device));
+  const int bufRc = ensureFrameBufferFor(s, p);
+  if(bufRc != MGS_OK)
+  {
+    if(rccl().CommAbort)
+      (void)rccl().CommAbort(s->comm);
+    else
+      (void)rccl().CommDestroy(s->comm);
+    s->comm      = nullptr;
+    s->commWorld = 1;
+    s->commRank  = 0;
+    return localRc != MGS_OK ? localRc : bufRc;
   }
   // exchange in place: rank r's rows are broadcast from r into the same rows of everybody's frame buffer.  One group
   // = one fused launch on the render stream; it overlaps with the next frame's key/sort when frames are in flight.
-  HIPCHK(hipSetDevice(s->device));
   ncclResult_t ne = rccl().GroupStart();
   if(ne != ncclSuccess)
     return rcclFail("ncclGroupStart", ne);
@@ -2331,9 +2545,18 @@ static int mgs_render_gathered_impl(MgsScene s, const MgsFrameParams* p, MgsFram
   ne = rccl().GroupEnd();
   if(ne != ncclSuccess)
     return rcclFail("ncclGroupEnd", ne);
-  // the frame is whole again: downloads address all rows
+  if(localRc != MGS_OK)
+  {
+    setError("mgs_render_gathered: this rank's strip failed (" + localErr + "); the exchange was still joined");
+    return localRc;
+  }
+  // the frame is whole again: downloads address all rows.  The bin lists of the last frame cover this rank's rows only.
+  s->lastParams                 = q;
   s->lastParams.strip_row_begin = 0;
   s->lastParams.strip_row_end   = tilesY;
+  s->haveFrame                  = true;
+  s->lastWasSortOnly            = false;
+  s->lastListsPartial           = s->commWorld > 1;
   return MGS_OK;
 }
 int mgs_render_gathered(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out)
@@ -2351,6 +2574,12 @@ int mgs_frame_row_costs(MgsScene s, uint32_t* cost, size_t rows)
   if(!s->haveFrame || s->lastWasSortOnly)
   {
     setError("mgs_frame_row_costs: no frame rendered yet");
+    return MGS_ERR_STATE;
+  }
+  if(s->lastListsPartial)
+  {  // every rank would see its own rows only and derive a different table: the exchange sizes would no longer agree
+    setError("mgs_frame_row_costs: the last frame came from mgs_render_gathered (bin lists of this rank's strip only); "
+             "calibrate on a full-frame mgs_render");
     return MGS_ERR_STATE;
   }
   return guarded("mgs_frame_row_costs", [&]() -> int {
@@ -2402,7 +2631,7 @@ static int mgs_frame_download_projected_impl(MgsScene s, const uint32_t* ids, si
     return MGS_ERR_STATE;
   }
   for(size_t i = 0; i < count; ++i)
-    if(ids[i] >= s->totalSplats)
+    if(ids[i] >= s->d->totalSplats)
     {
       setError("mgs_frame_download_projected: id out of range");
       return MGS_ERR_INVALID_ARG;
@@ -2411,10 +2640,10 @@ static int mgs_frame_download_projected_impl(MgsScene s, const uint32_t* ids, si
   HIPCHK(hipStreamSynchronize(s->stream));
   std::vector<uint32_t> sid(ids, ids + count);
   mapIdsToStorage(s, sid.data(), count);
-  std::vector<SplatRec> rec(s->totalSplats);
-  std::vector<uint32_t> rect(s->totalSplats);
-  HIPCHK(hipMemcpy(rec.data(), s->rec.p, (size_t)s->totalSplats * sizeof(SplatRec), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(rect.data(), s->rect.p, (size_t)s->totalSplats * 4, hipMemcpyDeviceToHost));
+  std::vector<SplatRec> rec(s->d->totalSplats);
+  std::vector<uint32_t> rect(s->d->totalSplats);
+  HIPCHK(hipMemcpy(rec.data(), s->rec.p, (size_t)s->d->totalSplats * sizeof(SplatRec), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(rect.data(), s->rect.p, (size_t)s->d->totalSplats * 4, hipMemcpyDeviceToHost));
   for(size_t i = 0; i < count; ++i)
   {
     const SplatRec& r = rec[sid[i]];
@@ -2463,11 +2692,13 @@ int mgs_sort_keys(MgsScene s, const MgsFrameParams* p, MgsSortOut* out)
     setError("mgs_sort_keys: null argument");
     return MGS_ERR_INVALID_ARG;
   }
-  if(!s->committed)
+  if(!s->d->committed)
   {
     setError("mgs_sort_keys: call mgs_scene_commit first");
     return MGS_ERR_STATE;
   }
+  if(int wrc = ensureWorkingSet(s))
+    return wrc;
   HIPCHK(hipSetDevice(s->device));
   std::memset(out, 0, sizeof(*out));
   if(p->sort_mode == MGS_SORT_CPU_ASYNC)
@@ -2489,11 +2720,15 @@ int mgs_sort_keys(MgsScene s, const MgsFrameParams* p, MgsSortOut* out)
   if(rc != MGS_OK)
     return rc;
   hipStream_t st = s->stream;
+  // the metric hook returns dist.comp.slang's stream for the whole frame: a strip set on the scene culls footprints, which is
+  // the raster stage's business, so it does not apply here
+  A.f.stripRow0 = 0;
+  A.f.stripRow1 = A.f.tilesY;
   if((rc = s->ranges.ensure(1))) return rc;
   if((rc = s->dArgs.ensure(1))) return rc;
   HIPCHK(hipMemcpyAsync(s->dArgs.p, &A, offsetof(FrameArgs, inst) + (size_t)A.f.nInstances * sizeof(InstanceConst), hipMemcpyHostToDevice, st));
   HIPCHK(hipEventRecord(s->ev[0], st));
-  if(A.f.partitionCull && s->totalParts > 0)
+  if(A.f.partitionCull && s->d->totalParts > 0)
     launchPartitionCull(st, A, s->dArgs.p, s->partSkip.p, s->partR.p, reinterpret_cast<uint32_t*>(s->ctr.p),
                         (uint32_t)(sizeof(FrameCounters) / 4), reinterpret_cast<uint32_t*>(s->plans.p),
                         (uint32_t)(2 * sizeof(SortPlan) / 4), nullptr, 0u);
