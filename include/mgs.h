@@ -310,10 +310,12 @@ typedef struct MgsSortOut {
   float    sort_ms;    /* radix sort (GPU) / std::sort (CPU) */
   float    hist_ms;    /* GPU: the up-front histogram kernel, included in sort_ms */
   uint32_t passes;     /* GPU: radix passes executed */
-  uint32_t reserved[3]; /* opt-in sample sort (MGS_SORT=sample) statistics: slices, buckets, buckets streamed through HBM */
+  uint32_t reserved[3]; /* [0] 1: pass 2 sorted on the rank of key >> 16 and pass 3 did not run; [1] occurring values of key >> 16 */
 } MgsSortOut;
 int mgs_sort_keys(MgsScene scene, const MgsFrameParams* params, MgsSortOut* out);
-/* download the sorted keys (GPU mode: u32 encodeMinMaxFp32 keys; CPU mode: fp32 distances) and global ids */
+/* download the sorted keys (GPU mode: u32 encodeMinMaxFp32 keys; CPU mode: fp32 distances) and global ids.  `keys` may be
+ * NULL.  In GPU mode the sorted keys exist after mgs_sort_keys only (a frame's last sort pass writes the ids alone, as the
+ * raster stage reads nothing else): asking for them after mgs_render returns MGS_ERR_STATE. */
 int mgs_sort_download(MgsScene scene, uint32_t* keys, uint32_t* ids, uint32_t capacity);
 
 /* sort an arbitrary device-resident (key,value) u32 array with the frame's sort kernels (reduce-then-scan LSD radix)

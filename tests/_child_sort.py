@@ -1,5 +1,5 @@
-"""child process of test_gpu_parity.test_sample_sort_path_is_bit_identical_to_the_stable_sort: runs under
-MGS_SORT=sample (and once under the default) and checks every sort against numpy's stable sort"""
+"""child process of test_gpu_parity.test_key_sort_variants_are_bit_identical_to_the_stable_sort: runs under the sort knobs
+(MGS_SORT_REMAP, MGS_RAW_SORT) and checks every sort against numpy's stable sort"""
 import hashlib
 import os
 import sys
@@ -20,9 +20,10 @@ def check(k, v, name):
     assert np.array_equal(vs, v[o]), name
 
 
-# sizes around the structural thresholds: one bucket, the LDS capacity of a finisher, the sample capacity, strip-sized,
-# multi-million
-for n in [0, 1, 2, 1791, 1792, 1793, 6143, 6144, 6145, 16383, 16385, 40_000, 2_500_000, 5_000_011]:
+# sizes around the structural thresholds: one partition (4096), one look-back group (32 partitions = 131072), one window of
+# groups (16 groups = 2 M), strip-sized, multi-million
+for n in [0, 1, 2, 255, 256, 257, 4095, 4096, 4097, 8191, 8193, 40_000, 131_071, 131_072, 131_073, 262_145, 2_097_152, 2_097_153,
+          2_500_000, 5_000_011]:
     rng = np.random.default_rng(n)
     check(rng.integers(0, 2**32, n, dtype=np.uint32), rng.integers(0, 2**32, n, dtype=np.uint32), f"n={n}")
 rng = np.random.default_rng(99)
@@ -44,7 +45,7 @@ cases = {
 for name, k in cases.items():
     assert k.size == n, name
     check(k.astype(np.uint32), v, name)
-# a streaming bucket fed by thousands of slices
+# one value over thousands of partitions (every digit count sits in one column of the look-back)
 n2 = 6_000_000
 k2 = np.full(n2, 5, np.uint32)
 k2[rng.integers(0, n2, 1000)] = rng.integers(0, 2**32, 1000, dtype=np.uint32)
@@ -67,7 +68,7 @@ for pose, (eye, (w, h)) in enumerate(views):
     gk, gi = scene.sort_download(so.count)
     hh.update(gk.tobytes())
     hh.update(gi.tobytes())
-    print("STATS view", pose, "count", so.count, "passes", so.passes, "slices/buckets/streamed", list(so.reserved))
+    print("STATS view", pose, "count", so.count, "passes", so.passes, "remap on / values", list(so.reserved)[:2])
     o = scene.render(p)
     hh.update(np.ascontiguousarray(scene.download_frame(p)).tobytes())
     for strip in ((0, 8), (10, 20)):

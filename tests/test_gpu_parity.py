@@ -139,24 +139,23 @@ def test_radix_sort_depth_like_keys_with_outliers(scene_small, ob):
     assert np.array_equal(ks, k[o]) and np.array_equal(vs, v2[o])
 
 
-def test_sample_sort_path_is_bit_identical_to_the_stable_sort():
-    """the opt-in sample sort (k_ssort.hip, MGS_SORT=sample; libmgs reads its knobs once per process, hence the child
-    interpreter): sizes around its structural thresholds, distributions on which quantile splitters cannot balance
-    the buckets (streaming path, all-equal buckets, duplicate splitters), and whole frames — every sorted stream must
-    equal the stable sort bit for bit, every frame must equal the default (LSD) build's frame"""
+def test_key_sort_variants_are_bit_identical_to_the_stable_sort():
+    """the sort kernels under their build-time knobs (libmgs reads them once per process, hence the child interpreter): the
+    frame's key sort with the pass elision (default), with four plain passes (MGS_SORT_REMAP=0), and the stand-alone sorts on
+    the generic reduce-then-scan kernels instead of the key sort's (MGS_RAW_SORT=generic).  Sizes around the partition and
+    look-back group boundaries, distributions with giant runs / few values / many exponents, and whole frames — every sorted
+    stream must equal the stable sort bit for bit, every frame must be the same frame"""
     import subprocess
     import sys
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_child_sort.py")
     out = {}
-    for mode in ("sample", "lsd", "lsd_plain"):
-        # lsd: the default (four LSD passes with the top-16-bit pass elision); lsd_plain: the elision switched off
-        env = dict(os.environ, MGS_SORT=mode.split("_")[0], MGS_SORT_REMAP="0" if mode == "lsd_plain" else "1")
-        r = subprocess.run([sys.executable, child], env=env, capture_output=True, text=True, timeout=900)
+    for mode, env_extra in (("default", {}), ("plain", {"MGS_SORT_REMAP": "0"}), ("generic", {"MGS_RAW_SORT": "generic"})):
+        r = subprocess.run([sys.executable, child], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
         assert "SORTS_OK" in r.stdout, r.stdout[-3000:]
         out[mode] = [l for l in r.stdout.splitlines() if l.startswith("FRAMES_SHA1")]
         print(mode, [l for l in r.stdout.splitlines() if l.startswith("STATS")])
-    assert out["sample"] and out["sample"] == out["lsd"] == out["lsd_plain"]
+    assert out["default"] and out["default"] == out["plain"] == out["generic"]
 
 
 def test_upload_transform_matches_oracle_bitwise(scene_small, ob):
@@ -881,7 +880,6 @@ def test_binning_paths_bit_identical():
     ref = run({})
     assert run({"MGS_DIRECT_BIN": "0"}) == ref
     # optional fusions / culling refinements must not change a bit either
-    assert run({"MGS_FUSE_RECT": "1"}) == ref      # rect gather fused into the last key-sort pass
     assert run({"MGS_LOOSE_MASK": "1"}) == ref     # compositor quarter masks from the footprint box only
     for shift in ("1,1", "2,3", "4,4"):
         a = run({"MGS_BIN_SHIFT": shift})

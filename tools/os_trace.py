@@ -1,0 +1,44 @@
+"""Debug-build experiment (csrc/k_osort.hip built with -DMGS_OS_TRACE): per-workgroup phase stamps of the key sort's passes on
+the garden-sized frame.  Usage: MGS_GRAPH=0 MGS_OS_TRACE_FILE=/tmp/o.bin python tools/os_trace.py [pose ...]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import vk_gaussian_splatting_amd as mgs
+from vk_gaussian_splatting_amd import capi, synth
+
+poses = [int(x) for x in sys.argv[1:]] or [0]
+W, H = 1920, 1080
+sc = synth.make_scene(5_830_000, seed=1)
+scene = mgs.Scene(0)
+scene.add_instance(mgs.SplatSet.from_arrays(**sc))
+scene.commit()
+names = ["table + zeroing", "loads + digits", "ranking", "publish + level-1 issue + scans + level-1 consume + level-2 issue", "LDS re-order + level-2 consume / poll", "scatter stores (drained)"]
+for pose in poses:
+    eye = synth.orbit_pose(pose)
+    V, P = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, W, H)
+    p = capi.default_params(W, H)
+    capi.set_camera(p, V, P, eye)
+    for _ in range(4):
+        scene.render(p, want_stats=True)
+    raw = np.fromfile(os.environ["MGS_OS_TRACE_FILE"], np.uint64)
+    maxp = int(raw[0])
+    a = raw[2:].reshape(4, maxp, 8)
+    for ps in range(4):
+        b = a[ps]
+        ran = b[:, 6] > 0
+        if not ran.any():
+            print(f"--- pose {pose} pass {ps}: did not run")
+            continue
+        b = b[ran].astype(np.int64)
+        base = b[:, 0].min()
+        st = (b[:, 0] - base) / 100.0
+        en = (b[:, 6] - base) / 100.0
+        ph = np.diff(b[:, :7], axis=1) / 100.0
+        cnt = b[:, 7] >> 32
+        spins = b[:, 7] & 0xFFFFFFFF
+        print(f"--- pose {pose} pass {ps}: {int(ran.sum())} workgroups; span {en.max():.1f} us; sum of durations {(en - st).sum():.0f} us "
+              f"(= {(en - st).sum() / en.max():.0f} resident on average); keys/workgroup median {np.median(cnt):.0f}; spins median {np.median(spins):.0f} max {spins.max()}")
+        print("   duration us 10/50/90/max:", np.percentile(en - st, [10, 50, 90, 100]).round(1), " start us 50/90/max:", np.percentile(st, [50, 90, 100]).round(1))
+        for i, n in enumerate(names):
+            print(f"   {n:34s} median {np.median(ph[:, i]):6.2f} us  p90 {np.percentile(ph[:, i], 90):6.2f}  total {ph[:, i].sum():8.0f} workgroup-us")

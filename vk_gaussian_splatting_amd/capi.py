@@ -375,6 +375,7 @@ class Scene:
 
     def render(self, params, want_stats=False):
         out = FrameOut()
+        self._sort_only = False
         _check(self._lib.mgs_render(self._h, C.byref(params), C.byref(out)))
         if want_stats and not params.collect_timings:
             _check(self._lib.mgs_frame_stats(self._h, C.byref(out)))
@@ -443,6 +444,7 @@ class Scene:
 
     def render_gathered(self, params):
         out = FrameOut()
+        self._sort_only = False
         _check(self._lib.mgs_render_gathered(self._h, C.byref(params), C.byref(out)))
         return out
 
@@ -464,14 +466,17 @@ class Scene:
     def sort_keys(self, params):
         out = SortOut()
         _check(self._lib.mgs_sort_keys(self._h, C.byref(params), C.byref(out)))
+        self._sort_only = True
         return out
 
     def sort_download(self, count):
-        keys = np.zeros(max(count, 1), np.uint32)
+        """(keys, ids) of the last sort.  The sorted keys exist after sort_keys() only: a frame's last sort pass writes the ids
+        alone, and keys is None then."""
         ids = np.zeros(max(count, 1), np.uint32)
-        _check(self._lib.mgs_sort_download(self._h, keys.ctypes.data_as(C.POINTER(C.c_uint32)),
-                                           ids.ctypes.data_as(C.POINTER(C.c_uint32)), keys.size))
-        return keys[:count], ids[:count]
+        keys = np.zeros(max(count, 1), np.uint32) if getattr(self, "_sort_only", False) else None
+        kp = keys.ctypes.data_as(C.POINTER(C.c_uint32)) if keys is not None else None
+        _check(self._lib.mgs_sort_download(self._h, kp, ids.ctypes.data_as(C.POINTER(C.c_uint32)), ids.size))
+        return (keys[:count] if keys is not None else None), ids[:count]
 
     def radix_sort_host(self, keys, values, begin_bit=0, end_bit=32):
         k = np.ascontiguousarray(keys, np.uint32).copy()

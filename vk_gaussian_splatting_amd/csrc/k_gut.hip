@@ -22,6 +22,7 @@
 #include "sh_eval.h"
 #include "surface_normal.h"
 #include "sort_plan.h"
+#include "slot_emit.h"
 
 namespace mgs {
 
@@ -257,25 +258,25 @@ __device__ __forceinline__ bool projectSplatGut(const FrameConst& F, const Insta
 // Phase 1 (key + frustum cull + ordered compaction) is k_project's, statement for statement: the sorted (key, id)
 // stream of a 3DGUT frame is bit-identical to the 3DGS frame's before the front-end rejections.
 __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __restrict__ Ap, FrameCounters* __restrict__ ctr,
-                                                             uint32_t* __restrict__ keysSlot, uint32_t* __restrict__ idsSlot,
-                                                             uint32_t* __restrict__ slotCount, GutRec* __restrict__ rec,
-                                                             uint32_t* __restrict__ rect, const uint32_t* __restrict__ partSkip,
-                                                             uint32_t* __restrict__ slotHist, uint32_t histStride, SortPlan* __restrict__ planKeys)
+                                                             uint2* __restrict__ densePairs, uint32_t* __restrict__ prjStatus,
+                                                             GutRec* __restrict__ rec, uint32_t* __restrict__ rect,
+                                                             const uint32_t* __restrict__ partSkip, uint32_t* __restrict__ slotHist2,
+                                                             uint32_t* __restrict__ top16Rec, uint32_t* __restrict__ top16Count,
+                                                             OsPlan* __restrict__ osPlan)
 {
   const FrameArgs& A = *Ap;
   if(partSkip != nullptr && (partSkip[blockIdx.x] & 1u) != 0u)
   {
-    if(threadIdx.x == 0)
-      slotCount[blockIdx.x] = 0u;
-    slotHist[(size_t)threadIdx.x * histStride + blockIdx.x] = 0u;
+    emitEmptySlot<kGutThreads>(prjStatus, A.f.totalPartitions, slotHist2, top16Rec, ctr, blockIdx.x);
     return;
   }
-  __shared__ uint32_t s_hist[256];
+  __shared__ uint32_t s_hist2[512];
   __shared__ uint16_t s_li[kGutPart];
   __shared__ uint32_t s_key[kGutPart];
   __shared__ uint32_t s_cnt[32];
   __shared__ uint32_t s_base[33];
-  s_hist[threadIdx.x] = 0u;
+  for(int i = threadIdx.x; i < 512; i += kGutThreads)
+    s_hist2[i] = 0u;
   const int      t = threadIdx.x, lane = laneId(), w = t >> 6;
   const uint32_t part = blockIdx.x;
   int            k    = 0;
@@ -329,7 +330,6 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
   if(t == 0 && Mv)
     atomicAdd(&ctr->frustumCount, Mv);
   // ---- 3DGUT front end over the survivors ----
-  const size_t slotBase = (size_t)part * kGutPart;
   // The 96-byte records leave through LDS (as k_project's do): every lane builds one record, then the wave stores its 64 records
   // six lanes per record, so that a store instruction covers whole sectors wherever neighbouring ids both survive (a wave's
   // survivors are mostly consecutive ids: 6 KB contiguous).  Written lane-per-record, each of the six instructions put 16 bytes
@@ -372,45 +372,9 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
-#pragma unroll
-  for(int r = 0; r < kGutItems; ++r)
-  {
-    const uint32_t j = r * kGutThreads + t;
-    vis[r]           = (j < Mv) && (s_li[j] & 0x8000u);
-    bal[r]           = __ballot(vis[r]);
-    if(lane == 0)
-      s_cnt[r * 4 + w] = (uint32_t)__popcll(bal[r]);
-  }
-  const uint32_t outCount = scanRoundWaveCounts(s_cnt, s_base);
-  uint32_t       tmn = 0xFFFFu, tmx = 0u;
-#pragma unroll
-  for(int r = 0; r < kGutItems; ++r)
-    if(vis[r])
-    {
-      const uint32_t j         = r * kGutThreads + t;
-      const uint32_t pos       = s_base[r * 4 + w] + lanesBelow(bal[r]);
-      keysSlot[slotBase + pos] = s_key[j];
-      idsSlot[slotBase + pos]  = I.globalOffset + local0 + (s_li[j] & 0x7FFFu);
-      atomicAdd(&s_hist[s_key[j] & 255u], 1u);
-      tmn = min(tmn, s_key[j] >> 16);
-      tmx = max(tmx, s_key[j] >> 16);
-    }
-  sortTop16Post<4>(tmn, tmx, s_cnt);  // pass elision of the key sort (sort_plan.h), as in k_project
-  if(t == 0)
-  {
-    slotCount[part] = outCount;
-    if(outCount)
-      atomicAdd(&ctr->sortedCount, outCount);
-  }
-  __syncthreads();
-  slotHist[(size_t)t * histStride + part] = s_hist[t];
-  if(sortTop16Mark<4>(planKeys, outCount, s_cnt))
-  {
-#pragma unroll
-    for(int r = 0; r < kGutItems; ++r)
-      if(vis[r])
-        sortMarkTop16(planKeys, s_key[r * kGutThreads + t] >> 16);
-  }
+  // second ordered compaction into the partition's slot + what the key sort needs up front (slot_emit.h)
+  emitSlot<kGutThreads, kGutItems>(Mv, false, s_li, s_key, s_cnt, s_base, s_hist2, densePairs, prjStatus, A.f.totalPartitions, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
+                                   I.globalOffset + local0);
 }
 
 // world-space ray direction of the pixel whose centre is (pcx, pcy) (threedgut_raster.frag.slang:101-111); false: outside the
@@ -986,14 +950,14 @@ __global__ __launch_bounds__(256) void k_composite_gut2(const FrameArgs* __restr
 
 // ---------------------------------------------------------------------------------------------
 void launchProjectGut(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, int shFormat, FrameCounters* ctr,
-                      uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, GutRec* rec, uint32_t* rect,
-                      const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride, SortPlan* planKeys)
+                      uint2* densePairs, uint32_t* prjStatus, GutRec* rec, uint32_t* rect, const uint32_t* partSkip,
+                      uint32_t* slotHist2, uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan)
 {
   (void)shFormat;
   if(args.f.totalPartitions == 0)
     return;
-  hipLaunchKernelGGL(k_project_gut, dim3(args.f.totalPartitions), dim3(kGutThreads), 0, stream, dArgs, ctr, keysSlot, idsSlot, slotCount,
-                     rec, rect, partSkip, slotHist, histStride, planKeys);
+  hipLaunchKernelGGL(k_project_gut, dim3(args.f.totalPartitions), dim3(kGutThreads), 0, stream, dArgs, ctr, densePairs, prjStatus, rec, rect,
+                     partSkip, slotHist2, top16Rec, top16Count, osPlan);
 }
 
 void launchCompositeGut(hipStream_t stream, const FrameArgs& A, const FrameArgs* dArgs, const uint2* ranges, const uint32_t* valX,

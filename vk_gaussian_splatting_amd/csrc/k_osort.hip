@@ -1,0 +1,763 @@
+// k_osort.hip — the frame's depth-key sort: stable LSD radix sort of (u32 key, u32 id) pairs in single-kernel passes.
+//
+// Behavioural spec: vrdxCmdSortKeyValueIndirect (3rdparty/vrdx/src/vk_radix_sort.cc:262-416: stable, ascending, 8-bit
+// digits, element count read on the device).  vrdx runs upsweep / spine / downsweep per pass (12 dispatches); the generic
+// sort of this build (k_sort.hip) runs histogram / scan / scatter per pass.  This file is what the in-frame key sort uses
+// instead: every pass is ONE kernel — each partition publishes its digit counts, resolves its digit prefixes from the
+// partitions before it while it ranks its keys, and scatters ("onesweep" structure; the look-back is re-designed for
+// MI355X, below) — and the digit totals every pass needs up front come for free from the producer:
+//   * k_project leaves a two-digit histogram per slot (bits 0-7 and 8-15, built while the keys are on chip) and, per wave, a
+//     record of how often each value of key >> 16 occurs (a partition is a compact cell of space: 1-3 values);
+//   * k_os_prepare reduces the slot histograms to totals, folds the records into a 64 K-entry count table (one atomic per
+//     occurring value per 32 slots) and turns the table into the totals of the upper passes: when at
+//     most 256 values of key >> 16 occur (depth keys span one or two binades) pass 2 sorts on the RANK of key >> 16 among
+//     them — an order-preserving 8-bit digit that covers the top 16 bits — and pass 3 does not run; otherwise plain digits.
+//   => launches per sort: prepare + 3 passes (+ 1 that exits at once), against 11 for reduce-then-scan with the elision.
+//
+// Look-back, re-designed: the classic chain resolves partition p from p-1, one dependent cross-CU load per hop; with all
+// ~1 000 partitions of a frame's sort resident at once that serialises (measured 1.27 us per hop, tools/micro/
+// lookback_rate.hip).  Here the prefix is resolved in TWO LEVELS of fan-in 32, every level one batch of independent loads:
+//   1. member m of a group sums the published counts of the m members before it (<= 31 loads in flight per thread);
+//   2. the group's last member publishes the group total, resolves the group's base with a windowed look-back over the
+//      GROUP totals (16 per batch, stopping at the first inclusive prefix) and publishes the inclusive group prefix;
+//   3. every member reads ONE word: the inclusive prefix of the previous group.
+// Three round trips whatever the partition count, overlapped with the ranking.  Status words carry flag and value in one
+// 32-bit word written by one relaxed agent-scope store (sc1: the data is the flag, no fence to order), polled with relaxed
+// agent-scope loads.  The level-1 loads are issued right after a partition has published its own counts and consumed behind
+// its ranking, the group level behind its LDS re-order: the round trips overlap the pass's own work.
+// Partition = blockIdx.x.  A workgroup waits only for lower-numbered ones, and the dispatcher starts the workgroups of a 1-D
+// grid in index order on every XCD, so whatever is waited for is running or done.  A ticket per workgroup (partitions in
+// observed start order) would not have to lean on that; it was measured and dropped: one word takes ~88 returning atomics
+// per microsecond (MI355X_MICROARCH.md "dequeue"), so the ~1 000 workgroups of a pass that start together wait up to 10 us
+// for their number.  Every spin is bounded: if the order were ever violated, the wait gives up and raises kErrSpinTimeout
+// (the frame is wrong, the GPU does not hang).
+//
+// Pairs travel interleaved (uint2): one 8-byte access per element, digit runs of 16 elements are 128 contiguous bytes; the
+// last pass writes the ids alone (the keys are dead; the sort-only hook asks for them explicitly).
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "kernels_common.h"
+#include "sort_plan.h"
+
+namespace mgs {
+
+namespace {
+constexpr int      kThreads = 256;
+constexpr int      kKpt     = kOsPart / kThreads;  // 16
+constexpr int      kWaves   = kThreads / 64;
+constexpr uint32_t kAgg = 1u << 30, kInc = 2u << 30, kValMask = (1u << 30) - 1u;
+constexpr int      kGroupWindow = 16;
+constexpr uint32_t kSpinMax     = 1u << 21;  // polls before a wait gives up (seconds; a healthy wait is a few polls)
+static_assert(kOsGroup == 32, "the member mask is one 32-bit word");
+
+__device__ __forceinline__ uint32_t ldAgent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void     stAgent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// exclusive scan of one value per digit over the 256 threads of the block
+__device__ __forceinline__ uint32_t scan256(uint32_t v, uint32_t* s_tmp /*4*/)
+{
+  const int      lane = laneId(), w = threadIdx.x >> 6;
+  const uint32_t inc  = waveInclusiveScan(v);
+  if(lane == 63)
+    s_tmp[w] = inc;
+  __syncthreads();
+  uint32_t base = 0;
+  if(w > 0) base += s_tmp[0];
+  if(w > 1) base += s_tmp[1];
+  if(w > 2) base += s_tmp[2];
+  __syncthreads();
+  return base + inc - v;
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// (a) uniform input only (the stand-alone sort API): digit totals of all four passes in one read of the keys
+__global__ __launch_bounds__(256) void k_os_hist(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ nPtr, OsPlan* __restrict__ plan)
+{
+  __shared__ uint32_t s_h[4][256];
+  const int      t = threadIdx.x;
+  const uint32_t n = *nPtr;
+  for(int q = 0; q < 4; ++q)
+    s_h[q][t] = 0u;
+  __syncthreads();
+  for(uint64_t i0 = (uint64_t)blockIdx.x * 2048u; i0 < n; i0 += (uint64_t)gridDim.x * 2048u)
+  {
+    uint32_t kk[8];
+#pragma unroll
+    for(int u = 0; u < 8; ++u)
+    {
+      const uint64_t i = i0 + (uint64_t)u * 256u + (uint64_t)t;
+      kk[u]            = keys[i < n ? i : (uint64_t)n - 1u];  // clamped, not predicated
+    }
+#pragma unroll
+    for(int u = 0; u < 8; ++u)
+      if(i0 + (uint64_t)u * 256u + (uint64_t)t < n)
+      {
+#pragma unroll
+        for(int q = 0; q < 4; ++q)
+          atomicAdd(&s_h[q][(kk[u] >> (8 * q)) & 255u], 1u);
+      }
+  }
+  __syncthreads();
+#pragma unroll
+  for(int q = 0; q < 4; ++q)
+    if(s_h[q][t])
+      atomicAdd(&plan->total[q][t], s_h[q][t]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// (b) prepare: the digit totals of all passes from what the producer left, and the look-back state of pass 0 zeroed.
+// Grid: reduce workgroups of 1024 threads, 32 slots each (+ idle ones that only zero).  A reduce workgroup
+//   * sums its slots' two-digit histograms into plan->total[0..1] (<= 512 atomics, one per non-empty bin);
+//   * folds its slots' key >> 16 records (slot_emit.h: one 32-word record per producer wave: counts of the values lo..lo+24)
+//     in an LDS table and adds each occurring value ONCE to the 64 K-entry count table.  The producers do not touch that
+//     table themselves: thousands of partitions hold the same handful of values, and that many atomics on a few addresses
+//     serialise (measured: 0.13 -> 0.55 ms for k_project).  Partitions that span more than 24 values (a cell around the
+//     camera) are the exception: their keys are spread over many addresses and were added one by one.
+// The workgroup that finishes last (arrival counter) then owns the occurring range of the table: at most 256 values within a
+// span < 4096 -> pass 2 sorts on their rank and the table gives that pass's totals; otherwise plain digits for passes 2 and 3.
+// It clears what it read, so the table is clean for the next sort of this context.
+__global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict__ slotHist2, const uint32_t* __restrict__ top16Rec, uint32_t prjParts,
+                                                     uint32_t* __restrict__ top16Count, OsPlan* __restrict__ plan, const uint32_t* __restrict__ nPtr,
+                                                     int allowRemap, uint32_t* __restrict__ zStatus, uint32_t zWords, uint32_t reduceWgs)
+{
+  const int t = threadIdx.x, lane = laneId(), w = t >> 6;
+  // every workgroup clears its share of pass 0's look-back words (they were last written by an earlier sort's pass 2)
+  for(uint32_t i = blockIdx.x * 1024u + t; i < zWords; i += gridDim.x * 1024u)
+    zStatus[i] = 0u;
+  if(blockIdx.x == 0 && t == 0)
+    plan->n = *nPtr;
+  if(slotHist2 == nullptr || blockIdx.x >= reduceWgs)
+    return;
+  __shared__ uint32_t s_part[512];
+  __shared__ uint32_t s_tab[2048];
+  __shared__ uint32_t s_hdr[128];
+  __shared__ uint32_t s_lo, s_hi, s_last;
+  __shared__ uint32_t s_tmp[16], s_mm[32];
+  const uint32_t slot0 = blockIdx.x * 32u;
+  {  // two-digit histograms: thread = (half of the slots, bin column)
+    const uint32_t col = t & 511u, half = t >> 9;
+    uint32_t       acc = 0;
+#pragma unroll 4
+    for(uint32_t q = half; q < 32u; q += 2u)
+      if(slot0 + q < prjParts)
+        acc += slotHist2[(size_t)(slot0 + q) * 512u + col];
+    if(half == 1)
+      s_part[col] = acc;
+    s_tab[t]         = 0u;
+    s_tab[t + 1024u] = 0u;
+    if(t == 0)
+    {
+      s_lo = 0xFFFFu;
+      s_hi = 0u;
+    }
+    __syncthreads();
+    if(half == 0)
+    {
+      acc += s_part[col];
+      if(acc)
+        atomicAdd(&plan->total[col >> 8][col & 255u], acc);
+    }
+  }
+  // key >> 16 records of the 32 slots x 4 producer waves: header word 31 = lo | span << 16 (0xFFFFFFFF: nothing to fold)
+  if(t < 128)
+  {
+    const uint32_t slot = slot0 + (uint32_t)t / 4u;
+    const uint32_t hdr  = slot < prjParts ? top16Rec[((size_t)slot * 4u + ((uint32_t)t & 3u)) * 32u + 31u] : 0xFFFFFFFFu;
+    s_hdr[t]            = hdr;
+    if(hdr != 0xFFFFFFFFu)
+    {
+      atomicMin(&s_lo, hdr & 0xFFFFu);
+      atomicMax(&s_hi, (hdr & 0xFFFFu) + (hdr >> 16));
+    }
+  }
+  __syncthreads();
+  {
+    const uint32_t r = (uint32_t)t >> 3, j0 = ((uint32_t)t & 7u) * 4u, hdr = s_hdr[r];
+    if(hdr != 0xFFFFFFFFu && j0 <= (hdr >> 16))
+    {
+      const uint32_t slot = slot0 + r / 4u;
+      const uint4    c    = *reinterpret_cast<const uint4*>(&top16Rec[((size_t)slot * 4u + (r & 3u)) * 32u + j0]);
+      const uint32_t cv[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+      for(int j = 0; j < 4; ++j)
+        if(j0 + j <= (hdr >> 16) && cv[j])
+        {
+          const uint32_t v = (hdr & 0xFFFFu) + j0 + j, idx = v - s_lo;
+          if(idx < 2048u)
+            atomicAdd(&s_tab[idx], cv[j]);
+          else
+            atomicAdd(&top16Count[v], cv[j]);
+        }
+    }
+  }
+  __syncthreads();
+  for(uint32_t b = t; b < 2048u; b += 1024u)
+    if(s_tab[b])
+      atomicAdd(&top16Count[s_lo + b], s_tab[b]);
+  if(t == 0 && s_hi >= s_lo && s_lo != 0xFFFFu)
+  {  // occurring range over all workgroups (the plan is zeroed per sort: both as maxima)
+    atomicMax(&plan->top16MinInv, 0x10000u - s_lo);
+    atomicMax(&plan->top16MaxP1, s_hi + 1u);
+  }
+  // ---- arrival: the last workgroup folds the table.  Every wave drains its own atomics (they are performed at the memory
+  // side, so "acknowledged" is "visible"), then one lane takes the ticket: no fence by 1024 threads ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if(t == 0)
+    s_last = (atomicAdd(&plan->arrived, 1u) == reduceWgs - 1u) ? 1u : 0u;
+  __syncthreads();
+  if(!s_last)
+    return;
+  const uint32_t minInv = ldAgent(&plan->top16MinInv), maxP1 = ldAgent(&plan->top16MaxP1);
+  if(minInv == 0u || maxP1 == 0u)
+  {  // no keys at all
+    if(t == 0)
+      plan->remapOn = plan->remapCount = plan->remapBase = 0u;
+    return;
+  }
+  const uint32_t vlo = 0x10000u - minInv, span = maxP1 - vlo;  // values vlo .. vlo + span - 1
+  if(span <= kRemapSpan - 1u)
+  {  // thread t owns 4 consecutive values; ordered compaction by a block scan
+    uint32_t c[4], nz = 0;
+#pragma unroll
+    for(int i = 0; i < 4; ++i)
+    {
+      const uint32_t k = (uint32_t)t * 4u + i;
+      c[i]             = k < span ? ldAgent(&top16Count[vlo + k]) : 0u;
+      if(k < span)
+        top16Count[vlo + k] = 0u;  // consumed: clean for the next sort of this context
+      nz += c[i] ? 1u : 0u;
+    }
+    const uint32_t inc = waveInclusiveScan(nz);
+    if(lane == 63)
+      s_tmp[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for(int q = 0; q < 16; ++q)
+    {
+      if(q < w) base += s_tmp[q];
+      total += s_tmp[q];
+    }
+    const bool on = allowRemap != 0 && total >= 1u && total <= 256u;
+    uint32_t   run = base + inc - nz;
+    if(t < 256)
+      s_part[t] = s_part[256 + t] = 0u;
+    __syncthreads();
+#pragma unroll
+    for(int i = 0; i < 4; ++i)
+      if(c[i])
+      {
+        const uint32_t v = vlo + (uint32_t)t * 4u + i;
+        if(on)
+        {
+          plan->remapVals[run] = (uint16_t)v;
+          plan->total[2][run]  = c[i];  // pass 2 sorts on the rank
+          ++run;
+        }
+        else
+        {
+          atomicAdd(&s_part[v & 255u], c[i]);
+          atomicAdd(&s_part[256u + (v >> 8)], c[i]);
+        }
+      }
+    __syncthreads();
+    if(!on && t < 256)
+    {
+      plan->total[2][t] = s_part[t];
+      plan->total[3][t] = s_part[256 + t];
+    }
+    if(t == 0)
+    {
+      plan->remapOn    = on ? 1u : 0u;
+      plan->remapCount = on ? total : 0u;
+      plan->remapBase  = on ? vlo : 0u;
+    }
+    return;
+  }
+  // wide range (camera inside the cloud): plain digits of bits 16-23 and 24-31
+  if(t < 256)
+    s_part[t] = s_part[256 + t] = 0u;
+  __syncthreads();
+  for(uint32_t k = t; k < span; k += 1024u)
+  {
+    const uint32_t c = ldAgent(&top16Count[vlo + k]);
+    if(c)
+    {
+      const uint32_t v   = vlo + k;
+      top16Count[v]      = 0u;
+      atomicAdd(&s_part[v & 255u], c);
+      atomicAdd(&s_part[256u + (v >> 8)], c);
+    }
+  }
+  __syncthreads();
+  if(t < 256)
+  {
+    plan->total[2][t] = s_part[t];
+    plan->total[3][t] = s_part[256 + t];
+  }
+  if(t == 0)
+    plan->remapOn = plan->remapCount = plan->remapBase = 0u;
+  (void)s_mm;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// (c) one pass.  IN: 0 pairs (every pass of a frame: the project kernels emit one dense array), 2 split key / value arrays
+// (pass 0 of the stand-alone sort).
+#ifdef MGS_OS_TRACE  // debug build (tools/os_trace.py): per-workgroup wall-clock stamps (100 MHz) of the phases of every pass
+#define MGS_OS_STAMP(i) if(threadIdx.x == 0) trc[i] = wall_clock64();
+#else
+#define MGS_OS_STAMP(i)
+#endif
+struct OsPassArgs
+{
+#ifdef MGS_OS_TRACE
+  uint64_t* trace;  // [partition][8]
+#endif
+  const uint2*    srcPairs;
+  const uint32_t* srcKeys;
+  const uint32_t* srcVals;
+  uint2*          dstPairs;
+  uint32_t*       dstKeys;  // final pass: may be null (the frame does not need the keys again)
+  uint32_t*       dstVals;
+  OsPlan*         plan;
+  SortPlan*       planOut;  // what the consumers of the sorted ids read: n, finalSel (always 0 here), passesRun
+  uint32_t*       status;   // [maxParts][256] this pass: one 1 KB row of digit counts per partition
+  uint32_t*       gstatus;  // [ceil(maxParts / 32)][256]
+  uint32_t*       zStatus;  // the other buffer: cleared here for the next pass
+  uint32_t        zWords;
+  const uint32_t* nPtr;
+  FrameCounters*  ctr;
+  int             pass;
+  int             digitMode;  // 0 plain byte `pass`; 1 pass 2: rank of key >> 16 when the plan says remap, else plain; 2 pass 3: exits when remapped
+  int             finalMode;  // 0 writes pairs; 1 writes the result; 2 writes the result iff the plan says remap (pass 2)
+};
+
+template <int IN, bool REMAP>
+__global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
+{
+  __shared__ uint2    s_pair[kOsPart];       // 32 KB: the partition's pairs ordered by digit
+  __shared__ uint16_t s_whist[kWaves][256];  //  2 KB: per wave digit counts -> offsets
+  __shared__ uint16_t s_loff[256];           //  partition-local exclusive digit offsets
+  __shared__ uint32_t s_cnt[256];            //  digit counts of the partition, later the global base of every digit
+  __shared__ uint8_t  s_rv[REMAP ? kRemapSpan : 4];  // 4 KB: rank table of key >> 16 (remapped pass)
+  __shared__ uint32_t s_tmp[8];
+
+  const int t = threadIdx.x, lane = laneId(), w = t >> 6;
+  OsPlan*   plan = a.plan;
+  const bool remapped = plan->remapOn != 0u;
+  if(a.digitMode == 2 && remapped)
+    return;  // pass 2 sorted on the rank of the top 16 bits and wrote the result
+#ifdef MGS_OS_TRACE
+  __shared__ uint64_t trc[8];
+  MGS_OS_STAMP(0)
+#endif
+  // clear the other look-back buffer for the next pass (stream order: nobody reads it any more)
+  for(uint32_t i = blockIdx.x * kThreads + t; i < a.zWords; i += gridDim.x * kThreads)
+    a.zStatus[i] = 0u;
+  for(int i = t; i < kWaves * 256; i += kThreads)
+    (&s_whist[0][0])[i] = 0;
+  const bool useRemap = REMAP && remapped;
+  if constexpr(REMAP)
+    if(useRemap)
+    {  // every entry holds the largest rank first: a value outside the table (padding keys) sorts behind every real key
+      const uint32_t count = plan->remapCount, base = plan->remapBase;
+      const uint32_t fill  = (count - 1u) * 0x01010101u;
+      for(int i = t; i < (int)kRemapSpan / 4; i += kThreads)
+        reinterpret_cast<uint32_t*>(s_rv)[i] = fill;
+      __syncthreads();
+      for(uint32_t i = t; i < count; i += kThreads)
+        s_rv[(uint32_t)plan->remapVals[i] - base] = (uint8_t)i;
+    }
+  __syncthreads();
+  const uint32_t p = blockIdx.x;  // partitions in dispatch order (header: why no ticket)
+  const uint32_t n     = *a.nPtr;
+  const uint32_t parts = (uint32_t)(((uint64_t)n + kOsPart - 1u) / kOsPart);
+  if(p >= parts)
+    return;
+  const bool finalOut = a.finalMode == 1 || (a.finalMode == 2 && remapped);
+  if(p == 0 && t == 0 && a.planOut != nullptr && (finalOut || a.digitMode == 2))
+  {
+    a.planOut->n         = plan->n;
+    a.planOut->finalSel  = 0u;
+    a.planOut->passesRun = (uint32_t)a.pass + 1u;
+  }
+
+  // ---- load: wave w owns a contiguous quarter of the partition, lane-interleaved, so (wave, round, lane) is memory order.
+  // The rounds adapt to the element count (the last partition is ragged).
+  const uint32_t count = (uint32_t)min((uint64_t)kOsPart, (uint64_t)n - (uint64_t)p * kOsPart);
+  const uint32_t rounds = (count + kThreads - 1u) / kThreads;  // per wave: `rounds` rounds of 64 keys
+  const uint32_t wofs   = w * 64u * rounds;
+  uint32_t       key[kKpt], val[kKpt];
+  MGS_OS_STAMP(1)
+  // clamped, not predicated: a predicated load becomes a branch + wait and serialises the fetches
+#pragma unroll
+  for(int i = 0; i < kKpt; ++i)
+  {
+    key[i] = 0xFFFFFFFFu;
+    val[i] = 0u;
+    if((uint32_t)i < rounds)  // wave-uniform
+    {
+      const uint32_t idx = min(wofs + (uint32_t)i * 64u + lane, count - 1u);
+      if(IN == 2)
+      {
+        key[i] = a.srcKeys[(size_t)p * kOsPart + idx];
+        val[i] = a.srcVals[(size_t)p * kOsPart + idx];
+      }
+      else
+      {
+        const uint2 kv = a.srcPairs[(size_t)p * kOsPart + idx];
+        key[i] = kv.x;
+        val[i] = kv.y;
+      }
+    }
+  }
+#pragma unroll
+  for(int i = 0; i < kKpt; ++i)
+    if(wofs + (uint32_t)i * 64u + lane >= count)
+    {
+      key[i] = 0xFFFFFFFFu;
+      val[i] = 0u;
+    }
+  const int      shift = 8 * a.pass;
+  const uint32_t rbase = plan->remapBase;
+  uint32_t       rd[kKpt];  // digit << 16 | rank inside the wave (one register per key)
+#pragma unroll
+  for(int i = 0; i < kKpt; ++i)
+  {
+    uint32_t d;
+    if(REMAP && useRemap)
+      d = s_rv[min((key[i] >> 16) - rbase, kRemapSpan - 1u)];
+    else
+      d = (key[i] >> shift) & 255u;
+    rd[i] = d << 16;
+  }
+  const uint32_t g = p / kOsGroup, m = p % kOsGroup;
+  MGS_OS_STAMP(2)
+
+  // ---- (the look-back is software-pipelined with the rest of the pass: level 1 is issued right after the partition's own
+  // counts are published, behind the ranking, and consumed behind the scans; level 2 travels behind the LDS re-order) ----
+
+  // ---- per-wave multi-split: rank of each key among the keys of its wave with the same digit (stable) ----
+#pragma unroll
+  for(int i = 0; i < kKpt; ++i)
+  {
+    if((uint32_t)i < rounds)  // wave-uniform: skipped rounds hold nothing
+    {
+      // padding lanes (idx >= count) carry key 0xFFFFFFFF: the largest digit, behind every real key of the partition
+      // lanes holding the same digit: per bit, x = 0 / ~0 from the bit (one bfe), the ballot of the bit, and
+      // mask &= ~(ballot ^ x) on both halves — 6 vector instructions per bit
+      const uint32_t d = rd[i] >> 16;
+      uint32_t       mlo = ~0u, mhi = ~0u;
+#pragma unroll
+      for(int b = 0; b < 8; ++b)
+      {
+        const uint32_t x   = (uint32_t)((int32_t)(d << (31 - b)) >> 31);
+        const uint64_t bal = __ballot(x != 0u);
+        mlo &= ~((uint32_t)bal ^ x);
+        mhi &= ~((uint32_t)(bal >> 32) ^ x);
+      }
+      const uint32_t lower = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+      const uint32_t cnt   = (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
+      const uint32_t pre   = s_whist[w][d];
+      rd[i] |= pre + lower;
+      __builtin_amdgcn_wave_barrier();  // every lane of the group has read `pre` before the leader bumps it
+      if(lower == 0)
+        s_whist[w][d] = (uint16_t)(pre + cnt);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  MGS_OS_STAMP(3)
+  // thread t == digit t: the partition's count of digit t (the ranking counted the padding lanes too: they sit in the
+  // largest digit) -> published; per wave offsets
+  uint32_t tot = 0;
+#pragma unroll
+  for(int q = 0; q < kWaves; ++q)
+  {
+    const uint32_t c = s_whist[q][t];
+    s_whist[q][t]    = (uint16_t)tot;
+    tot += c;
+  }
+  const uint32_t padDigit = (REMAP && useRemap) ? plan->remapCount - 1u : 255u;
+  const uint32_t myCount  = tot - (((uint32_t)t == padDigit) ? rounds * kThreads - count : 0u);
+  stAgent(&a.status[(size_t)p * 256u + t], kAgg | myCount);
+  // Level 1 by rows: the counts a member published are one 1 KB row (256 digits).  Wave w folds the rows w, w + 4, ... of the
+  // members before me for four digits per lane (lane l: digits 4 l .. 4 l + 3);
+  // the four waves' partial sums meet in LDS.  Issued now, consumed behind the scans.
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  const uint32_t wu = (uint32_t)__builtin_amdgcn_readfirstlane(w);  // the compiler does not know that the wave index is uniform
+  // four dword sc1 loads per lane and row (a wave instruction covers 256 contiguous bytes).  One 16-byte
+  // buffer_load_dwordx4 ... sc1 per lane was tried and does NOT work: re-polls kept returning the zeros of the first read
+  // (every wait ran into its bound), while dword / dwordx2 sc1 loads of the same words see the update.
+  auto loadRow = [&](uint32_t row) -> v4u {
+    const uint32_t* q = a.status + ((size_t)g * kOsGroup + row) * 256u + (uint32_t)lane * 4u;
+    return v4u{ldAgent(q), ldAgent(q + 1), ldAgent(q + 2), ldAgent(q + 3)};
+  };
+  v4u rv[8];
+#pragma unroll
+  for(int k = 0; k < 8; ++k)
+  {
+    const uint32_t row = wu + 4u * k;
+    rv[k]              = v4u{kAgg, kAgg, kAgg, kAgg};
+    if(row < m)
+      rv[k] = loadRow(row);
+  }
+  // local exclusive scan over the digits (padding included)
+  const uint32_t loff = scan256(tot, s_tmp);
+  s_loff[t]           = (uint16_t)loff;
+  // digit bases of the whole array: exclusive scan of the totals (known before the pass started)
+  const uint32_t below = scan256(plan->total[a.pass][t], s_tmp);
+  uint32_t spins = 0;
+  bool     bad   = false;
+  {
+    uint32_t acc[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for(int k = 0; k < 8; ++k)
+    {
+      const uint32_t row = wu + 4u * k;
+      if(row < m)
+      {
+        // a member that had not published all four words when they were read: re-poll its row
+        while(((rv[k].x >> 30) == 0u || (rv[k].y >> 30) == 0u || (rv[k].z >> 30) == 0u || (rv[k].w >> 30) == 0u) && !bad)
+        {
+          rv[k] = loadRow(row);
+          if(++spins > kSpinMax)
+            bad = true;
+        }
+        acc[0] += rv[k].x & kValMask;
+        acc[1] += rv[k].y & kValMask;
+        acc[2] += rv[k].z & kValMask;
+        acc[3] += rv[k].w & kValMask;
+      }
+    }
+    // s_pair is not in use yet: its first 4 KB carry the four waves' partial sums
+    reinterpret_cast<uint4*>(s_pair)[wu * 64 + lane] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+  }
+  __syncthreads();
+  const uint32_t* s_l1  = reinterpret_cast<const uint32_t*>(s_pair);
+  const uint32_t  intra = s_l1[t] + s_l1[256 + t] + s_l1[512 + t] + s_l1[768 + t];
+  // level 2: the group's last member publishes the group total and looks back over the groups (16 per batch, down to the
+  // first inclusive prefix); its window loads travel behind the LDS re-order
+  const bool     lastMember = m == kOsGroup - 1u;
+  const uint32_t gtotal     = intra + myCount;
+  uint32_t       gw[kGroupWindow];
+  int            gq = (int)g - 1;
+  if(lastMember)
+  {
+    stAgent(&a.gstatus[(size_t)g * 256u + t], kAgg | gtotal);
+#pragma unroll
+    for(int j = 0; j < kGroupWindow; ++j)
+      gw[j] = (gq - j >= 0) ? ldAgent(&a.gstatus[(size_t)(gq - j) * 256u + t]) : kInc;
+  }
+  __syncthreads();  // everybody has read the partial sums: s_pair may be overwritten
+  MGS_OS_STAMP(4)
+  // ---- re-order through LDS so that equal digits are contiguous ----
+#pragma unroll
+  for(int i = 0; i < kKpt; ++i)
+    if((uint32_t)i < rounds)
+    {
+      const uint32_t d   = rd[i] >> 16;
+      const uint32_t pos = (uint32_t)s_loff[d] + (uint32_t)s_whist[w][d] + (rd[i] & 0xFFFFu);
+      s_pair[pos]        = make_uint2(key[i], val[i]);
+    }
+  uint32_t base = 0;
+  if(lastMember)
+  {
+    bool first = true;
+    while(gq >= 0 && !bad)
+    {
+      if(!first)
+      {
+#pragma unroll
+        for(int j = 0; j < kGroupWindow; ++j)
+          gw[j] = (gq - j >= 0) ? ldAgent(&a.gstatus[(size_t)(gq - j) * 256u + t]) : kInc;
+      }
+      first     = false;
+      bool done = false;
+#pragma unroll
+      for(int j = 0; j < kGroupWindow; ++j)
+      {
+        if(done)
+          continue;
+        if((gw[j] >> 30) == 0u)
+        {  // not published yet: resume the window at this group
+          done = true;
+          gq -= j;
+          if(++spins > kSpinMax)
+            bad = true;
+          continue;
+        }
+        base += gw[j] & kValMask;
+        if((gw[j] >> 30) == 2u)
+        {
+          done = true;
+          gq   = -1;
+        }
+        else if(j == kGroupWindow - 1)
+        {
+          done = true;
+          gq -= kGroupWindow;
+        }
+      }
+    }
+    stAgent(&a.gstatus[(size_t)g * 256u + t], kInc | ((base + gtotal) & kValMask));
+  }
+  else if(g > 0u)
+  {  // everybody else: the inclusive prefix of the previous group is one word
+    uint32_t v;
+    while(((v = ldAgent(&a.gstatus[(size_t)(g - 1u) * 256u + t])) >> 30) != 2u)
+      if(++spins > kSpinMax)
+      {
+        bad = true;
+        break;
+      }
+    base = v & kValMask;
+  }
+  if(bad)
+    atomicOr(&a.ctr->errorFlags, kErrSpinTimeout);
+  s_cnt[t] = below + (base + intra) - loff;  // wraps are fine: only base + idx is used
+  __syncthreads();
+  MGS_OS_STAMP(5)
+
+  // ---- coalesced scatter: consecutive threads write consecutive addresses inside each digit run ----
+#pragma unroll
+  for(int i = 0; i < kKpt; ++i)
+    if((uint32_t)i < rounds)
+    {
+      const uint32_t idx = (uint32_t)i * kThreads + t;
+      if(idx < count)
+      {
+        const uint2 kv = s_pair[idx];
+        uint32_t    d;
+        if(REMAP && useRemap)
+          d = s_rv[min((kv.x >> 16) - rbase, kRemapSpan - 1u)];
+        else
+          d = (kv.x >> shift) & 255u;
+        const uint32_t dst = s_cnt[d] + idx;
+        if(finalOut)
+        {
+          a.dstVals[dst] = kv.y;
+          if(a.dstKeys != nullptr)
+            a.dstKeys[dst] = kv.x;
+        }
+        else
+          a.dstPairs[dst] = kv;
+      }
+    }
+#ifdef MGS_OS_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  MGS_OS_STAMP(6)
+  if(t == 0 && a.trace)
+  {
+    uint64_t* o = a.trace + (size_t)p * 8;
+    for(int i = 0; i < 7; ++i) o[i] = trc[i];
+    o[7] = ((uint64_t)count << 32) | spins;
+  }
+#endif
+}
+
+// small state clear for the stand-alone sort (inside a frame the frame-init kernel zeroes the plan)
+__global__ void k_os_plan_clear(OsPlan* plan)
+{
+  uint32_t* w = reinterpret_cast<uint32_t*>(plan);
+  for(uint32_t i = threadIdx.x; i < sizeof(OsPlan) / 4; i += blockDim.x)
+    w[i] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+uint32_t osSortMaxParts(uint32_t maxElems)
+{
+  return (uint32_t)(((uint64_t)maxElems + kOsPart - 1u) / kOsPart);
+}
+size_t osSortStatusWords(uint32_t maxParts)
+{  // per buffer: partition rows [partition][digit] (rounded up to whole groups) followed by group rows [group][digit]
+  const size_t groups = (maxParts + kOsGroup - 1u) / kOsGroup + 1u;
+  return groups * 256u * kOsGroup + groups * 256u;
+}
+
+void launchOsSortClearPlan(hipStream_t stream, OsPlan* plan)
+{
+  hipLaunchKernelGGL(k_os_plan_clear, dim3(1), dim3(256), 0, stream, plan);
+}
+
+void launchOsSort(hipStream_t stream, const OsLaunch& L)
+{
+  if(L.maxElems == 0)
+    return;
+  const bool     frame    = L.pairs0 != nullptr;  // the project kernels' dense pairs + their histograms / records
+  const uint32_t maxParts = osSortMaxParts(L.maxElems);
+  const uint32_t sWords   = (uint32_t)osSortStatusWords(maxParts);
+  uint32_t*      st[2]    = {L.status, L.status + sWords};
+  auto gOf = [&](uint32_t* s) { return s + (size_t)((maxParts + kOsGroup - 1u) / kOsGroup + 1u) * 256u * kOsGroup; };
+  if(!frame)
+    hipLaunchKernelGGL(k_os_hist, dim3(std::min<uint32_t>((L.maxElems + 2047u) / 2048u, 1024u)), dim3(256), 0, stream, L.keys0, L.nPtr, L.plan);
+  const uint32_t reduceWgs = frame ? (L.prjParts + 31u) / 32u : 0u;
+  hipLaunchKernelGGL(k_os_prepare, dim3(std::max(reduceWgs, 16u)), dim3(1024), 0, stream, frame ? L.slotHist2 : nullptr, L.top16Rec, L.prjParts,
+                     L.top16Count, L.plan, L.nPtr, (frame && L.allowRemap) ? 1 : 0, st[0], sWords, reduceWgs);
+#ifdef MGS_OS_TRACE
+  static uint64_t* traceBuf = nullptr;
+  const char*      tracePath = std::getenv("MGS_OS_TRACE_FILE");
+  const size_t     traceN = (size_t)maxParts * 8;
+  if(tracePath && frame)
+  {
+    if(!traceBuf)
+      (void)hipMalloc(&traceBuf, (size_t)4 << 24);
+    (void)hipMemsetAsync(traceBuf, 0, 4 * traceN * 8, stream);
+  }
+#endif
+  for(int pass = 0; pass < 4; ++pass)
+  {
+    OsPassArgs a{};
+#ifdef MGS_OS_TRACE
+    a.trace = (tracePath && frame) ? traceBuf + (size_t)pass * traceN : nullptr;
+#endif
+    a.plan    = L.plan;
+    a.planOut = L.planOut;
+    a.status  = st[pass & 1];
+    a.gstatus = gOf(st[pass & 1]);
+    a.zStatus = st[(pass + 1) & 1];
+    a.zWords  = sWords;
+    a.nPtr    = L.nPtr;
+    a.ctr     = L.ctr;
+    a.pass    = pass;
+    a.dstKeys = L.outKeys;
+    a.dstVals = L.outVals;
+    // pass 0 -> A, 1 -> B, 2 -> A (or the result), 3 -> the result.  A frame's pass 0 reads the dense pairs, which live in B.
+    a.srcPairs  = (pass == 0) ? L.pairs0 : ((pass & 1) ? L.pairA : L.pairB);
+    a.dstPairs  = (pass & 1) ? L.pairB : L.pairA;
+    a.srcKeys   = L.keys0;
+    a.srcVals   = L.vals0;
+    a.digitMode = (pass == 2 && frame) ? 1 : (pass == 3 ? 2 : 0);
+    a.finalMode = (pass == 3) ? 1 : ((pass == 2 && frame) ? 2 : 0);
+    const uint32_t grid = maxParts;
+    if(grid == 0)
+      continue;
+    if(pass == 0 && !frame)
+      hipLaunchKernelGGL((k_os_pass<2, false>), dim3(grid), dim3(kThreads), 0, stream, a);
+    else if(pass == 2 && frame)
+      hipLaunchKernelGGL((k_os_pass<0, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+    else
+      hipLaunchKernelGGL((k_os_pass<0, false>), dim3(grid), dim3(kThreads), 0, stream, a);
+  }
+#ifdef MGS_OS_TRACE
+  if(tracePath && frame)
+  {
+    (void)hipStreamSynchronize(stream);
+    std::vector<uint64_t> h(4 * traceN);
+    (void)hipMemcpy(h.data(), traceBuf, 4 * traceN * 8, hipMemcpyDeviceToHost);
+    if(FILE* fp = std::fopen(tracePath, "wb"))
+    {
+      const uint64_t hdr[2] = {maxParts, 0};
+      std::fwrite(hdr, 8, 2, fp);
+      std::fwrite(h.data(), 8, 4 * traceN, fp);
+      std::fclose(fp);
+    }
+  }
+#endif
+}
+
+}  // namespace mgs

@@ -22,6 +22,7 @@
 #include <vector>
 #include "kernels_common.h"
 #include "sort_plan.h"
+#include "slot_emit.h"
 
 namespace mgs {
 
@@ -185,10 +186,6 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   return true;
 }
 
-// pass elision of the key sort: sortTop16Post / sortTop16Mark (sort_plan.h)
-__device__ __forceinline__ void top16Post(uint32_t mn, uint32_t mx, uint32_t* s_red) { sortTop16Post<kPrjWaves>(mn, mx, s_red); }
-__device__ __forceinline__ bool top16Mark(SortPlan* plan, uint32_t count, const uint32_t* s_red) { return sortTop16Mark<kPrjWaves>(plan, count, s_red); }
-
 #ifdef MGS_PRJ_TRACE  // debug build (tools/prj_trace.py): per-workgroup wall-clock stamps (100 MHz) of the phases
 __device__ uint64_t* g_prjTrace = nullptr;
 #define MGS_PRJ_STAMP(i) if(threadIdx.x == 0) trc[i] = wall_clock64();
@@ -197,11 +194,11 @@ __device__ uint64_t* g_prjTrace = nullptr;
 #endif
 template <bool FULL>
 __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __restrict__ Ap, FrameCounters* __restrict__ ctr,
-                                                         uint32_t* __restrict__ keysSlot, uint32_t* __restrict__ idsSlot,
-                                                         uint32_t* __restrict__ slotCount, SplatRec* __restrict__ rec,
-                                                         uint32_t* __restrict__ rect, const uint32_t* __restrict__ partSkip,
-                                                         uint32_t* __restrict__ slotHist, uint32_t histStride,
-                                                         SortPlan* __restrict__ planKeys, const float* __restrict__ partR)
+                                                         uint2* __restrict__ densePairs, uint32_t* __restrict__ prjStatus,
+                                                         SplatRec* __restrict__ rec, uint32_t* __restrict__ rect,
+                                                         const uint32_t* __restrict__ partSkip, uint32_t* __restrict__ slotHist2,
+                                                         uint32_t* __restrict__ top16Rec, uint32_t* __restrict__ top16Count,
+                                                         OsPlan* __restrict__ osPlan, const float* __restrict__ partR)
 {
   const FrameArgs& A = *Ap;  // frame constants live in device memory (same pointer every frame: graph-replayable)
 #ifdef MGS_PRJ_TRACE
@@ -209,22 +206,19 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   if(threadIdx.x < 8) trc[threadIdx.x] = 0;
   MGS_PRJ_STAMP(0)
 #endif
-  // slotHist[d * histStride + partition] = survivors of this partition whose low key byte is d: the radix
-  // sort's pass-0 partition histogram, produced here while the keys are still on chip.
+  // slotHist2[partition][2][256]: this partition's survivors by key bits 0-7 and 8-15 (slot_emit.h), produced here while
+  // the keys are still on chip.
   // partition flags of k_partition_cull: bit 0 skip, bit 1 every centre passes the frustum test, bit 2 all centres finite
   const uint32_t pflag = partSkip != nullptr ? partSkip[blockIdx.x] : 0u;
   if(pflag & 1u)
   {  // k_partition_cull proved that no splat of this partition can survive the cull / reach the strip
-    if(threadIdx.x == 0)
-      slotCount[blockIdx.x] = 0u;
-    if(threadIdx.x < 256)
-      slotHist[(size_t)threadIdx.x * histStride + blockIdx.x] = 0u;
+    emitEmptySlot<kPrjThreads>(prjStatus, A.f.totalPartitions, slotHist2, top16Rec, ctr, blockIdx.x);
     return;
   }
-  __shared__ uint32_t s_hist[256];
+  __shared__ uint32_t s_hist2[512];
   __shared__ float4   s_rec[FULL ? kPrjWaves : 1][FULL ? 64 * 3 : 1];  // per wave: 64 records at a 48-byte pitch
-  if(threadIdx.x < 256)
-    s_hist[threadIdx.x] = 0u;  // ordered before its first use by the barriers of phase 1
+  for(int i = threadIdx.x; i < 512; i += kPrjThreads)
+    s_hist2[i] = 0u;  // ordered before its first use by the barriers of phase 1
   __shared__ uint16_t s_li[kPrjPart];   // bit 15: survived phase 2
   __shared__ uint32_t s_key[kPrjPart];
   __shared__ uint32_t s_cnt[32];
@@ -328,32 +322,11 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
     atomicAdd(&ctr->frustumCount, M);
 
   MGS_PRJ_STAMP(3)
-  const size_t slotBase = (size_t)part * kPrjPart;
   if constexpr(!FULL)
   {
     // sort-only hook: survivors of the dist stage, exactly dist.comp.slang's (key, id) stream
-    uint32_t tmn = 0xFFFFu, tmx = 0u;
-    for(uint32_t j = t; j < M; j += kPrjThreads)
-    {
-      keysSlot[slotBase + j] = s_key[j];
-      idsSlot[slotBase + j]  = I.globalOffset + local0 + s_li[j];
-      atomicAdd(&s_hist[s_key[j] & 255u], 1u);
-      tmn = min(tmn, s_key[j] >> 16);
-      tmx = max(tmx, s_key[j] >> 16);
-    }
-    top16Post(tmn, tmx, s_cnt);
-    if(t == 0)
-    {
-      slotCount[part] = M;
-      if(M)
-        atomicAdd(&ctr->sortedCount, M);
-    }
-    __syncthreads();
-    if(t < 256)
-      slotHist[(size_t)t * histStride + part] = s_hist[t];
-    if(top16Mark(planKeys, M, s_cnt))
-      for(uint32_t j = t; j < M; j += kPrjThreads)
-        sortMarkTop16(planKeys, s_key[j] >> 16);
+    emitSlot<kPrjThreads, kPrjItems>(M, true, s_li, s_key, s_cnt, s_base, s_hist2, densePairs, prjStatus, A.f.totalPartitions, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
+                                     I.globalOffset + local0);
     return;
   }
   else
@@ -412,49 +385,12 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
       cur   = nxt;
       liCur = liNxt;
     }
-    // ---- second ordered compaction straight into the partition's slot region ---------------------------
+    // ---- second ordered compaction straight into the partition's slot region (slot_emit.h) ----
     __syncthreads();
     MGS_PRJ_STAMP(4)
-#pragma unroll
-    for(int r = 0; r < kPrjItems; ++r)
-    {
-      const uint32_t j = r * kPrjThreads + t;
-      vis[r]           = (j < M) && (s_li[j] & 0x8000u);
-      bal[r]           = __ballot(vis[r]);
-      if(lane == 0)
-        s_cnt[r * kPrjWaves + w] = (uint32_t)__popcll(bal[r]);
-    }
-    const uint32_t outCount = scanRoundWaveCounts(s_cnt, s_base);
-    uint32_t       tmn = 0xFFFFu, tmx = 0u;
-#pragma unroll
-    for(int r = 0; r < kPrjItems; ++r)
-      if(vis[r])
-      {
-        const uint32_t j         = r * kPrjThreads + t;
-        const uint32_t pos       = s_base[r * kPrjWaves + w] + lanesBelow(bal[r]);
-        keysSlot[slotBase + pos] = s_key[j];
-        idsSlot[slotBase + pos]  = I.globalOffset + local0 + (s_li[j] & 0x7FFFu);
-        atomicAdd(&s_hist[s_key[j] & 255u], 1u);
-        tmn = min(tmn, s_key[j] >> 16);
-        tmx = max(tmx, s_key[j] >> 16);
-      }
-    top16Post(tmn, tmx, s_cnt);
-    if(t == 0)
-    {
-      slotCount[part] = outCount;
-      if(outCount)
-        atomicAdd(&ctr->sortedCount, outCount);
-    }
-    __syncthreads();
-    if(t < 256)
-      slotHist[(size_t)t * histStride + part] = s_hist[t];
-    if(top16Mark(planKeys, outCount, s_cnt))
-    {
-#pragma unroll
-      for(int r = 0; r < kPrjItems; ++r)
-        if(vis[r])
-          sortMarkTop16(planKeys, s_key[r * kPrjThreads + t] >> 16);
-    }
+    const uint32_t outCount = emitSlot<kPrjThreads, kPrjItems>(M, false, s_li, s_key, s_cnt, s_base, s_hist2, densePairs, prjStatus, A.f.totalPartitions, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
+                                                               I.globalOffset + local0);
+    (void)outCount;
 #ifdef MGS_PRJ_TRACE
     MGS_PRJ_STAMP(5)
     if(threadIdx.x == 0 && g_prjTrace)
@@ -594,10 +530,9 @@ void launchPartitionCull(hipStream_t stream, const FrameArgs& args, const FrameA
 
 // ---------------------------------------------------------------------------------------------
 // host-callable launcher
-void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full,
-                   FrameCounters* ctr,
-                   uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, SplatRec* rec, uint32_t* rect,
-                   const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride, SortPlan* planKeys, const float* partR)
+void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full, FrameCounters* ctr, uint2* densePairs,
+                   uint32_t* prjStatus, SplatRec* rec, uint32_t* rect, const uint32_t* partSkip, uint32_t* slotHist2,
+                   uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan, const float* partR)
 {
   const dim3 grid(args.f.totalPartitions), block(kPrjThreads);
   if(args.f.totalPartitions == 0)
@@ -617,8 +552,8 @@ void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* d
   }
 #endif
 #define MGS_LAUNCH(FULLV)                                                                                                \
-  hipLaunchKernelGGL((k_project<FULLV>), grid, block, 0, stream, dArgs, ctr, keysSlot, idsSlot, slotCount, rec, rect, partSkip, \
-                     slotHist, histStride, planKeys, partR)
+  hipLaunchKernelGGL((k_project<FULLV>), grid, block, 0, stream, dArgs, ctr, densePairs, prjStatus, rec, rect, partSkip, slotHist2, \
+                     top16Rec, top16Count, osPlan, partR)
   if(full)
     MGS_LAUNCH(true);
   else

@@ -30,19 +30,14 @@ __device__ __forceinline__ uint32_t rectTiles(uint32_t r)
 }
 
 // ---- frame init: zero counters, both sort plans and the tile ranges -------------------------
-__global__ void k_frame_init(FrameCounters* ctr, SortPlan* planKeys, SortPlan* planPairs, uint2* ranges, uint32_t nTiles)
+__global__ void k_frame_init(FrameCounters* ctr, uint32_t* plans, uint32_t planWords, uint2* ranges, uint32_t nTiles)
 {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
   uint32_t*      c   = reinterpret_cast<uint32_t*>(ctr);
   for(uint32_t i = gid; i < sizeof(FrameCounters) / 4; i += gsz)
     c[i] = 0;
-  uint32_t* a = reinterpret_cast<uint32_t*>(planKeys);
-  uint32_t* b = reinterpret_cast<uint32_t*>(planPairs);
-  for(uint32_t i = gid; i < sizeof(SortPlan) / 4; i += gsz)
-  {
-    a[i] = 0;
-    b[i] = 0;
-  }
+  for(uint32_t i = gid; i < planWords; i += gsz)
+    plans[i] = 0;
   for(uint32_t i = gid; i < nTiles; i += gsz)
     ranges[i] = make_uint2(0u, 0u);
 }
@@ -1080,11 +1075,10 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
 }
 
 // ---------------------------------------------------------------------------------------------
-void launchFrameInit(hipStream_t stream, FrameCounters* ctr, SortPlan* planKeys, SortPlan* planPairs, uint2* ranges,
-                     uint32_t nTiles)
+void launchFrameInit(hipStream_t stream, FrameCounters* ctr, uint32_t* plans, uint32_t planWords, uint2* ranges, uint32_t nTiles)
 {
-  const uint32_t blocks = (nTiles + 255u) / 256u < 1u ? 1u : min((nTiles + 255u) / 256u, 256u);
-  hipLaunchKernelGGL(k_frame_init, dim3(blocks), dim3(256), 0, stream, ctr, planKeys, planPairs, ranges, nTiles);
+  const uint32_t blocks = (nTiles + 255u) / 256u < 4u ? 4u : min((nTiles + 255u) / 256u, 256u);
+  hipLaunchKernelGGL(k_frame_init, dim3(blocks), dim3(256), 0, stream, ctr, plans, planWords, ranges, nTiles);
 }
 
 void launchBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,

@@ -1,25 +1,18 @@
-// k_sort.hip — stable LSD radix sort of (u32 key, u32 value) pairs for gfx950, device-side count.
+// k_sort.hip — generic stable LSD radix sort of (u32 key, u32 value) pairs for gfx950: any bit range, device-side count.
+// Users: the record-path pair sort of the binning fallback (> 256 bins) and the stand-alone sort API with a partial bit
+// range.  The frame's depth-key sort is k_osort.hip (single-kernel passes).
 //
 // Behavioural spec: vrdxCmdSortKeyValueIndirect (3rdparty/vrdx/include/vk_radix_sort.h:73-78,
 // 3rdparty/vrdx/src/vk_radix_sort.cc:262-416): stable, ascending, 8-bit digits, element count read on
-// the device.  The implementation is new and wave64-native:
-//   * reduce-then-scan per pass (partition histograms -> per-digit row scan -> ranked scatter).  A
-//     decoupled-look-back (onesweep) chain was rejected for MI355X: a cross-CU hand-off costs
-//     ~1-3 us (MI355X_MICROARCH.md "handoff-1to1"), and with every partition co-resident on 256 CUs
-//     the chain serialises at one hop per partition (measured: tools/micro/lookback_rate.hip, 1.3 ms for the look-back of
-//     1 020 partitions x 256 digits alone = 1.27 us per hop).  Reduce-then-scan has no inter-workgroup
-//     dependency inside a launch, so nothing can spin or hang.
+// the device.  The implementation is wave64-native:
+//   * reduce-then-scan per pass (partition histograms -> per-digit row scan -> ranked scatter): no inter-workgroup
+//     dependency inside a launch.
 //   * ranking inside a partition uses 64-lane ballots (8 per key) to find the lanes holding the same
 //     digit, one LDS counter row per wave, then an LDS re-order so the global scatter is coalesced.
-//   * pass 0 can read "slotted" input (the project kernel's per-partition survivor lists), which
-//     fuses the stream compaction into the sort; the producer also hands over the pass-0 digit
-//     histogram of every slot, so the in-frame sort starts directly with a scan.
 //   * no global atomics anywhere: the scan kernel leaves each digit row's total in the plan and the
-//     scatter workgroups turn the 256 totals into digit bases themselves (a 256-wide scan is noise
-//     next to ranking 8192 keys).
-//   * a pass whose digit is identical for every key (the top byte of a depth key, typically) is
-//     detected by its scan kernel and its scatter exits; the ping-pong selection is derived from the
-//     skip flags on the device.
+//     scatter workgroups turn the 256 totals into digit bases themselves.
+//   * a pass whose digit is identical for every key (the high byte of a bin id) is detected by its scan kernel and
+//     its scatter exits; the ping-pong selection is derived from the skip flags on the device.
 #include <cstdlib>
 
 #include "kernels_common.h"
@@ -27,19 +20,16 @@
 
 namespace mgs {
 
-constexpr int kSlotPart = 2048;  // slotted pass-0 partitions == the project kernel's partitions
-
-// Uniform partition p covers [p*part, p*part+count).  A slotted partition covers part/2048 consecutive
-// slots of the project kernel (each a 2048-entry region holding slotCount[slot] compacted survivors).
-__device__ __forceinline__ uint32_t partitionCount(const uint32_t* slotCount, uint32_t n, uint32_t p, uint32_t part)
+// partition p covers [p*part, p*part+count)
+__device__ __forceinline__ uint32_t partitionCount(uint32_t n, uint32_t p, uint32_t part)
 {
   const uint64_t base = (uint64_t)p * part;
   return (n > base) ? (uint32_t)min((uint64_t)part, (uint64_t)n - base) : 0u;
 }
 
 // LDS histogram add with run aggregation: lanes holding the same digit as their left neighbour are
-// folded into the run's first lane, so long runs of equal digits (the high byte of a tile id, the top
-// bytes of depth keys) cost one LDS atomic instead of a 64-way serialised one.
+// folded into the run's first lane, so long runs of equal digits (the high byte of a bin id) cost one
+// LDS atomic instead of a 64-way serialised one.
 __device__ __forceinline__ void histAddRuns(uint32_t* hist, uint32_t digit, bool valid)
 {
   const int      lane = laneId();
@@ -55,23 +45,6 @@ __device__ __forceinline__ void histAddRuns(uint32_t* hist, uint32_t digit, bool
   }
 }
 
-// digit of pass 2 when the top 16 bits are remapped: the rank of key >> 16 among the occurring values, read from a
-// per-workgroup LDS table indexed by (key >> 16) - base (the occurring values span < 4096, checked by the scan kernel;
-// padding keys clamp to the last entry, which holds the largest rank)
-constexpr uint32_t kRemapSpan = 4096;
-__device__ __forceinline__ void remapBuildTable(uint8_t* s_tab, const SortPlan* plan, int t, int threads)
-{
-  const uint32_t count = plan->remapCount, base = plan->remapBase;
-  for(uint32_t i = t; i < count; i += threads)
-    s_tab[(uint32_t)plan->remapVals[i] - base] = (uint8_t)i;
-  if(t == 0)
-    s_tab[kRemapSpan - 1] = (uint8_t)(count - 1u);
-}
-__device__ __forceinline__ uint32_t remapDigit(const uint8_t* s_tab, uint32_t base, uint32_t key)
-{
-  return s_tab[min((key >> 16) - base, kRemapSpan - 1u)];
-}
-
 // where pass `pass` (> 0) reads from: 0 = X, 1 = Y.  Pass 0 writes X; every executed pass flips.
 __device__ __forceinline__ uint32_t planSrcSel(const SortPlan* __restrict__ plan, int pass)
 {
@@ -81,22 +54,15 @@ __device__ __forceinline__ uint32_t planSrcSel(const SortPlan* __restrict__ plan
   return cur;
 }
 
-// (a) per-partition digit histogram of one pass (pass 0 of a slotted sort gets it from the producer instead)
+// (a) per-partition digit histogram of one pass
 __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ keysX, const uint32_t* __restrict__ keysY,
                                                    const uint32_t* __restrict__ keys0, const uint32_t* __restrict__ nPtr,
                                                    const SortPlan* __restrict__ plan, uint32_t* __restrict__ partHist,
                                                    uint32_t pStride, int pass, int beginBit, uint32_t part)
 {
   __shared__ uint32_t s_h[256];
-  __shared__ uint8_t s_rv[kRemapSpan];
   const int       t     = threadIdx.x;
   const uint32_t  n     = *nPtr;
-  const bool      remap = plan->remapOn != 0u;
-  if(remap && pass == 3)
-    return;  // pass 2 sorted on the rank of the top 16 bits: nothing left to do
-  const uint32_t rcount = plan->remapBase;
-  if(remap && pass == 2)
-    remapBuildTable(s_rv, plan, t, 256);
   const uint32_t* keys  = (pass == 0) ? keys0 : (planSrcSel(plan, pass) ? keysY : keysX);
   const uint32_t  parts = (uint32_t)(((uint64_t)n + part - 1) / part);
   const int       shift = beginBit + 8 * pass;
@@ -104,7 +70,7 @@ __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ 
   {
     s_h[t] = 0;
     __syncthreads();
-    const uint32_t  count = partitionCount(nullptr, n, p, part);
+    const uint32_t  count = partitionCount(n, p, part);
     const uint32_t* src   = keys + (size_t)p * part;
     // 8 loads in flight per thread, then the LDS work (the loop was one dependent round trip per key)
     for(uint32_t i0 = 0; i0 < count; i0 += 2048u)
@@ -118,8 +84,7 @@ __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ 
       }
 #pragma unroll
       for(int u = 0; u < 8; ++u)
-        histAddRuns(s_h, (remap && pass == 2) ? remapDigit(s_rv, rcount, kk[u]) : ((kk[u] >> shift) & 255u),
-                    i0 + (uint32_t)u * 256u + (uint32_t)t < count);
+        histAddRuns(s_h, (kk[u] >> shift) & 255u, i0 + (uint32_t)u * 256u + (uint32_t)t < count);
     }
     __syncthreads();
     partHist[(size_t)t * pStride + p] = s_h[t];
@@ -129,19 +94,13 @@ __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ 
 
 // (b) one workgroup per digit: exclusive scan of that digit's row of partition counts, in place.  The row
 // total goes to plan->ghist[pass][d]; a row that holds every key marks the pass as skippable.
-__global__ __launch_bounds__(256) void k_sort_scan(const uint32_t* __restrict__ nPtr, uint32_t partsSlotted,
-                                                   SortPlan* __restrict__ plan, uint32_t* __restrict__ partHist,
-                                                   uint32_t pStride, int pass, uint32_t part, int allowRemap)
+__global__ __launch_bounds__(256) void k_sort_scan(const uint32_t* __restrict__ nPtr, SortPlan* __restrict__ plan,
+                                                   uint32_t* __restrict__ partHist, uint32_t pStride, int pass, uint32_t part)
 {
   __shared__ uint32_t s_tmp[4];
   const int      t = threadIdx.x, d = blockIdx.x;
   const uint32_t n     = *nPtr;
-  if(pass == 3 && plan->remapOn != 0u)
-    return;  // skip[3] was set together with remapOn
-  // slotted pass 0: the producer wrote one histogram per 2048-key slot; a partition takes spp = part/2048 slots.
-  // In place is safe: slot index >= partition index, and the block scan's barriers sit between reads and writes.
-  const uint32_t spp   = partsSlotted ? part / kSlotPart : 1u;
-  const uint32_t parts = partsSlotted ? (partsSlotted + spp - 1) / spp : (uint32_t)(((uint64_t)n + part - 1) / part);
+  const uint32_t parts = (uint32_t)(((uint64_t)n + part - 1) / part);
   uint32_t       carry = 0;
   uint32_t*      row   = partHist + (size_t)d * pStride;
   for(uint32_t base = 0; base < parts; base += 2048)
@@ -151,15 +110,7 @@ __global__ __launch_bounds__(256) void k_sort_scan(const uint32_t* __restrict__ 
 #pragma unroll
     for(int i = 0; i < 8; ++i)
     {
-      v[i] = 0u;
-      if(p0 + i < parts)
-      {
-        if(spp == 1u)
-          v[i] = row[p0 + i];
-        else
-          for(uint32_t q = 0; q < spp; ++q)
-            v[i] += ((p0 + i) * spp + q < partsSlotted) ? row[(p0 + i) * spp + q] : 0u;
-      }
+      v[i] = (p0 + i < parts) ? row[p0 + i] : 0u;
       sum += v[i];
     }
     uint32_t chunk;
@@ -178,69 +129,6 @@ __global__ __launch_bounds__(256) void k_sort_scan(const uint32_t* __restrict__ 
     plan->ghist[pass][d] = carry;
     if(pass > 0 && n > 0 && carry == n)
       plan->skip[pass] = 1u;  // every key has this digit: the pass would be the identity permutation
-  }
-  // pass elision: after the producer's marks are complete (this kernel runs behind it), workgroup 0 of pass 1 turns the
-  // presence bitmap of key >> 16 into the ascending value table; <= 256 values -> pass 2 takes their rank as its digit
-  if(allowRemap && pass == 1 && d == 0)
-  {
-    uint32_t c[8], sum = 0;
-#pragma unroll
-    for(int q = 0; q < 8; ++q)
-    {
-      c[q] = (uint32_t)__popc(plan->topBitmap[t * 8 + q]);
-      sum += c[q];
-    }
-    uint32_t total;
-    uint32_t run = blockExclusiveScan256(sum, s_tmp, &total);
-    // smallest / largest occurring value (wave + block reductions over the per-thread words)
-    uint32_t vmin = 0xFFFFFFFFu, vmax = 0u;
-#pragma unroll
-    for(int q = 0; q < 8; ++q)
-    {
-      const uint32_t bits = plan->topBitmap[t * 8 + q];
-      if(bits)
-      {
-        vmin = min(vmin, (uint32_t)((t * 8 + q) * 32 + __builtin_ctz(bits)));
-        vmax = max(vmax, (uint32_t)((t * 8 + q) * 32 + 31 - __builtin_clz(bits)));
-      }
-    }
-#pragma unroll
-    for(int o = 32; o > 0; o >>= 1)
-    {
-      vmin = min(vmin, (uint32_t)__shfl_xor(vmin, o, 64));
-      vmax = max(vmax, (uint32_t)__shfl_xor(vmax, o, 64));
-    }
-    __shared__ uint32_t s_mm[8];
-    if((t & 63) == 0)
-    {
-      s_mm[t >> 6]       = vmin;
-      s_mm[4 + (t >> 6)] = vmax;
-    }
-    __syncthreads();
-    vmin = min(min(s_mm[0], s_mm[1]), min(s_mm[2], s_mm[3]));
-    vmax = max(max(s_mm[4], s_mm[5]), max(s_mm[6], s_mm[7]));
-    const bool on = total >= 1u && total <= 256u && (vmax - vmin) < kRemapSpan - 1u;
-    if(on)
-    {
-#pragma unroll
-      for(int q = 0; q < 8; ++q)
-      {
-        uint32_t bits = plan->topBitmap[t * 8 + q];
-        while(bits)
-        {
-          const uint32_t b = (uint32_t)__builtin_ctz(bits);
-          bits &= bits - 1u;
-          plan->remapVals[run++] = (uint16_t)((t * 8 + q) * 32 + b);
-        }
-      }
-    }
-    if(t == 0 && on)
-    {
-      plan->remapCount = total;
-      plan->remapBase  = vmin;
-      plan->remapOn    = 1u;
-      plan->skip[3]    = 1u;
-    }
   }
 }
 
@@ -264,22 +152,15 @@ __device__ __forceinline__ uint32_t digitExclusiveScan(uint32_t v, uint32_t* s_t
 // (c) ranked scatter of one partition of THREADS*KPT keys.  Workgroup 0 of the last pass also publishes the
 // outcome (which buffer holds the result, how many passes ran); on a single-pass sort the digit histogram IS the
 // sorted layout, so the caller's per-digit ranges are written there too.
-template <bool FIRST, int THREADS, int KPT, bool GATHER = false>
+template <bool FIRST, int THREADS, int KPT>
 __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __restrict__ keys0, const uint32_t* __restrict__ vals0,
                                                           uint32_t* __restrict__ keysX, uint32_t* __restrict__ valsX,
                                                           uint32_t* __restrict__ keysY, uint32_t* __restrict__ valsY,
-                                                          const uint32_t* __restrict__ slotCount, const uint32_t* __restrict__ nPtr,
-                                                          uint32_t partsSlotted, SortPlan* __restrict__ plan,
+                                                          const uint32_t* __restrict__ nPtr, SortPlan* __restrict__ plan,
                                                           const uint32_t* __restrict__ partHist, uint32_t pStride, int pass,
-                                                          int beginBit, int nPasses, uint2* __restrict__ ranges,
-                                                          const uint32_t* __restrict__ gatherSrc, uint32_t* __restrict__ gatherDst)
+                                                          int beginBit, int nPasses, uint2* __restrict__ ranges)
 {
-  // GATHER (last pass of the in-frame key sort only): the keys are dead after this pass, so the workgroup writes
-  // gatherDst[sortedPos] = gatherSrc[value] in their place (the splat's bin rect, which the binning stage needs in
-  // sorted order).  The random 4-byte gathers are issued as soon as the values are loaded and land while the keys are
-  // being ranked, instead of being the exposed dependent trip of their own kernel.
   constexpr int PART  = THREADS * KPT;
-  constexpr int SPP   = PART / kSlotPart;  // slots per slotted partition
   constexpr int WAVES = THREADS / 64;
   __shared__ uint32_t s_whist[WAVES][256];
   __shared__ uint32_t s_k[PART];
@@ -287,12 +168,9 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
   __shared__ uint32_t s_loff[256];
   __shared__ uint32_t s_gbase[256];
   __shared__ uint32_t s_tmp[WAVES];
-  __shared__ uint8_t  s_dig[GATHER ? PART : 1];
-  __shared__ uint8_t  s_rv[FIRST ? 1 : kRemapSpan];
 
   const int t = threadIdx.x, lane = laneId(), w = t >> 6;
   const bool     skipped = !FIRST && plan->skip[pass] != 0u;
-  const bool     slotted = FIRST && (slotCount != nullptr);
   const uint32_t n       = *nPtr;
   if(blockIdx.x == 0 && t == 0 && pass == nPasses - 1)
   {
@@ -302,28 +180,14 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
     plan->finalSel  = planSrcSel(plan, nPasses);
     plan->passesRun = run;
     plan->n         = n;
-    if(GATHER)
-      plan->reserved[0] = skipped ? 0u : 1u;  // gatherDst is valid: consumers need not gather themselves
   }
   if(skipped)
     return;
-  const uint32_t parts   = slotted ? (partsSlotted + SPP - 1) / SPP : (uint32_t)(((uint64_t)n + PART - 1) / PART);
-  const uint32_t p       = blockIdx.x;
+  const uint32_t parts = (uint32_t)(((uint64_t)n + PART - 1) / PART);
+  const uint32_t p     = blockIdx.x;
   if(p >= parts)
     return;
-  // slotted: prefix of the SPP slot counts -> compact index inside the partition maps to (slot, offset)
-  uint32_t pre[SPP + 1];
-  pre[0] = 0;
-  if(slotted)
-  {
-#pragma unroll
-    for(int q = 0; q < SPP; ++q)
-    {
-      const uint32_t slot = p * SPP + q;
-      pre[q + 1]          = pre[q] + (slot < partsSlotted ? slotCount[slot] : 0u);
-    }
-  }
-  const uint32_t count = slotted ? pre[SPP] : partitionCount(nullptr, n, p, PART);
+  const uint32_t count = partitionCount(n, p, PART);
   const uint32_t *kin, *vin;
   uint32_t *      kout, *vout;
   if(FIRST)
@@ -348,12 +212,6 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
     vout = valsY;
   }
   const int shift = beginBit + 8 * pass;
-  // pass 2 of a remapped sort: digit = rank of key >> 16 among the occurring values (see SortPlan)
-  const bool     remap  = !FIRST && pass == 2 && plan->remapOn != 0u;
-  const uint32_t rcount = plan->remapBase;
-  if constexpr(!FIRST)
-    if(remap)
-      remapBuildTable(s_rv, plan, t, THREADS);
 
   for(int i = t; i < WAVES * 256; i += THREADS)
     (&s_whist[0][0])[i] = 0;
@@ -367,28 +225,9 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
   {
     const uint32_t idx = wofs + i * 64 + lane;
     const bool     in  = idx < count;
-    size_t         src = (size_t)p * PART + idx;
-    if(slotted)
-    {
-      uint32_t q = 0;
-#pragma unroll
-      for(int z = 1; z < SPP; ++z)
-        q += (idx >= pre[z]) ? 1u : 0u;
-      uint32_t pq = pre[0];
-#pragma unroll
-      for(int z = 1; z < SPP; ++z)
-        pq = (q >= (uint32_t)z) ? pre[z] : pq;
-      src = ((size_t)p * SPP + q) * kSlotPart + (idx - pq);
-    }
+    const size_t   src = (size_t)p * PART + idx;
     key[i] = in ? kin[src] : 0xFFFFFFFFu;
     val[i] = in ? vin[src] : 0u;
-  }
-  uint32_t gat[GATHER ? KPT : 1];
-  if constexpr(GATHER)
-  {
-#pragma unroll
-    for(int i = 0; i < KPT; ++i)
-      gat[i] = (wofs + i * 64 + lane < count) ? gatherSrc[val[i]] : 0u;
   }
   __syncthreads();
 
@@ -399,7 +238,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
   for(int i = 0; i < KPT; ++i)
   {
     // padding keys (idx >= count) carry digit 255 and sit behind every real key of the partition
-    const uint32_t d = remap ? remapDigit(s_rv, rcount, key[i]) : ((key[i] >> shift) & 255u);
+    const uint32_t d = (key[i] >> shift) & 255u;
     dig[i]           = (uint8_t)d;
     uint64_t       m = ~0ull;
 #pragma unroll
@@ -453,13 +292,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
     const uint32_t d   = dig[i];
     const uint32_t pos = s_loff[d] + s_whist[w][d] + rank[i];
     s_v[pos]           = val[i];
-    if constexpr(GATHER)
-    {
-      s_k[pos]   = gat[i];
-      s_dig[pos] = (uint8_t)d;
-    }
-    else
-      s_k[pos] = key[i];
+    s_k[pos]           = key[i];
   }
   __syncthreads();
 
@@ -472,13 +305,9 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const uint32_t* __rest
     {
       const uint32_t k   = s_k[idx];
       const uint32_t v   = s_v[idx];
-      const uint32_t d   = GATHER ? (uint32_t)s_dig[idx] : (remap ? remapDigit(s_rv, rcount, k) : ((k >> shift) & 255u));
-      const uint32_t dst = s_gbase[d] + idx;
-      if constexpr(GATHER)
-        gatherDst[dst] = k;
-      else
-        kout[dst] = k;
-      vout[dst] = v;
+      const uint32_t dst = s_gbase[(k >> shift) & 255u] + idx;
+      kout[dst]          = k;
+      vout[dst]          = v;
     }
   }
 }
@@ -503,63 +332,37 @@ void launchRadixSort(hipStream_t stream, const SortLaunch& s)
   const int nPasses = (s.endBit - s.beginBit + 7) / 8;
   if(nPasses <= 0 || s.maxElems == 0)
     return;
-  const bool     slotted = s.slotCount != nullptr;  // pass 0: 2048-key slots + the producer's slot histograms
   // big sorts use 4096-key partitions (digit runs of ~16 keys = 64-byte scatter segments), small ones keep 2048 so
-  // that 256 CUs still see enough workgroups.  8192 (512 threads, 72 KB of LDS) is 2 % faster on an idle GPU but its
-  // workgroups wait for a whole free half CU when frames overlap: 77 us instead of 21.5 us per scatter with three
-  // frames in flight (profiles/r1_h), 2450 vs 2540 frames/s.
+  // that 256 CUs still see enough workgroups
   static const uint32_t kPartOverride = [] { const char* e = std::getenv("MGS_SORT_PART"); return e ? (uint32_t)std::atoi(e) : 0u; }();
-  const uint32_t part    = kPartOverride ? kPartOverride : ((s.maxElems >= (2u << 20)) ? 4096u : 2048u);
-  static const uint32_t kSlotPartOverride = [] { const char* e = std::getenv("MGS_SLOT_PART"); return e ? (uint32_t)std::atoi(e) : 0u; }();
-  auto partOf  = [&](int pass) { return (pass == 0 && slotted && kSlotPartOverride) ? kSlotPartOverride : part; };
-  auto partsOf = [&](int pass) {
-    const uint32_t pp = partOf(pass);
-    return (pass == 0 && slotted) ? (s.partsSlotted + pp / 2048u - 1) / (pp / 2048u) : (uint32_t)(((uint64_t)s.maxElems + pp - 1) / pp);
-  };
+  const uint32_t part  = kPartOverride ? kPartOverride : ((s.maxElems >= (2u << 20)) ? 4096u : 2048u);
+  const uint32_t parts = (uint32_t)(((uint64_t)s.maxElems + part - 1) / part);
   for(int pass = 0; pass < nPasses; ++pass)
   {
-    const uint32_t parts = partsOf(pass), pp = partOf(pass);
-    if(parts == 0)
-      continue;
-    if(!(pass == 0 && slotted))
-      hipLaunchKernelGGL(k_sort_hist, dim3(parts), dim3(256), 0, stream, s.keysX, s.keysY, s.keys0, s.nPtr, s.plan, s.partHist,
-                         s.pStride, pass, s.beginBit, pp);
-    hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, stream, s.nPtr, (pass == 0 && slotted) ? s.partsSlotted : 0u, s.plan,
-                       s.partHist, s.pStride, pass, pp, (s.allowRemap && nPasses == 4 && s.beginBit == 0) ? 1 : 0);
-#define MGS_SCATTER(FIRSTV, TH, KP, SLOTS)                                                                                  \
-  hipLaunchKernelGGL((k_sort_scatter<FIRSTV, TH, KP>), dim3(parts), dim3(TH), 0, stream, s.keys0, s.vals0, s.keysX, s.valsX, \
-                     s.keysY, s.valsY, SLOTS, s.nPtr, s.partsSlotted, s.plan, s.partHist, s.pStride, pass, s.beginBit, nPasses, \
-                     s.ranges, s.gatherSrc, s.gatherDst)
-#define MGS_SCATTER_G(TH, KP)                                                                                               \
-  hipLaunchKernelGGL((k_sort_scatter<false, TH, KP, true>), dim3(parts), dim3(TH), 0, stream, s.keys0, s.vals0, s.keysX,     \
-                     s.valsX, s.keysY, s.valsY, (const uint32_t*)nullptr, s.nPtr, s.partsSlotted, s.plan, s.partHist,        \
-                     s.pStride, pass, s.beginBit, nPasses, s.ranges, s.gatherSrc, s.gatherDst)
+    hipLaunchKernelGGL(k_sort_hist, dim3(parts), dim3(256), 0, stream, s.keysX, s.keysY, s.keys0, s.nPtr, s.plan, s.partHist, s.pStride,
+                       pass, s.beginBit, part);
+    hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, stream, s.nPtr, s.plan, s.partHist, s.pStride, pass, part);
+#define MGS_SCATTER(FIRSTV, TH, KP)                                                                                              \
+  hipLaunchKernelGGL((k_sort_scatter<FIRSTV, TH, KP>), dim3(parts), dim3(TH), 0, stream, s.keys0, s.vals0, s.keysX, s.valsX, s.keysY, \
+                     s.valsY, s.nPtr, s.plan, s.partHist, s.pStride, pass, s.beginBit, nPasses, s.ranges)
     if(pass == 0)
     {
-      if(pp == 2048u)
-        MGS_SCATTER(true, 256, 8, s.slotCount);
-      else if(pp == 4096u)
-        MGS_SCATTER(true, 256, 16, s.slotCount);
+      if(part == 2048u)
+        MGS_SCATTER(true, 256, 8);
+      else if(part == 4096u)
+        MGS_SCATTER(true, 256, 16);
       else
-        MGS_SCATTER(true, 512, 16, s.slotCount);
-    }
-    else if(s.gatherSrc != nullptr && pass == nPasses - 1 && pp != 4096u)
-    {
-      if(pp == 2048u)
-        MGS_SCATTER_G(256, 8);
-      else
-        MGS_SCATTER_G(512, 16);
+        MGS_SCATTER(true, 512, 16);
     }
     else
     {
-      if(pp == 2048u)
-        MGS_SCATTER(false, 256, 8, (const uint32_t*)nullptr);
-      else if(pp == 4096u)
-        MGS_SCATTER(false, 256, 16, (const uint32_t*)nullptr);
+      if(part == 2048u)
+        MGS_SCATTER(false, 256, 8);
+      else if(part == 4096u)
+        MGS_SCATTER(false, 256, 16);
       else
-        MGS_SCATTER(false, 512, 16, (const uint32_t*)nullptr);
+        MGS_SCATTER(false, 512, 16);
     }
-#undef MGS_SCATTER_G
 #undef MGS_SCATTER
   }
 }

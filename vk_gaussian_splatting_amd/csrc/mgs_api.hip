@@ -32,14 +32,12 @@
 
 namespace mgs {
 // kernels_*.hip
-void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full,
-                   FrameCounters* ctr,
-                   uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, SplatRec* rec, uint32_t* rect,
-                   const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride, SortPlan* planKeys, const float* partR);
+void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full, FrameCounters* ctr, uint2* densePairs,
+                   uint32_t* prjStatus, SplatRec* rec, uint32_t* rect, const uint32_t* partSkip, uint32_t* slotHist2,
+                   uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan, const float* partR);
 void launchPartitionCull(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, uint32_t* partSkip, float* partR,
                          uint32_t* zero0, uint32_t n0, uint32_t* zero1, uint32_t n1, uint32_t* zero2, uint32_t n2);
-void launchFrameInit(hipStream_t stream, FrameCounters* ctr, SortPlan* planKeys, SortPlan* planPairs, uint2* ranges,
-                     uint32_t nTiles);
+void launchFrameInit(hipStream_t stream, FrameCounters* ctr, uint32_t* plans, uint32_t planWords, uint2* ranges, uint32_t nTiles);
 void launchBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
                    const uint32_t* rect, uint32_t* blockCount, uint32_t maxBlocks, FrameCounters* ctr, uint32_t* sortedRect,
                    uint32_t* splatOffset, uint32_t* chunkStart, uint32_t* pairKey, uint32_t* pairVal, uint32_t capacity,
@@ -56,8 +54,8 @@ void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges
                      int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId, const void* instTable, const FrameArgs* dArgs,
                      float4* outNormal);
 void launchProjectGut(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, int shFormat, FrameCounters* ctr,
-                      uint32_t* keysSlot, uint32_t* idsSlot, uint32_t* slotCount, GutRec* rec, uint32_t* rect,
-                      const uint32_t* partSkip, uint32_t* slotHist, uint32_t histStride, SortPlan* planKeys);
+                      uint2* densePairs, uint32_t* prjStatus, GutRec* rec, uint32_t* rect, const uint32_t* partSkip,
+                      uint32_t* slotHist2, uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan);
 void launchCompositeGut(hipStream_t stream, const FrameArgs& A, const FrameArgs* dArgs, const uint2* ranges, const uint32_t* valX,
                         const uint32_t* valY, const SortPlan* planPairs, const GutRec* rec, void* image, int halfOut,
                         FrameCounters* ctr, int shFormat, float* outDepth, uint32_t* outSplatId, float4* outNormal);
@@ -270,7 +268,10 @@ struct MgsScene_t
   uint64_t    wsEpoch   = ~0ull;  // d->epoch the working set below was sized for
 
   // frame buffers
-  DevBuf<uint32_t>      keysSlot, idsSlot, slotCount, keysA, idsA, keysB, idsB, rect, partHist, blockCount;
+  DevBuf<uint2>         pairA, pairB;  // ping-pong of the key sort; the project kernels append their dense (key, id) pairs to B
+  DevBuf<uint32_t>      slotHist2, top16Rec, top16Count, osStatus;  // what the key sort needs besides (k_osort.hip)
+  DevBuf<uint32_t>      keysA, idsA;  // the sorted ids (and, for the sort-only hook, the sorted keys)
+  DevBuf<uint32_t>      rect, partHist, blockCount;
   DevBuf<uint32_t>      sortedRect, splatOffset, chunkStart, partSkip;
   DevBuf<float>         partR;       // per partition: footprint bound in pixels (strips), written by k_partition_cull
   DevBuf<uint64_t>      dbinMasks;
@@ -295,12 +296,13 @@ struct MgsScene_t
   DevBuf<uint2>         ranges;
   DevBuf<uint8_t>       image;
   DevBuf<FrameCounters> ctr;
-  DevBuf<SortPlan>      plans;  // [0] keys, [1] pairs
+  DevBuf<FramePlans>    plans;  // [0]: keys, pairs, os (sort_plan.h); behind it the look-back words of the project kernels (slot_emit.h)
+  uint32_t              planWords = 0;  // words the frame's first kernel zeroes: FramePlans + those look-back words
   uint32_t              pairCapacity = 0, pStride = 0;
 
   // pinned readback
   FrameCounters* hCtr   = nullptr;
-  SortPlan*      hPlans = nullptr;
+  FramePlans*    hPlans = nullptr;
 
   static constexpr int kRing = 128;
   hipEvent_t ev[8] = {};              // [0..2] sort-only hook, [6..7] raw radix sort
@@ -316,35 +318,10 @@ struct MgsScene_t
   MgsSortOut     lastSort{};
 
   DevBuf<uint32_t>      rsKeys, rsVals, rsHist, rsCount;  // mgs_radix_sort_u32 scratch
-  DevBuf<uint32_t>      rsKeysY, rsValsY;
+  DevBuf<uint2>         rsPairA, rsPairB;
+  DevBuf<uint32_t>      rsStatus;
+  DevBuf<OsPlan>        rsOsPlan;
   DevBuf<SortPlan>      rsPlan;
-  // sample-sort scratch (k_ssort.hip): [0] the frame's key sort, [1] mgs_radix_sort_u32
-  struct SsBufs
-  {
-    DevBuf<uint32_t>           samples, splitters;
-    DevBuf<unsigned long long> bucketCount;
-    DevBuf<uint2>              desc;
-    uint32_t                   maxBuckets = 0;
-    int ensure(uint32_t maxElems, uint32_t parts)
-    {
-      maxBuckets = sampleSortBuckets(maxElems);
-      int rc;
-      if((rc = samples.ensure(16384))) return rc;
-      if((rc = splitters.ensure(4096))) return rc;
-      if((rc = bucketCount.ensure(4096))) return rc;
-      return desc.ensure((size_t)maxBuckets * std::max<uint32_t>(parts, 1u));
-    }
-    void fill(SampleSortBuffers& o) const
-    {
-      o.samples     = samples.p;
-      o.splitters   = splitters.p;
-      o.bucketCount = bucketCount.p;
-      o.desc        = desc.p;
-      o.maxBuckets  = maxBuckets;
-    }
-    void release() { samples.release(); splitters.release(); bucketCount.release(); desc.release(); }
-  } ssFrame, ssRaw;
-
   // multi-GPU strips (RCCL)
   ncclComm_t            comm = nullptr;
   int                   commRank = 0, commWorld = 1;
@@ -664,7 +641,7 @@ static int mgs_scene_create_impl(int device, MgsScene* out)
   }
   s->stream = s->ownStream;
   if(hipHostMalloc((void**)&s->hCtr, sizeof(FrameCounters)) != hipSuccess
-     || hipHostMalloc((void**)&s->hPlans, 2 * sizeof(SortPlan)) != hipSuccess)
+     || hipHostMalloc((void**)&s->hPlans, sizeof(FramePlans)) != hipSuccess)
   {
     if(s->hCtr) (void)hipHostFree(s->hCtr);
     (void)hipStreamDestroy(s->ownStream);
@@ -673,7 +650,7 @@ static int mgs_scene_create_impl(int device, MgsScene* out)
     return MGS_ERR_OOM;
   }
   std::memset(s->hCtr, 0, sizeof(FrameCounters));
-  std::memset(s->hPlans, 0, 2 * sizeof(SortPlan));
+  std::memset(s->hPlans, 0, sizeof(FramePlans));
   bool evOk = true;
   for(auto& e : s->ev)
     evOk = evOk && hipEventCreate(&e) == hipSuccess;
@@ -737,8 +714,8 @@ void mgs_scene_destroy(MgsScene s)
     auto& h = s->d->handles;
     h.erase(std::remove(h.begin(), h.end(), s), h.end());
   }
-  s->keysSlot.release(); s->idsSlot.release(); s->slotCount.release(); s->keysA.release(); s->idsA.release();
-  s->keysB.release(); s->idsB.release(); s->rect.release(); s->partHist.release(); s->blockCount.release();
+  s->pairA.release(); s->pairB.release(); s->slotHist2.release(); s->top16Rec.release(); s->top16Count.release();
+  s->osStatus.release(); s->keysA.release(); s->idsA.release(); s->rect.release(); s->partHist.release(); s->blockCount.release();
   s->rec.release(); s->recGut.release(); s->pairKey0.release(); s->pairVal0.release(); s->pairKey1.release(); s->pairVal1.release();
   s->sortedRect.release(); s->splatOffset.release(); s->chunkStart.release(); s->partSkip.release(); s->partR.release();
   s->surfDepth.release(); s->surfId.release(); s->surfNormal.release(); s->accum.release(); s->dArgs.release(); s->dbinMasks.release();
@@ -746,7 +723,7 @@ void mgs_scene_destroy(MgsScene s)
   s->graphs.clear();
   s->ranges.release(); s->image.release(); s->ctr.release(); s->plans.release(); s->cpuDistDev.release();
   s->rsKeys.release(); s->rsVals.release(); s->rsHist.release(); s->rsCount.release(); s->rsPlan.release();
-  s->rsKeysY.release(); s->rsValsY.release(); s->ssFrame.release(); s->ssRaw.release();
+  s->rsPairA.release(); s->rsPairB.release(); s->rsStatus.release(); s->rsOsPlan.release();
   if(s->hCtr) (void)hipHostFree(s->hCtr);
   if(s->hPlans) (void)hipHostFree(s->hPlans);
   if(s->evReady)
@@ -844,11 +821,11 @@ int mgs_scene_memory_usage(MgsScene s, uint64_t* sceneBytes, uint64_t* workingBy
   {
     uint64_t b = 0;
     auto add = [&](auto& buf) { b += (uint64_t)buf.n * sizeof(*buf.p); };
-    add(s->keysSlot); add(s->idsSlot); add(s->slotCount); add(s->keysA); add(s->idsA); add(s->keysB); add(s->idsB); add(s->rect);
+    add(s->pairA); add(s->pairB); add(s->slotHist2); add(s->top16Rec); add(s->top16Count); add(s->osStatus); add(s->keysA); add(s->idsA); add(s->rect);
     add(s->partHist); add(s->blockCount); add(s->sortedRect); add(s->splatOffset); add(s->chunkStart); add(s->partSkip); add(s->partR);
     add(s->dbinMasks); add(s->dArgs); add(s->surfDepth); add(s->surfId); add(s->surfNormal); add(s->accum); add(s->rec); add(s->recGut);
     add(s->pairKey0); add(s->pairVal0); add(s->pairKey1); add(s->pairVal1); add(s->ranges); add(s->image); add(s->ctr); add(s->plans);
-    add(s->rsKeys); add(s->rsVals); add(s->rsHist); add(s->rsCount); add(s->rsKeysY); add(s->rsValsY); add(s->rsPlan); add(s->cpuDistDev);
+    add(s->rsKeys); add(s->rsVals); add(s->rsHist); add(s->rsCount); add(s->rsPairA); add(s->rsPairB); add(s->rsStatus); add(s->rsOsPlan); add(s->rsPlan); add(s->cpuDistDev);
     *workingBytes = b;
   }
   return MGS_OK;
@@ -1202,25 +1179,34 @@ static int sizeWorkingSet(MgsScene s)
   const uint64_t total = s->d->totalSplats, parts = s->d->totalParts;
   int rc = MGS_OK;
   const size_t slots = (size_t)parts * kPart;
-  if((rc = s->keysSlot.ensure(slots))) return rc;
-  if((rc = s->idsSlot.ensure(slots))) return rc;
-  if((rc = s->slotCount.ensure(parts))) return rc;
+  if((rc = s->slotHist2.ensure((size_t)parts * 512u))) return rc;
+  if((rc = s->top16Rec.ensure((size_t)parts * 128u))) return rc;
+  // occurrences of key >> 16: the sort's prepare kernel consumes and clears it every frame; zeroed here as well, so that a
+  // frame that died between the two kernels cannot leak counts into the next scene
+  if((rc = s->top16Count.ensure(65536u))) return rc;
+  HIPCHK(hipMemset(s->top16Count.p, 0, 65536u * 4u));
+  {  // look-back words of the key sort's passes: zero once, every pass clears the other buffer for its successor
+    const size_t words = 2u * osSortStatusWords(osSortMaxParts((uint32_t)total));
+    if(s->osStatus.n < words)
+    {
+      if((rc = s->osStatus.ensure(words))) return rc;
+      HIPCHK(hipMemset(s->osStatus.p, 0, words * 4u));
+    }
+  }
   if((rc = s->partSkip.ensure(parts))) return rc;
   if((rc = s->partR.ensure(parts))) return rc;
   HIPCHK(hipMemset(s->partSkip.p, 0, parts * sizeof(uint32_t)));
-  if((rc = s->keysA.ensure(total))) return rc;
+  if((rc = s->pairA.ensure(total))) return rc;
+  if((rc = s->pairB.ensure(total))) return rc;
   if((rc = s->idsA.ensure(total))) return rc;
-  if((rc = s->keysB.ensure(total))) return rc;
-  if((rc = s->idsB.ensure(total))) return rc;
   if((rc = s->rect.ensure(total))) return rc;
   if((rc = s->rec.ensure(total))) return rc;
   if((rc = s->sortedRect.ensure(total))) return rc;
   if((rc = s->ctr.ensure(1))) return rc;
-  if((rc = s->plans.ensure(2))) return rc;
-  {
-    const char* e = std::getenv("MGS_SORT");
-    if(e && std::strcmp(e, "sample") == 0)
-      if((rc = s->ssFrame.ensure((uint32_t)total, (uint32_t)parts))) return rc;
+  {  // FramePlans + the look-back words of the project kernels, contiguous: one zero sweep by the frame's first kernel
+    const uint32_t prjWords = prjStatusWords((uint32_t)parts);
+    s->planWords            = (uint32_t)(sizeof(FramePlans) / 4) + prjWords;
+    if((rc = s->plans.ensure(1 + ((size_t)prjWords * 4 + sizeof(FramePlans) - 1) / sizeof(FramePlans)))) return rc;
   }
 
   uint64_t cap = std::max<uint64_t>(32ull * total, 64ull << 20);  // 16 B per pair: 3 GB for a garden-sized scene
@@ -1239,7 +1225,7 @@ static int sizeWorkingSet(MgsScene s)
   if((rc = s->partHist.ensure(256ull * maxParts))) return rc;
   if((rc = s->blockCount.ensure(std::max<uint64_t>((total + kPart - 1) / kPart, 1)))) return rc;
   HIPCHK(hipMemset(s->ctr.p, 0, sizeof(FrameCounters)));
-  HIPCHK(hipMemset(s->plans.p, 0, 2 * sizeof(SortPlan)));
+  HIPCHK(hipMemset(s->plans.p, 0, (size_t)s->planWords * 4));
   // hipMemset on device memory is asynchronous on the NULL stream, and the render stream is non-blocking:
   // without this the memsets above can land in the middle of the first frame (caught by the test suite)
   HIPCHK(hipDeviceSynchronize());
@@ -1641,39 +1627,27 @@ static int pairSortBits(int nTiles)
 // pass elision of the key sort (sort_plan.h): on by default, MGS_SORT_REMAP=0 keeps the four plain passes
 static const bool kRemap = [] { const char* e = std::getenv("MGS_SORT_REMAP"); return e ? std::atoi(e) != 0 : true; }();
 
-static void keySort(MgsScene s, hipStream_t st, bool fuseRectGather, bool allowRemap)
+// the frame's key sort (k_osort.hip): slots of the project kernel -> sorted ids in idsA (keys in keysA when wanted)
+static void keySort(MgsScene s, hipStream_t st, bool wantKeys, bool allowRemap)
 {
-  SortLaunch L{};
-  L.allowRemap = allowRemap;
-  if(fuseRectGather)
-  {
-    L.gatherSrc = s->rect.p;
-    L.gatherDst = s->sortedRect.p;
-  }
-  L.keys0 = s->keysSlot.p;
-  L.vals0 = s->idsSlot.p;
-  L.keysX = s->keysA.p;
-  L.valsX = s->idsA.p;
-  L.keysY = s->keysB.p;
-  L.valsY = s->idsB.p;
-  L.slotCount    = s->slotCount.p;
-  L.partsSlotted = s->d->totalParts;
+  OsLaunch L{};
+  L.pairs0       = s->pairB.p;
+  L.prjParts     = s->d->totalParts;
+  L.slotHist2    = s->slotHist2.p;
+  L.top16Rec     = s->top16Rec.p;
+  L.top16Count   = s->top16Count.p;
   L.nPtr         = &s->ctr.p->sortedCount;
-  L.plan         = &s->plans.p[0];
-  L.partHist     = s->partHist.p;
-  L.pStride      = s->pStride;
   L.maxElems     = s->d->totalSplats;
-  L.beginBit     = 0;
-  L.endBit       = 32;
-  // default: four LSD passes (k_sort.hip).  MGS_SORT=sample selects the two-round-trip sample sort (k_ssort.hip):
-  // bit-identical results, measured slower on depth keys of Morton-ordered splats
-  static const bool kSample = [] { const char* e = std::getenv("MGS_SORT"); return e && std::strcmp(e, "sample") == 0; }();
-  if(kSample)
-    s->ssFrame.fill(L.ss);
-  if(kSample && sampleSortSupported(L))
-    launchSampleSort(st, L);
-  else
-    launchRadixSort(st, L);
+  L.pairA        = s->pairA.p;
+  L.pairB        = s->pairB.p;
+  L.outVals      = s->idsA.p;
+  L.outKeys      = wantKeys ? s->keysA.p : nullptr;
+  L.plan         = &s->plans.p->os;
+  L.planOut      = &s->plans.p->keys;
+  L.status       = s->osStatus.p;
+  L.ctr          = s->ctr.p;
+  L.allowRemap   = allowRemap;
+  launchOsSort(st, L);
 }
 
 // CPU_ASYNC path: tryConsumeAndUploadCpuSortingResult (src/splat_set_manager_vk.cpp:3334-3416)
@@ -1945,8 +1919,8 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
   hipStream_t st    = s->stream;
   const bool  timed = p->collect_timings != 0;
   FrameCounters* ctr = s->ctr.p;
-  SortPlan*      planK = &s->plans.p[0];
-  SortPlan*      planP = &s->plans.p[1];
+  SortPlan*      planK = &s->plans.p->keys;
+  SortPlan*      planP = &s->plans.p->pairs;
 
   hipEvent_t* fev = s->evRing[s->frameIndex % MgsScene_t::kRing];
   const bool  cpuModeOuter = (p->sort_mode == MGS_SORT_CPU_ASYNC);
@@ -1960,26 +1934,25 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     static_assert(sizeof(SortPlan) % 4 == 0 && sizeof(FrameCounters) % 4 == 0, "word-sized state");
     if(F.partitionCull && s->d->totalParts > 0)
       launchPartitionCull(st, A, s->dArgs.p, s->partSkip.p, s->partR.p, reinterpret_cast<uint32_t*>(ctr), (uint32_t)(sizeof(FrameCounters) / 4),
-                          reinterpret_cast<uint32_t*>(planK), (uint32_t)(2 * sizeof(SortPlan) / 4),
+                          reinterpret_cast<uint32_t*>(s->plans.p), s->planWords,
                           reinterpret_cast<uint32_t*>(s->ranges.p), 2u * nTiles);
     else
-      launchFrameInit(st, ctr, planK, planP, s->ranges.p, nTiles);
+      launchFrameInit(st, ctr, reinterpret_cast<uint32_t*>(s->plans.p), s->planWords, s->ranges.p, nTiles);
     if(withEvents) HIPCHK(hipEventRecord(fev[6], st));  // MGS_STAGE_CULL ends here; it is part of MGS_STAGE_PROJECT too
     const bool cpuMode = (p->sort_mode == MGS_SORT_CPU_ASYNC);
     if(cpuMode)  // rejected splats must look empty to the binning stage: rect with x0 > x1
       hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, st, s->rect.p, 1u, s->d->totalSplats);
     if(gut)
-      launchProjectGut(st, A, s->dArgs.p, s->d->shFormat, ctr, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->recGut.p, s->rect.p,
-                       F.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride, kRemap ? planK : nullptr);
+      launchProjectGut(st, A, s->dArgs.p, s->d->shFormat, ctr, s->pairB.p, reinterpret_cast<uint32_t*>(s->plans.p + 1), s->recGut.p, s->rect.p,
+                       F.partitionCull ? s->partSkip.p : nullptr, s->slotHist2.p, s->top16Rec.p, cpuMode ? nullptr : s->top16Count.p,
+                       &s->plans.p->os);
     else
-      launchProject(st, A, s->dArgs.p, true, ctr, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p,
-                    s->rect.p, F.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride, kRemap ? planK : nullptr,
-                    F.partitionCull ? s->partR.p : nullptr);
+      launchProject(st, A, s->dArgs.p, true, ctr, s->pairB.p, reinterpret_cast<uint32_t*>(s->plans.p + 1), s->rec.p, s->rect.p,
+                    F.partitionCull ? s->partSkip.p : nullptr, s->slotHist2.p, s->top16Rec.p, cpuMode ? nullptr : s->top16Count.p,
+                    &s->plans.p->os, F.partitionCull ? s->partR.p : nullptr);
     if(withEvents) HIPCHK(hipEventRecord(fev[1], st));
-    static const bool kFuseRect = [] { const char* e = std::getenv("MGS_FUSE_RECT"); return e ? std::atoi(e) != 0 : false; }();  // measured: +43 us in the scatter for -17 us in the count kernel
-    const bool direct0 = directBinningSupported(F.binsX, F.binsY);
     if(!cpuMode)
-      keySort(s, st, kFuseRect && direct0, kRemap);
+      keySort(s, st, false, kRemap);
     else
     {
       rc = cpuSortStep(s, p, p->cpu_sort_blocking != 0);
@@ -2001,14 +1974,14 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     const bool direct = kDirectBin && directBinningSupported(F.binsX, F.binsY);
     if(direct)
     {
-      launchDirectBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, s->sortedRect.p, s->dbinMasks.p, s->d->totalSplats,
+      launchDirectBinning(st, s->idsA.p, s->idsA.p, planK, s->rect.p, s->sortedRect.p, s->dbinMasks.p, s->d->totalSplats,
                           s->partHist.p, s->pStride, &planP->ghist[0][0], s->pairVal1.p, s->ranges.p, ctr, s->pairCapacity,
                           F.binsX, F.binsY);
       if(withEvents) HIPCHK(hipEventRecord(fev[3], st));
     }
     else
     {
-      launchBinning(st, s->idsA.p, s->idsB.p, planK, s->rect.p, s->blockCount.p, (s->d->totalSplats + kPart - 1) / kPart, ctr,
+      launchBinning(st, s->idsA.p, s->idsA.p, planK, s->rect.p, s->blockCount.p, (s->d->totalSplats + kPart - 1) / kPart, ctr,
                     s->sortedRect.p, s->splatOffset.p, s->chunkStart.p, s->pairKey0.p, s->pairVal0.p, s->pairCapacity, F.binsX, true);
       if(withEvents) HIPCHK(hipEventRecord(fev[3], st));
       {
@@ -2019,7 +1992,6 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
         L.valsX = s->pairVal1.p;
         L.keysY = s->pairKey0.p;
         L.valsY = s->pairVal0.p;
-        L.slotCount = nullptr;
         L.nPtr      = &ctr->pairCount;
         L.plan      = planP;
         L.partHist  = s->partHist.p;
@@ -2170,7 +2142,7 @@ int mgs_frame_stats(MgsScene s, MgsFrameOut* out)
   if(!s->lastWasSortOnly)
   {
     HIPCHK(hipMemcpyAsync(s->hCtr, s->ctr.p, sizeof(FrameCounters), hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipMemcpyAsync(s->hPlans, s->plans.p, 2 * sizeof(SortPlan), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(s->hPlans, s->plans.p, sizeof(FramePlans), hipMemcpyDeviceToHost, s->stream));
   }
   HIPCHK(hipStreamSynchronize(s->stream));
   std::memset(out->stage_ms, 0, sizeof(out->stage_ms));
@@ -2730,18 +2702,18 @@ int mgs_sort_keys(MgsScene s, const MgsFrameParams* p, MgsSortOut* out)
   HIPCHK(hipEventRecord(s->ev[0], st));
   if(A.f.partitionCull && s->d->totalParts > 0)
     launchPartitionCull(st, A, s->dArgs.p, s->partSkip.p, s->partR.p, reinterpret_cast<uint32_t*>(s->ctr.p),
-                        (uint32_t)(sizeof(FrameCounters) / 4), reinterpret_cast<uint32_t*>(s->plans.p),
-                        (uint32_t)(2 * sizeof(SortPlan) / 4), nullptr, 0u);
+                        (uint32_t)(sizeof(FrameCounters) / 4), reinterpret_cast<uint32_t*>(s->plans.p), s->planWords, nullptr, 0u);
   else
-    launchFrameInit(st, s->ctr.p, &s->plans.p[0], &s->plans.p[1], s->ranges.p, 0);
-  launchProject(st, A, s->dArgs.p, false, s->ctr.p, s->keysSlot.p, s->idsSlot.p, s->slotCount.p, s->rec.p, s->rect.p,
-                A.f.partitionCull ? s->partSkip.p : nullptr, s->partHist.p, s->pStride, kRemap ? &s->plans.p[0] : nullptr,
+    launchFrameInit(st, s->ctr.p, reinterpret_cast<uint32_t*>(s->plans.p), s->planWords, s->ranges.p, 0);
+  launchProject(st, A, s->dArgs.p, false, s->ctr.p, s->pairB.p, reinterpret_cast<uint32_t*>(s->plans.p + 1), s->rec.p, s->rect.p,
+                A.f.partitionCull ? s->partSkip.p : nullptr, s->slotHist2.p, s->top16Rec.p, s->top16Count.p, &s->plans.p->os,
                 A.f.partitionCull ? s->partR.p : nullptr);
   HIPCHK(hipEventRecord(s->ev[1], st));
-  keySort(s, st, false, kRemap);
+  if((rc = s->keysA.ensure(s->d->totalSplats))) return rc;  // the hook returns the sorted keys too
+  keySort(s, st, true, kRemap);
   HIPCHK(hipEventRecord(s->ev[2], st));
   HIPCHK(hipMemcpyAsync(s->hCtr, s->ctr.p, sizeof(FrameCounters), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(s->hPlans, s->plans.p, 2 * sizeof(SortPlan), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(s->hPlans, s->plans.p, sizeof(FramePlans), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
   float ms = 0;
@@ -2750,10 +2722,9 @@ int mgs_sort_keys(MgsScene s, const MgsFrameParams* p, MgsSortOut* out)
   HIPCHK(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
   out->sort_ms = ms;
   out->count   = s->hCtr->sortedCount;
-  out->passes  = s->hPlans[0].passesRun;
-  out->reserved[0] = s->hPlans[0].pad[0];       // sample sort: (partition, bucket) slices
-  out->reserved[1] = s->hPlans[0].reserved[2];  //              buckets in use
-  out->reserved[2] = s->hPlans[0].reserved[3];  //              buckets that took the streaming path
+  out->passes  = s->hPlans->keys.passesRun;
+  out->reserved[0] = s->hPlans->os.remapOn;     // pass 2 sorted on the rank of key >> 16
+  out->reserved[1] = s->hPlans->os.remapCount;  // occurring values of key >> 16
   s->lastSort  = *out;
   s->lastWasSortOnly = true;
   s->haveFrame       = true;
@@ -2795,7 +2766,7 @@ int mgs_sort_download(MgsScene s, uint32_t* keys, uint32_t* ids, uint32_t capaci
   if(!s->lastWasSortOnly)
   {  // after a full frame the counters are still on the device
     HIPCHK(hipMemcpyAsync(s->hCtr, s->ctr.p, sizeof(FrameCounters), hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipMemcpyAsync(s->hPlans, s->plans.p, 2 * sizeof(SortPlan), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(s->hPlans, s->plans.p, sizeof(FramePlans), hipMemcpyDeviceToHost, s->stream));
   }
   HIPCHK(hipStreamSynchronize(s->stream));
   const uint32_t n = s->hCtr->sortedCount;
@@ -2804,12 +2775,18 @@ int mgs_sort_download(MgsScene s, uint32_t* keys, uint32_t* ids, uint32_t capaci
     setError("mgs_sort_download: capacity too small");
     return MGS_ERR_INVALID_ARG;
   }
-  const bool y = s->hPlans[0].finalSel != 0;
   if(n)
   {
     if(keys)
-      HIPCHK(hipMemcpy(keys, y ? s->keysB.p : s->keysA.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(ids, y ? s->idsB.p : s->idsA.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    {
+      if(!s->lastWasSortOnly || s->keysA.n < n)
+      {
+        setError("mgs_sort_download: the sorted keys exist after mgs_sort_keys only (a frame's last sort pass writes the ids alone)");
+        return MGS_ERR_STATE;
+      }
+      HIPCHK(hipMemcpy(keys, s->keysA.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
+    HIPCHK(hipMemcpy(ids, s->idsA.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     mapIdsToCaller(s, ids, n);  // the pipeline works on storage ids
   }
   return MGS_OK;
@@ -2835,42 +2812,67 @@ int mgs_radix_sort_u32(MgsScene s, void* keysDev, void* valsDev, uint32_t count,
   if((rc = hist.ensure(256ull * parts))) return rc;
   if((rc = nDev.ensure(1))) return rc;
   if((rc = plan.ensure(1))) return rc;
-  static const bool kSampleRaw = [] { const char* e = std::getenv("MGS_SORT"); return e && std::strcmp(e, "sample") == 0; }();
-  const bool sample = kSampleRaw && beginBit == 0 && endBit == 32 && parts <= 131072u && count <= 7000000u;
-  if(sample)
-  {  // the sample sort keeps its input intact until the finishers have read it: Y cannot alias the caller's arrays
-    if((rc = s->rsKeysY.ensure(count))) return rc;
-    if((rc = s->rsValsY.ensure(count))) return rc;
-    if((rc = s->ssRaw.ensure(count, parts))) return rc;
+  // a full-width sort runs on the frame key sort's kernels (k_osort.hip, uniform input, four plain passes): the battery of
+  // the stand-alone sort tests exercises exactly what the frame uses; partial bit ranges take the generic sort (k_sort.hip).
+  // MGS_RAW_SORT=generic forces the generic one for every range (A/B).
+  static const bool kRawGeneric = [] { const char* e = std::getenv("MGS_RAW_SORT"); return e && std::strcmp(e, "generic") == 0; }();
+  const bool os = !kRawGeneric && beginBit == 0 && endBit == 32;
+  if(os)
+  {
+    if((rc = s->rsPairA.ensure(count))) return rc;
+    if((rc = s->rsPairB.ensure(count))) return rc;
+    if((rc = s->rsOsPlan.ensure(1))) return rc;
+    const size_t words = 2u * osSortStatusWords(osSortMaxParts(count));
+    if(s->rsStatus.n < words)
+    {
+      if((rc = s->rsStatus.ensure(words))) return rc;
+      HIPCHK(hipMemset(s->rsStatus.p, 0, words * 4u));
+      HIPCHK(hipDeviceSynchronize());
+    }
   }
   hipStream_t st = s->stream;
   HIPCHK(hipMemcpyAsync(nDev.p, &count, 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipEventRecord(s->ev[6], st));
   launchSortClearPlan(st, plan.p);
-  SortLaunch L{};
-  L.keys0 = (uint32_t*)keysDev;
-  L.vals0 = (uint32_t*)valsDev;
-  L.keysX = kX.p;
-  L.valsX = vX.p;
-  L.keysY = (uint32_t*)keysDev;
-  L.valsY = (uint32_t*)valsDev;
-  L.nPtr     = nDev.p;
-  L.plan     = plan.p;
-  L.partHist = hist.p;
-  L.pStride  = parts;
-  L.maxElems = count;
-  L.beginBit = beginBit;
-  L.endBit   = endBit;
-  if(sample)
+  if(os)
   {
-    L.keysY = s->rsKeysY.p;
-    L.valsY = s->rsValsY.p;
-    s->ssRaw.fill(L.ss);
-    launchSampleSort(st, L);
+    launchOsSortClearPlan(st, s->rsOsPlan.p);
+    OsLaunch O{};
+    O.keys0    = (const uint32_t*)keysDev;
+    O.vals0    = (const uint32_t*)valsDev;
+    O.nPtr     = nDev.p;
+    O.maxElems = count;
+    O.pairA    = s->rsPairA.p;
+    O.pairB    = s->rsPairB.p;
+    O.outKeys  = kX.p;
+    O.outVals  = vX.p;
+    O.plan     = s->rsOsPlan.p;
+    O.planOut  = plan.p;  // finalSel = 0: the result is in X
+    if((rc = s->ctr.ensure(1))) return rc;
+    O.ctr      = s->ctr.p;
+    O.status   = s->rsStatus.p;
+    O.allowRemap = false;
+    launchOsSort(st, O);
   }
   else
+  {
+    SortLaunch L{};
+    L.keys0 = (uint32_t*)keysDev;
+    L.vals0 = (uint32_t*)valsDev;
+    L.keysX = kX.p;
+    L.valsX = vX.p;
+    L.keysY = (uint32_t*)keysDev;
+    L.valsY = (uint32_t*)valsDev;
+    L.nPtr     = nDev.p;
+    L.plan     = plan.p;
+    L.partHist = hist.p;
+    L.pStride  = parts;
+    L.maxElems = count;
+    L.beginBit = beginBit;
+    L.endBit   = endBit;
     launchRadixSort(st, L);
+  }
   HIPCHK(hipEventRecord(s->ev[7], st));
   SortPlan hp;
   HIPCHK(hipMemcpyAsync(&hp, plan.p, sizeof(SortPlan), hipMemcpyDeviceToHost, st));

@@ -1,8 +1,12 @@
-// sort_plan.h — device-resident plan of one radix sort and the host-side launch descriptor.
+// sort_plan.h — device-resident plans of the radix sorts and the host-side launch descriptors.
+//   k_sort.hip   generic reduce-then-scan LSD sort (any bit range; the record-path pair sort, the stand-alone sort API)
+//   k_osort.hip  the frame's depth-key sort: single-kernel passes with an in-kernel two-level look-back
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+
+#include "device_types.h"
 
 namespace mgs {
 
@@ -10,34 +14,102 @@ struct SortPlan
 {
   uint32_t ghist[4][256];  // digit totals of every pass, written by that pass's scan kernel
   uint32_t skip[4];        // pass is the identity permutation (single occupied digit) -> its scatter exits
-  uint32_t reserved[4];    // [0]: the last pass left gatherDst filled (fused gather); [1..3]: sample sort (cursor, buckets, streamed buckets)
+  uint32_t reserved[4];
   uint32_t finalSel;       // result lives in X (0) or Y (1); written by the last pass
   uint32_t passesRun;
   uint32_t n;
   uint32_t pad[5];
-  // Pass elision for depth keys (k_sort.hip): the producer marks which values of key >> 16 occur (as small ranges per
-  // partition); when at most 256 do, pass 2 sorts on the RANK of key >> 16 among them — an order-preserving 8-bit
-  // digit that covers the top 16 bits at once — and pass 3 is skipped.
-  uint32_t remapOn;          // decided by the pass-1 scan kernel
-  uint32_t remapCount;
-  uint32_t remapBase;        // smallest occurring value: the kernels index a 4096-entry LDS table with (key >> 16) - remapBase
-  uint32_t remapPad;
-  uint32_t topBitmap[2048];  // presence of key >> 16
-  uint16_t remapVals[256];   // the occurring values, ascending
 };
 
-// mark one value of key >> 16 as present.  Thousands of partitions mark the same handful of values: look first (a stale
-// miss only costs a redundant atomic), so that the atomics on those few words do not serialise the grid.
-__device__ __forceinline__ void sortMarkTop16(SortPlan* plan, uint32_t v)
+struct SortLaunch
 {
-  if(((__hip_atomic_load(&plan->topBitmap[v >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (v & 31u)) & 1u) == 0u)
-    atomicOr(&plan->topBitmap[v >> 5], 1u << (v & 31u));
-}
+  const uint32_t* keys0;  // pass-0 source
+  const uint32_t* vals0;
+  uint32_t*       keysX;
+  uint32_t*       valsX;
+  uint32_t*       keysY;
+  uint32_t*       valsY;
+  const uint32_t* nPtr;      // device-side element count
+  SortPlan*       plan;      // must be zeroed before the launch (launchSortClearPlan / frame init)
+  uint32_t*       partHist;  // [256][pStride], pStride >= ceil(maxElems/2048)
+  uint32_t        pStride;
+  uint32_t        maxElems;  // host-side upper bound of the element count (sizes the grids)
+  int             beginBit, endBit;
+  uint2*          ranges = nullptr;  // optional, single-pass sorts: ranges[digit] = [begin,end) in the sorted output
+};
 
-// Pass elision of the key sort: the producer's workgroup marks which values of key >> 16 it hands to the sort.  A partition is
-// a compact cell of space, so its keys span one to three values: thread 0 marks the range; a partition that spans many (a cell
-// around the camera) has every thread mark its own keys.  Split in two so that it needs no barrier of its own and the marking's
-// memory latency overlaps the kernel's last stores: post the per-wave min / max before the kernel's final barrier, mark after it.
+void launchSortClearPlan(hipStream_t stream, SortPlan* plan);
+void launchRadixSort(hipStream_t stream, const SortLaunch& s);
+
+// ---- the frame's key sort (k_osort.hip) -------------------------------------------------------------------------------
+constexpr uint32_t kOsPart    = 4096;  // pairs per partition (256 threads x 16)
+constexpr uint32_t kOsGroup   = 32;    // partitions per look-back group
+constexpr uint32_t kRemapSpan = 4096;  // pass 2 of a depth-key sort indexes a 4096-entry LDS table with (key >> 16) - remapBase
+
+struct OsPlan
+{
+  uint32_t total[4][256];  // digit totals of every pass, complete before pass 0 starts (pass 2: per rank when remapOn)
+  uint32_t ticket[4];      // partitions are handed out in start order
+  // Pass elision for depth keys: when at most 256 values of key >> 16 occur (within a span < 4096), pass 2 sorts on the RANK
+  // of key >> 16 among them — an order-preserving 8-bit digit that covers the top 16 bits at once — and pass 3 does not run.
+  uint32_t remapOn, remapCount, remapBase;
+  uint32_t n;               // element count (copied from the device-side counter by k_os_prepare)
+  uint32_t arrived;         // reduce workgroups of k_os_prepare that are done (the last one folds the count table)
+  uint32_t top16MinInv;     // 0x10000 - (smallest occurring value of key >> 16); 0 = none   } both kept as maxima: the plan
+  uint32_t top16MaxP1;      // largest occurring value + 1; 0 = none                          } starts zeroed
+  uint32_t pad;
+  uint16_t remapVals[256];  // the occurring values, ascending
+};
+
+// host descriptor of the frame key sort / the stand-alone full-width sort
+struct OsLaunch
+{
+  // input, exactly one of: the project kernels' dense (key, id) pairs with their per-partition histograms and records ...
+  const uint2*    pairs0     = nullptr;  // n pairs (n = *nPtr); may alias pairB (pass 0 reads it before pass 1 writes B)
+  uint32_t        prjParts   = 0;        // project partitions (2048 splats each)
+  const uint32_t* slotHist2  = nullptr;  // [partition][2][256]: histograms of key bits 0-7 and 8-15
+  const uint32_t* top16Rec   = nullptr;  // [partition][4 waves][32]: counts of key >> 16 per producer wave (slot_emit.h)
+  uint32_t*       top16Count = nullptr;  // [65536] occurrences of key >> 16 (filled, consumed and cleared by k_os_prepare;
+                                         // partitions that span > 24 values add their keys themselves)
+  // ... or a uniform array of keys and values
+  const uint32_t* keys0 = nullptr;
+  const uint32_t* vals0 = nullptr;
+  const uint32_t* nPtr     = nullptr;  // device-side element count
+  uint32_t        maxElems = 0;        // host-side upper bound (sizes the grids)
+  uint2*          pairA    = nullptr;  // ping-pong, maxElems pairs each
+  uint2*          pairB    = nullptr;
+  uint32_t*       outVals  = nullptr;  // the sorted values
+  uint32_t*       outKeys  = nullptr;  // the sorted keys (null: not needed)
+  OsPlan*         plan     = nullptr;  // zeroed before the launch (frame init / launchOsSortClearPlan)
+  SortPlan*       planOut  = nullptr;  // n / finalSel = 0 / passesRun for the consumers of the sorted ids
+  uint32_t*       status   = nullptr;  // 2 x osSortStatusWords(osSortMaxParts(...)) words, zero on first use
+  FrameCounters*  ctr      = nullptr;  // errorFlags |= kErrSpinTimeout if a look-back wait ever gives up
+  bool            allowRemap = true;
+};
+
+// the per-frame sort state of one context, contiguous so that the frame's first kernel zeroes it in one sweep
+struct FramePlans
+{
+  SortPlan keys;   // what the consumers of the sorted ids read (n, finalSel, passesRun)
+  SortPlan pairs;  // the record path's pair sort / the direct binning's per-bin totals
+  OsPlan   os;     // the key sort's own plan
+};
+
+uint32_t osSortMaxParts(uint32_t maxElems);
+size_t   osSortStatusWords(uint32_t maxParts);
+void     launchOsSortClearPlan(hipStream_t stream, OsPlan* plan);
+void     launchOsSort(hipStream_t stream, const OsLaunch& L);
+
+// ---- what the project kernels hand to the key sort (k_project.hip, k_gut.hip; device side in slot_emit.h) -----------------
+constexpr uint32_t kPrjGroup = 64;  // project workgroups per look-back group == lanes of the wave that reads them
+// words of the look-back state for `parts` project workgroups: one per workgroup, then one per group (zeroed per frame)
+inline uint32_t prjStatusWords(uint32_t parts) { return parts + (parts + kPrjGroup - 1u) / kPrjGroup + 1u; }
+
+// The producer counts which values of key >> 16 it hands to the sort.  A partition is a compact cell of space, so its keys
+// span one to three values: every wave leaves a 32-word record (counts of the values lo .. lo + 24, header lo | span << 16
+// in word 31) and k_os_prepare folds the records; a partition that spans more than 24 values (a cell around the camera)
+// adds its keys to the count table one by one.  Split in two so that it needs no barrier of its own: post the per-wave
+// min / max before the kernel's last barrier, count after it.
 template <int WAVES>
 __device__ __forceinline__ void sortTop16Post(uint32_t mn, uint32_t mx, uint32_t* s_red /* 2 * WAVES free words */)
 {
@@ -53,66 +125,22 @@ __device__ __forceinline__ void sortTop16Post(uint32_t mn, uint32_t mx, uint32_t
     s_red[WAVES + (threadIdx.x >> 6)] = mx;
   }
 }
-// returns true when the caller's threads must mark their own keys
 template <int WAVES>
-__device__ __forceinline__ bool sortTop16Mark(SortPlan* plan, uint32_t count, const uint32_t* s_red)
+__device__ __forceinline__ void sortTop16Range(uint32_t count, const uint32_t* s_red, uint32_t& lo, uint32_t& hi)
 {
-  if(plan == nullptr || count == 0u)
-    return false;
-  uint32_t lo = s_red[0], hi = s_red[WAVES];
+  lo = s_red[0];
+  hi = s_red[WAVES];
 #pragma unroll
   for(int i = 1; i < WAVES; ++i)
   {
     lo = min(lo, s_red[i]);
     hi = max(hi, s_red[WAVES + i]);
   }
-  if(hi - lo > 24u)
-    return true;
-  if(threadIdx.x == 0)
-    for(uint32_t v = lo; v <= hi; ++v)
-      sortMarkTop16(plan, v);
-  return false;
+  if(count == 0u)
+  {
+    lo = 1u;
+    hi = 0u;
+  }
 }
-
-// scratch of the sample sort (k_ssort.hip); all device pointers, owned by the caller
-struct SampleSortBuffers
-{
-  uint32_t*           samples     = nullptr;  // [16384]
-  uint32_t*           splitters   = nullptr;  // [maxBuckets]
-  unsigned long long* bucketCount = nullptr;  // [maxBuckets]: slices << 32 | keys, per bucket
-  uint2*              desc        = nullptr;  // [maxBuckets][parts]: (source index, partition << 11 | count - 1)
-  uint32_t            maxBuckets  = 0;        // sampleSortBuckets(maxElems)
-};
-
-struct SortLaunch
-{
-  const uint32_t* keys0;  // pass-0 source
-  const uint32_t* vals0;
-  uint32_t*       keysX;
-  uint32_t*       valsX;
-  uint32_t*       keysY;
-  uint32_t*       valsY;
-  const uint32_t* slotCount;     // non-null: pass 0 reads slotted partitions (stride 2048) with these counts, and the
-                                 // producer has already written their pass-0 digit histograms into partHist
-  uint32_t        partsSlotted;  // number of slotted partitions
-  const uint32_t* nPtr;          // device-side element count (uniform partitions)
-  SortPlan*       plan;          // must be zeroed before the launch (launchSortClearPlan / frame init)
-  uint32_t*       partHist;      // [256][pStride], pStride >= max(partsSlotted, ceil(maxElems/2048))
-  uint32_t        pStride;
-  uint32_t        maxElems;      // host-side upper bound of the element count (sizes the grids)
-  int             beginBit, endBit;
-  uint2*          ranges    = nullptr;  // optional, single-pass sorts: ranges[digit] = [begin,end) in the sorted output
-  const uint32_t* gatherSrc = nullptr;  // optional (multi-pass sorts): the LAST pass writes gatherDst[pos] = gatherSrc[value]
-  uint32_t*       gatherDst = nullptr;  //   instead of the keys, and sets plan->reserved[0] when it ran (not skipped)
-  SampleSortBuffers ss;                 // non-null desc: full 32-bit sorts take the sample sort (k_ssort.hip)
-  bool            allowRemap = false;   // the producer marked plan->topBitmap (full 32-bit key sorts of a frame only)
-};
-
-void launchSortClearPlan(hipStream_t stream, SortPlan* plan);
-void launchRadixSort(hipStream_t stream, const SortLaunch& s);
-// sample sort: 4 launches, 32 B/key; src0 is permuted in place inside its 2048-key partitions, result in X
-uint32_t sampleSortBuckets(uint32_t maxElems);
-bool     sampleSortSupported(const SortLaunch& s);
-void     launchSampleSort(hipStream_t stream, const SortLaunch& s);
 
 }  // namespace mgs
