@@ -270,12 +270,13 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
     emitEmptySlot<kGutThreads>(prjStatus, A.f.totalPartitions, slotHist2, top16Rec, ctr, blockIdx.x);
     return;
   }
-  __shared__ uint32_t s_hist2[512];
+  __shared__ uint32_t s_hist2[256];  // 2 x 256 sixteen-bit counters (slot_emit.h)
   __shared__ uint16_t s_li[kGutPart];
   __shared__ uint32_t s_key[kGutPart];
   __shared__ uint32_t s_cnt[32];
   __shared__ uint32_t s_base[33];
-  for(int i = threadIdx.x; i < 512; i += kGutThreads)
+  __shared__ uint32_t s_keep[2];
+  for(int i = threadIdx.x; i < 256; i += kGutThreads)
     s_hist2[i] = 0u;
   const int      t = threadIdx.x, lane = laneId(), w = t >> 6;
   const uint32_t part = blockIdx.x;
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
   }
   __syncthreads();
   // second ordered compaction into the partition's slot + what the key sort needs up front (slot_emit.h)
-  emitSlot<kGutThreads, kGutItems>(Mv, false, s_li, s_key, s_cnt, s_base, s_hist2, densePairs, prjStatus, A.f.totalPartitions, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
+  emitSlot<kGutThreads, kGutItems>(Mv, false, s_li, s_key, s_cnt, s_base, s_hist2, s_keep, densePairs, prjStatus, A.f.totalPartitions, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
                                    I.globalOffset + local0);
 }
 

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
     return;
   const uint32_t minInv = ldAgent(&plan->top16MinInv), maxP1 = ldAgent(&plan->top16MaxP1);
   if(minInv == 0u || maxP1 == 0u)
-  {  // no keys at all
+  {  // no real keys at all
     if(t == 0)
       plan->remapOn = plan->remapCount = plan->remapBase = 0u;
     return;
@@ -271,9 +271,10 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
     }
     if(t == 0)
     {
-      plan->remapOn    = on ? 1u : 0u;
-      plan->remapCount = on ? total : 0u;
-      plan->remapBase  = on ? vlo : 0u;
+      plan->remapOn      = on ? 1u : 0u;
+      plan->remapCount   = on ? total : 0u;
+      plan->remapBase    = on ? vlo : 0u;
+      plan->remapPadRank = on ? total - 1u : 0u;  // keys outside the table (padding) take the largest rank
     }
     return;
   }
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
     if(useRemap)
     {  // every entry holds the largest rank first: a value outside the table (padding keys) sorts behind every real key
       const uint32_t count = plan->remapCount, base = plan->remapBase;
-      const uint32_t fill  = (count - 1u) * 0x01010101u;
+      const uint32_t fill  = plan->remapPadRank * 0x01010101u;
       for(int i = t; i < (int)kRemapSpan / 4; i += kThreads)
         reinterpret_cast<uint32_t*>(s_rv)[i] = fill;
       __syncthreads();
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
     s_whist[q][t]    = (uint16_t)tot;
     tot += c;
   }
-  const uint32_t padDigit = (REMAP && useRemap) ? plan->remapCount - 1u : 255u;
+  const uint32_t padDigit = (REMAP && useRemap) ? plan->remapPadRank : 255u;
   const uint32_t myCount  = tot - (((uint32_t)t == padDigit) ? rounds * kThreads - count : 0u);
   stAgent(&a.status[(size_t)p * 256u + t], kAgg | myCount);
   // Level 1 by rows: the counts a member published are one 1 KB row (256 digits).  Wave w folds the rows w, w + 4, ... of the

@@ -215,14 +215,15 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
     emitEmptySlot<kPrjThreads>(prjStatus, A.f.totalPartitions, slotHist2, top16Rec, ctr, blockIdx.x);
     return;
   }
-  __shared__ uint32_t s_hist2[512];
+  __shared__ uint32_t s_hist2[256];  // 2 x 256 sixteen-bit counters (slot_emit.h)
   __shared__ float4   s_rec[FULL ? kPrjWaves : 1][FULL ? 64 * 3 : 1];  // per wave: 64 records at a 48-byte pitch
-  for(int i = threadIdx.x; i < 512; i += kPrjThreads)
+  for(int i = threadIdx.x; i < 256; i += kPrjThreads)
     s_hist2[i] = 0u;  // ordered before its first use by the barriers of phase 1
   __shared__ uint16_t s_li[kPrjPart];   // bit 15: survived phase 2
   __shared__ uint32_t s_key[kPrjPart];
   __shared__ uint32_t s_cnt[32];
   __shared__ uint32_t s_base[33];
+  __shared__ uint32_t s_keep[2];
 
   const int      t = threadIdx.x, lane = laneId(), w = t >> 6;
   const uint32_t part = blockIdx.x;
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   if constexpr(!FULL)
   {
     // sort-only hook: survivors of the dist stage, exactly dist.comp.slang's (key, id) stream
-    emitSlot<kPrjThreads, kPrjItems>(M, true, s_li, s_key, s_cnt, s_base, s_hist2, densePairs, prjStatus, A.f.totalPartitions, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
+    emitSlot<kPrjThreads, kPrjItems>(M, true, s_li, s_key, s_cnt, s_base, s_hist2, s_keep, densePairs, prjStatus, A.f.totalPartitions, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
                                      I.globalOffset + local0);
     return;
   }
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
     // ---- second ordered compaction straight into the partition's slot region (slot_emit.h) ----
     __syncthreads();
     MGS_PRJ_STAMP(4)
-    const uint32_t outCount = emitSlot<kPrjThreads, kPrjItems>(M, false, s_li, s_key, s_cnt, s_base, s_hist2, densePairs, prjStatus, A.f.totalPartitions, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
+    const uint32_t outCount = emitSlot<kPrjThreads, kPrjItems>(M, false, s_li, s_key, s_cnt, s_base, s_hist2, s_keep, densePairs, prjStatus, A.f.totalPartitions, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
                                                                I.globalOffset + local0);
     (void)outCount;
 #ifdef MGS_PRJ_TRACE

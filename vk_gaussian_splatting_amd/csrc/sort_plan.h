@@ -54,10 +54,11 @@ struct OsPlan
   // of key >> 16 among them — an order-preserving 8-bit digit that covers the top 16 bits at once — and pass 3 does not run.
   uint32_t remapOn, remapCount, remapBase;
   uint32_t n;               // element count (copied from the device-side counter by k_os_prepare)
+  uint32_t remapPadRank;    // pass 2 when remapOn: the rank of keys outside the table (padding lanes): the largest
   uint32_t arrived;         // reduce workgroups of k_os_prepare that are done (the last one folds the count table)
   uint32_t top16MinInv;     // 0x10000 - (smallest occurring value of key >> 16); 0 = none   } both kept as maxima: the plan
   uint32_t top16MaxP1;      // largest occurring value + 1; 0 = none                          } starts zeroed
-  uint32_t pad;
+  uint32_t pad[4];
   uint16_t remapVals[256];  // the occurring values, ascending
 };
 
