@@ -506,14 +506,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
     if(row < m)
       rv[k] = loadRow(row);
   }
-  // local exclusive scan over the digits (padding included)
-  const uint32_t loff = scan256(tot, s_tmp);
-  s_loff[t]           = (uint16_t)loff;
-  // digit bases of the whole array: exclusive scan of the totals (known before the pass started)
-  const uint32_t below = scan256(plan->total[a.pass][t], s_tmp);
-  uint32_t spins = 0;
+  uint32_t spins = 0, intra = 0, base = 0;
   bool     bad   = false;
-  {
+  // level 1, consume: fold the rows (a member that had not published all four words when they were read is re-polled);
+  // the four waves' partial sums meet in the first 4 KB of s_pair, which is not in use before the re-order
+  auto foldRows = [&]() {
     uint32_t acc[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for(int k = 0; k < 8; ++k)
@@ -521,7 +518,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
       const uint32_t row = wu + 4u * k;
       if(row < m)
       {
-        // a member that had not published all four words when they were read: re-poll its row
         while(((rv[k].x >> 30) == 0u || (rv[k].y >> 30) == 0u || (rv[k].z >> 30) == 0u || (rv[k].w >> 30) == 0u) && !bad)
         {
           rv[k] = loadRow(row);
@@ -534,49 +530,29 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
         acc[3] += rv[k].w & kValMask;
       }
     }
-    // s_pair is not in use yet: its first 4 KB carry the four waves' partial sums
     reinterpret_cast<uint4*>(s_pair)[wu * 64 + lane] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
-  }
-  __syncthreads();
-  const uint32_t* s_l1  = reinterpret_cast<const uint32_t*>(s_pair);
-  const uint32_t  intra = s_l1[t] + s_l1[256 + t] + s_l1[512 + t] + s_l1[768 + t];
-  // level 2: the group's last member publishes the group total and looks back over the groups (16 per batch, down to the
-  // first inclusive prefix); its window loads travel behind the LDS re-order
-  const bool     lastMember = m == kOsGroup - 1u;
-  const uint32_t gtotal     = intra + myCount;
-  uint32_t       gw[kGroupWindow];
-  int            gq = (int)g - 1;
+    __syncthreads();
+    const uint32_t* s_l1 = reinterpret_cast<const uint32_t*>(s_pair);
+    intra                = s_l1[t] + s_l1[256 + t] + s_l1[512 + t] + s_l1[768 + t];
+  };
+  // level 2.  The group's LAST member does the group's work at once, before its own scans: it folds its rows (the other
+  // members published at the same moment), publishes the group total, looks back over the groups (16 per batch, down to the
+  // first inclusive prefix) and publishes the inclusive prefix — so that the 31 other members, which fold behind their scans
+  // and need that one word behind their LDS re-order, find it there.  It finishes ~3 us behind them instead of all of them
+  // waiting ~5 us for it.
+  const bool lastMember = m == kOsGroup - 1u;
   if(lastMember)
   {
+    foldRows();
+    const uint32_t gtotal = intra + myCount;
     stAgent(&a.gstatus[(size_t)g * 256u + t], kAgg | gtotal);
-#pragma unroll
-    for(int j = 0; j < kGroupWindow; ++j)
-      gw[j] = (gq - j >= 0) ? ldAgent(&a.gstatus[(size_t)(gq - j) * 256u + t]) : kInc;
-  }
-  __syncthreads();  // everybody has read the partial sums: s_pair may be overwritten
-  MGS_OS_STAMP(4)
-  // ---- re-order through LDS so that equal digits are contiguous ----
-#pragma unroll
-  for(int i = 0; i < kKpt; ++i)
-    if((uint32_t)i < rounds)
-    {
-      const uint32_t d   = rd[i] >> 16;
-      const uint32_t pos = (uint32_t)s_loff[d] + (uint32_t)s_whist[w][d] + (rd[i] & 0xFFFFu);
-      s_pair[pos]        = make_uint2(key[i], val[i]);
-    }
-  uint32_t base = 0;
-  if(lastMember)
-  {
-    bool first = true;
+    int gq = (int)g - 1;
     while(gq >= 0 && !bad)
     {
-      if(!first)
-      {
+      uint32_t gw[kGroupWindow];
 #pragma unroll
-        for(int j = 0; j < kGroupWindow; ++j)
-          gw[j] = (gq - j >= 0) ? ldAgent(&a.gstatus[(size_t)(gq - j) * 256u + t]) : kInc;
-      }
-      first     = false;
+      for(int j = 0; j < kGroupWindow; ++j)
+        gw[j] = (gq - j >= 0) ? ldAgent(&a.gstatus[(size_t)(gq - j) * 256u + t]) : kInc;
       bool done = false;
 #pragma unroll
       for(int j = 0; j < kGroupWindow; ++j)
@@ -606,8 +582,26 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
     }
     stAgent(&a.gstatus[(size_t)g * 256u + t], kInc | ((base + gtotal) & kValMask));
   }
-  else if(g > 0u)
-  {  // everybody else: the inclusive prefix of the previous group is one word
+  // local exclusive scan over the digits (padding included)
+  const uint32_t loff = scan256(tot, s_tmp);
+  s_loff[t]           = (uint16_t)loff;
+  // digit bases of the whole array: exclusive scan of the totals (known before the pass started)
+  const uint32_t below = scan256(plan->total[a.pass][t], s_tmp);
+  if(!lastMember)
+    foldRows();
+  __syncthreads();  // everybody has read the partial sums: s_pair may be overwritten
+  MGS_OS_STAMP(4)
+  // ---- re-order through LDS so that equal digits are contiguous ----
+#pragma unroll
+  for(int i = 0; i < kKpt; ++i)
+    if((uint32_t)i < rounds)
+    {
+      const uint32_t d   = rd[i] >> 16;
+      const uint32_t pos = (uint32_t)s_loff[d] + (uint32_t)s_whist[w][d] + (rd[i] & 0xFFFFu);
+      s_pair[pos]        = make_uint2(key[i], val[i]);
+    }
+  if(!lastMember && g > 0u)
+  {  // the inclusive prefix of the previous group is one word
     uint32_t v;
     while(((v = ldAgent(&a.gstatus[(size_t)(g - 1u) * 256u + t])) >> 30) != 2u)
       if(++spins > kSpinMax)
