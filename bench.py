@@ -17,7 +17,10 @@ off).  The throughput partition (alternate frames: rank r renders poses r, r+N, 
 the same run and reported in the secondary `alternate_frames` object.
 
 The JSON line also carries
-  roofline      — the dominant kernel's algorithmic bytes / its mean HIP-event duration in the timed region
+  roofline      — SURVEY.md 8d's algorithmic bytes of the longest HBM-bound stage (project / sort / bin, chosen by measured
+                  single-stream time) / its HIP-event duration; roofline_project, roofline_sort, roofline_bin, roofline_frame
+                  (bytes actually moved) and roofline_composite (VALU) beside it
+  value_single_frame — frames/s with one frame in flight (value: --inflight frames, default 3)
   cpu_baseline  — the oracle's restatement of the reference's CPU sorter (splat_sorter_async.cpp:92-141),
                   timed on this box's host cores (rank 0, N=1 only); a baseline, not a target.
 """
@@ -33,8 +36,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_SQ_FILE = "r2_h_pmc_sq_composite.json"  # {"k_composite": {"SQ_INSTS_VALU": per-launch mean, ...}}
-PMC_FILE = "r2_h_pmc_hbm_traffic.json"  # written by tools/pmc_traffic.py from rocprofv3 --pmc passes of this command
+PMC_SQ_FILE = "r3_s_pmc_sq_composite.json"  # {"k_composite": {"SQ_INSTS_VALU": per-launch mean, ...}}
+PMC_FILE = "r3_s_pmc_hbm_traffic.json"  # written by tools/pmc_traffic.py from rocprofv3 --pmc passes of this command
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 STAGES = ["project", "sort", "bin", "pairsort", "composite", "total"]
 
@@ -396,12 +399,13 @@ def main():
         # list entries actually walked + their 32-B record; colour + centre + the 192-B SH record of the staged ones; RGBA16F frame
         "composite": (4 + 32) * scanned + (16 + 12 + 192) * shaded + 8 * Ppix,
     }
-    # `roofline` describes the dominant HBM-bound KERNEL: k_project (the project stage is that one kernel plus a 7 us
-    # cull; the sort and binning stages are 11 and 3 kernels of at most ~60 us each, reported by `roofline_sort`).  The
-    # compositor can be the longest kernel of the frame, but it is bound by fp32 VALU issue (exp + blend per pixel-splat
-    # pair; no matrix contraction, so neither "hbm" nor "mfma" describes it): it gets its own `roofline_composite`
-    # object with its VALU utilisation instead of a made-up HBM fraction.
-    dom = 0
+    # `roofline` is SURVEY.md 8d's figure for the longest HBM-bound STAGE of the frame by measured (single-stream) time, chosen
+    # at run time among project / sort / bin.  The compositor can be the longest stage, but it is bound by fp32 VALU issue (exp
+    # + blend per pixel-splat pair; no matrix contraction, so neither "hbm" nor "mfma" describes it): it gets its own
+    # `roofline_composite` object with its VALU utilisation instead of a made-up HBM fraction.  `roofline_project` and
+    # `roofline_sort` are always there.
+    hbm_stages = [0, 1, 2]
+    dom = max(hbm_stages, key=lambda j: calib_ms[j] - (calib_ms[6] if j == 0 else 0.0))
     dom_name = STAGES[dom]
     longest = STAGES[max(range(5), key=lambda j: calib_ms[j])]
     # kernel duration: HIP events around the stage on an otherwise idle GPU (the untimed calibration frames).  With
@@ -410,7 +414,14 @@ def main():
     # k_project alone: the project stage minus its head (partition cull + state reset, MGS_STAGE_CULL), both from the
     # calibration frames — what rocprofv3 reports as the kernel's own average duration
     cull_ms = float(calib_ms[6])
-    dom_ms = float(calib_ms[dom]) - cull_ms
+
+    def stage_roofline(j):
+        ms = float(calib_ms[j]) - (cull_ms if j == 0 else 0.0)
+        ach = alg[STAGES[j]] / (ms * 1e-3) if ms > 0 else 0.0
+        return {"bound": "hbm", "stage": STAGES[j], "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
+                "algorithmic_bytes_per_launch": alg[STAGES[j]], "launch_ms": ms}
+
+    dom_ms = float(calib_ms[dom]) - (cull_ms if dom == 0 else 0.0)
     achieved = alg[dom_name] / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
     b_frame = 12 * N + Vs * (16 + 24 + 180) + 8 * Vs + 68 * Vs + 2 * 48 * Vs + 8 * Ppix
     b_moved = alg["project"] + alg["sort"] + alg["bin"] + alg["composite"]  # what this build's kernels move (deferred shading: no 180 B/splat SH stream)
@@ -462,31 +473,35 @@ def main():
                                           "note": "time between consecutive frame completions in the timed region (HIP events at each frame's end)"},
         "frame_span_ms_percentiles": {"p50": float(np.percentile(st[:, 5], 50)), "p95": float(np.percentile(st[:, 5], 95)),
                                       "min": float(st[:, 5].min()), "max": float(st[:, 5].max())},
-        "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+        "value_single_frame": 1e3 / float(calib_ms[5]) if calib_ms[5] > 0 else None,  # frames/s with ONE frame in flight
+        "roofline": {"bound": "hbm", "stage": dom_name,
+                     "kernels": {"project": "k_project", "sort": "k_os_prepare + 3 x k_os_pass (+ 1 that exits)",
+                                 "bin": "k_dbin_count + k_dbin_scan + k_dbin_emit"}[dom_name],
+                     "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                      "traffic_source": (f"profiles/{PMC_FILE}: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --inflight 1` "
                                         "(2*FETCH + WRITE per launch, MI355X_MICROARCH.md HBM section); not measured in this run") if traffic else None,
                      "algorithmic_bytes_per_launch": alg[dom_name], "launch_ms": float(dom_ms),
-                     "stage_ms_incl_partition_cull": float(calib_ms[dom]), "partition_cull_ms": cull_ms,
-                     "stage_span_ms_in_timed_region": float(stage_ms[dom]),
-                     "note": f"dominant HBM-bound kernel (k_project, its own duration: HIP events after the partition cull and "
-                             f"after the kernel, single-stream calibration frames); the longest stage of the frame is `{longest}`"
+                     "note": f"the longest HBM-bound stage of the frame by measured single-stream time (HIP events on the untimed calibration "
+                             f"frames), SURVEY.md 8d's bytes for it; the longest stage overall is `{longest}`"
                              + (" (fp32-VALU bound, see roofline_composite)" if longest == "composite" else "")},
+        "roofline_project": dict(stage_roofline(0), stage_ms_incl_partition_cull=float(calib_ms[0]), partition_cull_ms=cull_ms),
         "roofline_composite": composite_roofline(calib_ms[4] if K > 1 else stage_ms[4], alg["composite"], world, N, args),
         "roofline_sort": {"bound": "hbm", "achieved": (68 * Vs / (sort_ms * 1e-3)) / 1e9 if sort_ms > 0 else None,
                           "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                          "frac": (68 * Vs / (sort_ms * 1e-3)) / HBM_PEAK if sort_ms > 0 else None},
-        # throughput form: bytes SURVEY.md 8d says a frame must move x frames/s per GPU (== the latency form when one
-        # frame is in flight); `frac_single_frame` is the same bytes over the GPU time of one frame in the timed region
-        "roofline_frame": {"bound": "hbm", "achieved": b_frame * fps / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                           "frac": b_frame * fps / HBM_PEAK if world == 1 else None,
-                           "frac_single_frame": (b_frame / (frame_gpu_ms * 1e-3)) / HBM_PEAK if frame_gpu_ms > 0 else None,
-                           "algorithmic_bytes_per_frame": b_frame,
+                          "frac": (68 * Vs / (sort_ms * 1e-3)) / HBM_PEAK if sort_ms > 0 else None, "launch_ms": float(sort_ms),
+                          "algorithmic_bytes_per_launch": 68 * Vs},
+        "roofline_bin": stage_roofline(2),
+        # the frame as a whole: the bytes this build's kernels move (sum of the per-stage algorithmic bytes; deferred shading
+        # means the 180 B/splat SH stream of SURVEY.md 8d's B_frame does not exist) x frames/s; `frac_single_frame` is the same
+        # bytes over the GPU time of one frame.  The B_frame form is kept as `frac_survey_bytes`.
+        "roofline_frame": {"bound": "hbm", "achieved": b_moved * fps / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                           "frac": b_moved * fps / HBM_PEAK if world == 1 else None,
+                           "frac_single_frame": (b_moved / (frame_gpu_ms * 1e-3)) / HBM_PEAK if frame_gpu_ms > 0 else None,
                            "bytes_moved_per_frame": b_moved,
-                           "frac_bytes_moved": b_moved * fps / HBM_PEAK if world == 1 else None,
-                           "frac_bytes_moved_single_frame": (b_moved / (frame_gpu_ms * 1e-3)) / HBM_PEAK if frame_gpu_ms > 0 else None,
-                           "note": "algorithmic_bytes_per_frame is SURVEY.md 8d's B_frame (includes 180 B/splat of SH the build no longer "
-                                   "streams); bytes_moved_per_frame sums the per-stage algorithmic bytes of the kernels as built"},
+                           "survey_bytes_per_frame": b_frame,
+                           "frac_survey_bytes": b_frame * fps / HBM_PEAK if world == 1 else None,
+                           "frac_survey_bytes_single_frame": (b_frame / (frame_gpu_ms * 1e-3)) / HBM_PEAK if frame_gpu_ms > 0 else None},
         "error_flags": err,
         "setup_s": setup_s,
     }

@@ -1001,6 +1001,16 @@ def test_bench_prints_one_strict_json_line_with_the_contract_keys():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in d["roofline"], k
     assert d["roofline"]["bound"] in ("hbm", "mfma") and 0 < d["roofline"]["frac"] < 1
+    # the roofline object is SURVEY 8d's figure of the longest HBM-bound stage, chosen at run time; the others sit beside it
+    assert d["roofline"]["stage"] in ("project", "sort", "bin")
+    per_stage = {k: d[f"roofline_{k}"]["launch_ms"] for k in ("project", "sort", "bin")}
+    assert d["roofline"]["stage"] == max(per_stage, key=per_stage.get)
+    for k in ("roofline_project", "roofline_sort", "roofline_bin", "roofline_composite", "roofline_frame"):
+        assert k in d, k
+    assert 0 < d["roofline_sort"]["frac"] < 1 and d["roofline_sort"]["algorithmic_bytes_per_launch"] == 68 * d["visible_splats"]["sorted"]
+    for k in ("frac", "bytes_moved_per_frame", "survey_bytes_per_frame", "frac_survey_bytes"):
+        assert k in d["roofline_frame"], k
+    assert d["value_single_frame"] > 0 and d["frames_in_flight"] == 3
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
     assert d["error_flags"] == 0

@@ -23,7 +23,18 @@ for pose in poses:
         scene.render(p, want_stats=True)
     raw = np.fromfile(os.environ["MGS_OS_TRACE_FILE"], np.uint64)
     maxp = int(raw[0])
-    a = raw[2:].reshape(4, maxp, 8)
+    a = raw[2:2 + 4 * maxp * 8].reshape(4, maxp, 8)
+    pr = raw[2 + 4 * maxp * 8:].reshape(-1, 8).astype(np.int64)
+    pr = pr[pr[:, 0] > 0]
+    if len(pr):
+        b0 = pr[:, 0].min()
+        ph = np.diff(pr[:, :5], axis=1) / 100.0
+        print(f"--- pose {pose} k_os_prepare: {len(pr)} reduce workgroups; start spread {(pr[:, 0].max() - b0) / 100.0:.1f} us; all arrived at {(pr[:, 4].max() - b0) / 100.0:.1f} us")
+        for i, n in enumerate(["zeroing + slot histograms + total atomics", "records -> LDS table -> count-table atomics", "drain (vmcnt 0) + barrier", "arrival atomic + barrier"]):
+            print(f"   {n:48s} median {np.median(ph[:, i]):6.2f} us  max {ph[:, i].max():6.2f}")
+        last = pr[pr[:, 7] == 1]
+        if len(last):
+            print(f"   the last arriver's fold of the count table: {(last[0, 5] - last[0, 4]) / 100.0:.2f} us; kernel body ends at {(last[0, 5] - b0) / 100.0:.1f} us")
     for ps in range(4):
         b = a[ps]
         ran = b[:, 6] > 0

@@ -107,6 +107,12 @@ __global__ __launch_bounds__(256) void k_os_hist(const uint32_t* __restrict__ ke
       atomicAdd(&plan->total[q][t], s_h[q][t]);
 }
 
+#ifdef MGS_OS_TRACE  // debug build (tools/os_trace.py): per-workgroup wall-clock stamps (100 MHz) of the phases of every pass
+#define MGS_OS_STAMP(i) if(threadIdx.x == 0) trc[i] = wall_clock64();
+__device__ uint64_t* g_osPrepTrace = nullptr;  // [reduce workgroup][8]
+#else
+#define MGS_OS_STAMP(i)
+#endif
 // ---------------------------------------------------------------------------------------------------------------------
 // (b) prepare: the digit totals of all passes from what the producer left, and the look-back state of pass 0 zeroed.
 // Grid: reduce workgroups of 1024 threads, 32 slots each (+ idle ones that only zero).  A reduce workgroup
@@ -124,6 +130,11 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
                                                      int allowRemap, uint32_t* __restrict__ zStatus, uint32_t zWords, uint32_t reduceWgs)
 {
   const int t = threadIdx.x, lane = laneId(), w = t >> 6;
+#ifdef MGS_OS_TRACE
+  __shared__ uint64_t trc[8];
+  if(t < 8) trc[t] = 0;
+  MGS_OS_STAMP(0)
+#endif
   // every workgroup clears its share of pass 0's look-back words (they were last written by an earlier sort's pass 2)
   for(uint32_t i = blockIdx.x * 1024u + t; i < zWords; i += gridDim.x * 1024u)
     zStatus[i] = 0u;
@@ -133,10 +144,20 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
     return;
   __shared__ uint32_t s_part[512];
   __shared__ uint32_t s_tab[2048];
-  __shared__ uint32_t s_hdr[128];
   __shared__ uint32_t s_lo, s_hi, s_last;
   __shared__ uint32_t s_tmp[16], s_mm[32];
   const uint32_t slot0 = blockIdx.x * 32u;
+  // the records' loads go out with the histograms' (one round trip instead of three): thread t owns words j0 .. j0 + 3 of
+  // record t / 8, and reads that record's header itself
+  const uint32_t recR = (uint32_t)t >> 3, recJ0 = ((uint32_t)t & 7u) * 4u, recSlot = slot0 + recR / 4u;
+  uint32_t       recHdr = 0xFFFFFFFFu;
+  uint4          recC   = make_uint4(0u, 0u, 0u, 0u);
+  if(recSlot < prjParts)
+  {
+    const uint32_t* rp = &top16Rec[((size_t)recSlot * 4u + (recR & 3u)) * 32u];
+    recHdr             = rp[31];
+    recC               = *reinterpret_cast<const uint4*>(rp + recJ0);
+  }
   {  // two-digit histograms: thread = (half of the slots, bin column)
     const uint32_t col = t & 511u, half = t >> 9;
     uint32_t       acc = 0;
@@ -161,37 +182,27 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
         atomicAdd(&plan->total[col >> 8][col & 255u], acc);
     }
   }
+  MGS_OS_STAMP(1)
   // key >> 16 records of the 32 slots x 4 producer waves: header word 31 = lo | span << 16 (0xFFFFFFFF: nothing to fold)
-  if(t < 128)
+  if((t & 7) == 0 && recHdr != 0xFFFFFFFFu)
   {
-    const uint32_t slot = slot0 + (uint32_t)t / 4u;
-    const uint32_t hdr  = slot < prjParts ? top16Rec[((size_t)slot * 4u + ((uint32_t)t & 3u)) * 32u + 31u] : 0xFFFFFFFFu;
-    s_hdr[t]            = hdr;
-    if(hdr != 0xFFFFFFFFu)
-    {
-      atomicMin(&s_lo, hdr & 0xFFFFu);
-      atomicMax(&s_hi, (hdr & 0xFFFFu) + (hdr >> 16));
-    }
+    atomicMin(&s_lo, recHdr & 0xFFFFu);
+    atomicMax(&s_hi, (recHdr & 0xFFFFu) + (recHdr >> 16));
   }
   __syncthreads();
+  if(recHdr != 0xFFFFFFFFu && recJ0 <= (recHdr >> 16))
   {
-    const uint32_t r = (uint32_t)t >> 3, j0 = ((uint32_t)t & 7u) * 4u, hdr = s_hdr[r];
-    if(hdr != 0xFFFFFFFFu && j0 <= (hdr >> 16))
-    {
-      const uint32_t slot = slot0 + r / 4u;
-      const uint4    c    = *reinterpret_cast<const uint4*>(&top16Rec[((size_t)slot * 4u + (r & 3u)) * 32u + j0]);
-      const uint32_t cv[4] = {c.x, c.y, c.z, c.w};
+    const uint32_t cv[4] = {recC.x, recC.y, recC.z, recC.w};
 #pragma unroll
-      for(int j = 0; j < 4; ++j)
-        if(j0 + j <= (hdr >> 16) && cv[j])
-        {
-          const uint32_t v = (hdr & 0xFFFFu) + j0 + j, idx = v - s_lo;
-          if(idx < 2048u)
-            atomicAdd(&s_tab[idx], cv[j]);
-          else
-            atomicAdd(&top16Count[v], cv[j]);
-        }
-    }
+    for(int j = 0; j < 4; ++j)
+      if(recJ0 + j <= (recHdr >> 16) && cv[j])
+      {
+        const uint32_t v = (recHdr & 0xFFFFu) + recJ0 + j, idx = v - s_lo;
+        if(idx < 2048u)
+          atomicAdd(&s_tab[idx], cv[j]);
+        else
+          atomicAdd(&top16Count[v], cv[j]);
+      }
   }
   __syncthreads();
   for(uint32_t b = t; b < 2048u; b += 1024u)
@@ -204,11 +215,18 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
   }
   // ---- arrival: the last workgroup folds the table.  Every wave drains its own atomics (they are performed at the memory
   // side, so "acknowledged" is "visible"), then one lane takes the ticket: no fence by 1024 threads ----
+  MGS_OS_STAMP(2)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  MGS_OS_STAMP(3)
   if(t == 0)
     s_last = (atomicAdd(&plan->arrived, 1u) == reduceWgs - 1u) ? 1u : 0u;
   __syncthreads();
+  MGS_OS_STAMP(4)
+#ifdef MGS_OS_TRACE
+  if(t == 0 && g_osPrepTrace && !s_last)
+    for(int i = 0; i < 8; ++i) g_osPrepTrace[(size_t)blockIdx.x * 8 + i] = trc[i];
+#endif
   if(!s_last)
     return;
   const uint32_t minInv = ldAgent(&plan->top16MinInv), maxP1 = ldAgent(&plan->top16MaxP1);
@@ -276,6 +294,15 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
       plan->remapBase    = on ? vlo : 0u;
       plan->remapPadRank = on ? total - 1u : 0u;  // keys outside the table (padding) take the largest rank
     }
+#ifdef MGS_OS_TRACE
+    __syncthreads();
+    MGS_OS_STAMP(5)
+    if(t == 0 && g_osPrepTrace)
+    {
+      for(int i = 0; i < 8; ++i) g_osPrepTrace[(size_t)blockIdx.x * 8 + i] = trc[i];
+      g_osPrepTrace[(size_t)blockIdx.x * 8 + 7] = 1;  // the last arriver
+    }
+#endif
     return;
   }
   // wide range (camera inside the cloud): plain digits of bits 16-23 and 24-31
@@ -307,11 +334,6 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
 // ---------------------------------------------------------------------------------------------------------------------
 // (c) one pass.  IN: 0 pairs (every pass of a frame: the project kernels emit one dense array), 2 split key / value arrays
 // (pass 0 of the stand-alone sort).
-#ifdef MGS_OS_TRACE  // debug build (tools/os_trace.py): per-workgroup wall-clock stamps (100 MHz) of the phases of every pass
-#define MGS_OS_STAMP(i) if(threadIdx.x == 0) trc[i] = wall_clock64();
-#else
-#define MGS_OS_STAMP(i)
-#endif
 struct OsPassArgs
 {
 #ifdef MGS_OS_TRACE
@@ -688,22 +710,28 @@ void launchOsSort(hipStream_t stream, const OsLaunch& L)
   const uint32_t sWords   = (uint32_t)osSortStatusWords(maxParts);
   uint32_t*      st[2]    = {L.status, L.status + sWords};
   auto gOf = [&](uint32_t* s) { return s + (size_t)((maxParts + kOsGroup - 1u) / kOsGroup + 1u) * 256u * kOsGroup; };
+#ifdef MGS_OS_TRACE
+  static uint64_t* traceBuf = nullptr;
+  const char*      tracePath = std::getenv("MGS_OS_TRACE_FILE");
+  const size_t     traceN = (size_t)maxParts * 8;
+  static uint64_t* prepBuf = nullptr;
+  if(tracePath && frame)
+  {
+    if(!traceBuf)
+    {
+      (void)hipMalloc(&traceBuf, (size_t)4 << 24);
+      (void)hipMalloc(&prepBuf, 4096 * 64);
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_osPrepTrace), &prepBuf, sizeof(prepBuf));
+    }
+    (void)hipMemsetAsync(traceBuf, 0, 4 * traceN * 8, stream);
+    (void)hipMemsetAsync(prepBuf, 0, 4096 * 64, stream);
+  }
+#endif
   if(!frame)
     hipLaunchKernelGGL(k_os_hist, dim3(std::min<uint32_t>((L.maxElems + 2047u) / 2048u, 1024u)), dim3(256), 0, stream, L.keys0, L.nPtr, L.plan);
   const uint32_t reduceWgs = frame ? (L.prjParts + 31u) / 32u : 0u;
   hipLaunchKernelGGL(k_os_prepare, dim3(std::max(reduceWgs, 16u)), dim3(1024), 0, stream, frame ? L.slotHist2 : nullptr, L.top16Rec, L.prjParts,
                      L.top16Count, L.plan, L.nPtr, (frame && L.allowRemap) ? 1 : 0, st[0], sWords, reduceWgs);
-#ifdef MGS_OS_TRACE
-  static uint64_t* traceBuf = nullptr;
-  const char*      tracePath = std::getenv("MGS_OS_TRACE_FILE");
-  const size_t     traceN = (size_t)maxParts * 8;
-  if(tracePath && frame)
-  {
-    if(!traceBuf)
-      (void)hipMalloc(&traceBuf, (size_t)4 << 24);
-    (void)hipMemsetAsync(traceBuf, 0, 4 * traceN * 8, stream);
-  }
-#endif
   for(int pass = 0; pass < 4; ++pass)
   {
     OsPassArgs a{};
@@ -749,6 +777,9 @@ void launchOsSort(hipStream_t stream, const OsLaunch& L)
       const uint64_t hdr[2] = {maxParts, 0};
       std::fwrite(hdr, 8, 2, fp);
       std::fwrite(h.data(), 8, 4 * traceN, fp);
+      std::vector<uint64_t> hp(4096 * 8);
+      (void)hipMemcpy(hp.data(), prepBuf, 4096 * 64, hipMemcpyDeviceToHost);
+      std::fwrite(hp.data(), 8, hp.size(), fp);
       std::fclose(fp);
     }
   }
