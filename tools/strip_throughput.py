@@ -13,8 +13,9 @@ K = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 sc = synth.make_scene(N, seed=0xC0FFEE + 2)
 ss = mgs.SplatSet.from_arrays(**sc)
 scenes, streams = [], []
-for _ in range(K):
-    s = mgs.Scene(0); s.add_instance(ss); s.commit()
+base = mgs.Scene(0); base.add_instance(ss); base.commit()   # one committed scene, K frame contexts over it
+for c in range(K):
+    s = base if c == 0 else base.frame_context()
     st = torch.cuda.Stream(); s.set_stream(st.cuda_stream)
     scenes.append(s); streams.append(st)
 poses = []

@@ -114,8 +114,8 @@ __device__ uint64_t* g_osPrepTrace = nullptr;  // [reduce workgroup][8]
 #define MGS_OS_STAMP(i)
 #endif
 // ---------------------------------------------------------------------------------------------------------------------
-// (b) prepare: the digit totals of all passes from what the producer left, and the look-back state of pass 0 zeroed.
-// Grid: reduce workgroups of 1024 threads, 32 slots each (+ idle ones that only zero).  A reduce workgroup
+// (b) prepare: the digit totals of all passes from what the producer left.
+// Grid: reduce workgroups of 1024 threads, 32 slots each .  A reduce workgroup
 //   * sums its slots' two-digit histograms into plan->total[0..1] (<= 512 atomics, one per non-empty bin);
 //   * folds its slots' key >> 16 records (slot_emit.h: one 32-word record per producer wave: counts of the values lo..lo+24)
 //     in an LDS table and adds each occurring value ONCE to the 64 K-entry count table.  The producers do not touch that
@@ -127,7 +127,7 @@ __device__ uint64_t* g_osPrepTrace = nullptr;  // [reduce workgroup][8]
 // It clears what it read, so the table is clean for the next sort of this context.
 __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict__ slotHist2, const uint32_t* __restrict__ top16Rec, uint32_t prjParts,
                                                      uint32_t* __restrict__ top16Count, OsPlan* __restrict__ plan, const uint32_t* __restrict__ nPtr,
-                                                     int allowRemap, uint32_t* __restrict__ zStatus, uint32_t zWords, uint32_t reduceWgs)
+                                                     int allowRemap, uint32_t reduceWgs)
 {
   const int t = threadIdx.x, lane = laneId(), w = t >> 6;
 #ifdef MGS_OS_TRACE
@@ -135,9 +135,6 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
   if(t < 8) trc[t] = 0;
   MGS_OS_STAMP(0)
 #endif
-  // every workgroup clears its share of pass 0's look-back words (they were last written by an earlier sort's pass 2)
-  for(uint32_t i = blockIdx.x * 1024u + t; i < zWords; i += gridDim.x * 1024u)
-    zStatus[i] = 0u;
   if(blockIdx.x == 0 && t == 0)
     plan->n = *nPtr;
   if(slotHist2 == nullptr || blockIdx.x >= reduceWgs)
@@ -158,29 +155,35 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
     recHdr             = rp[31];
     recC               = *reinterpret_cast<const uint4*>(rp + recJ0);
   }
-  {  // two-digit histograms: thread = (half of the slots, bin column)
-    const uint32_t col = t & 511u, half = t >> 9;
-    uint32_t       acc = 0;
-#pragma unroll 4
-    for(uint32_t q = half; q < 32u; q += 2u)
-      if(slot0 + q < prjParts)
-        acc += slotHist2[(size_t)(slot0 + q) * 512u + col];
-    if(half == 1)
-      s_part[col] = acc;
+  {  // two-digit histograms, two 16-bit counters per word: thread = (quarter of the slots, packed column)
+    const uint32_t col = t & 255u, quarter = t >> 8;
+    uint32_t       lo16 = 0, hi16 = 0;
+#pragma unroll
+    for(uint32_t q = quarter; q < 32u; q += 4u)
+    {
+      const uint32_t v = (slot0 + q < prjParts) ? slotHist2[(size_t)min(slot0 + q, prjParts - 1u) * 256u + col] : 0u;
+      lo16 += v & 0xFFFFu;
+      hi16 += v >> 16;
+    }
     s_tab[t]         = 0u;
     s_tab[t + 1024u] = 0u;
+    if(t < 512)
+      s_part[t] = 0u;
     if(t == 0)
     {
       s_lo = 0xFFFFu;
       s_hi = 0u;
     }
     __syncthreads();
-    if(half == 0)
-    {
-      acc += s_part[col];
-      if(acc)
-        atomicAdd(&plan->total[col >> 8][col & 255u], acc);
-    }
+    // packed column c holds bins 2 (c & 127) and 2 (c & 127) + 1 of digit c >> 7
+    const uint32_t bin0 = (col >> 7) * 256u + (col & 127u) * 2u;
+    if(lo16)
+      atomicAdd(&s_part[bin0], lo16);
+    if(hi16)
+      atomicAdd(&s_part[bin0 + 1u], hi16);
+    __syncthreads();
+    if(t < 512 && s_part[t])
+      atomicAdd(&plan->total[t >> 8][t & 255u], s_part[t]);
   }
   MGS_OS_STAMP(1)
   // key >> 16 records of the 32 slots x 4 producer waves: header word 31 = lo | span << 16 (0xFFFFFFFF: nothing to fold)
@@ -349,7 +352,7 @@ struct OsPassArgs
   SortPlan*       planOut;  // what the consumers of the sorted ids read: n, finalSel (always 0 here), passesRun
   uint32_t*       status;   // [maxParts][256] this pass: one 1 KB row of digit counts per partition
   uint32_t*       gstatus;  // [ceil(maxParts / 32)][256]
-  uint32_t*       zStatus;  // the other buffer: cleared here for the next pass
+  uint32_t*       zStatus;  // look-back words no pass is using: cleared here for a later pass (launchOsSort has the rota)
   uint32_t        zWords;
   const uint32_t* nPtr;
   FrameCounters*  ctr;
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
   __shared__ uint64_t trc[8];
   MGS_OS_STAMP(0)
 #endif
-  // clear the other look-back buffer for the next pass (stream order: nobody reads it any more)
+  // clear look-back words for a later pass (stream order: nobody reads them any more)
   for(uint32_t i = blockIdx.x * kThreads + t; i < a.zWords; i += gridDim.x * kThreads)
     a.zStatus[i] = 0u;
   for(int i = t; i < kWaves * 256; i += kThreads)
@@ -708,7 +711,10 @@ void launchOsSort(hipStream_t stream, const OsLaunch& L)
   const bool     frame    = L.pairs0 != nullptr;  // the project kernels' dense pairs + their histograms / records
   const uint32_t maxParts = osSortMaxParts(L.maxElems);
   const uint32_t sWords   = (uint32_t)osSortStatusWords(maxParts);
-  uint32_t*      st[2]    = {L.status, L.status + sWords};
+  // Three sets of look-back words: pass 0 uses set 0, pass 1 set 1, pass 2 set 2, pass 3 set 1 again.  Every set is zero when its
+  // pass starts: pass 0 clears sets 1 and 2 (whatever the previous sort left there, whether its pass 3 ran or not), pass 1
+  // clears set 0 for the next sort, pass 2 clears set 1 for pass 3.
+  uint32_t*      st[3]    = {L.status, L.status + sWords, L.status + 2 * (size_t)sWords};
   auto gOf = [&](uint32_t* s) { return s + (size_t)((maxParts + kOsGroup - 1u) / kOsGroup + 1u) * 256u * kOsGroup; };
 #ifdef MGS_OS_TRACE
   static uint64_t* traceBuf = nullptr;
@@ -730,8 +736,8 @@ void launchOsSort(hipStream_t stream, const OsLaunch& L)
   if(!frame)
     hipLaunchKernelGGL(k_os_hist, dim3(std::min<uint32_t>((L.maxElems + 2047u) / 2048u, 1024u)), dim3(256), 0, stream, L.keys0, L.nPtr, L.plan);
   const uint32_t reduceWgs = frame ? (L.prjParts + 31u) / 32u : 0u;
-  hipLaunchKernelGGL(k_os_prepare, dim3(std::max(reduceWgs, 16u)), dim3(1024), 0, stream, frame ? L.slotHist2 : nullptr, L.top16Rec, L.prjParts,
-                     L.top16Count, L.plan, L.nPtr, (frame && L.allowRemap) ? 1 : 0, st[0], sWords, reduceWgs);
+  hipLaunchKernelGGL(k_os_prepare, dim3(std::max(reduceWgs, 1u)), dim3(1024), 0, stream, frame ? L.slotHist2 : nullptr, L.top16Rec, L.prjParts,
+                     L.top16Count, L.plan, L.nPtr, (frame && L.allowRemap) ? 1 : 0, reduceWgs);
   for(int pass = 0; pass < 4; ++pass)
   {
     OsPassArgs a{};
@@ -740,10 +746,11 @@ void launchOsSort(hipStream_t stream, const OsLaunch& L)
 #endif
     a.plan    = L.plan;
     a.planOut = L.planOut;
-    a.status  = st[pass & 1];
-    a.gstatus = gOf(st[pass & 1]);
-    a.zStatus = st[(pass + 1) & 1];
-    a.zWords  = sWords;
+    const int set = pass == 3 ? 1 : pass;
+    a.status  = st[set];
+    a.gstatus = gOf(st[set]);
+    a.zStatus = pass == 1 ? st[0] : st[1];
+    a.zWords  = pass == 0 ? 2u * sWords : (pass == 3 ? 0u : sWords);
     a.nPtr    = L.nPtr;
     a.ctr     = L.ctr;
     a.pass    = pass;

@@ -309,13 +309,6 @@ __global__ __launch_bounds__(256) void k_dbin_count(const uint32_t* __restrict__
   const uint32_t* ids = plan->finalSel ? idsY : idsX;
   const uint32_t  e0  = blockIdx.x * (uint32_t)kDbChunk + (uint32_t)w * (kDbRounds * 64) + (uint32_t)lane;
   uint32_t        r[kDbRounds];
-  if(plan->reserved[0])
-  {  // the key sort's last pass already laid the rects out in sorted order (fused gather)
-#pragma unroll
-    for(int i = 0; i < kDbRounds; ++i)
-      r[i] = sortedRect[min(e0 + i * 64u, n - 1u)];
-  }
-  else
   {
     uint32_t id[kDbRounds];
 #pragma unroll
@@ -323,7 +316,8 @@ __global__ __launch_bounds__(256) void k_dbin_count(const uint32_t* __restrict__
       id[i] = ids[min(e0 + i * 64u, n - 1u)];  // clamped, not predicated: all loads in flight
 #pragma unroll
     for(int i = 0; i < kDbRounds; ++i)
-      r[i] = rect[id[i]];  // the stage's one random gather
+      r[i] = rect[id[i]];  // the stage's one random gather (moving it into the sort's final pass was measured twice: the
+                           // pass pays +36 us for the -16 us here — 4-byte gathers run at ~120 G/s wherever they are issued)
   }
   const int      nb = binsX * binsY, S = binsX + binsY;
   const LaneBins L  = laneBins(binsX, nb);

@@ -320,6 +320,7 @@ struct MgsScene_t
   DevBuf<uint32_t>      rsKeys, rsVals, rsHist, rsCount;  // mgs_radix_sort_u32 scratch
   DevBuf<uint2>         rsPairA, rsPairB;
   DevBuf<uint32_t>      rsStatus;
+  uint32_t              rsStatusParts = 0;  // partition bound the look-back words of the stand-alone sort are laid out for
   DevBuf<OsPlan>        rsOsPlan;
   DevBuf<SortPlan>      rsPlan;
   // multi-GPU strips (RCCL)
@@ -1178,20 +1179,17 @@ static int sizeWorkingSet(MgsScene s)
   s->graphs.clear();
   const uint64_t total = s->d->totalSplats, parts = s->d->totalParts;
   int rc = MGS_OK;
-  const size_t slots = (size_t)parts * kPart;
-  if((rc = s->slotHist2.ensure((size_t)parts * 512u))) return rc;
+  if((rc = s->slotHist2.ensure((size_t)parts * 256u))) return rc;
   if((rc = s->top16Rec.ensure((size_t)parts * 128u))) return rc;
   // occurrences of key >> 16: the sort's prepare kernel consumes and clears it every frame; zeroed here as well, so that a
   // frame that died between the two kernels cannot leak counts into the next scene
   if((rc = s->top16Count.ensure(65536u))) return rc;
   HIPCHK(hipMemset(s->top16Count.p, 0, 65536u * 4u));
-  {  // look-back words of the key sort's passes: zero once, every pass clears the other buffer for its successor
-    const size_t words = 2u * osSortStatusWords(osSortMaxParts((uint32_t)total));
-    if(s->osStatus.n < words)
-    {
-      if((rc = s->osStatus.ensure(words))) return rc;
-      HIPCHK(hipMemset(s->osStatus.p, 0, words * 4u));
-    }
+  {  // look-back words of the key sort's passes: zero once, the passes clear them for their successors (k_osort.hip)
+    // (the three sets' offsets depend on the element bound: a re-sized working set starts from zeroed words)
+    const size_t words = 3u * osSortStatusWords(osSortMaxParts((uint32_t)total));
+    if((rc = s->osStatus.ensure(words))) return rc;
+    HIPCHK(hipMemset(s->osStatus.p, 0, words * 4u));
   }
   if((rc = s->partSkip.ensure(parts))) return rc;
   if((rc = s->partR.ensure(parts))) return rc;
@@ -2822,12 +2820,15 @@ int mgs_radix_sort_u32(MgsScene s, void* keysDev, void* valsDev, uint32_t count,
     if((rc = s->rsPairA.ensure(count))) return rc;
     if((rc = s->rsPairB.ensure(count))) return rc;
     if((rc = s->rsOsPlan.ensure(1))) return rc;
-    const size_t words = 2u * osSortStatusWords(osSortMaxParts(count));
-    if(s->rsStatus.n < words)
+    // the passes keep the three sets of look-back words zeroed for each other (k_osort.hip); the sets' offsets depend on
+    // the count, so a sort of another size starts from freshly zeroed words
+    const size_t words = 3u * osSortStatusWords(osSortMaxParts(count));
+    if(s->rsStatus.n < words || s->rsStatusParts != osSortMaxParts(count))
     {
       if((rc = s->rsStatus.ensure(words))) return rc;
-      HIPCHK(hipMemset(s->rsStatus.p, 0, words * 4u));
+      HIPCHK(hipMemset(s->rsStatus.p, 0, s->rsStatus.n * 4u));
       HIPCHK(hipDeviceSynchronize());
+      s->rsStatusParts = osSortMaxParts(count);
     }
   }
   hipStream_t st = s->stream;

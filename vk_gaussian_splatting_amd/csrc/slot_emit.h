@@ -7,7 +7,8 @@
 // second one covers 64 groups): workgroup = blockIdx.x, it waits only for lower-numbered ones, which the dispatcher has
 // started (k_osort.hip's header has the argument); bounded spins, kErrSpinTimeout instead of a hang.
 // It also leaves what the sort needs before its first pass, computed while the keys are still on chip:
-//   * slotHist2[part][2][256]: the partition's histograms of key bits 0-7 and 8-15 (k_os_prepare reduces them to digit totals);
+//   * slotHist2[part][256]: the partition's histograms of key bits 0-7 and 8-15, two 16-bit counters per word (k_os_prepare
+//     reduces them to digit totals);
 //   * top16Rec[part][wave][32]: how often each value of key >> 16 occurs in the wave (the totals of the upper passes and the
 //     pass-elision decision come from these; k_os_prepare folds them).
 #pragma once
@@ -146,8 +147,8 @@ __device__ __forceinline__ void emitEmptySlot(uint32_t* __restrict__ prjStatus, 
                                               uint32_t* __restrict__ top16Rec, FrameCounters* __restrict__ ctr, uint32_t part)
 {
   __shared__ uint32_t s_b[2];
-  for(int i = threadIdx.x; i < 512; i += THREADS)
-    slotHist2[(size_t)part * 512u + i] = 0u;
+  for(int i = threadIdx.x; i < 256; i += THREADS)
+    slotHist2[(size_t)part * 256u + i] = 0u;
   if(threadIdx.x < THREADS / 64)
     top16Rec[((size_t)part * (THREADS / 64) + threadIdx.x) * 32u + 31u] = 0xFFFFFFFFu;
   prjReserve(prjStatus, parts, part, 0u, s_b, ctr);  // nothing to place, but a group's last member owes the group its prefix
@@ -206,8 +207,8 @@ __device__ __forceinline__ uint32_t emitSlot(uint32_t M, bool allSurvive, const 
   if(t == 0 && outCount)
     atomicAdd(&ctr->sortedCount, outCount);
   __syncthreads();
-  for(int i = t; i < 512; i += THREADS)
-    slotHist2[(size_t)part * 512u + i] = (s_hist2[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+  for(int i = t; i < 256; i += THREADS)
+    slotHist2[(size_t)part * 256u + i] = s_hist2[i];  // packed as counted: bins 2 i and 2 i + 1 of digit i >> 7
   uint32_t lo, hi;
   sortTop16Range<WAVES>(outCount, s_cnt, lo, hi);
   // this wave's record of key >> 16: counts of lo .. lo + 24 in words 0-24, header in word 31

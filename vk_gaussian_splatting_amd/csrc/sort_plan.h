@@ -68,7 +68,7 @@ struct OsLaunch
   // input, exactly one of: the project kernels' dense (key, id) pairs with their per-partition histograms and records ...
   const uint2*    pairs0     = nullptr;  // n pairs (n = *nPtr); may alias pairB (pass 0 reads it before pass 1 writes B)
   uint32_t        prjParts   = 0;        // project partitions (2048 splats each)
-  const uint32_t* slotHist2  = nullptr;  // [partition][2][256]: histograms of key bits 0-7 and 8-15
+  const uint32_t* slotHist2  = nullptr;  // [partition][256]: histograms of key bits 0-7 and 8-15, two 16-bit counters per word
   const uint32_t* top16Rec   = nullptr;  // [partition][4 waves][32]: counts of key >> 16 per producer wave (slot_emit.h)
   uint32_t*       top16Count = nullptr;  // [65536] occurrences of key >> 16 (filled, consumed and cleared by k_os_prepare;
                                          // partitions that span > 24 values add their keys themselves)
@@ -83,7 +83,7 @@ struct OsLaunch
   uint32_t*       outKeys  = nullptr;  // the sorted keys (null: not needed)
   OsPlan*         plan     = nullptr;  // zeroed before the launch (frame init / launchOsSortClearPlan)
   SortPlan*       planOut  = nullptr;  // n / finalSel = 0 / passesRun for the consumers of the sorted ids
-  uint32_t*       status   = nullptr;  // 2 x osSortStatusWords(osSortMaxParts(...)) words, zero on first use
+  uint32_t*       status   = nullptr;  // 3 x osSortStatusWords(osSortMaxParts(...)) words, zero on first use
   FrameCounters*  ctr      = nullptr;  // errorFlags |= kErrSpinTimeout if a look-back wait ever gives up
   bool            allowRemap = true;
 };
