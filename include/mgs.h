@@ -63,6 +63,7 @@ enum { MGS_DEBUG_POINT_CLOUD = 1, MGS_DEBUG_SH_ONLY = 2, MGS_DEBUG_OPACITY_GAUSS
 /* alpha channel meaning: the reference's default back-to-front pipeline accumulates
  * A = sum(alpha) (src/gaussian_splatting.cpp:2083-2084); its FTB pipeline yields 1-T (:2071-2076). */
 enum { MGS_ALPHA_COVERAGE = 0 /* 1-T */, MGS_ALPHA_SUM = 1 /* sum(alpha); disables early termination */ };
+enum { MGS_NORMAL_MAX_DENSITY_PLANE = 0, MGS_NORMAL_ISO_SURFACE = 1 };
 /* raster pipelines (parameters.h PIPELINE_MESH / PIPELINE_MESH_3DGUT), 3DGUT camera models and quad extents */
 enum { MGS_PIPELINE_3DGS = 0, MGS_PIPELINE_3DGUT = 1 };
 enum { MGS_CAMERA_PINHOLE = 0, MGS_CAMERA_FISHEYE = 1 };
@@ -223,7 +224,11 @@ typedef struct MgsFrameParams {
                                    or the scene changed, as updateFrameSampleId does); kept in fp32 */
   int32_t kernel_degree;        /* 3DGUT: KERNEL_DEGREE (shaderio.h:112-119, default 2 = quadratic, parameters.h:215): the generalised
                                    Gaussian of particleRayMaxKernelResponse (threedgrt.h.slang:83-127); 0,1,2,3,4,5,8 */
-  int32_t reserved_[2];
+  int32_t normal_method;        /* 3DGUT + surface_outputs: NORMAL_METHOD (shaderio.h:126-128, parameters.h:121-125) — MGS_NORMAL_MAX_DENSITY_PLANE
+                                   (default) | MGS_NORMAL_ISO_SURFACE: the fragment's normal is the normal of the kernel ellipsoid
+                                   (3 sigma) where the pixel's ray enters it (threedgrt.h.slang:423-497).  The 3DGS pipeline's
+                                   mesh shader always uses the max-density plane (threedgs_raster.mesh.slang:219). */
+  int32_t reserved_[1];
 } MgsFrameParams;
 
 void mgs_frame_params_default(MgsFrameParams* p); /* fills the defaults cited above */

@@ -20,7 +20,8 @@ class OrcFrame(C.Structure):
                 ("size_culling", C.c_int), ("size_culling_min_pixels", C.c_float), ("debug_flags", C.c_int),
                 ("camera_model", C.c_int), ("extent_method", C.c_int), ("fov_rad", C.c_float), ("alpha_clamp", C.c_float),
                 ("kernel_min_response", C.c_float), ("stochastic", C.c_int), ("dof_mode", C.c_int), ("focus_dist", C.c_float),
-                ("aperture", C.c_float), ("frame_sample_id", C.c_int), ("kernel_degree", C.c_int), ("pipeline_3dgut", C.c_int)]
+                ("aperture", C.c_float), ("frame_sample_id", C.c_int), ("kernel_degree", C.c_int), ("pipeline_3dgut", C.c_int),
+                ("normal_method", C.c_int)]
 
 
 class OrcInstance(C.Structure):
@@ -168,7 +169,8 @@ def make_frame(view, proj, camera_pos, width, height, splat_scale=1.0, frustum_d
                alpha_cull=1.0 / 255.0, sh_degree=3, front_to_back=0, frustum_culling=1, target_fp16=0,
                ms_antialiasing=0, debug_flags=0, size_culling=0, size_culling_min_pixels=1.0,
                camera_model=0, extent_method=1, fov_rad=None, alpha_clamp=0.99, kernel_min_response=0.0113,
-               stochastic=0, dof_mode=0, focus_dist=1.3, aperture=0.001, frame_sample_id=0, kernel_degree=2, pipeline_3dgut=0):
+               stochastic=0, dof_mode=0, focus_dist=1.3, aperture=0.001, frame_sample_id=0, kernel_degree=2, pipeline_3dgut=0,
+               normal_method=0):
     f = OrcFrame()
     v = f32(view).T.reshape(-1)
     p = f32(proj).T.reshape(-1)
@@ -188,6 +190,7 @@ def make_frame(view, proj, camera_pos, width, height, splat_scale=1.0, frustum_d
     f.alpha_clamp, f.kernel_min_response = alpha_clamp, kernel_min_response
     f.kernel_degree = kernel_degree
     f.pipeline_3dgut = pipeline_3dgut
+    f.normal_method = normal_method
     f.stochastic, f.dof_mode, f.focus_dist, f.aperture, f.frame_sample_id = stochastic, dof_mode, focus_dist, aperture, frame_sample_id
     return f
 
@@ -264,6 +267,17 @@ def gut_fragment(frame, inst, k, P, px, py):
     op = C.c_float()
     ok = fn(C.byref(frame), C.byref(inst[k]), C.byref(P), int(px), int(py), C.byref(op))
     return float(op.value) if ok else None
+
+
+def gut_fragment_iso(frame, inst, k, P, px, py, thin_particle_threshold=1e-6):
+    """(opacity, world normal under NORMAL_METHOD_ISO_SURFACE) of the fragment, or None when the hit is rejected"""
+    fn = lib().orc_gut_fragment_iso
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(OrcFrame), C.POINTER(OrcInstance), C.POINTER(OrcGutProjected), C.c_int, C.c_int, F32P, C.c_float, C.c_void_p]
+    op = C.c_float()
+    n = np.zeros(3, np.float32)
+    ok = fn(C.byref(frame), C.byref(inst[k]), C.byref(P), int(px), int(py), C.byref(op), float(thin_particle_threshold), n.ctypes.data)
+    return (float(op.value), n) if ok else None
 
 
 def render_gut(frame, inst, order):

@@ -1068,6 +1068,12 @@ void orc_project_gut(const OrcFrame* f, const OrcInstance* Ip, uint32_t i, OrcGu
 // threedgut_raster.frag.slang:87-127 for pixel (px, py): ray, model-space ray, particleProcessHitGut
 int orc_gut_fragment(const OrcFrame* f, const OrcInstance* I, const OrcGutProjected* P, int px, int py, float* opacity)
 {
+  return orc_gut_fragment_iso(f, I, P, px, py, opacity, 0.0f, nullptr);
+}
+
+int orc_gut_fragment_iso(const OrcFrame* f, const OrcInstance* I, const OrcGutProjected* P, int px, int py, float* opacity,
+                         float thinThreshold, float* normalWorld)
+{
   float viewInv[16], projInv[16];
   orc_mat4_inverse(f->view, viewInv);   // gaussian_splatting.cpp:1166
   orc_mat4_inverse(f->proj, projInv);   // :1200
@@ -1173,6 +1179,66 @@ int orc_gut_fragment(const OrcFrame* f, const OrcInstance* I, const OrcGutProjec
   if(!accept)
     return 0;
   *opacity = (f->debug_flags & 4) ? 1.0f : alpha;
+  if(normalWorld)
+  {  // computeEllipsoidNormal, threedgrt.h.slang:423-497
+    const float maxScale  = std::max(std::max(P->scale[0], P->scale[1]), P->scale[2]);
+    const float flatness  = std::max(0.02f * maxScale, thinThreshold);
+    const int   small[3]  = {P->scale[0] < flatness, P->scale[1] < flatness, P->scale[2] < flatness};
+    const int   smallCount = small[0] + small[1] + small[2];
+    const float local[3]  = {g[0], g[1], g[2]};  // modelRayOrigin - particle.position
+    float       nm[3];
+    bool        haveNormal = false;
+    if(smallCount == 0)
+    {  // raySphereIntersection(particleRayOrigin, particleRayDirection, 3.0, 0, INF), :502-540
+      const float a = (prd[0] * prd[0] + prd[1] * prd[1]) + prd[2] * prd[2];
+      const float b = 2.0f * ((pro[0] * prd[0] + pro[1] * prd[1]) + pro[2] * prd[2]);
+      const float c = ((pro[0] * pro[0] + pro[1] * pro[1]) + pro[2] * pro[2]) - 3.0f * 3.0f;
+      const float disc = b * b - 4.0f * a * c;
+      if(disc >= 0.0f)
+      {
+        const float sq = std::sqrt(disc), invA = 1.0f / (2.0f * a);
+        const float t1 = (-b - sq) * invA, t2 = (-b + sq) * invA;
+        float       t  = -1.0f;
+        if(t1 >= 0.0f)
+          t = t1;
+        else if(t2 >= 0.0f)
+          t = t2;
+        if(t >= 0.0f)
+        {
+          float h[3] = {pro[0] + t * prd[0], pro[1] + t * prd[1], pro[2] + t * prd[2]};
+          const float hl = std::sqrt((h[0] * h[0] + h[1] * h[1]) + h[2] * h[2]);
+          const float ns[3] = {h[0] / hl / P->scale[0], h[1] / hl / P->scale[1], h[2] / hl / P->scale[2]};
+          // mul(normalScaled, rotMat), rotMat = transpose(invRotation)
+          for(int k = 0; k < 3; ++k)
+            nm[k] = (ns[0] * P->inv_rot[3 * k] + ns[1] * P->inv_rot[3 * k + 1]) + ns[2] * P->inv_rot[3 * k + 2];
+          const float l = std::sqrt((nm[0] * nm[0] + nm[1] * nm[1]) + nm[2] * nm[2]);
+          nm[0] /= l; nm[1] /= l; nm[2] /= l;
+          haveNormal = true;
+        }
+      }
+    }
+    else if(smallCount == 1)
+    {
+      const int a = small[0] ? 0 : (small[1] ? 1 : 2);
+      for(int k = 0; k < 3; ++k)
+        nm[k] = P->inv_rot[3 * k + a];  // mul(axisLocal, rotMat): row a of transpose(invRotation)
+      if((nm[0] * local[0] + nm[1] * local[1]) + nm[2] * local[2] < 0.0f)
+        for(int k = 0; k < 3; ++k)
+          nm[k] = -nm[k];
+      haveNormal = true;
+    }
+    if(!haveNormal)
+      for(int k = 0; k < 3; ++k)
+        nm[k] = -md[k];  // -modelRayDirection
+    // normalize(mul(normalModel, modelToWorldRS)), :337-345
+    const float* M = I->transform;
+    float        nw[3];
+    for(int r = 0; r < 3; ++r)
+      nw[r] = M[r] * nm[0] + M[4 + r] * nm[1] + M[8 + r] * nm[2];
+    const float l = std::sqrt((nw[0] * nw[0] + nw[1] * nw[1]) + nw[2] * nw[2]);
+    for(int r = 0; r < 3; ++r)
+      normalWorld[r] = nw[r] / l;
+  }
   return 1;
 }
 
@@ -1516,7 +1582,7 @@ void orc_render_surface_gut(const OrcFrame* f, const OrcInstance* inst, int n_in
     const int   y0 = (int)std::max(0.0f, std::floor(fy0)), y1 = (int)std::min((float)(H - 1), std::ceil(fy1));
     const float n1 = P.half1[0] * P.half1[0] + P.half1[1] * P.half1[1], n2 = P.half2[0] * P.half2[0] + P.half2[1] * P.half2[1];
     float       nrm[3] = {0.f, 0.f, 0.f};
-    if(normal_out)
+    if(normal_out && f->normal_method != 1)
       orc_splat_normal(f, &inst[k], g - offsets[k], thin_particle_threshold, 0, nrm);
     for(int y = y0; y <= y1; ++y)
       for(int x = x0; x <= x1; ++x)
@@ -1526,7 +1592,8 @@ void orc_render_surface_gut(const OrcFrame* f, const OrcInstance* inst, int n_in
         if(std::fabs(u) > 1.0f || std::fabs(w) > 1.0f)
           continue;
         float opacity;
-        if(!orc_gut_fragment(f, &inst[k], &P, x, y, &opacity))
+        const bool iso = normal_out && f->normal_method == 1;
+        if(!orc_gut_fragment_iso(f, &inst[k], &P, x, y, &opacity, thin_particle_threshold, iso ? nrm : nullptr))
           continue;
         const size_t i = (size_t)y * W + x;
         if(normal_out)

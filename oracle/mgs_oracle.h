@@ -79,6 +79,9 @@ typedef struct OrcFrame {
   int   pipeline_3dgut;       /* 1: the frame runs a 3DGUT pipeline.  Only consumer: frameInfo.focal as the DIST stage sees it —
                                  the fisheye focal for a fisheye camera on a 3DGUT pipeline, the pinhole focal otherwise
                                  (gaussian_splatting.cpp:1239-1251).  The orc_gut_* entry points imply 1. */
+  int   normal_method;        /* NORMAL_METHOD (shaderio.h:126-128, gaussian_splatting.cpp:1678): 0 max-density plane, 1 iso-surface
+                                 (ray / kernel-ellipsoid intersection).  Only consumer: the 3DGUT fragment's normal
+                                 (threedgrt.h.slang:330-335); the 3DGS mesh shader always uses the max-density plane (mesh.slang:219) */
 } OrcFrame;
 
 /* atan2 as both the oracle and the kernels evaluate it in the fisheye dist-stage cull (dist.comp.slang:75-90): the reference's
@@ -164,6 +167,10 @@ typedef struct OrcGutProjected {
 void     orc_project_gut(const OrcFrame* f, const OrcInstance* inst, uint32_t local_idx, OrcGutProjected* out);
 /* one fragment: returns 1 and the opacity if the hit is accepted (threedgut_raster.frag.slang:87-127) */
 int      orc_gut_fragment(const OrcFrame* f, const OrcInstance* inst, const OrcGutProjected* P, int px, int py, float* opacity);
+/* the same, plus the fragment's world normal under NORMAL_METHOD_ISO_SURFACE (computeEllipsoidNormal, threedgrt.h.slang:423-497,
+ * raySphereIntersection :502-540; to world space as particleProcessHitGutWithNormal :337-345); normal_world may be NULL */
+int      orc_gut_fragment_iso(const OrcFrame* f, const OrcInstance* inst, const OrcGutProjected* P, int px, int py, float* opacity,
+                              float thin_particle_threshold, float* normal_world);
 /* whole frame in the supplied draw order (global ids); same blending / target semantics as orc_render_order */
 uint64_t orc_render_gut_order(const OrcFrame* f, const OrcInstance* inst, int n_inst,
                               const uint32_t* ids, uint32_t v, float* rgba_out, uint64_t* stats);

@@ -232,6 +232,40 @@ def gut_opacity(g, i, density, M, V, P, W, H, px, py, alpha_clamp=0.99, min_resp
 
 
 # ---- dist stage: which splats survive (dist.comp.slang:55-91), float64, the shader's row-vector form ------------------
+def gut_iso_normal(g, i, V, P, W, H, px, py, thin=1e-6):
+    """NORMAL_METHOD_ISO_SURFACE for splat i at pixel (px, py), identity instance transform, float64, written from the geometry
+    rather than from the shader's steps: the kernel ellipsoid is the quadric (x - c)^T Q (x - c) = 9 with Q = A^T diag(1/s^2) A;
+    the normal where the pixel's ray enters it is the quadric's gradient Q (x - c).  One small axis (< max(0.02 max scale, thin)):
+    that axis, towards the camera; two or three: minus the ray."""
+    S_V, S_P = slang(V), slang(P)
+    vi, pi = np.linalg.inv(S_V), np.linalg.inv(S_P)
+    origin = (np.array([0, 0, 0, 1.0]) @ vi)[:3]
+    inuv = (np.array([px + 0.5, py + 0.5]) + 0.5) / np.array([W, H])
+    d = inuv * 2.0 - 1.0
+    target = np.array([d[0], d[1], 1.0, 1.0]) @ pi
+    rd = (np.array([target[0], target[1], target[2], 0.0]) @ vi)[:3]
+    rd /= np.linalg.norm(rd)
+    A, sc, c = g["axes"][i].astype(np.float64), g["scale"][i].astype(np.float64), g["position"][i].astype(np.float64)
+    small = sc < max(0.02 * sc.max(), thin)
+    if small.sum() >= 2:
+        return -rd
+    if small.sum() == 1:
+        n = A[int(np.argmax(small))]
+        return n if n @ (origin - c) >= 0 else -n
+    Q = A.T @ np.diag(1.0 / sc**2) @ A
+    o = origin - c
+    qa, qb, qc = rd @ Q @ rd, 2.0 * (rd @ Q @ o), o @ Q @ o - 9.0
+    disc = qb * qb - 4 * qa * qc
+    if disc < 0:
+        return -rd
+    t1, t2 = (-qb - np.sqrt(disc)) / (2 * qa), (-qb + np.sqrt(disc)) / (2 * qa)
+    t = t1 if t1 >= 0 else (t2 if t2 >= 0 else None)
+    if t is None:
+        return -rd
+    n = Q @ (o + t * rd)
+    return n / np.linalg.norm(n)
+
+
 def dist_cull(centers, M, V, P, W, H, dilation=0.2, fisheye=False, focal=None):
     """returns (survives[n] bool, margin[n]): margin = distance of the decision from its nearest threshold, relative, so that a
     caller comparing against an fp32 implementation can set borderline splats aside.

@@ -700,6 +700,48 @@ def test_gut_kernel_degrees_against_the_closed_form(ob, degree):
     assert frag > 150
 
 
+@pytest.mark.parametrize("thin", [1e-6, 0.03])
+def test_gut_iso_surface_normal_against_the_quadric_gradient(ob, thin):
+    """NORMAL_METHOD_ISO_SURFACE (threedgrt.h.slang:423-540): the oracle's shader-step restatement (canonical ray, sphere of radius
+    3, normal / scale, rotate) against the gradient of the kernel ellipsoid's quadric at the entry point, float64
+    (np_reference.gut_iso_normal); thin = 0.03 exercises the flat (axis normal) and degenerate (minus the ray) particles"""
+    import np_reference as npr
+    n = 500
+    sc = synth.make_scene(n, seed=29)
+    ps = ob.PreparedSet(sc)
+    inst = ob.make_instances([(ps, None)])
+    W, H = 256, 160
+    eye = np.array([2.5, 1.2, -1.8], np.float32)
+    V, P = lookat(eye, [0, 0, 0], [0, 1, 0]), persp(55, W / H, 0.1, 2000)
+    fr = ob.make_frame(V, P, eye, W, H, normal_method=1)
+    g = npr.gut_project(ps.positions, sc["scale"], sc["rotation"], ps.rgba, np.eye(4), V, P, W, H)
+    rng = np.random.default_rng(5)
+    frag, kinds, errs = 0, set(), []
+    for i in range(n):
+        q = ob.project_gut(fr, inst, 0, i)
+        if not (q.valid and g["valid"][i]):
+            continue
+        s = g["scale"][i]
+        kinds.add(int((s < max(0.02 * s.max(), thin)).sum()))
+        for _ in range(3):
+            px = int(np.clip(q.center_px[0] + rng.integers(-3, 4), 0, W - 1))
+            py = int(np.clip(q.center_px[1] + rng.integers(-3, 4), 0, H - 1))
+            a = ob.gut_fragment_iso(fr, inst, 0, q, px, py, thin)
+            if a is None:
+                continue
+            op, nrm = a
+            assert op == ob.gut_fragment(fr, inst, 0, q, px, py)  # the normal method does not touch the opacity
+            want = npr.gut_iso_normal(g, i, V, P, W, H, px, py, thin)
+            assert abs(np.linalg.norm(nrm) - 1.0) < 1e-5
+            # fp32 conditioning: the canonical origin lies hundreds of radii from a small particle, so b^2 - 4ac of the sphere
+            # intersection cancels (the shader has the same arithmetic)
+            errs.append(np.abs(nrm - want).max())
+            assert errs[-1] < 1e-2, (i, px, py, nrm, want)
+            frag += 1
+    print(f"iso-surface normal vs quadric gradient (thin {thin}): {frag} fragments, max {max(errs):.2e} mean {np.mean(errs):.2e}, small-axis counts {kinds}")
+    assert frag > 150 and np.mean(errs) < 3e-4 and (thin < 1e-3 or {0, 1} <= kinds)
+
+
 def test_gut_depth_of_field_against_independent_numpy_fp64(ob):
     """depthOfField (cameras.h.slang:85-108) in the oracle's 3DGUT fragment vs the float64 restatement, the lens sample drawn with
     the integer-only restatement of the random numbers: seed = xxhash32(px, py, sample), r1 = rand * 2 pi, r2 = rand * aperture"""

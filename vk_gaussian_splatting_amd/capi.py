@@ -15,6 +15,7 @@ TARGET_RGBA16F, TARGET_RGBA32F, TARGET_RGBA8 = 0, 1, 2
 ALPHA_COVERAGE, ALPHA_SUM = 0, 1
 DEBUG_POINT_CLOUD, DEBUG_SH_ONLY, DEBUG_OPACITY_GAUSSIAN_DISABLED = 1, 2, 4
 PIPELINE_3DGS, PIPELINE_3DGUT = 0, 1
+NORMAL_MAX_DENSITY_PLANE, NORMAL_ISO_SURFACE = 0, 1
 CAMERA_PINHOLE, CAMERA_FISHEYE = 0, 1
 EXTENT_EIGEN, EXTENT_CONIC = 0, 1
 STAGE_NAMES = ["project", "sort", "bin", "pairsort", "composite", "total"]
@@ -52,7 +53,7 @@ class FrameParams(C.Structure):
                 ("alpha_clamp", C.c_float), ("kernel_min_response", C.c_float),
                 ("dof_mode", C.c_int32), ("focus_dist", C.c_float), ("aperture", C.c_float),
                 ("frame_sample_id", C.c_int32), ("temporal_sampling", C.c_int32), ("kernel_degree", C.c_int32),
-                ("reserved_", C.c_int32 * 2)]
+                ("normal_method", C.c_int32), ("reserved_", C.c_int32 * 1)]
 
 
 class FrameOut(C.Structure):

@@ -91,6 +91,7 @@ struct FrameConst
   int32_t  temporalSampling;       // 1: the frame is folded into the running mean of the samples 0..frameSampleId
   float    focusDist, aperture;    // shaderio.h:278-279
   int32_t  kernelDegree;           // KERNEL_DEGREE (3DGUT particle response), 2 = quadratic
+  int32_t  normalMethod;           // NORMAL_METHOD (shaderio.h:126-128): 0 max-density plane, 1 iso-surface (3DGUT fragment normal)
 };
 
 struct FrameArgs

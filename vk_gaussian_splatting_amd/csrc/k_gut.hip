@@ -418,7 +418,7 @@ __device__ __forceinline__ bool gutPixelRay(const FrameConst& F, float pcx, floa
 // ---- compositor: one workgroup per 16x16 tile, one pixel per thread -------------------------------------------------------
 constexpr int kGutBatch = 256;  // list entries scanned per round == staging capacity
 
-// XT 1 (2: + the non-quadratic particle kernels, the surface side outputs and their LDS): the variant with depth of field (frag.slang:104-109, cameras.h.slang:85-108), stochastic splats (:150-172) and/or
+// XT 1 (2: + the non-quadratic particle kernels, the surface side outputs and their LDS; 3: + NORMAL_METHOD_ISO_SURFACE): the variant with depth of field (frag.slang:104-109, cameras.h.slang:85-108), stochastic splats (:150-172) and/or
 // a particle kernel other than the quadratic one, and/or the surface side outputs (picked depth, splat id, integrated normal)
 template <int SHF, int XT>
 __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restrict__ Ap, const uint2* __restrict__ ranges,
@@ -430,8 +430,9 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
 {
   __shared__ float4   s_r[kGutBatch][6];
   __shared__ uint32_t s_gid[XT ? kGutBatch : 1];
-  __shared__ float4   s_n[XT == 2 ? kGutBatch : 1];  // surface outputs (XT 2): world normal of the record (.w = 1: minus the pixel's ray)
-  __shared__ float    s_z[XT == 2 ? kGutBatch : 1];  //                         fragCoord.z of the record's quad
+  __shared__ float4   s_n[XT >= 2 ? kGutBatch : 1];  // surface outputs (XT 2): world normal of the record (.w = 1: minus the pixel's ray)
+  __shared__ float    s_z[XT >= 2 ? kGutBatch : 1];  //                         fragCoord.z of the record's quad
+  __shared__ float4   s_iso[XT == 3 ? kGutBatch : 1][3];  // NORMAL_METHOD_ISO_SURFACE: canonical -> world normal matrix (surface_normal.h)
   __shared__ uint32_t s_wc[4];
   __shared__ uint32_t s_live;
   const FrameConst& F = Ap->f;
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
   const int      bin   = (ty >> F.binShiftY) * F.binsX + (tx >> F.binShiftX);
   const uint2    range = ranges[bin];
   float T = (inside && rayOk) ? 1.0f : 0.0f, cr = 0.f, cg = 0.f, cb = 0.f, asum = 0.f;
-  const bool surf = XT == 2 && F.surfaceOutputs != 0;
+  const bool surf = XT >= 2 && F.surfaceOutputs != 0;
   float      nx = 0.f, ny = 0.f, nz = 0.f, pickZ = 0.f;
   uint32_t   pickId = 0xFFFFFFFFu;
   uint32_t hi = range.y;
@@ -541,12 +542,24 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
       if constexpr(XT != 0)
       {
         s_gid[pos] = g;
-        if constexpr(XT == 2)
+        if constexpr(XT >= 2)
         {  // frag.slang:127-131 -> particleProcessHitGutWithNormal (threedgrt.h.slang:281-345): the max-density-plane normal is a
           // per-splat quantity (ray ORIGIN only) except for particles with two degenerate axes; no octahedral round trip here
           // (the normal is computed in the fragment shader, not carried through an interstage variable).  fragCoord.z: the
           // quad sits at the pinhole depth of the centre (mesh.slang:221-226)
-          s_n[pos] = splatWorldNormal(F, I, li, false);
+          if constexpr(XT == 3)
+          {  // the fragment's own normal: where its ray enters the kernel ellipsoid (threedgrt.h.slang:330-335, 423-497)
+            float4 isoRec[3];
+            splatIsoNormalRec(F, I, li, isoRec);
+            s_iso[pos][0] = isoRec[0];
+            s_iso[pos][1] = isoRec[1];
+            s_iso[pos][2] = isoRec[2];
+            s_n[pos]      = make_float4(isoRec[0].x, isoRec[0].y, isoRec[0].z, isoRec[0].w == 2.0f ? 1.0f : 0.0f);
+          }
+          else
+          {
+            s_n[pos] = splatWorldNormal(F, I, li, false);
+          }
           const float  cpx = I.centers[3 * (size_t)li], cpy = I.centers[3 * (size_t)li + 1], cpz = I.centers[3 * (size_t)li + 2];
           const float* MV = I.modelView;
           const float* P  = F.proj;
@@ -619,13 +632,40 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
       cb += wgt * c4.z;
       asum += op;
       T -= wgt;
-      if constexpr(XT == 2)
+      if constexpr(XT >= 2)
       {
         if(surf)
         {  // frag.slang:195-228: normal attachment "under"-blended with (normal * opacity, opacity); picked depth = the
           // fragment after which the transmittance is below the threshold, and the splat that set it
-          const float4 n1 = s_n[j];
-          const bool   ray = n1.w != 0.0f;  // degenerate particle: -rayDirection (model -> world: minus the pixel's world ray)
+          float4 n1  = s_n[j];
+          bool   ray = n1.w != 0.0f;  // degenerate particle: -rayDirection (model -> world: minus the pixel's world ray)
+          if constexpr(XT == 3)
+          if(wgt != 0.0f && !ray && s_iso[j][0].w == 0.0f)
+          {  // raySphereIntersection(canonical origin, canonical direction, 3, 0, inf), threedgrt.h.slang:502-540.  The same two
+            // roots, written around the point of closest approach (t_mid = -(o.g)/(g.g), half chord = sqrt((9 - dist^2)/(g.g)))
+            // instead of b^2 - 4ac: the canonical origin lies hundreds of radii from a small particle and the discriminant of
+            // the textbook form cancels in fp32 (the oracle follows the shader; tests/test_oracle_cpu.py has the numbers)
+            const float qa = gx * gx + gy * gy + gz * gz;
+            const float tm = -(rox * gx + roy * gy + roz * gz) * gRcp(qa);
+            const float dd = 9.0f - dist2;
+            ray = true;  // no intersection in front of the origin: -rayDirection (:468-472)
+            if(dd >= 0.0f)
+            {
+              const float half = sqrtf(dd * gRcp(qa));
+              const float th   = (tm - half >= 0.0f) ? tm - half : tm + half;
+              if(th >= 0.0f)
+              {
+                const float  hx = rox + th * gx, hy = roy + th * gy, hz = roz + th * gz;
+                const float4 i0 = s_iso[j][0], i1 = s_iso[j][1], i2 = s_iso[j][2];
+                const float  wx = i0.x * hx + i0.y * hy + i0.z * hz;
+                const float  wy = i1.x * hx + i1.y * hy + i1.z * hz;
+                const float  wz = i2.x * hx + i2.y * hy + i2.z * hz;
+                const float  rl = rsqrtf(wx * wx + wy * wy + wz * wz);
+                n1  = make_float4(wx * rl, wy * rl, wz * rl, 0.0f);
+                ray = false;
+              }
+            }
+          }
           nx += wgt * (ray ? -dxw : n1.x);
           ny += wgt * (ray ? -dyw : n1.y);
           nz += wgt * (ray ? -dzw : n1.z);
@@ -657,7 +697,7 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
     return;
   const float alphaOut = F.alphaMode == 1 ? asum : 1.0f - ((inside && rayOk) ? T : 1.0f);
   const size_t pix = (size_t)py * F.width + px;
-  if constexpr(XT == 2)
+  if constexpr(XT >= 2)
   {
     if(surf)
     {
@@ -1005,7 +1045,9 @@ void launchCompositeGut(hipStream_t stream, const FrameArgs& A, const FrameArgs*
 #define MGS_LAUNCH_X(SHF)            \
   do                                 \
   {                                  \
-    if(A.f.surfaceOutputs != 0 || A.f.kernelDegree != 2) \
+    if(A.f.surfaceOutputs != 0 && A.f.normalMethod == 1) \
+      MGS_LAUNCH(SHF, 3);            \
+    else if(A.f.surfaceOutputs != 0 || A.f.kernelDegree != 2) \
       MGS_LAUNCH(SHF, 2);            \
     else if(extras)                  \
       MGS_LAUNCH(SHF, 1);            \

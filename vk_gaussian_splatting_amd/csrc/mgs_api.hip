@@ -1391,6 +1391,7 @@ void mgs_frame_params_default(MgsFrameParams* p)
   p->frame_sample_id         = 0;
   p->temporal_sampling       = 0;
   p->kernel_degree           = 2;       // parameters.h:215
+  p->normal_method           = MGS_NORMAL_MAX_DENSITY_PLANE;  // parameters.h:162
 }
 
 // storage global id <-> caller global id.  Instances are concatenated in creation order in both spaces;
@@ -1523,6 +1524,7 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
   F.frameSampleId    = p->frame_sample_id;
   F.temporalSampling = p->temporal_sampling ? 1 : 0;
   F.kernelDegree     = p->kernel_degree;
+  F.normalMethod     = p->normal_method;
   if(p->camera_model == MGS_CAMERA_FISHEYE && p->pipeline == MGS_PIPELINE_3DGUT)
   {  // gaussian_splatting.cpp:1239-1244: frameInfo.focal is the fisheye focal only for the 3DGUT pipelines; a fisheye camera on
      // the 3DGS pipelines keeps the pinhole focal (and dist.comp's fisheye cull then runs on that)
@@ -1856,6 +1858,11 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
       setError("frame: kernel_degree must be one of 0, 1, 2, 3, 4, 5, 8 (shaderio.h:112-119)");
       return MGS_ERR_INVALID_ARG;
     }
+    if(p->normal_method != MGS_NORMAL_MAX_DENSITY_PLANE && p->normal_method != MGS_NORMAL_ISO_SURFACE)
+    {
+      setError("frame: normal_method must be MGS_NORMAL_MAX_DENSITY_PLANE or MGS_NORMAL_ISO_SURFACE (shaderio.h:126-128)");
+      return MGS_ERR_INVALID_ARG;
+    }
     if(s->recGut.n < s->d->totalSplats)
     {  // first 3DGUT frame of this scene: its record buffer (captured frames do not reference it yet)
       if((rc = s->recGut.ensure(s->d->totalSplats))) return rc;
@@ -2033,7 +2040,8 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     // everything the compositor receives by value (CompositeArgs) must be part of the key
     const int32_t kv[16] = {F.width, F.height, F.stripRow0, F.stripRow1, F.binShiftX, F.binShiftY, F.partitionCull, F.alphaMode,
                             F.debugFlags & (2 | 4 | 256), F.surfaceOutputs, half, F.nInstances, F.shDegree, isoBits,
-                            F.pipeline, F.stochastic | (F.dofMode << 1) | (F.temporalSampling << 2) | ((F.pipeline == 1 && F.kernelDegree != 2) ? 8 : 0)};
+                            F.pipeline, F.stochastic | (F.dofMode << 1) | (F.temporalSampling << 2) | ((F.pipeline == 1 && F.kernelDegree != 2) ? 8 : 0) |
+                                ((F.pipeline == 1 && F.normalMethod == 1) ? 16 : 0)};  // ... and everything that selects a kernel variant
     std::memcpy(key.v, kv, sizeof(kv));
     key.p[0] = s->image.p;
     key.p[1] = s->surfDepth.p;
