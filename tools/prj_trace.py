@@ -18,6 +18,8 @@ for pose in poses:
     V, P = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, W, H)
     p = capi.default_params(W, H)
     capi.set_camera(p, V, P, eye)
+    if os.environ.get("STRIP"):  # tile rows "begin end": one device's strip of a multi-GPU frame
+        p.strip_row_begin, p.strip_row_end = (int(x) for x in os.environ["STRIP"].split())
     for _ in range(4):
         scene.render(p, want_stats=True)
     a = np.fromfile(os.environ["MGS_PRJ_TRACE_FILE"], np.uint64).reshape(-1, 8)

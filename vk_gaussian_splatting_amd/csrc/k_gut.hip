@@ -258,7 +258,7 @@ __device__ __forceinline__ bool projectSplatGut(const FrameConst& F, const Insta
 // Phase 1 (key + frustum cull + ordered compaction) is k_project's, statement for statement: the sorted (key, id)
 // stream of a 3DGUT frame is bit-identical to the 3DGS frame's before the front-end rejections.
 __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __restrict__ Ap, FrameCounters* __restrict__ ctr,
-                                                             uint2* __restrict__ densePairs, uint32_t* __restrict__ prjStatus,
+                                                             uint2* __restrict__ slotPairs, uint32_t* __restrict__ slotCount,
                                                              GutRec* __restrict__ rec, uint32_t* __restrict__ rect,
                                                              const uint32_t* __restrict__ partSkip, uint32_t* __restrict__ slotHist2,
                                                              uint32_t* __restrict__ top16Rec, uint32_t* __restrict__ top16Count,
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
   const FrameArgs& A = *Ap;
   if(partSkip != nullptr && (partSkip[blockIdx.x] & 1u) != 0u)
   {
-    emitEmptySlot<kGutThreads>(prjStatus, A.f.totalPartitions, slotHist2, top16Rec, ctr, blockIdx.x);
+    emitEmptySlot<kGutThreads>(slotCount, slotHist2, top16Rec, blockIdx.x);
     return;
   }
   __shared__ uint32_t s_hist2[256];  // 2 x 256 sixteen-bit counters (slot_emit.h)
@@ -275,7 +275,6 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
   __shared__ uint32_t s_key[kGutPart];
   __shared__ uint32_t s_cnt[32];
   __shared__ uint32_t s_base[33];
-  __shared__ uint32_t s_keep[2];
   for(int i = threadIdx.x; i < 256; i += kGutThreads)
     s_hist2[i] = 0u;
   const int      t = threadIdx.x, lane = laneId(), w = t >> 6;
@@ -374,7 +373,7 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
   }
   __syncthreads();
   // second ordered compaction into the partition's slot + what the key sort needs up front (slot_emit.h)
-  emitSlot<kGutThreads, kGutItems>(Mv, false, s_li, s_key, s_cnt, s_base, s_hist2, s_keep, densePairs, prjStatus, A.f.totalPartitions, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
+  emitSlot<kGutThreads, kGutItems>(Mv, false, s_li, s_key, s_cnt, s_base, s_hist2, slotPairs, slotCount, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
                                    I.globalOffset + local0);
 }
 
@@ -991,13 +990,13 @@ __global__ __launch_bounds__(256) void k_composite_gut2(const FrameArgs* __restr
 
 // ---------------------------------------------------------------------------------------------
 void launchProjectGut(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, int shFormat, FrameCounters* ctr,
-                      uint2* densePairs, uint32_t* prjStatus, GutRec* rec, uint32_t* rect, const uint32_t* partSkip,
+                      uint2* slotPairs, uint32_t* slotCount, GutRec* rec, uint32_t* rect, const uint32_t* partSkip,
                       uint32_t* slotHist2, uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan)
 {
   (void)shFormat;
   if(args.f.totalPartitions == 0)
     return;
-  hipLaunchKernelGGL(k_project_gut, dim3(args.f.totalPartitions), dim3(kGutThreads), 0, stream, dArgs, ctr, densePairs, prjStatus, rec, rect,
+  hipLaunchKernelGGL(k_project_gut, dim3(args.f.totalPartitions), dim3(kGutThreads), 0, stream, dArgs, ctr, slotPairs, slotCount, rec, rect,
                      partSkip, slotHist2, top16Rec, top16Count, osPlan);
 }
 

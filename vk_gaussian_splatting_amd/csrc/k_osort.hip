@@ -125,9 +125,16 @@ __device__ uint64_t* g_osPrepTrace = nullptr;  // [reduce workgroup][8]
 // The workgroup that finishes last (arrival counter) then owns the occurring range of the table: at most 256 values within a
 // span < 4096 -> pass 2 sorts on their rank and the table gives that pass's totals; otherwise plain digits for passes 2 and 3.
 // It clears what it read, so the table is clean for the next sort of this context.
+// One more workgroup (the last of the grid) works on the side: it turns the slots' counts into their positions in the dense
+// order the passes sort — slotBase[] = exclusive prefix of slotCount[]; part0[q] = the slot that holds pair 4096 q, where the
+// gather of dense partition q starts (k_os_pass); part0's second half, the partitions' WINDOWS: for the first kOsWin slots
+// from part0[q] on, where the slot starts relative to pair 4096 q (0x7FFFFFFF behind the last slot that starts inside the
+// partition) — what pass 0 needs to find every pair's slot with one load — and the frame's count of sorted pairs.
 __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict__ slotHist2, const uint32_t* __restrict__ top16Rec, uint32_t prjParts,
                                                      uint32_t* __restrict__ top16Count, OsPlan* __restrict__ plan, const uint32_t* __restrict__ nPtr,
-                                                     int allowRemap, uint32_t reduceWgs)
+                                                     int allowRemap, uint32_t reduceWgs, const uint32_t* __restrict__ slotCount,
+                                                     uint32_t* __restrict__ slotBase, uint32_t* part0, uint32_t winOffset,
+                                                     uint32_t* __restrict__ nOut)
 {
   const int t = threadIdx.x, lane = laneId(), w = t >> 6;
 #ifdef MGS_OS_TRACE
@@ -135,12 +142,95 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
   if(t < 8) trc[t] = 0;
   MGS_OS_STAMP(0)
 #endif
-  if(blockIdx.x == 0 && t == 0)
-    plan->n = *nPtr;
-  if(slotHist2 == nullptr || blockIdx.x >= reduceWgs)
+  if(slotHist2 == nullptr)
+  {  // uniform input (stand-alone sort): k_os_hist has the totals
+    if(blockIdx.x == 0 && t == 0)
+      plan->n = *nPtr;
+    return;
+  }
+  __shared__ uint32_t s_tab[2048];
+  if(blockIdx.x == reduceWgs)
+  {  // thread t owns `per` consecutive slots (<= 4 up to 8.4 M splats: their counts stay in registers)
+    __shared__ uint32_t s_scan[16];
+    const uint32_t per = (prjParts + 1023u) / 1024u, s0 = (uint32_t)t * per, s1 = min(prjParts, s0 + per);
+    uint32_t       cnt[4] = {0u, 0u, 0u, 0u};
+    uint32_t       sum = 0;
+    if(per <= 4u)
+    {
+#pragma unroll
+      for(uint32_t j = 0; j < 4u; ++j)
+        if(j < per && s0 + j < s1)
+          cnt[j] = slotCount[s0 + j];
+      sum = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    }
+    else
+      for(uint32_t q = s0; q < s1; ++q)
+        sum += slotCount[q];
+    auto pick = [&](uint32_t j) { return j == 0u ? cnt[0] : (j == 1u ? cnt[1] : (j == 2u ? cnt[2] : cnt[3])); };  // no scratch
+    const uint32_t inc = waveInclusiveScan(sum);
+    if(lane == 63)
+      s_scan[w] = inc;
+    __syncthreads();
+    uint32_t base = inc - sum, total = 0;
+    for(int q = 0; q < 16; ++q)
+    {
+      if(q < w) base += s_scan[q];
+      total += s_scan[q];
+    }
+    const uint32_t osParts = (uint32_t)(((uint64_t)total + kOsPart - 1u) / kOsPart);
+    const bool     inLds   = osParts <= 2048u;  // part0 is needed again below: kept in LDS when it fits
+    int32_t*       win     = reinterpret_cast<int32_t*>(part0 + winOffset);
+    for(uint32_t i = t; i < osParts * kOsWin; i += 1024u)
+      win[i] = 0x7FFFFFFF;
+    const uint32_t base0 = base;
+    for(uint32_t q = s0; q < s1; ++q)
+    {
+      const uint32_t c = per <= 4u ? pick(q - s0) : slotCount[q];
+      slotBase[q]      = base;
+      if(c)
+      {  // at most one multiple of 4096 in [base, base + c): c <= 2048
+        const uint32_t d = (base + kOsPart - 1u) / kOsPart;
+        if((uint64_t)d * kOsPart < (uint64_t)base + c)
+        {
+          part0[d] = q;
+          if(inLds)
+            s_tab[d] = q;
+        }
+      }
+      base += c;
+    }
+    if(t == 0)
+    {
+      slotBase[prjParts] = total;
+      plan->n            = total;
+      *nOut              = total;
+    }
+    // the windows need part0 complete.  From LDS behind a barrier; when it does not fit, from memory: behind a fence and with
+    // agent-scope loads (the stores went through this CU's L1 to the L2, a plain load could still hit a stale L1 line)
+    if(!inLds)
+      __threadfence();
+    __syncthreads();
+    base = base0;
+    for(uint32_t q = s0; q < s1; ++q)
+    {
+      const uint32_t c = per <= 4u ? pick(q - s0) : slotCount[q];
+      if(base < total)
+      {  // a slot belongs to the window of every partition it has pairs in; an empty one to the partition its successor starts in
+        const uint32_t d0 = base / kOsPart, d1 = c ? (base + c - 1u) / kOsPart : d0;
+        for(uint32_t d = d0; d <= d1; ++d)
+        {
+          const uint32_t k = q - (inLds ? s_tab[d] : ldAgent(&part0[d]));
+          if(k < kOsWin)
+            win[d * kOsWin + k] = (int32_t)(base - d * kOsPart);
+        }
+      }
+      base += c;
+    }
+    return;
+  }
+  if(blockIdx.x >= reduceWgs)
     return;
   __shared__ uint32_t s_part[512];
-  __shared__ uint32_t s_tab[2048];
   __shared__ uint32_t s_lo, s_hi, s_last;
   __shared__ uint32_t s_tmp[16], s_mm[32];
   const uint32_t slot0 = blockIdx.x * 32u;
@@ -335,14 +425,19 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// (c) one pass.  IN: 0 pairs (every pass of a frame: the project kernels emit one dense array), 2 split key / value arrays
-// (pass 0 of the stand-alone sort).
+// (c) one pass.  IN: 0 dense pairs (the output of the pass before), 1 the project kernels' slots (pass 0 of a frame: dense
+// partition p = pairs [4096 p, 4096 p + count) of the concatenation of the slots, gathered through slotBase / part0),
+// 2 split key / value arrays (pass 0 of the stand-alone sort).
 struct OsPassArgs
 {
 #ifdef MGS_OS_TRACE
   uint64_t* trace;  // [partition][8]
 #endif
   const uint2*    srcPairs;
+  const uint32_t* slotBase;  // IN 1: [slots + 1] exclusive prefix of the slots' counts
+  const uint32_t* part0;     // IN 1: [partitions] the slot holding the first pair of every dense partition, and at winOffset ...
+  uint32_t        winOffset; // ... [partitions][kOsWin]: where the first kOsWin slots from there on start, relative to the partition
+  uint32_t        slots;
   const uint32_t* srcKeys;
   const uint32_t* srcVals;
   uint2*          dstPairs;
@@ -380,6 +475,17 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
   __shared__ uint64_t trc[8];
   MGS_OS_STAMP(0)
 #endif
+  const uint32_t p = blockIdx.x;  // partitions in dispatch order (header: why no ticket)
+  const uint32_t n = *a.nPtr;
+  // IN 1: what locates this partition's pairs in the project kernels' slots (below) is fetched first of all: the pairs' own
+  // loads depend on it, and its round trip passes behind the set-up
+  [[maybe_unused]] int32_t  winMine  = 0;
+  [[maybe_unused]] uint32_t winFirst = 0;
+  if constexpr(IN == 1)
+  {
+    winMine  = reinterpret_cast<const int32_t*>(a.part0 + a.winOffset)[(size_t)p * kOsWin + (lane & (kOsWin - 1))];
+    winFirst = a.part0[p];
+  }
   // clear look-back words for a later pass (stream order: nobody reads them any more)
   for(uint32_t i = blockIdx.x * kThreads + t; i < a.zWords; i += gridDim.x * kThreads)
     a.zStatus[i] = 0u;
@@ -398,8 +504,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
         s_rv[(uint32_t)plan->remapVals[i] - base] = (uint8_t)i;
     }
   __syncthreads();
-  const uint32_t p = blockIdx.x;  // partitions in dispatch order (header: why no ticket)
-  const uint32_t n     = *a.nPtr;
   const uint32_t parts = (uint32_t)(((uint64_t)n + kOsPart - 1u) / kOsPart);
   if(p >= parts)
     return;
@@ -418,6 +522,100 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
   const uint32_t wofs   = w * 64u * rounds;
   uint32_t       key[kKpt], val[kKpt];
   MGS_OS_STAMP(1)
+  // IN 1: the slots that hold this partition's pairs.  Pair idx of the partition is pair idx - w[i] of slot first + i, where
+  // w[i] = slotBase[first + i] - 4096 p (<= 0 for i = 0) and i is the last slot that starts at or before idx (slots that are
+  // empty share their start with their successor and lose the comparison).  Usually the window is a handful of slots and
+  // k_os_prepare's table has all of it: one 32-byte load per wave, the search is seven compares.  A longer window (a strip of a
+  // multi-GPU frame leaves most slots nearly empty) is read from slotBase into s_pair (unused until the re-order; a barrier lies
+  // between) and searched there.
+  [[maybe_unused]] int32_t* s_win = reinterpret_cast<int32_t*>(s_pair);
+  [[maybe_unused]] uint32_t winLen = 0;
+  [[maybe_unused]] int32_t  wq[kOsWin];
+  [[maybe_unused]] bool     winShort = false;
+  if constexpr(IN == 1)
+  {
+    const uint32_t start = p * kOsPart, end = start + count;
+#pragma unroll
+    for(int k = 0; k < (int)kOsWin; ++k)
+      wq[k] = __builtin_amdgcn_readlane(winMine, k);
+    winShort = wq[kOsWin - 1] >= (int32_t)count;  // the table reaches the partition's end (0x7FFFFFFF behind the last slot)
+    if(!winShort)
+    {
+      if(t == 0)
+        s_tmp[4] = 0xFFFFFFFFu;
+      __syncthreads();
+      for(uint32_t c0 = 0; c0 < 2u * kOsPart; c0 += kThreads)
+      {  // (a table of 8192 slots is 32 KB == s_pair; a partition of 4096 pairs that needs more slots than that takes the
+         // slow path below)
+        const uint32_t i = c0 + (uint32_t)t, sl = winFirst + i;
+        const uint32_t b = sl <= a.slots ? a.slotBase[sl] : 0xFFFFFFFFu;
+        s_win[i]         = (int32_t)(b - start);
+        if(b >= end)
+          atomicMin(&s_tmp[4], i);
+        if(__syncthreads_or(b >= end ? 1 : 0))
+          break;
+      }
+      winLen = s_tmp[4];  // 0xFFFFFFFF: not within the table
+    }
+  }
+  // IN 1: where every pair of the partition lies, computed for all of them BEFORE the first load is issued (the three ways to
+  // find the slot are branches; loads behind a branch each wait for their own arrival)
+  [[maybe_unused]] uint32_t srcAt[IN == 1 ? kKpt : 1];
+  if constexpr(IN == 1)
+  {
+    if(winShort)
+    {
+#pragma unroll
+      for(int i = 0; i < kKpt; ++i)
+      {
+        const uint32_t idx = min(wofs + (uint32_t)i * 64u + lane, count - 1u);
+        uint32_t       lo  = 0;
+        int32_t        wl  = wq[0];
+#pragma unroll
+        for(int k = 1; k < (int)kOsWin; ++k)
+        {
+          const bool in = wq[k] <= (int32_t)idx;
+          lo            = in ? (uint32_t)k : lo;
+          wl            = in ? wq[k] : wl;
+        }
+        srcAt[i] = lo * kOsSlot + (idx - (uint32_t)wl);
+      }
+    }
+    else if(winLen != 0xFFFFFFFFu)
+    {
+      for(int i = 0; i < kKpt; ++i)
+      {
+        const uint32_t idx = min(wofs + (uint32_t)i * 64u + lane, count - 1u);
+        uint32_t       lo = 0, hi = winLen;  // s_win[lo] <= idx < s_win[hi] throughout
+        while(hi - lo > 1u)
+        {
+          const uint32_t mid = (lo + hi) >> 1;
+          if(s_win[mid] <= (int32_t)idx)
+            lo = mid;
+          else
+            hi = mid;
+        }
+        srcAt[i] = lo * kOsSlot + (idx - (uint32_t)s_win[lo]);
+      }
+    }
+    else
+    {  // more than 8192 slots for 4096 pairs: search the prefix array itself
+      for(int i = 0; i < kKpt; ++i)
+      {
+        const uint32_t e  = p * kOsPart + min(wofs + (uint32_t)i * 64u + lane, count - 1u);
+        uint32_t       lo = 0, hi = a.slots - winFirst;
+        while(hi - lo > 1u)
+        {
+          const uint32_t mid = (lo + hi) >> 1;
+          if(a.slotBase[winFirst + mid] <= e)
+            lo = mid;
+          else
+            hi = mid;
+        }
+        srcAt[i] = lo * kOsSlot + (e - a.slotBase[winFirst + lo]);
+      }
+    }
+  }
   // clamped, not predicated: a predicated load becomes a branch + wait and serialises the fetches
 #pragma unroll
   for(int i = 0; i < kKpt; ++i)
@@ -434,7 +632,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
       }
       else
       {
-        const uint2 kv = a.srcPairs[(size_t)p * kOsPart + idx];
+        const uint2 kv = IN == 1 ? a.srcPairs[(size_t)winFirst * kOsSlot + srcAt[IN == 1 ? i : 0]] : a.srcPairs[(size_t)p * kOsPart + idx];
         key[i] = kv.x;
         val[i] = kv.y;
       }
@@ -736,8 +934,9 @@ void launchOsSort(hipStream_t stream, const OsLaunch& L)
   if(!frame)
     hipLaunchKernelGGL(k_os_hist, dim3(std::min<uint32_t>((L.maxElems + 2047u) / 2048u, 1024u)), dim3(256), 0, stream, L.keys0, L.nPtr, L.plan);
   const uint32_t reduceWgs = frame ? (L.prjParts + 31u) / 32u : 0u;
-  hipLaunchKernelGGL(k_os_prepare, dim3(std::max(reduceWgs, 1u)), dim3(1024), 0, stream, frame ? L.slotHist2 : nullptr, L.top16Rec, L.prjParts,
-                     L.top16Count, L.plan, L.nPtr, (frame && L.allowRemap) ? 1 : 0, reduceWgs);
+  hipLaunchKernelGGL(k_os_prepare, dim3(reduceWgs + 1u), dim3(1024), 0, stream, frame ? L.slotHist2 : nullptr, L.top16Rec, L.prjParts,
+                     L.top16Count, L.plan, L.nPtr, (frame && L.allowRemap) ? 1 : 0, reduceWgs, L.slotCount, L.slotBase, L.part0, maxParts + 1u,
+                     L.nOut);
   for(int pass = 0; pass < 4; ++pass)
   {
     OsPassArgs a{};
@@ -759,6 +958,10 @@ void launchOsSort(hipStream_t stream, const OsLaunch& L)
     // pass 0 -> A, 1 -> B, 2 -> A (or the result), 3 -> the result.  A frame's pass 0 reads the dense pairs, which live in B.
     a.srcPairs  = (pass == 0) ? L.pairs0 : ((pass & 1) ? L.pairA : L.pairB);
     a.dstPairs  = (pass & 1) ? L.pairB : L.pairA;
+    a.slotBase  = L.slotBase;
+    a.part0     = L.part0;
+    a.winOffset = maxParts + 1u;
+    a.slots     = L.prjParts;
     a.srcKeys   = L.keys0;
     a.srcVals   = L.vals0;
     a.digitMode = (pass == 2 && frame) ? 1 : (pass == 3 ? 2 : 0);
@@ -768,6 +971,8 @@ void launchOsSort(hipStream_t stream, const OsLaunch& L)
       continue;
     if(pass == 0 && !frame)
       hipLaunchKernelGGL((k_os_pass<2, false>), dim3(grid), dim3(kThreads), 0, stream, a);
+    else if(pass == 0)
+      hipLaunchKernelGGL((k_os_pass<1, false>), dim3(grid), dim3(kThreads), 0, stream, a);
     else if(pass == 2 && frame)
       hipLaunchKernelGGL((k_os_pass<0, true>), dim3(grid), dim3(kThreads), 0, stream, a);
     else

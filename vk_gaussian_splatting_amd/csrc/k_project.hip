@@ -194,7 +194,7 @@ __device__ uint64_t* g_prjTrace = nullptr;
 #endif
 template <bool FULL>
 __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __restrict__ Ap, FrameCounters* __restrict__ ctr,
-                                                         uint2* __restrict__ densePairs, uint32_t* __restrict__ prjStatus,
+                                                         uint2* __restrict__ slotPairs, uint32_t* __restrict__ slotCount,
                                                          SplatRec* __restrict__ rec, uint32_t* __restrict__ rect,
                                                          const uint32_t* __restrict__ partSkip, uint32_t* __restrict__ slotHist2,
                                                          uint32_t* __restrict__ top16Rec, uint32_t* __restrict__ top16Count,
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   const uint32_t pflag = partSkip != nullptr ? partSkip[blockIdx.x] : 0u;
   if(pflag & 1u)
   {  // k_partition_cull proved that no splat of this partition can survive the cull / reach the strip
-    emitEmptySlot<kPrjThreads>(prjStatus, A.f.totalPartitions, slotHist2, top16Rec, ctr, blockIdx.x);
+    emitEmptySlot<kPrjThreads>(slotCount, slotHist2, top16Rec, blockIdx.x);
     return;
   }
   __shared__ uint32_t s_hist2[256];  // 2 x 256 sixteen-bit counters (slot_emit.h)
@@ -223,7 +223,6 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   __shared__ uint32_t s_key[kPrjPart];
   __shared__ uint32_t s_cnt[32];
   __shared__ uint32_t s_base[33];
-  __shared__ uint32_t s_keep[2];
 
   const int      t = threadIdx.x, lane = laneId(), w = t >> 6;
   const uint32_t part = blockIdx.x;
@@ -326,7 +325,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   if constexpr(!FULL)
   {
     // sort-only hook: survivors of the dist stage, exactly dist.comp.slang's (key, id) stream
-    emitSlot<kPrjThreads, kPrjItems>(M, true, s_li, s_key, s_cnt, s_base, s_hist2, s_keep, densePairs, prjStatus, A.f.totalPartitions, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
+    emitSlot<kPrjThreads, kPrjItems>(M, true, s_li, s_key, s_cnt, s_base, s_hist2, slotPairs, slotCount, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
                                      I.globalOffset + local0);
     return;
   }
@@ -389,7 +388,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
     // ---- second ordered compaction straight into the partition's slot region (slot_emit.h) ----
     __syncthreads();
     MGS_PRJ_STAMP(4)
-    const uint32_t outCount = emitSlot<kPrjThreads, kPrjItems>(M, false, s_li, s_key, s_cnt, s_base, s_hist2, s_keep, densePairs, prjStatus, A.f.totalPartitions, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
+    const uint32_t outCount = emitSlot<kPrjThreads, kPrjItems>(M, false, s_li, s_key, s_cnt, s_base, s_hist2, slotPairs, slotCount, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
                                                                I.globalOffset + local0);
     (void)outCount;
 #ifdef MGS_PRJ_TRACE
@@ -531,8 +530,8 @@ void launchPartitionCull(hipStream_t stream, const FrameArgs& args, const FrameA
 
 // ---------------------------------------------------------------------------------------------
 // host-callable launcher
-void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full, FrameCounters* ctr, uint2* densePairs,
-                   uint32_t* prjStatus, SplatRec* rec, uint32_t* rect, const uint32_t* partSkip, uint32_t* slotHist2,
+void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full, FrameCounters* ctr, uint2* slotPairs,
+                   uint32_t* slotCount, SplatRec* rec, uint32_t* rect, const uint32_t* partSkip, uint32_t* slotHist2,
                    uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan, const float* partR)
 {
   const dim3 grid(args.f.totalPartitions), block(kPrjThreads);
@@ -553,7 +552,7 @@ void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* d
   }
 #endif
 #define MGS_LAUNCH(FULLV)                                                                                                \
-  hipLaunchKernelGGL((k_project<FULLV>), grid, block, 0, stream, dArgs, ctr, densePairs, prjStatus, rec, rect, partSkip, slotHist2, \
+  hipLaunchKernelGGL((k_project<FULLV>), grid, block, 0, stream, dArgs, ctr, slotPairs, slotCount, rec, rect, partSkip, slotHist2, \
                      top16Rec, top16Count, osPlan, partR)
   if(full)
     MGS_LAUNCH(true);

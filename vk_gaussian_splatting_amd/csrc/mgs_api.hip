@@ -32,8 +32,8 @@
 
 namespace mgs {
 // kernels_*.hip
-void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full, FrameCounters* ctr, uint2* densePairs,
-                   uint32_t* prjStatus, SplatRec* rec, uint32_t* rect, const uint32_t* partSkip, uint32_t* slotHist2,
+void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full, FrameCounters* ctr, uint2* slotPairs,
+                   uint32_t* slotCount, SplatRec* rec, uint32_t* rect, const uint32_t* partSkip, uint32_t* slotHist2,
                    uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan, const float* partR);
 void launchPartitionCull(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, uint32_t* partSkip, float* partR,
                          uint32_t* zero0, uint32_t n0, uint32_t* zero1, uint32_t n1, uint32_t* zero2, uint32_t n2);
@@ -54,7 +54,7 @@ void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges
                      int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId, const void* instTable, const FrameArgs* dArgs,
                      float4* outNormal);
 void launchProjectGut(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, int shFormat, FrameCounters* ctr,
-                      uint2* densePairs, uint32_t* prjStatus, GutRec* rec, uint32_t* rect, const uint32_t* partSkip,
+                      uint2* densePairs, uint32_t* slotCount, GutRec* rec, uint32_t* rect, const uint32_t* partSkip,
                       uint32_t* slotHist2, uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan);
 void launchCompositeGut(hipStream_t stream, const FrameArgs& A, const FrameArgs* dArgs, const uint2* ranges, const uint32_t* valX,
                         const uint32_t* valY, const SortPlan* planPairs, const GutRec* rec, void* image, int halfOut,
@@ -268,8 +268,10 @@ struct MgsScene_t
   uint64_t    wsEpoch   = ~0ull;  // d->epoch the working set below was sized for
 
   // frame buffers
-  DevBuf<uint2>         pairA, pairB;  // ping-pong of the key sort; the project kernels append their dense (key, id) pairs to B
+  DevBuf<uint2>         pairA, pairB;  // ping-pong of the key sort; the project kernels leave their (key, id) pairs in B, one
+                                       // slot of 2048 entries per partition
   DevBuf<uint32_t>      slotHist2, top16Rec, top16Count, osStatus;  // what the key sort needs besides (k_osort.hip)
+  DevBuf<uint32_t>      slotCount, slotBase, part0;  // pairs per slot; their exclusive prefix; first slot of every sort partition
   DevBuf<uint32_t>      keysA, idsA;  // the sorted ids (and, for the sort-only hook, the sorted keys)
   DevBuf<uint32_t>      rect, partHist, blockCount;
   DevBuf<uint32_t>      sortedRect, splatOffset, chunkStart, partSkip;
@@ -715,7 +717,7 @@ void mgs_scene_destroy(MgsScene s)
     auto& h = s->d->handles;
     h.erase(std::remove(h.begin(), h.end(), s), h.end());
   }
-  s->pairA.release(); s->pairB.release(); s->slotHist2.release(); s->top16Rec.release(); s->top16Count.release();
+  s->pairA.release(); s->pairB.release(); s->slotCount.release(); s->slotBase.release(); s->part0.release(); s->slotHist2.release(); s->top16Rec.release(); s->top16Count.release();
   s->osStatus.release(); s->keysA.release(); s->idsA.release(); s->rect.release(); s->partHist.release(); s->blockCount.release();
   s->rec.release(); s->recGut.release(); s->pairKey0.release(); s->pairVal0.release(); s->pairKey1.release(); s->pairVal1.release();
   s->sortedRect.release(); s->splatOffset.release(); s->chunkStart.release(); s->partSkip.release(); s->partR.release();
@@ -822,7 +824,7 @@ int mgs_scene_memory_usage(MgsScene s, uint64_t* sceneBytes, uint64_t* workingBy
   {
     uint64_t b = 0;
     auto add = [&](auto& buf) { b += (uint64_t)buf.n * sizeof(*buf.p); };
-    add(s->pairA); add(s->pairB); add(s->slotHist2); add(s->top16Rec); add(s->top16Count); add(s->osStatus); add(s->keysA); add(s->idsA); add(s->rect);
+    add(s->pairA); add(s->pairB); add(s->slotCount); add(s->slotBase); add(s->part0); add(s->slotHist2); add(s->top16Rec); add(s->top16Count); add(s->osStatus); add(s->keysA); add(s->idsA); add(s->rect);
     add(s->partHist); add(s->blockCount); add(s->sortedRect); add(s->splatOffset); add(s->chunkStart); add(s->partSkip); add(s->partR);
     add(s->dbinMasks); add(s->dArgs); add(s->surfDepth); add(s->surfId); add(s->surfNormal); add(s->accum); add(s->rec); add(s->recGut);
     add(s->pairKey0); add(s->pairVal0); add(s->pairKey1); add(s->pairVal1); add(s->ranges); add(s->image); add(s->ctr); add(s->plans);
@@ -1195,17 +1197,17 @@ static int sizeWorkingSet(MgsScene s)
   if((rc = s->partR.ensure(parts))) return rc;
   HIPCHK(hipMemset(s->partSkip.p, 0, parts * sizeof(uint32_t)));
   if((rc = s->pairA.ensure(total))) return rc;
-  if((rc = s->pairB.ensure(total))) return rc;
+  if((rc = s->pairB.ensure(std::max<uint64_t>(total, parts * (uint64_t)kOsSlot)))) return rc;  // whole slots
+  if((rc = s->slotCount.ensure(parts))) return rc;
+  if((rc = s->slotBase.ensure(parts + 1))) return rc;
+  if((rc = s->part0.ensure(((size_t)osSortMaxParts((uint32_t)total) + 1) * (1 + kOsWin)))) return rc;
   if((rc = s->idsA.ensure(total))) return rc;
   if((rc = s->rect.ensure(total))) return rc;
   if((rc = s->rec.ensure(total))) return rc;
   if((rc = s->sortedRect.ensure(total))) return rc;
   if((rc = s->ctr.ensure(1))) return rc;
-  {  // FramePlans + the look-back words of the project kernels, contiguous: one zero sweep by the frame's first kernel
-    const uint32_t prjWords = prjStatusWords((uint32_t)parts);
-    s->planWords            = (uint32_t)(sizeof(FramePlans) / 4) + prjWords;
-    if((rc = s->plans.ensure(1 + ((size_t)prjWords * 4 + sizeof(FramePlans) - 1) / sizeof(FramePlans)))) return rc;
-  }
+  s->planWords = (uint32_t)(sizeof(FramePlans) / 4);  // zeroed by the frame's first kernel
+  if((rc = s->plans.ensure(1))) return rc;
 
   uint64_t cap = std::max<uint64_t>(32ull * total, 64ull << 20);  // 16 B per pair: 3 GB for a garden-sized scene
   if(const char* e = std::getenv("MGS_PAIR_CAPACITY"))
@@ -1633,6 +1635,10 @@ static void keySort(MgsScene s, hipStream_t st, bool wantKeys, bool allowRemap)
   OsLaunch L{};
   L.pairs0       = s->pairB.p;
   L.prjParts     = s->d->totalParts;
+  L.slotCount    = s->slotCount.p;
+  L.slotBase     = s->slotBase.p;
+  L.part0        = s->part0.p;
+  L.nOut         = &s->ctr.p->sortedCount;
   L.slotHist2    = s->slotHist2.p;
   L.top16Rec     = s->top16Rec.p;
   L.top16Count   = s->top16Count.p;
@@ -1948,11 +1954,11 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     if(cpuMode)  // rejected splats must look empty to the binning stage: rect with x0 > x1
       hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, st, s->rect.p, 1u, s->d->totalSplats);
     if(gut)
-      launchProjectGut(st, A, s->dArgs.p, s->d->shFormat, ctr, s->pairB.p, reinterpret_cast<uint32_t*>(s->plans.p + 1), s->recGut.p, s->rect.p,
+      launchProjectGut(st, A, s->dArgs.p, s->d->shFormat, ctr, s->pairB.p, s->slotCount.p, s->recGut.p, s->rect.p,
                        F.partitionCull ? s->partSkip.p : nullptr, s->slotHist2.p, s->top16Rec.p, cpuMode ? nullptr : s->top16Count.p,
                        &s->plans.p->os);
     else
-      launchProject(st, A, s->dArgs.p, true, ctr, s->pairB.p, reinterpret_cast<uint32_t*>(s->plans.p + 1), s->rec.p, s->rect.p,
+      launchProject(st, A, s->dArgs.p, true, ctr, s->pairB.p, s->slotCount.p, s->rec.p, s->rect.p,
                     F.partitionCull ? s->partSkip.p : nullptr, s->slotHist2.p, s->top16Rec.p, cpuMode ? nullptr : s->top16Count.p,
                     &s->plans.p->os, F.partitionCull ? s->partR.p : nullptr);
     if(withEvents) HIPCHK(hipEventRecord(fev[1], st));
@@ -2711,7 +2717,7 @@ int mgs_sort_keys(MgsScene s, const MgsFrameParams* p, MgsSortOut* out)
                         (uint32_t)(sizeof(FrameCounters) / 4), reinterpret_cast<uint32_t*>(s->plans.p), s->planWords, nullptr, 0u);
   else
     launchFrameInit(st, s->ctr.p, reinterpret_cast<uint32_t*>(s->plans.p), s->planWords, s->ranges.p, 0);
-  launchProject(st, A, s->dArgs.p, false, s->ctr.p, s->pairB.p, reinterpret_cast<uint32_t*>(s->plans.p + 1), s->rec.p, s->rect.p,
+  launchProject(st, A, s->dArgs.p, false, s->ctr.p, s->pairB.p, s->slotCount.p, s->rec.p, s->rect.p,
                 A.f.partitionCull ? s->partSkip.p : nullptr, s->slotHist2.p, s->top16Rec.p, s->top16Count.p, &s->plans.p->os,
                 A.f.partitionCull ? s->partR.p : nullptr);
   HIPCHK(hipEventRecord(s->ev[1], st));

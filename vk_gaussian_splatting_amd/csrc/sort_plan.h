@@ -43,6 +43,8 @@ void launchRadixSort(hipStream_t stream, const SortLaunch& s);
 
 // ---- the frame's key sort (k_osort.hip) -------------------------------------------------------------------------------
 constexpr uint32_t kOsPart    = 4096;  // pairs per partition (256 threads x 16)
+constexpr uint32_t kOsSlot    = 2048;  // pairs a project workgroup's slot can hold (== its partition of splats)
+constexpr uint32_t kOsWin     = 8;     // slots per sort partition whose start k_os_prepare tabulates (power of two <= 64)
 constexpr uint32_t kOsGroup   = 32;    // partitions per look-back group
 constexpr uint32_t kRemapSpan = 4096;  // pass 2 of a depth-key sort indexes a 4096-entry LDS table with (key >> 16) - remapBase
 
@@ -65,9 +67,15 @@ struct OsPlan
 // host descriptor of the frame key sort / the stand-alone full-width sort
 struct OsLaunch
 {
-  // input, exactly one of: the project kernels' dense (key, id) pairs with their per-partition histograms and records ...
-  const uint2*    pairs0     = nullptr;  // n pairs (n = *nPtr); may alias pairB (pass 0 reads it before pass 1 writes B)
-  uint32_t        prjParts   = 0;        // project partitions (2048 splats each)
+  // input, exactly one of: the project kernels' slots of (key, id) pairs with their per-partition histograms and records ...
+  const uint2*    pairs0     = nullptr;  // slot p = pairs [kOsSlot p, kOsSlot p + slotCount[p]); may alias pairB (pass 0 reads it
+                                         // before pass 1 writes B)
+  uint32_t        prjParts   = 0;        // project partitions == slots (2048 splats each)
+  const uint32_t* slotCount  = nullptr;  // [prjParts] pairs in every slot
+  uint32_t*       slotBase   = nullptr;  // [prjParts + 1] scratch: exclusive prefix of slotCount (k_os_prepare)
+  uint32_t*       part0      = nullptr;  // [(osSortMaxParts + 1) (1 + kOsWin)] scratch: the slot that holds the first pair of every
+                                         // dense partition, then the partitions' windows (k_os_prepare)
+  uint32_t*       nOut       = nullptr;  // the frame's count of sorted pairs (== *nPtr afterwards), written by k_os_prepare
   const uint32_t* slotHist2  = nullptr;  // [partition][256]: histograms of key bits 0-7 and 8-15, two 16-bit counters per word
   const uint32_t* top16Rec   = nullptr;  // [partition][4 waves][32]: counts of key >> 16 per producer wave (slot_emit.h)
   uint32_t*       top16Count = nullptr;  // [65536] occurrences of key >> 16 (filled, consumed and cleared by k_os_prepare;
@@ -102,9 +110,6 @@ void     launchOsSortClearPlan(hipStream_t stream, OsPlan* plan);
 void     launchOsSort(hipStream_t stream, const OsLaunch& L);
 
 // ---- what the project kernels hand to the key sort (k_project.hip, k_gut.hip; device side in slot_emit.h) -----------------
-constexpr uint32_t kPrjGroup = 64;  // project workgroups per look-back group == lanes of the wave that reads them
-// words of the look-back state for `parts` project workgroups: one per workgroup, then one per group (zeroed per frame)
-inline uint32_t prjStatusWords(uint32_t parts) { return parts + (parts + kPrjGroup - 1u) / kPrjGroup + 1u; }
 
 // The producer counts which values of key >> 16 it hands to the sort.  A partition is a compact cell of space, so its keys
 // span one to three values: every wave leaves a 32-word record (counts of the values lo .. lo + 24, header lo | span << 16
