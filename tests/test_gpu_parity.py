@@ -1271,6 +1271,27 @@ def test_full_size_eight_instances_unified_sort():
     scene.render(p)
     part = scene.download_frame(p).view(np.uint16)
     assert np.array_equal(part[480:608], full[480:608])
+    # a needle of a frustum (0.7 degrees): ~6 800 survivors spread over the 22 775 slots of the project kernels, 0.3 per slot —
+    # the sort's first pass gathers a partition of 4096 pairs from more than 8192 slots (the path that searches the prefix of
+    # the slot counts itself, k_osort.hip) and a ragged second one
+    Vn, Pn = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 0.7, 0.1, 2000.0, W, H)
+    pn = capi.default_params(W, H)
+    capi.set_camera(pn, Vn, Pn, eye)
+    son = scene.sort_keys(pn)
+    kn, idn = scene.sort_download(son.count)
+    totn = 0
+    for M in Ms:
+        clip = pos @ (Pn.astype(np.float64) @ Vn.astype(np.float64) @ M.astype(np.float64)).T
+        ndc = clip[:, :3] / clip[:, 3:4]
+        totn += int(((np.abs(ndc[:, 0]) <= 1.2) & (np.abs(ndc[:, 1]) <= 1.2) & (ndc[:, 2] >= -0.2) & (ndc[:, 2] <= 1.0)).sum())
+    print(f"  needle frustum: V {son.count} (fp64 cull {totn})")
+    assert 4096 < son.count < 20_000 and abs(totn - int(son.count)) <= 40
+    assert np.all(kn[1:] >= kn[:-1]) and np.unique(idn).size == idn.size and idn.max() < n * k
+    gsn = (idn // n).astype(np.uint64) * n + inv[idn % n]
+    samen = kn[1:] == kn[:-1]
+    assert np.all(gsn[1:][samen] > gsn[:-1][samen])
+    outn = scene.render(pn, want_stats=True)
+    assert outn.error_flags == 0 and outn.sorted_count <= son.count
     # the bench's own orbit pose too (camera inside the grid)
     p2, *_ = camera(0, W, H)
     o2 = scene.render(p2, want_stats=True)
