@@ -23,6 +23,7 @@
 #include "surface_normal.h"
 #include "sort_plan.h"
 #include "slot_emit.h"
+#include "partition_cull.h"
 
 namespace mgs {
 
@@ -260,23 +261,16 @@ __device__ __forceinline__ bool projectSplatGut(const FrameConst& F, const Insta
 __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __restrict__ Ap, FrameCounters* __restrict__ ctr,
                                                              uint2* __restrict__ slotPairs, uint32_t* __restrict__ slotCount,
                                                              GutRec* __restrict__ rec, uint32_t* __restrict__ rect,
-                                                             const uint32_t* __restrict__ partSkip, uint32_t* __restrict__ slotHist2,
+                                                             uint32_t* __restrict__ slotHist2,
                                                              uint32_t* __restrict__ top16Rec, uint32_t* __restrict__ top16Count,
                                                              OsPlan* __restrict__ osPlan)
 {
   const FrameArgs& A = *Ap;
-  if(partSkip != nullptr && (partSkip[blockIdx.x] & 1u) != 0u)
-  {
-    emitEmptySlot<kGutThreads>(slotCount, slotHist2, top16Rec, blockIdx.x);
-    return;
-  }
   __shared__ uint32_t s_hist2[256];  // 2 x 256 sixteen-bit counters (slot_emit.h)
   __shared__ uint16_t s_li[kGutPart];
   __shared__ uint32_t s_key[kGutPart];
   __shared__ uint32_t s_cnt[32];
   __shared__ uint32_t s_base[33];
-  for(int i = threadIdx.x; i < 256; i += kGutThreads)
-    s_hist2[i] = 0u;
   const int      t = threadIdx.x, lane = laneId(), w = t >> 6;
   const uint32_t part = blockIdx.x;
   int            k    = 0;
@@ -285,6 +279,7 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
       k = i;
   const InstanceConst& I      = A.inst[k];
   const uint32_t       local0 = (part - I.blockBegin) * kGutPart;
+  const PartitionBox pbox = partitionLoad(I, part - I.blockBegin);  // ahead of the centres (partition_cull.h)
   float px[kGutItems], py[kGutItems], pz[kGutItems];
 #pragma unroll
   for(int it = 0; it < kGutItems; ++it)
@@ -294,6 +289,16 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
     py[it] = I.centers[3 * (size_t)li + 1];
     pz[it] = I.centers[3 * (size_t)li + 2];
   }
+  {  // the partition as a whole (partition_cull.h): no splat of it can survive the cull / reach the strip
+    float partRadius;
+    if(A.f.partitionCull && (partitionTest(A, I, pbox, partRadius) & 1u) != 0u)
+    {
+      emitEmptySlot<kGutThreads>(slotCount, slotHist2, top16Rec, part);
+      return;
+    }
+  }
+  for(int i = threadIdx.x; i < 256; i += kGutThreads)
+    s_hist2[i] = 0u;
   uint32_t key[kGutItems];
   uint64_t bal[kGutItems];
   bool     vis[kGutItems];
@@ -990,14 +995,14 @@ __global__ __launch_bounds__(256) void k_composite_gut2(const FrameArgs* __restr
 
 // ---------------------------------------------------------------------------------------------
 void launchProjectGut(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, int shFormat, FrameCounters* ctr,
-                      uint2* slotPairs, uint32_t* slotCount, GutRec* rec, uint32_t* rect, const uint32_t* partSkip,
+                      uint2* slotPairs, uint32_t* slotCount, GutRec* rec, uint32_t* rect,
                       uint32_t* slotHist2, uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan)
 {
   (void)shFormat;
   if(args.f.totalPartitions == 0)
     return;
   hipLaunchKernelGGL(k_project_gut, dim3(args.f.totalPartitions), dim3(kGutThreads), 0, stream, dArgs, ctr, slotPairs, slotCount, rec, rect,
-                     partSkip, slotHist2, top16Rec, top16Count, osPlan);
+                     slotHist2, top16Rec, top16Count, osPlan);
 }
 
 void launchCompositeGut(hipStream_t stream, const FrameArgs& A, const FrameArgs* dArgs, const uint2* ranges, const uint32_t* valX,

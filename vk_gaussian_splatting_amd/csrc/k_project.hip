@@ -23,6 +23,7 @@
 #include "kernels_common.h"
 #include "sort_plan.h"
 #include "slot_emit.h"
+#include "partition_cull.h"
 
 namespace mgs {
 
@@ -196,9 +197,9 @@ template <bool FULL>
 __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __restrict__ Ap, FrameCounters* __restrict__ ctr,
                                                          uint2* __restrict__ slotPairs, uint32_t* __restrict__ slotCount,
                                                          SplatRec* __restrict__ rec, uint32_t* __restrict__ rect,
-                                                         const uint32_t* __restrict__ partSkip, uint32_t* __restrict__ slotHist2,
+                                                         uint32_t* __restrict__ slotHist2,
                                                          uint32_t* __restrict__ top16Rec, uint32_t* __restrict__ top16Count,
-                                                         OsPlan* __restrict__ osPlan, const float* __restrict__ partR)
+                                                         OsPlan* __restrict__ osPlan)
 {
   const FrameArgs& A = *Ap;  // frame constants live in device memory (same pointer every frame: graph-replayable)
 #ifdef MGS_PRJ_TRACE
@@ -206,19 +207,8 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   if(threadIdx.x < 8) trc[threadIdx.x] = 0;
   MGS_PRJ_STAMP(0)
 #endif
-  // slotHist2[partition][2][256]: this partition's survivors by key bits 0-7 and 8-15 (slot_emit.h), produced here while
-  // the keys are still on chip.
-  // partition flags of k_partition_cull: bit 0 skip, bit 1 every centre passes the frustum test, bit 2 all centres finite
-  const uint32_t pflag = partSkip != nullptr ? partSkip[blockIdx.x] : 0u;
-  if(pflag & 1u)
-  {  // k_partition_cull proved that no splat of this partition can survive the cull / reach the strip
-    emitEmptySlot<kPrjThreads>(slotCount, slotHist2, top16Rec, blockIdx.x);
-    return;
-  }
-  __shared__ uint32_t s_hist2[256];  // 2 x 256 sixteen-bit counters (slot_emit.h)
+  __shared__ uint32_t s_hist2[256];  // 2 x 256 sixteen-bit counters: the survivors by key bits 0-7 and 8-15 (slot_emit.h)
   __shared__ float4   s_rec[FULL ? kPrjWaves : 1][FULL ? 64 * 3 : 1];  // per wave: 64 records at a 48-byte pitch
-  for(int i = threadIdx.x; i < 256; i += kPrjThreads)
-    s_hist2[i] = 0u;  // ordered before its first use by the barriers of phase 1
   __shared__ uint16_t s_li[kPrjPart];   // bit 15: survived phase 2
   __shared__ uint32_t s_key[kPrjPart];
   __shared__ uint32_t s_cnt[32];
@@ -233,6 +223,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   const InstanceConst& I      = A.inst[k];
   const uint32_t       local0 = (part - I.blockBegin) * kPrjPart;
 
+  const PartitionBox pbox = partitionLoad(I, part - I.blockBegin);  // ahead of the centres (partition_cull.h)
   // ---- phase 1: key + frustum cull for 8 splats per thread -------------------------------------------
   float px[kPrjItems], py[kPrjItems], pz[kPrjItems];
 #pragma unroll
@@ -244,6 +235,17 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
     py[it] = I.centers[3 * (size_t)li + 1];
     pz[it] = I.centers[3 * (size_t)li + 2];
   }
+  // the partition as a whole (partition_cull.h; behind the centres' loads, which are in flight either way): bit 0 no splat of
+  // it can survive the cull / reach the strip, bit 1 every centre passes the frustum test, bit 2 all centres finite
+  float          partRadius = 3.0e38f;
+  const uint32_t pflag      = A.f.partitionCull ? partitionTest(A, I, pbox, partRadius) : 0u;
+  if(pflag & 1u)
+  {
+    emitEmptySlot<kPrjThreads>(slotCount, slotHist2, top16Rec, part);
+    return;
+  }
+  for(int i = threadIdx.x; i < 256; i += kPrjThreads)
+    s_hist2[i] = 0u;  // ordered before its first use by the barriers of phase 1
   uint32_t key[kPrjItems];
   uint64_t bal[kPrjItems];
   bool     vis[kPrjItems];
@@ -255,8 +257,8 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   // strips (multi-GPU): a splat whose centre lies further from this device's rows than the partition's footprint bound R
   // (k_partition_cull; valid for every splat of the partition) cannot reach them — dropped here, before the projection.
   // The exact footprint-vs-strip test of phase 2 would reject it anyway: the sorted set is unchanged.
-  const bool  stripPre = FULL && partR != nullptr && (A.f.stripRow1 - A.f.stripRow0) < A.f.tilesY;
-  const float stripR   = stripPre ? partR[blockIdx.x] : 3.0e38f;
+  const bool  stripPre = FULL && A.f.partitionCull && (A.f.stripRow1 - A.f.stripRow0) < A.f.tilesY;
+  const float stripR   = stripPre ? partRadius : 3.0e38f;
   const float stripY0  = (float)(A.f.stripRow0 * kTilePx), stripY1 = (float)min(A.f.stripRow1 * kTilePx, A.f.height);
   const bool  insideFast = (pflag & 2u) != 0u && A.f.cullMode == 1 && !stripPre;
 #pragma unroll
@@ -404,135 +406,12 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   }
 }
 
-// ---- partition-level culling ---------------------------------------------------------------------------
-// One thread per 2048-splat partition.  Storage order is Morton order, so a partition is a compact
-// cell of space; its 8 AABB corners go through the same P*V*M.  The per-splat test of dist.comp.slang
-// (:71-73) culls on ndc = clip/w; for points with w > 0 every one of its conditions is LINEAR in the
-// point (x > c*w, -x > c*w, ..., z > w, z < -d*w), so if all 8 corners satisfy the same condition every
-// centre inside the box does too.  Margins make the test conservative against fp32 rounding: a
-// partition is skipped only if every splat in it would certainly be culled.  For strips the footprint
-// of a splat of the partition is bounded by R = s*(k*fmax*S*rmax/zmin + 3.2) + 1 px (derivation in
-// DESIGN.md §3.1), and the partition is skipped when [ymin-R, ymax+R] misses the strip's pixel rows.
-// It is also the frame's first kernel, so it zeroes the per-frame device state (counters, both sort plans, the bin
-// ranges): one launch less than a separate init kernel.
-__global__ __launch_bounds__(256) void k_partition_cull(const FrameArgs* __restrict__ Ap, uint32_t* __restrict__ partSkip, float* __restrict__ partR,
-                                                        uint32_t* __restrict__ zero0, uint32_t n0, uint32_t* __restrict__ zero1,
-                                                        uint32_t n1, uint32_t* __restrict__ zero2, uint32_t n2)
-{
-  const FrameArgs& A = *Ap;
-  const uint32_t part = blockIdx.x * blockDim.x + threadIdx.x;
-  for(uint32_t i = part; i < n0; i += gridDim.x * blockDim.x)
-    zero0[i] = 0u;
-  for(uint32_t i = part; i < n1; i += gridDim.x * blockDim.x)
-    zero1[i] = 0u;
-  for(uint32_t i = part; i < n2; i += gridDim.x * blockDim.x)
-    zero2[i] = 0u;
-  if(part >= A.f.totalPartitions)
-    return;
-  int k = 0;
-  for(int i = 1; i < A.f.nInstances; ++i)
-    if(part >= A.inst[i].blockBegin)
-      k = i;
-  const InstanceConst& I  = A.inst[k];
-  const float*         bx = I.partBox + 8 * (size_t)(part - I.blockBegin);
-  uint32_t             skip = 0, inside = 0;
-  const uint32_t       finite = (bx[7] == 0.0f) ? 4u : 0u;
-  float                Rout = 3.0e38f;  // footprint bound of the partition's splats in pixels (strips only; "unknown" = infinite)
-  if(bx[7] == 0.0f)
-  {
-    const float c = 1.0f + A.f.frustumDilation, dl = A.f.frustumDilation;
-    const float m = 1.0e-3f;  // relative safety margin
-    bool  allWpos = true;
-    bool  outXp = true, outXn = true, outYp = true, outYn = true, outZf = true, outZn = true;
-    bool  allIn = true;  // every corner passes the per-splat test with margin -> so does every centre inside the box
-    float ymin = 3.4e38f, ymax = -3.4e38f, zvmin = 3.4e38f, rx = 0.f, ry = 0.f;
-    for(int q = 0; q < 8; ++q)
-    {
-      const float x = bx[(q & 1) ? 3 : 0], y = bx[(q & 2) ? 4 : 1], z = bx[(q & 4) ? 5 : 2];
-      const float* MV = I.modelView;
-      const float  tx = MV[0] * x + MV[4] * y + MV[8] * z + MV[12];
-      const float  ty = MV[1] * x + MV[5] * y + MV[9] * z + MV[13];
-      const float  tz = MV[2] * x + MV[6] * y + MV[10] * z + MV[14];
-      const float  tw = MV[3] * x + MV[7] * y + MV[11] * z + MV[15];
-      const float* P  = A.f.proj;
-      const float  cx = P[0] * tx + P[4] * ty + P[8] * tz + P[12] * tw;
-      const float  cy = P[1] * tx + P[5] * ty + P[9] * tz + P[13] * tw;
-      const float  cz = P[2] * tx + P[6] * ty + P[10] * tz + P[14] * tw;
-      const float  cw = P[3] * tx + P[7] * ty + P[11] * tz + P[15] * tw;
-      const float  aw = fabsf(cw), tol = m * (aw + fabsf(cx) + fabsf(cy) + fabsf(cz)) + 1e-6f;
-      allWpos = allWpos && (cw > tol);
-      outXp   = outXp && (cx > c * cw + tol);
-      outXn   = outXn && (-cx > c * cw + tol);
-      outYp   = outYp && (cy > c * cw + tol);
-      outYn   = outYn && (-cy > c * cw + tol);
-      outZf   = outZf && (cz > cw + tol);
-      outZn   = outZn && (cz < -dl * cw - tol);
-      allIn   = allIn && (cw > tol) && (fabsf(cx) < c * cw - tol) && (fabsf(cy) < c * cw - tol) && (cz > -dl * cw + tol) && (cz < cw - tol);
-      const float yp = (cy / cw + 1.0f) * 0.5f * (float)A.f.height;
-      ymin  = fminf(ymin, yp);
-      ymax  = fmaxf(ymax, yp);
-      zvmin = fminf(zvmin, -tz);  // view depth (camera looks down -z)
-      rx    = fmaxf(rx, fabsf(tx / tz));
-      ry    = fmaxf(ry, fabsf(ty / tz));
-    }
-    // CAMERA_FISHEYE (dist.comp.slang:75-90): the x/y box is replaced by the fisheye validity test (cone of maxAngle around the
-    // view axis + the image rectangle); the z test stays.  Conservative form: the z conditions as above, and the bounding
-    // sphere of the box against the cone.  "Every centre passes" is never claimed for fisheye frames.
-    const bool fisheye = A.f.cameraModel == 1;
-    if(allWpos && (outZf || outZn || (!fisheye && (outXp || outXn || outYp || outYn))))
-      skip = 1;
-    if(fisheye && !skip)
-    {
-      const float  mx = 0.5f * (bx[0] + bx[3]), my = 0.5f * (bx[1] + bx[4]), mz = 0.5f * (bx[2] + bx[5]);
-      const float  hx = 0.5f * (bx[3] - bx[0]), hy = 0.5f * (bx[4] - bx[1]), hz = 0.5f * (bx[5] - bx[2]);
-      const float* MV = I.modelView;
-      const float  sx = MV[0] * mx + MV[4] * my + MV[8] * mz + MV[12];
-      const float  sy = MV[1] * mx + MV[5] * my + MV[9] * mz + MV[13];
-      const float  sz = MV[2] * mx + MV[6] * my + MV[10] * mz + MV[14];
-      const float  rad  = sqrtf(hx * hx + hy * hy + hz * hz) * I.modelScale * 1.001f + 1e-6f;
-      const float  dist = sqrtf(sx * sx + sy * sy + sz * sz);
-      if(dist > rad * 1.001f)
-      {
-        const float thetaC = atan2f(sqrtf(sx * sx + sy * sy), -sz);
-        if(thetaC - asinf(rad / dist) > A.f.gutMaxAngle * 1.001f + 1e-3f)
-          skip = 1;
-      }
-    }
-    inside = (allIn && !skip && !fisheye) ? 2u : 0u;
-    // the strip bound R is the 3DGS (pinhole EWA) footprint: not valid for a 3DGUT fisheye frame
-    const bool strip = (A.f.stripRow1 - A.f.stripRow0) < A.f.tilesY && !(fisheye && A.f.pipeline == 1);
-    if(!skip && strip && allWpos && zvmin > 1e-4f)
-    {
-      const float S    = I.modelScale;  // largest singular value of the model 3x3 (host, per frame)
-      const float fmx  = fmaxf(fabsf(A.f.focal[0]), fabsf(A.f.focal[1]));
-      const float kk   = sqrtf(2.0f + rx * rx + ry * ry);
-      float       R    = A.f.splatScale * (kk * fmx * S * bx[6] / zvmin + 3.2f);
-      R                = fminf(R, 2897.0f * A.f.splatScale) * 1.01f + 2.0f;  // both bases are clamped at 2048 px
-      const float y0   = (float)(A.f.stripRow0 * kTilePx), y1 = (float)(min(A.f.stripRow1 * kTilePx, A.f.height));
-      if(ymax + R < y0 || ymin - R > y1)
-        skip = 1;
-      Rout = R;
-    }
-  }
-  if(partR != nullptr)
-    partR[part] = Rout;
-  partSkip[part] = skip | inside | finite;
-}
-
-void launchPartitionCull(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, uint32_t* partSkip, float* partR,
-                         uint32_t* zero0, uint32_t n0, uint32_t* zero1, uint32_t n1, uint32_t* zero2, uint32_t n2)
-{
-  if(args.f.totalPartitions == 0)
-    return;
-  hipLaunchKernelGGL(k_partition_cull, dim3((args.f.totalPartitions + 255) / 256), dim3(256), 0, stream, dArgs, partSkip, partR, zero0,
-                     n0, zero1, n1, zero2, n2);
-}
 
 // ---------------------------------------------------------------------------------------------
 // host-callable launcher
 void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full, FrameCounters* ctr, uint2* slotPairs,
-                   uint32_t* slotCount, SplatRec* rec, uint32_t* rect, const uint32_t* partSkip, uint32_t* slotHist2,
-                   uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan, const float* partR)
+                   uint32_t* slotCount, SplatRec* rec, uint32_t* rect, uint32_t* slotHist2,
+                   uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan)
 {
   const dim3 grid(args.f.totalPartitions), block(kPrjThreads);
   if(args.f.totalPartitions == 0)
@@ -552,8 +431,8 @@ void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* d
   }
 #endif
 #define MGS_LAUNCH(FULLV)                                                                                                \
-  hipLaunchKernelGGL((k_project<FULLV>), grid, block, 0, stream, dArgs, ctr, slotPairs, slotCount, rec, rect, partSkip, slotHist2, \
-                     top16Rec, top16Count, osPlan, partR)
+  hipLaunchKernelGGL((k_project<FULLV>), grid, block, 0, stream, dArgs, ctr, slotPairs, slotCount, rec, rect, slotHist2, \
+                     top16Rec, top16Count, osPlan)
   if(full)
     MGS_LAUNCH(true);
   else

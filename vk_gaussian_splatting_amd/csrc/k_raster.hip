@@ -29,15 +29,10 @@ __device__ __forceinline__ uint32_t rectTiles(uint32_t r)
   return (x1 - x0 + 1u) * (y1 - y0 + 1u);
 }
 
-// ---- frame init: zero counters, both sort plans and the tile ranges -------------------------
-__global__ void k_frame_init(FrameCounters* ctr, uint32_t* plans, uint32_t planWords, uint2* ranges, uint32_t nTiles)
+// ---- frame init of the record path: empty tile ranges (counters and sort plans arrive zeroed with the frame's upload) ----
+__global__ void k_frame_init(uint2* ranges, uint32_t nTiles)
 {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
-  uint32_t*      c   = reinterpret_cast<uint32_t*>(ctr);
-  for(uint32_t i = gid; i < sizeof(FrameCounters) / 4; i += gsz)
-    c[i] = 0;
-  for(uint32_t i = gid; i < planWords; i += gsz)
-    plans[i] = 0;
   for(uint32_t i = gid; i < nTiles; i += gsz)
     ranges[i] = make_uint2(0u, 0u);
 }
@@ -398,6 +393,8 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
   __shared__ uint32_t s_tmp[4];
   const uint32_t n      = plan->n;
   const uint32_t chunks = (n + kDbChunk - 1) / kDbChunk;
+  if(chunks == 0u && blockIdx.x == 0u && (int)threadIdx.x < binsX * binsY)
+    ranges[threadIdx.x] = make_uint2(0u, 0u);  // nothing sorted: every list is empty (nobody else writes the ranges)
   if(blockIdx.x >= chunks)
     return;
   // nearest splats (the end of the list) are the largest: start their chunks first
@@ -1069,10 +1066,10 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
 }
 
 // ---------------------------------------------------------------------------------------------
-void launchFrameInit(hipStream_t stream, FrameCounters* ctr, uint32_t* plans, uint32_t planWords, uint2* ranges, uint32_t nTiles)
+void launchFrameInit(hipStream_t stream, uint2* ranges, uint32_t nTiles)
 {
   const uint32_t blocks = (nTiles + 255u) / 256u < 4u ? 4u : min((nTiles + 255u) / 256u, 256u);
-  hipLaunchKernelGGL(k_frame_init, dim3(blocks), dim3(256), 0, stream, ctr, plans, planWords, ranges, nTiles);
+  hipLaunchKernelGGL(k_frame_init, dim3(blocks), dim3(256), 0, stream, ranges, nTiles);
 }
 
 void launchBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,

@@ -33,11 +33,9 @@
 namespace mgs {
 // kernels_*.hip
 void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full, FrameCounters* ctr, uint2* slotPairs,
-                   uint32_t* slotCount, SplatRec* rec, uint32_t* rect, const uint32_t* partSkip, uint32_t* slotHist2,
-                   uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan, const float* partR);
-void launchPartitionCull(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, uint32_t* partSkip, float* partR,
-                         uint32_t* zero0, uint32_t n0, uint32_t* zero1, uint32_t n1, uint32_t* zero2, uint32_t n2);
-void launchFrameInit(hipStream_t stream, FrameCounters* ctr, uint32_t* plans, uint32_t planWords, uint2* ranges, uint32_t nTiles);
+                   uint32_t* slotCount, SplatRec* rec, uint32_t* rect, uint32_t* slotHist2,
+                   uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan);
+void launchFrameInit(hipStream_t stream, uint2* ranges, uint32_t nTiles);
 void launchBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
                    const uint32_t* rect, uint32_t* blockCount, uint32_t maxBlocks, FrameCounters* ctr, uint32_t* sortedRect,
                    uint32_t* splatOffset, uint32_t* chunkStart, uint32_t* pairKey, uint32_t* pairVal, uint32_t capacity,
@@ -54,7 +52,7 @@ void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges
                      int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId, const void* instTable, const FrameArgs* dArgs,
                      float4* outNormal);
 void launchProjectGut(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, int shFormat, FrameCounters* ctr,
-                      uint2* densePairs, uint32_t* slotCount, GutRec* rec, uint32_t* rect, const uint32_t* partSkip,
+                      uint2* slotPairs, uint32_t* slotCount, GutRec* rec, uint32_t* rect,
                       uint32_t* slotHist2, uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan);
 void launchCompositeGut(hipStream_t stream, const FrameArgs& A, const FrameArgs* dArgs, const uint2* ranges, const uint32_t* valX,
                         const uint32_t* valY, const SortPlan* planPairs, const GutRec* rec, void* image, int halfOut,
@@ -136,6 +134,24 @@ struct DevBuf
     p = nullptr;
     n = 0;
   }
+};
+
+// a typed window into memory somebody else owns (the members of FrameState below)
+template <class T>
+struct DevView
+{
+  T* p = nullptr;
+};
+
+// One device block per handle: the per-frame device state that every frame starts from zero (counters, sort plans), followed by
+// the frame's constants.  A frame begins with ONE upload that carries the zeros along with the constants — no kernel has to
+// sweep them (the frame's first kernel used to).
+struct FrameState
+{
+  FrameCounters ctr;
+  FramePlans    plans;  // keys, pairs, os (sort_plan.h)
+  FrameArgs     args;   // view / proj, instances, knobs: the kernels read them through this pointer, so a captured frame graph
+                        // replays with nothing but the upload
 };
 
 // CPU async sorter: same protocol as SplatSorterAsync (src/splat_sorter_async.h:41-48,84-128)
@@ -274,11 +290,11 @@ struct MgsScene_t
   DevBuf<uint32_t>      slotCount, slotBase, part0;  // pairs per slot; their exclusive prefix; first slot of every sort partition
   DevBuf<uint32_t>      keysA, idsA;  // the sorted ids (and, for the sort-only hook, the sorted keys)
   DevBuf<uint32_t>      rect, partHist, blockCount;
-  DevBuf<uint32_t>      sortedRect, splatOffset, chunkStart, partSkip;
-  DevBuf<float>         partR;       // per partition: footprint bound in pixels (strips), written by k_partition_cull
+  DevBuf<uint32_t>      sortedRect, splatOffset, chunkStart;
   DevBuf<uint64_t>      dbinMasks;
-  DevBuf<FrameArgs>     dArgs;       // this frame's constants (view/proj, instances, knobs): the kernels read them through
-                                     // this pointer, so a captured frame graph replays with nothing but a 5 KB upload
+  DevBuf<FrameState>    fstate;      // counters + plans + this frame's constants: one block, one upload per frame (FrameState)
+  DevView<FrameArgs>    dArgs;       // = &fstate->args
+  std::vector<uint8_t>  hostFrame;   // the upload's source: zeros for counters and plans, then the constants
   struct GraphKey
   {
     int32_t v[16];
@@ -297,9 +313,8 @@ struct MgsScene_t
   DevBuf<uint32_t>      pairKey0, pairVal0, pairKey1, pairVal1;
   DevBuf<uint2>         ranges;
   DevBuf<uint8_t>       image;
-  DevBuf<FrameCounters> ctr;
-  DevBuf<FramePlans>    plans;  // [0]: keys, pairs, os (sort_plan.h); behind it the look-back words of the project kernels (slot_emit.h)
-  uint32_t              planWords = 0;  // words the frame's first kernel zeroes: FramePlans + those look-back words
+  DevView<FrameCounters> ctr;    // = &fstate->ctr
+  DevView<FramePlans>    plans;  // = &fstate->plans
   uint32_t              pairCapacity = 0, pStride = 0;
 
   // pinned readback
@@ -720,11 +735,11 @@ void mgs_scene_destroy(MgsScene s)
   s->pairA.release(); s->pairB.release(); s->slotCount.release(); s->slotBase.release(); s->part0.release(); s->slotHist2.release(); s->top16Rec.release(); s->top16Count.release();
   s->osStatus.release(); s->keysA.release(); s->idsA.release(); s->rect.release(); s->partHist.release(); s->blockCount.release();
   s->rec.release(); s->recGut.release(); s->pairKey0.release(); s->pairVal0.release(); s->pairKey1.release(); s->pairVal1.release();
-  s->sortedRect.release(); s->splatOffset.release(); s->chunkStart.release(); s->partSkip.release(); s->partR.release();
-  s->surfDepth.release(); s->surfId.release(); s->surfNormal.release(); s->accum.release(); s->dArgs.release(); s->dbinMasks.release();
+  s->sortedRect.release(); s->splatOffset.release(); s->chunkStart.release();
+  s->surfDepth.release(); s->surfId.release(); s->surfNormal.release(); s->accum.release(); s->fstate.release(); s->dbinMasks.release();
   for(auto& g : s->graphs) (void)hipGraphExecDestroy(g.second);
   s->graphs.clear();
-  s->ranges.release(); s->image.release(); s->ctr.release(); s->plans.release(); s->cpuDistDev.release();
+  s->ranges.release(); s->image.release(); s->cpuDistDev.release();
   s->rsKeys.release(); s->rsVals.release(); s->rsHist.release(); s->rsCount.release(); s->rsPlan.release();
   s->rsPairA.release(); s->rsPairB.release(); s->rsStatus.release(); s->rsOsPlan.release();
   if(s->hCtr) (void)hipHostFree(s->hCtr);
@@ -825,9 +840,9 @@ int mgs_scene_memory_usage(MgsScene s, uint64_t* sceneBytes, uint64_t* workingBy
     uint64_t b = 0;
     auto add = [&](auto& buf) { b += (uint64_t)buf.n * sizeof(*buf.p); };
     add(s->pairA); add(s->pairB); add(s->slotCount); add(s->slotBase); add(s->part0); add(s->slotHist2); add(s->top16Rec); add(s->top16Count); add(s->osStatus); add(s->keysA); add(s->idsA); add(s->rect);
-    add(s->partHist); add(s->blockCount); add(s->sortedRect); add(s->splatOffset); add(s->chunkStart); add(s->partSkip); add(s->partR);
-    add(s->dbinMasks); add(s->dArgs); add(s->surfDepth); add(s->surfId); add(s->surfNormal); add(s->accum); add(s->rec); add(s->recGut);
-    add(s->pairKey0); add(s->pairVal0); add(s->pairKey1); add(s->pairVal1); add(s->ranges); add(s->image); add(s->ctr); add(s->plans);
+    add(s->partHist); add(s->blockCount); add(s->sortedRect); add(s->splatOffset); add(s->chunkStart);
+    add(s->dbinMasks); add(s->fstate); add(s->surfDepth); add(s->surfId); add(s->surfNormal); add(s->accum); add(s->rec); add(s->recGut);
+    add(s->pairKey0); add(s->pairVal0); add(s->pairKey1); add(s->pairVal1); add(s->ranges); add(s->image);
     add(s->rsKeys); add(s->rsVals); add(s->rsHist); add(s->rsCount); add(s->rsPairA); add(s->rsPairB); add(s->rsStatus); add(s->rsOsPlan); add(s->rsPlan); add(s->cpuDistDev);
     *workingBytes = b;
   }
@@ -943,6 +958,37 @@ static int uploadFormatted(const std::vector<float>& src, int format, bool isSh,
     parallelBatches(n, [&](size_t i) { tmp[i] = toUint8(src[i], lo, 1.f); });
     HIPCHK(hipMemcpy(*dev, tmp.data(), n, hipMemcpyHostToDevice));
   }
+  return MGS_OK;
+}
+
+// the handle's FrameState block (allocated once; its address is baked into captured frame graphs)
+static int ensureFrameState(MgsScene s)
+{
+  if(s->fstate.p)
+    return MGS_OK;
+  int rc = s->fstate.ensure(1);
+  if(rc)
+    return rc;
+  HIPCHK(hipMemset(s->fstate.p, 0, sizeof(FrameState)));
+  HIPCHK(hipDeviceSynchronize());
+  s->ctr.p   = &s->fstate.p->ctr;
+  s->plans.p = &s->fstate.p->plans;
+  s->dArgs.p = &s->fstate.p->args;
+  return MGS_OK;
+}
+
+// A frame's first operation on its stream: counters and plans to zero, this frame's constants behind them, in one upload
+// (pageable source: staged by the runtime before the call returns).
+static int uploadFrameState(MgsScene s, const FrameArgs& A, hipStream_t st)
+{
+  int rc = ensureFrameState(s);
+  if(rc)
+    return rc;
+  const size_t head = offsetof(FrameState, args), used = offsetof(FrameArgs, inst) + (size_t)A.f.nInstances * sizeof(InstanceConst);
+  if(s->hostFrame.size() < head + sizeof(FrameArgs))
+    s->hostFrame.assign(head + sizeof(FrameArgs), 0);  // the head stays zero for good
+  std::memcpy(s->hostFrame.data() + head, &A, used);
+  HIPCHK(hipMemcpyAsync(s->fstate.p, s->hostFrame.data(), head + used, hipMemcpyHostToDevice, st));
   return MGS_OK;
 }
 
@@ -1193,9 +1239,6 @@ static int sizeWorkingSet(MgsScene s)
     if((rc = s->osStatus.ensure(words))) return rc;
     HIPCHK(hipMemset(s->osStatus.p, 0, words * 4u));
   }
-  if((rc = s->partSkip.ensure(parts))) return rc;
-  if((rc = s->partR.ensure(parts))) return rc;
-  HIPCHK(hipMemset(s->partSkip.p, 0, parts * sizeof(uint32_t)));
   if((rc = s->pairA.ensure(total))) return rc;
   if((rc = s->pairB.ensure(std::max<uint64_t>(total, parts * (uint64_t)kOsSlot)))) return rc;  // whole slots
   if((rc = s->slotCount.ensure(parts))) return rc;
@@ -1205,9 +1248,7 @@ static int sizeWorkingSet(MgsScene s)
   if((rc = s->rect.ensure(total))) return rc;
   if((rc = s->rec.ensure(total))) return rc;
   if((rc = s->sortedRect.ensure(total))) return rc;
-  if((rc = s->ctr.ensure(1))) return rc;
-  s->planWords = (uint32_t)(sizeof(FramePlans) / 4);  // zeroed by the frame's first kernel
-  if((rc = s->plans.ensure(1))) return rc;
+  if((rc = ensureFrameState(s))) return rc;
 
   uint64_t cap = std::max<uint64_t>(32ull * total, 64ull << 20);  // 16 B per pair: 3 GB for a garden-sized scene
   if(const char* e = std::getenv("MGS_PAIR_CAPACITY"))
@@ -1224,8 +1265,7 @@ static int sizeWorkingSet(MgsScene s)
   s->pStride              = (uint32_t)maxParts;
   if((rc = s->partHist.ensure(256ull * maxParts))) return rc;
   if((rc = s->blockCount.ensure(std::max<uint64_t>((total + kPart - 1) / kPart, 1)))) return rc;
-  HIPCHK(hipMemset(s->ctr.p, 0, sizeof(FrameCounters)));
-  HIPCHK(hipMemset(s->plans.p, 0, (size_t)s->planWords * 4));
+  HIPCHK(hipMemset(s->fstate.p, 0, offsetof(FrameState, args)));
   // hipMemset on device memory is asynchronous on the NULL stream, and the render stream is non-blocking:
   // without this the memsets above can land in the middle of the first frame (caught by the test suite)
   HIPCHK(hipDeviceSynchronize());
@@ -1626,6 +1666,10 @@ static int pairSortBits(int nTiles)
   return ((bits + 7) / 8) * 8;
 }
 
+// coarse bins (the default): stable multi-split straight into the per-bin lists, no records, no pair sort; MGS_DIRECT_BIN=0
+// forces the record + pair-sort path of frames with more than 256 bins
+static const bool kDirectBin = [] { const char* e = std::getenv("MGS_DIRECT_BIN"); return e ? std::atoi(e) != 0 : true; }();
+
 // pass elision of the key sort (sort_plan.h): on by default, MGS_SORT_REMAP=0 keeps the four plain passes
 static const bool kRemap = [] { const char* e = std::getenv("MGS_SORT_REMAP"); return e ? std::atoi(e) != 0 : true; }();
 
@@ -1905,8 +1949,7 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
   if(F.temporalSampling)
     if((rc = s->accum.ensure((size_t)F.width * F.height))) return rc;
   {
-    static const bool kDirectBin0 = [] { const char* e = std::getenv("MGS_DIRECT_BIN"); return e ? std::atoi(e) != 0 : true; }();
-    if(!(kDirectBin0 && directBinningSupported(F.binsX, F.binsY)) && s->pairKey0.n < s->pairCapacity)
+    if(!(kDirectBin && directBinningSupported(F.binsX, F.binsY)) && s->pairKey0.n < s->pairCapacity)
     {  // first frame on the record + pair-sort path (> 256 bins, or forced): its buffers
       const uint64_t cap = s->pairCapacity;
       if((rc = s->pairKey0.ensure(cap))) return rc;
@@ -1935,32 +1978,23 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
 
   hipEvent_t* fev = s->evRing[s->frameIndex % MgsScene_t::kRing];
   const bool  cpuModeOuter = (p->sort_mode == MGS_SORT_CPU_ASYNC);
-  // this frame's constants: a 5 KB upload (pageable source: staged by the runtime before the call returns)
-  if((rc = s->dArgs.ensure(1))) return rc;
-  HIPCHK(hipMemcpyAsync(s->dArgs.p, &A, offsetof(FrameArgs, inst) + (size_t)A.f.nInstances * sizeof(InstanceConst), hipMemcpyHostToDevice, st));
+  // this frame's constants, and its counters and plans zeroed: one 18 KB upload
+  if((rc = uploadFrameState(s, A, st))) return rc;
   auto issue = [&](bool withEvents) -> int {
     if(withEvents) HIPCHK(hipEventRecord(fev[0], st));
-    // per-frame device state: counters, both sort plans (adjacent), bin ranges.  The partition cull, when it runs, is
-    // the frame's first kernel and zeroes them on the way.
-    static_assert(sizeof(SortPlan) % 4 == 0 && sizeof(FrameCounters) % 4 == 0, "word-sized state");
-    if(F.partitionCull && s->d->totalParts > 0)
-      launchPartitionCull(st, A, s->dArgs.p, s->partSkip.p, s->partR.p, reinterpret_cast<uint32_t*>(ctr), (uint32_t)(sizeof(FrameCounters) / 4),
-                          reinterpret_cast<uint32_t*>(s->plans.p), s->planWords,
-                          reinterpret_cast<uint32_t*>(s->ranges.p), 2u * nTiles);
-    else
-      launchFrameInit(st, ctr, reinterpret_cast<uint32_t*>(s->plans.p), s->planWords, s->ranges.p, nTiles);
+    // (counters and sort plans arrive zeroed with the upload)
+    if(!(kDirectBin && directBinningSupported(F.binsX, F.binsY)))
+      launchFrameInit(st, s->ranges.p, nTiles);  // record path: tiles without entries keep an empty range
     if(withEvents) HIPCHK(hipEventRecord(fev[6], st));  // MGS_STAGE_CULL ends here; it is part of MGS_STAGE_PROJECT too
     const bool cpuMode = (p->sort_mode == MGS_SORT_CPU_ASYNC);
     if(cpuMode)  // rejected splats must look empty to the binning stage: rect with x0 > x1
       hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, st, s->rect.p, 1u, s->d->totalSplats);
     if(gut)
       launchProjectGut(st, A, s->dArgs.p, s->d->shFormat, ctr, s->pairB.p, s->slotCount.p, s->recGut.p, s->rect.p,
-                       F.partitionCull ? s->partSkip.p : nullptr, s->slotHist2.p, s->top16Rec.p, cpuMode ? nullptr : s->top16Count.p,
-                       &s->plans.p->os);
+                       s->slotHist2.p, s->top16Rec.p, cpuMode ? nullptr : s->top16Count.p, &s->plans.p->os);
     else
       launchProject(st, A, s->dArgs.p, true, ctr, s->pairB.p, s->slotCount.p, s->rec.p, s->rect.p,
-                    F.partitionCull ? s->partSkip.p : nullptr, s->slotHist2.p, s->top16Rec.p, cpuMode ? nullptr : s->top16Count.p,
-                    &s->plans.p->os, F.partitionCull ? s->partR.p : nullptr);
+                    s->slotHist2.p, s->top16Rec.p, cpuMode ? nullptr : s->top16Count.p, &s->plans.p->os);
     if(withEvents) HIPCHK(hipEventRecord(fev[1], st));
     if(!cpuMode)
       keySort(s, st, false, kRemap);
@@ -1981,7 +2015,6 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     }
     if(withEvents) HIPCHK(hipEventRecord(fev[2], st));
     // coarse bins (the default): stable multi-split straight into the per-bin lists, no records, no pair sort
-    static const bool kDirectBin = [] { const char* e = std::getenv("MGS_DIRECT_BIN"); return e ? std::atoi(e) != 0 : true; }();
     const bool direct = kDirectBin && directBinningSupported(F.binsX, F.binsY);
     if(direct)
     {
@@ -2709,17 +2742,10 @@ int mgs_sort_keys(MgsScene s, const MgsFrameParams* p, MgsSortOut* out)
   A.f.stripRow0 = 0;
   A.f.stripRow1 = A.f.tilesY;
   if((rc = s->ranges.ensure(1))) return rc;
-  if((rc = s->dArgs.ensure(1))) return rc;
-  HIPCHK(hipMemcpyAsync(s->dArgs.p, &A, offsetof(FrameArgs, inst) + (size_t)A.f.nInstances * sizeof(InstanceConst), hipMemcpyHostToDevice, st));
+  if((rc = uploadFrameState(s, A, st))) return rc;
   HIPCHK(hipEventRecord(s->ev[0], st));
-  if(A.f.partitionCull && s->d->totalParts > 0)
-    launchPartitionCull(st, A, s->dArgs.p, s->partSkip.p, s->partR.p, reinterpret_cast<uint32_t*>(s->ctr.p),
-                        (uint32_t)(sizeof(FrameCounters) / 4), reinterpret_cast<uint32_t*>(s->plans.p), s->planWords, nullptr, 0u);
-  else
-    launchFrameInit(st, s->ctr.p, reinterpret_cast<uint32_t*>(s->plans.p), s->planWords, s->ranges.p, 0);
   launchProject(st, A, s->dArgs.p, false, s->ctr.p, s->pairB.p, s->slotCount.p, s->rec.p, s->rect.p,
-                A.f.partitionCull ? s->partSkip.p : nullptr, s->slotHist2.p, s->top16Rec.p, s->top16Count.p, &s->plans.p->os,
-                A.f.partitionCull ? s->partR.p : nullptr);
+                s->slotHist2.p, s->top16Rec.p, s->top16Count.p, &s->plans.p->os);
   HIPCHK(hipEventRecord(s->ev[1], st));
   if((rc = s->keysA.ensure(s->d->totalSplats))) return rc;  // the hook returns the sorted keys too
   keySort(s, st, true, kRemap);
@@ -2864,7 +2890,7 @@ int mgs_radix_sort_u32(MgsScene s, void* keysDev, void* valsDev, uint32_t count,
     O.outVals  = vX.p;
     O.plan     = s->rsOsPlan.p;
     O.planOut  = plan.p;  // finalSel = 0: the result is in X
-    if((rc = s->ctr.ensure(1))) return rc;
+    if((rc = ensureFrameState(s))) return rc;
     O.ctr      = s->ctr.p;
     O.status   = s->rsStatus.p;
     O.allowRemap = false;
