@@ -411,7 +411,8 @@ def main():
     # kernel duration: HIP events around the stage on an otherwise idle GPU (the untimed calibration frames).  With
     # several frames in flight the event span of a stage also contains queueing behind the other streams' kernels —
     # rocprofv3's per-kernel duration of this same command agrees with the calibration value, not with the span.
-    # k_project alone: the project stage minus its head (partition cull + state reset, MGS_STAGE_CULL), both from the
+    # k_project alone: the project stage minus its head (MGS_STAGE_CULL: the span between the frame's first two event markers,
+    # behind the upload — until round 3 a partition-cull kernel ran there, now only the markers' own latency), both from the
     # calibration frames — what rocprofv3 reports as the kernel's own average duration
     cull_ms = float(calib_ms[6])
 
@@ -475,7 +476,7 @@ def main():
                                       "min": float(st[:, 5].min()), "max": float(st[:, 5].max())},
         "value_single_frame": 1e3 / float(calib_ms[5]) if calib_ms[5] > 0 else None,  # frames/s with ONE frame in flight
         "roofline": {"bound": "hbm", "stage": dom_name,
-                     "kernels": {"project": "k_project", "sort": "k_os_prepare + 3 x k_os_pass (+ 1 that exits)",
+                     "kernels": {"project": "k_project", "sort": "k_os_prepare + 3 x k_os_pass (+ 1 that exits at once)",
                                  "bin": "k_dbin_count + k_dbin_scan + k_dbin_emit"}[dom_name],
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
@@ -485,7 +486,7 @@ def main():
                      "note": f"the longest HBM-bound stage of the frame by measured single-stream time (HIP events on the untimed calibration "
                              f"frames), SURVEY.md 8d's bytes for it; the longest stage overall is `{longest}`"
                              + (" (fp32-VALU bound, see roofline_composite)" if longest == "composite" else "")},
-        "roofline_project": dict(stage_roofline(0), stage_ms_incl_partition_cull=float(calib_ms[0]), partition_cull_ms=cull_ms),
+        "roofline_project": dict(stage_roofline(0), stage_ms_incl_head=float(calib_ms[0]), head_ms=cull_ms),
         "roofline_composite": composite_roofline(calib_ms[4] if K > 1 else stage_ms[4], alg["composite"], world, N, args),
         "roofline_sort": {"bound": "hbm", "achieved": (68 * Vs / (sort_ms * 1e-3)) / 1e9 if sort_ms > 0 else None,
                           "peak": HBM_PEAK / 1e9, "unit": "GB/s",

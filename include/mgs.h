@@ -235,7 +235,8 @@ void mgs_frame_params_default(MgsFrameParams* p); /* fills the defaults cited ab
 
 enum { MGS_STAGE_PROJECT = 0, MGS_STAGE_SORT = 1, MGS_STAGE_BIN = 2, MGS_STAGE_PAIRSORT = 3,
        MGS_STAGE_COMPOSITE = 4, MGS_STAGE_TOTAL = 5,
-       MGS_STAGE_CULL = 6, /* the partition cull + per-frame state reset at the head of MGS_STAGE_PROJECT (included in it) */
+       MGS_STAGE_CULL = 6, /* the head of MGS_STAGE_PROJECT (included in it): from the frame's upload to the first kernel; the partition
+                              cull ran here as a kernel of its own until round 3, it is part of the project kernels now */
        MGS_STAGE_COUNT = 8 };
 
 typedef struct MgsFrameOut {
