@@ -720,6 +720,11 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
   // pixels outside the image start saturated (they are never stored), so "any T >= tMin" is the wave's liveness
   v2f  T = {in0 ? 1.0f : 0.0f, in1 ? 1.0f : 0.0f}, cr = {0.f, 0.f}, cg = {0.f, 0.f}, cb = {0.f, 0.f}, asum = {0.f, 0.f};
   bool waveDone = (__ballot(in0 || in1) == 0ull);
+  // MGS_ALPHA_SUM (no early-out: the additive alpha sees every fragment): once every pixel of the wave is saturated (T < 1e-4)
+  // the fragments that follow cannot change the colour any more (each weighs < 1e-4, as in the default mode, where the wave
+  // retires at this point) — they are only SUMMED: no colour, no transmittance, and once all four waves are there the batch is
+  // not shaded either (the SH sum is most of a staged record's cost).  The switch is checked per record, like the retirement.
+  bool waveSat = waveDone, allSat = false;  // (a wave without pixels inside the image has nothing to saturate)
 
   uint32_t hi   = range.y;
   uint32_t fill = 0;  // records currently in the LDS batch
@@ -859,7 +864,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
     // ---- shading: the SH sum of the staged splats (mesh.slang:243), one thread per record ---------------------
     // Deferred from the projection: only splats that reach an unsaturated region are ever shaded (a quarter of
     // the frustum survivors on the garden-sized bench), and their 192-byte SH records are the bulk of a splat.
-    for(uint32_t j = t; j < fill; j += 256)
+    for(uint32_t j = t; j < fill && !allSat; j += 256)
     {
       const uint32_t gid = s_g[j];
       CompositeArgs::Inst I = F.inst[0];
@@ -943,6 +948,20 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
           const float4 a1 = s_a[j], b1 = s_b[j], c1 = s_c[j];
           const v2f    s1 = lx * b1.x + (ly * b1.y + a1.x), u1 = lx * b1.z + (ly * b1.w + a1.y);
           const v2f    q  = s1 * s1 + u1 * u1;  // == (A/2) * log2 e of frag.slang:236
+          if(!early && waveSat)
+          {  // saturated wave in MGS_ALPHA_SUM mode: the fragment only adds its alpha
+            if(noGauss)
+            {
+              asum.x += (q.x <= a1.z) ? 1.0f : 0.0f;
+              asum.y += (q.y <= a1.z) ? 1.0f : 0.0f;
+            }
+            else
+            {
+              asum.x += (q.x <= a1.z) ? __builtin_amdgcn_exp2f(-q.x) * c1.w : 0.0f;
+              asum.y += (q.y <= a1.z) ? __builtin_amdgcn_exp2f(-q.y) * c1.w : 0.0f;
+            }
+            continue;
+          }
           v2f          al = {1.0f, 1.0f};
           if(!noGauss)  // frag.slang:248-254
           {
@@ -1004,6 +1023,8 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
             waveDone = true;
             break;
           }
+          if(!early && __ballot(T.x >= 1.0e-4f || T.y >= 1.0e-4f) == 0ull)
+            waveSat = true;
         }
         if(waveDone)
           break;
@@ -1013,8 +1034,10 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
 #ifdef MGS_CMP_TRACE
     ++traceIters;
 #endif
-    const int allDone = __syncthreads_and(waveDone ? 1 : 0);
+    const int allFlag = __syncthreads_and((early ? waveDone : waveSat) ? 1 : 0);
     MGS_TRACE_PHASE(traceB)
+    const bool allDone = early && allFlag != 0;
+    allSat             = !early && allFlag != 0;
     if(allDone || hi <= range.x)
       break;
   }
