@@ -378,6 +378,12 @@ __global__ __launch_bounds__(256) void k_dbin_scan(const SortPlan* __restrict__ 
     binTotal[blockIdx.x] = carry;
 }
 
+#ifdef MGS_DB_TRACE  // debug build (tools/db_trace.py): per-workgroup wall-clock stamps (100 MHz) of k_dbin_emit's phases
+__device__ uint64_t* g_dbTrace = nullptr;
+#define MGS_DB_STAMP(i) if(threadIdx.x == 0) dbt[i] = wall_clock64();
+#else
+#define MGS_DB_STAMP(i)
+#endif
 __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ idsX, const uint32_t* __restrict__ idsY,
                                                    const SortPlan* __restrict__ plan, const uint64_t* __restrict__ maskBuf,
                                                    const uint32_t* __restrict__ binHist, uint32_t pStride,
@@ -390,13 +396,17 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
   __shared__ uint32_t s_ids[kDbChunk];
   __shared__ uint32_t s_stage[kDbStage];  // (bin << 16) | position inside the chunk
   __shared__ uint32_t s_gdst[256], s_loc[256];
-  __shared__ uint32_t s_tmp[4];
+  __shared__ uint32_t s_tmp[4], s_tmp64[2];
   const uint32_t n      = plan->n;
   const uint32_t chunks = (n + kDbChunk - 1) / kDbChunk;
   if(chunks == 0u && blockIdx.x == 0u && (int)threadIdx.x < binsX * binsY)
     ranges[threadIdx.x] = make_uint2(0u, 0u);  // nothing sorted: every list is empty (nobody else writes the ranges)
   if(blockIdx.x >= chunks)
     return;
+#ifdef MGS_DB_TRACE
+  __shared__ uint64_t dbt[8];
+  MGS_DB_STAMP(0)
+#endif
   // nearest splats (the end of the list) are the largest: start their chunks first
   const uint32_t  chunk = chunks - 1u - blockIdx.x;
   const int       t = threadIdx.x, lane = laneId(), w = t >> 6;
@@ -406,6 +416,15 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
   const int       nb    = binsX * binsY;
   const LaneBins  L     = laneBins(binsX, nb);
   uint32_t        cnt[4] = {0u, 0u, 0u, 0u};
+  // where every bin's list starts = exclusive prefix of the bins' totals: the same for every chunk, so one wave does it on the
+  // side (four bins per lane, wave scans, no barrier of its own) instead of three block-wide scans per workgroup
+  uint32_t bt[4] = {0u, 0u, 0u, 0u};
+  if(w == 3)
+  {
+#pragma unroll
+    for(int i = 0; i < 4; ++i)
+      bt[i] = (4 * lane + i < nb) ? binTotal[4 * lane + i] : 0u;
+  }
   {
     const int       S   = binsX + binsY;
     const uint64_t* mIn = maskBuf + ((size_t)chunk * 4 + w) * kDbRounds * S;
@@ -440,22 +459,38 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
   for(int j = 0; j < 4; ++j)
     s_cnt[w][lane + 64 * j] = cnt[j];
   __syncthreads();
+  MGS_DB_STAMP(1)
 
   // thread t == bin t: where this chunk's run starts in the bin's list, and in the LDS stage
   const uint32_t c0 = s_cnt[0][t], c1 = s_cnt[1][t], c2 = s_cnt[2][t], c3 = s_cnt[3][t];
   const uint32_t tot   = (t < nb) ? c0 + c1 + c2 + c3 : 0u;
-  const uint32_t btot  = (t < nb) ? binTotal[t] : 0u;
-  uint32_t       D32, P;
-  const uint32_t binBase = blockExclusiveScan256(btot, s_tmp, &D32);
-  const uint32_t local   = blockExclusiveScan256(tot, s_tmp, &P);
-  // 64-bit total without 64-bit shuffles: sum the halves separately
-  uint32_t       dLo, dHi;
-  (void)blockExclusiveScan256(btot & 0xFFFFu, s_tmp, &dLo);
-  (void)blockExclusiveScan256(btot >> 16, s_tmp, &dHi);
-  const uint64_t D64     = ((uint64_t)dHi << 16) + dLo;
+  uint32_t       P;
+  if(w == 3)
+  {
+    const uint32_t sum4 = bt[0] + bt[1] + bt[2] + bt[3];
+    uint32_t       run  = waveInclusiveScan(sum4) - sum4;
+#pragma unroll
+    for(int i = 0; i < 4; ++i)
+    {
+      s_gdst[4 * lane + i] = run;  // bin base (consumed below, behind the block scan's barriers)
+      run += bt[i];
+    }
+    // the 64-bit total without 64-bit shuffles: the halves summed separately
+    const uint32_t dLo = waveSum((bt[0] & 0xFFFFu) + (bt[1] & 0xFFFFu) + (bt[2] & 0xFFFFu) + (bt[3] & 0xFFFFu));
+    const uint32_t dHi = waveSum((bt[0] >> 16) + (bt[1] >> 16) + (bt[2] >> 16) + (bt[3] >> 16));
+    if(lane == 0)
+    {
+      s_tmp64[0] = dLo;
+      s_tmp64[1] = dHi;
+    }
+  }
+  const uint32_t local   = blockExclusiveScan256(tot, s_tmp, &P);  // (two barriers: the bases above are visible behind them)
+  const uint32_t binBase = s_gdst[t];
+  const uint64_t D64     = ((uint64_t)s_tmp64[1] << 16) + s_tmp64[0];
   const bool     wrapped = D64 > 0xFFFFFFFFull;  // bin bases are meaningless: emit nothing, report the overflow
   const bool     staged  = P <= (uint32_t)kDbStage;
   const uint32_t gdst    = binBase + ((t < nb) ? binHist[(size_t)t * pStride + chunk] : 0u);
+  __syncthreads();  // everybody has read its base: s_gdst is overwritten
   s_gdst[t] = gdst;
   s_loc[t]  = local;
   {
@@ -470,6 +505,7 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
     // longest list first: the compositor hands its workgroups out in this bin order, so the regions with the most
     // to blend start early instead of forming the kernel's tail (binOrder[rank] = bin; ties by bin index)
     __shared__ uint32_t s_tot[256];
+    const uint32_t btot = (t < nb) ? binTotal[t] : 0u;
     s_tot[t] = btot;
     __syncthreads();
     if(t < nb)
@@ -492,6 +528,7 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
     }
   }
   __syncthreads();
+  MGS_DB_STAMP(2)
   if(wrapped)
     return;
 
@@ -537,6 +574,7 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
   if(!staged)
     return;
   __syncthreads();
+  MGS_DB_STAMP(3)
   for(uint32_t i = t; i < P; i += 256)
   {
     const uint32_t v   = s_stage[i];
@@ -545,6 +583,17 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
     if(dst < capacity)
       binList[dst] = s_ids[v & 0xFFFFu];
   }
+#ifdef MGS_DB_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  MGS_DB_STAMP(4)
+  if(t == 0 && g_dbTrace)
+  {
+    uint64_t* o = g_dbTrace + (size_t)blockIdx.x * 8;
+    for(int i = 0; i < 5; ++i) o[i] = dbt[i];
+    o[5] = P;
+  }
+#endif
 }
 
 // ---- tile ranges over the tile-sorted pair list ------------------------------------------------
@@ -1128,8 +1177,34 @@ void launchDirectBinning(hipStream_t stream, const uint32_t* idsX, const uint32_
   hipLaunchKernelGGL(k_dbin_count, dim3(maxChunks), dim3(256), 0, stream, idsX, idsY, planKeys, rect, sortedRect, maskBuf,
                      binHist, pStride, binsX, binsY);
   hipLaunchKernelGGL(k_dbin_scan, dim3(binsX * binsY), dim3(256), 0, stream, planKeys, binHist, pStride, binTotal);
+#ifdef MGS_DB_TRACE
+  static uint64_t* traceBuf = nullptr;
+  const char*      tracePath = std::getenv("MGS_DB_TRACE_FILE");
+  if(tracePath)
+  {
+    if(!traceBuf)
+    {
+      (void)hipMalloc(&traceBuf, (size_t)maxChunks * 64);
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbTrace), &traceBuf, sizeof(traceBuf));
+    }
+    (void)hipMemsetAsync(traceBuf, 0, (size_t)maxChunks * 64, stream);
+  }
+#endif
   hipLaunchKernelGGL(k_dbin_emit, dim3(maxChunks), dim3(256), 0, stream, idsX, idsY, planKeys, maskBuf, binHist, pStride,
                      binTotal, binList, ranges, ctr, capacity, binsX, binsY, binTotal + 256);
+#ifdef MGS_DB_TRACE
+  if(tracePath)
+  {
+    (void)hipStreamSynchronize(stream);
+    std::vector<uint64_t> h((size_t)maxChunks * 8);
+    (void)hipMemcpy(h.data(), traceBuf, h.size() * 8, hipMemcpyDeviceToHost);
+    if(FILE* fp = std::fopen(tracePath, "wb"))
+    {
+      std::fwrite(h.data(), 8, h.size(), fp);
+      std::fclose(fp);
+    }
+  }
+#endif
 }
 
 void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* keyY, const SortPlan* planPairs,
