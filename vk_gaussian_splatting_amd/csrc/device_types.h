@@ -92,6 +92,10 @@ struct FrameConst
   float    focusDist, aperture;    // shaderio.h:278-279
   int32_t  kernelDegree;           // KERNEL_DEGREE (3DGUT particle response), 2 = quadratic
   int32_t  normalMethod;           // NORMAL_METHOD (shaderio.h:126-128): 0 max-density plane, 1 iso-surface (3DGUT fragment normal)
+  // the bin rectangles ride through the key sort in the id word's spare bits (kernels_common.h: rideEncode)
+  int32_t  rideShift;              // bits the ids need; 0 = no ride
+  int32_t  rideShapes;             // how many of the shapes 1x1, 2x1, 1x2, 2x2 have codes
+  uint32_t rideEscape;             // the code of every other rectangle: (1 << code bits) - 1
 };
 
 struct FrameArgs

@@ -438,6 +438,11 @@ struct OsPassArgs
   const uint32_t* part0;     // IN 1: [partitions] the slot holding the first pair of every dense partition, and at winOffset ...
   uint32_t        winOffset; // ... [partitions][kOsWin]: where the first kOsWin slots from there on start, relative to the partition
   uint32_t        slots;
+  // the bin rectangles' codes ride above the ids (kernels_common.h: rideEncode); the final pass of a frame separates them:
+  // clean ids for everybody, the codes in sorted order for the binning stage
+  uint32_t        rideShift;   // bits of the id proper; 0 = nothing rides
+  uint32_t        rideInfo;    // what planOut->reserved[0] tells k_dbin_count: shapes | code bits << 8
+  uint16_t*       dstCode16;
   const uint32_t* srcKeys;
   const uint32_t* srcVals;
   uint2*          dstPairs;
@@ -513,6 +518,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
     a.planOut->n         = plan->n;
     a.planOut->finalSel  = 0u;
     a.planOut->passesRun = (uint32_t)a.pass + 1u;
+    if(finalOut)
+      a.planOut->reserved[0] = a.rideShift != 0u ? a.rideInfo : 0u;  // the binning stage finds the rectangles in sorted order
   }
 
   // ---- load: wave w owns a contiguous quarter of the partition, lane-interleaved, so (wave, round, lane) is memory order.
@@ -855,7 +862,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
         else
           d = (kv.x >> shift) & 255u;
         const uint32_t dst = s_cnt[d] + idx;
-        if(finalOut)
+        if(finalOut && a.rideShift != 0u)
+        {
+          a.dstVals[dst]   = kv.y & ((1u << a.rideShift) - 1u);
+          a.dstCode16[dst] = (uint16_t)(kv.y >> a.rideShift);
+        }
+        else if(finalOut)
         {
           a.dstVals[dst] = kv.y;
           if(a.dstKeys != nullptr)
@@ -962,6 +974,9 @@ void launchOsSort(hipStream_t stream, const OsLaunch& L)
     a.part0     = L.part0;
     a.winOffset = maxParts + 1u;
     a.slots     = L.prjParts;
+    a.rideShift = frame ? L.rideShift : 0u;
+    a.rideInfo  = L.rideInfo;
+    a.dstCode16 = L.outCode16;
     a.srcKeys   = L.keys0;
     a.srcVals   = L.vals0;
     a.digitMode = (pass == 2 && frame) ? 1 : (pass == 3 ? 2 : 0);

@@ -347,8 +347,18 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
       liCur = local0 + s_li[t];
       cur   = fetchSplat(I, liCur);
     }
-    for(uint32_t j0 = 0; j0 < M; j0 += kPrjThreads)
-    {
+    static_assert(kPrjItems == 8, "RideCodes holds eight rounds");
+    RideCodes      codes;
+    const uint32_t rideShift = (uint32_t)A.f.rideShift;
+#pragma unroll 1
+    for(uint32_t j0 = 0; j0 < (uint32_t)kPrjPart; j0 += kPrjThreads)
+    {  // always eight rounds (the codes' slots are counted from the last one); a round behind the survivors only shifts them
+      uint32_t code = 0u;
+      if(j0 >= M)
+      {
+        codes.push(code);
+        continue;
+      }
       const uint32_t j     = j0 + t;
       uint32_t       gidOk = 0xFFFFFFFFu;
       SplatFetch     nxt;
@@ -368,6 +378,8 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
           dst[0]      = make_float4(pr.rec.cx, pr.rec.cy, pr.rec.p1x, pr.rec.p1y);
           dst[1]      = make_float4(pr.rec.p2x, pr.rec.p2y, pr.rec.a, __uint_as_float(pr.rec.exey));
           rect[gidOk] = pr.rect;
+          if(rideShift != 0u)
+            code = rideEncode(pr.rect, A.f.binsX, A.f.binsY, A.f.rideShapes, A.f.rideEscape);
           s_li[j] |= 0x8000u;  // own entry only: no race
         }
       }
@@ -386,12 +398,13 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
       __builtin_amdgcn_wave_barrier();
       cur   = nxt;
       liCur = liNxt;
+      codes.push(code);
     }
     // ---- second ordered compaction straight into the partition's slot region (slot_emit.h) ----
     __syncthreads();
     MGS_PRJ_STAMP(4)
     const uint32_t outCount = emitSlot<kPrjThreads, kPrjItems>(M, false, s_li, s_key, s_cnt, s_base, s_hist2, slotPairs, slotCount, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
-                                                               I.globalOffset + local0);
+                                                               I.globalOffset + local0, rideShift, &codes);
     (void)outCount;
 #ifdef MGS_PRJ_TRACE
     MGS_PRJ_STAMP(5)

@@ -291,7 +291,7 @@ __device__ __forceinline__ LaneBins laneBins(int binsX, int nb)
 
 __global__ __launch_bounds__(256) void k_dbin_count(const uint32_t* __restrict__ idsX, const uint32_t* __restrict__ idsY,
                                                     const SortPlan* __restrict__ plan, const uint32_t* __restrict__ rect,
-                                                    const uint32_t* __restrict__ sortedRect, uint64_t* __restrict__ maskBuf,
+                                                    const uint16_t* __restrict__ sortedCode16, uint64_t* __restrict__ maskBuf,
                                                     uint32_t* __restrict__ binHist, uint32_t pStride, int binsX, int binsY)
 {
   __shared__ uint64_t s_col[4][kDbMaxDim], s_row[4][kDbMaxDim];
@@ -304,6 +304,20 @@ __global__ __launch_bounds__(256) void k_dbin_count(const uint32_t* __restrict__
   const uint32_t* ids = plan->finalSel ? idsY : idsX;
   const uint32_t  e0  = blockIdx.x * (uint32_t)kDbChunk + (uint32_t)w * (kDbRounds * 64) + (uint32_t)lane;
   uint32_t        r[kDbRounds];
+  const uint32_t  ride = plan->reserved[0];
+  if(ride != 0u)
+  {  // the rectangles rode through the key sort as codes above the ids and lie in sorted order (kernels_common.h: rideEncode);
+    // only the escapes — splats over more than 2 x 2 bins — are looked up by id
+    const uint32_t escape = (1u << (ride >> 8)) - 1u;
+    uint32_t       v[kDbRounds];
+#pragma unroll
+    for(int i = 0; i < kDbRounds; ++i)
+      v[i] = sortedCode16[min(e0 + i * 64u, n - 1u)];
+#pragma unroll
+    for(int i = 0; i < kDbRounds; ++i)
+      r[i] = (v[i] == escape) ? rect[ids[min(e0 + i * 64u, n - 1u)]] : rideDecode(v[i], binsX, binsY);
+  }
+  else
   {
     uint32_t id[kDbRounds];
 #pragma unroll
@@ -311,8 +325,8 @@ __global__ __launch_bounds__(256) void k_dbin_count(const uint32_t* __restrict__
       id[i] = ids[min(e0 + i * 64u, n - 1u)];  // clamped, not predicated: all loads in flight
 #pragma unroll
     for(int i = 0; i < kDbRounds; ++i)
-      r[i] = rect[id[i]];  // the stage's one random gather (moving it into the sort's final pass was measured twice: the
-                           // pass pays +36 us for the -16 us here — 4-byte gathers run at ~120 G/s wherever they are issued)
+      r[i] = rect[id[i]];  // one random gather per splat: 4.2 M of them run at ~120 G/s (L2-miss sectors), 35 us, wherever they
+                           // are issued (moving them into the sort's final pass was measured twice: +36 us there for -16 us here)
   }
   const int      nb = binsX * binsY, S = binsX + binsY;
   const LaneBins L  = laneBins(binsX, nb);
@@ -1167,14 +1181,14 @@ bool directBinningSupported(int binsX, int binsY)
 }
 
 void launchDirectBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
-                         const uint32_t* rect, const uint32_t* sortedRect, uint64_t* maskBuf, uint32_t maxSplats, uint32_t* binHist, uint32_t pStride,
+                         const uint32_t* rect, const uint16_t* sortedCode16, uint64_t* maskBuf, uint32_t maxSplats, uint32_t* binHist, uint32_t pStride,
                          uint32_t* binTotal, uint32_t* binList, uint2* ranges, FrameCounters* ctr, uint32_t capacity,
                          int binsX, int binsY)
 {
   const uint32_t maxChunks = (maxSplats + kDbChunk - 1) / kDbChunk;
   if(maxChunks == 0)
     return;
-  hipLaunchKernelGGL(k_dbin_count, dim3(maxChunks), dim3(256), 0, stream, idsX, idsY, planKeys, rect, sortedRect, maskBuf,
+  hipLaunchKernelGGL(k_dbin_count, dim3(maxChunks), dim3(256), 0, stream, idsX, idsY, planKeys, rect, sortedCode16, maskBuf,
                      binHist, pStride, binsX, binsY);
   hipLaunchKernelGGL(k_dbin_scan, dim3(binsX * binsY), dim3(256), 0, stream, planKeys, binHist, pStride, binTotal);
 #ifdef MGS_DB_TRACE

@@ -62,6 +62,53 @@ __device__ __forceinline__ uint32_t blockExclusiveScan256(uint32_t v, uint32_t* 
   return base + inc - v;
 }
 
+// The bin rectangle of a splat rides through the frame's key sort in the bits of the id word that the ids do not need, so that
+// the binning stage finds it in sorted order instead of gathering 4.2 M rectangles by id (35 us of random 4-byte loads).
+// Most splats cover one bin or two: the code enumerates (shape, x0, y0) for the shapes 1x1, 2x1, 1x2, 2x2 — as many of them
+// (`shapes`, in that order) as fit the spare bits —; every other rectangle is the escape code (all ones), looked up by id.
+//   code = base[shape] + y0 * (binsX - dx) + x0,  base = 0, nb, nb + (bx-1) by, nb + (bx-1) by + bx (by-1)
+// 1080p (15 x 9 bins, 5.83 M splats = 23 id bits): 493 codes in 9 bits.
+__device__ __forceinline__ uint32_t rideBase(int shape, int binsX, int binsY)
+{
+  const int nb = binsX * binsY;
+  return (uint32_t)(shape == 0 ? 0 : (shape == 1 ? nb : (shape == 2 ? nb + (binsX - 1) * binsY : nb + (binsX - 1) * binsY + binsX * (binsY - 1))));
+}
+__device__ __forceinline__ uint32_t rideEncode(uint32_t rect, int binsX, int binsY, int shapes, uint32_t escape)
+{
+  const uint32_t x0 = rect & 255u, y0 = (rect >> 8) & 255u, dx = ((rect >> 16) & 255u) - x0, dy = (rect >> 24) - y0;
+  const int      shape = (int)(dx | (dy << 1));
+  if(dx > 1u || dy > 1u || shape >= shapes)
+    return escape;
+  return rideBase(shape, binsX, binsY) + y0 * (uint32_t)(binsX - (int)dx) + x0;
+}
+__device__ __forceinline__ uint32_t rideDecode(uint32_t code, int binsX, int binsY)
+{
+  const uint32_t b1 = rideBase(1, binsX, binsY), b2 = rideBase(2, binsX, binsY), b3 = rideBase(3, binsX, binsY);
+  const uint32_t shape = code >= b3 ? 3u : (code >= b2 ? 2u : (code >= b1 ? 1u : 0u));
+  const uint32_t r  = code - (shape == 3u ? b3 : (shape == 2u ? b2 : (shape == 1u ? b1 : 0u)));
+  const uint32_t dx = shape & 1u, dy = shape >> 1, wS = (uint32_t)binsX - dx;
+  const uint32_t y0 = (uint32_t)__fdividef((float)r + 0.5f, (float)wS);  // r < 1024, wS <= 32: exact
+  const uint32_t x0 = r - y0 * wS;
+  return x0 | (y0 << 8) | ((x0 + dx) << 16) | ((y0 + dy) << 24);
+}
+
+// The codes of a thread's (up to) eight splats, collected over the rounds of a project kernel's front end and consumed by its
+// hand-over to the sort: a 128-bit shift register in four VGPRs.  Every round shifts it by 16 bits and inserts that round's
+// code, whether the round did anything or not, so after exactly eight rounds round r sits in slot 7 - r: static indexing on
+// both sides, although the front end's loop is rolled.
+struct RideCodes
+{
+  uint32_t c[4] = {0u, 0u, 0u, 0u};
+  __device__ __forceinline__ void push(uint32_t code)
+  {
+    c[3] = (c[3] << 16) | (c[2] >> 16);
+    c[2] = (c[2] << 16) | (c[1] >> 16);
+    c[1] = (c[1] << 16) | (c[0] >> 16);
+    c[0] = (c[0] << 16) | (code & 0xFFFFu);
+  }
+  __device__ __forceinline__ uint32_t get(int round) const { return (c[(7 - round) >> 1] >> (16 * ((7 - round) & 1))) & 0xFFFFu; }
+};
+
 // encodeMinMaxFp32 (shaders/dist.comp.slang:33-38): order-preserving fp32 -> u32
 __device__ __forceinline__ uint32_t encodeKey(float v)
 {

@@ -42,7 +42,7 @@ void launchBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* ids
                    int binsX, bool gatherRects);
 bool directBinningSupported(int binsX, int binsY);
 void launchDirectBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
-                         const uint32_t* rect, const uint32_t* sortedRect, uint64_t* maskBuf, uint32_t maxSplats, uint32_t* binHist, uint32_t pStride,
+                         const uint32_t* rect, const uint16_t* sortedCode16, uint64_t* maskBuf, uint32_t maxSplats, uint32_t* binHist, uint32_t pStride,
                          uint32_t* binTotal, uint32_t* binList, uint2* ranges, FrameCounters* ctr, uint32_t capacity,
                          int binsX, int binsY);
 void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* keyY, const SortPlan* planPairs,
@@ -288,6 +288,7 @@ struct MgsScene_t
                                        // slot of 2048 entries per partition
   DevBuf<uint32_t>      slotHist2, top16Rec, top16Count, osStatus;  // what the key sort needs besides (k_osort.hip)
   DevBuf<uint32_t>      slotCount, slotBase, part0;  // pairs per slot; their exclusive prefix; first slot of every sort partition
+  DevBuf<uint16_t>      sortedCode16;                // the bin rectangles' codes in sorted order (they ride through the key sort)
   DevBuf<uint32_t>      keysA, idsA;  // the sorted ids (and, for the sort-only hook, the sorted keys)
   DevBuf<uint32_t>      rect, partHist, blockCount;
   DevBuf<uint32_t>      sortedRect, splatOffset, chunkStart;
@@ -732,7 +733,7 @@ void mgs_scene_destroy(MgsScene s)
     auto& h = s->d->handles;
     h.erase(std::remove(h.begin(), h.end(), s), h.end());
   }
-  s->pairA.release(); s->pairB.release(); s->slotCount.release(); s->slotBase.release(); s->part0.release(); s->slotHist2.release(); s->top16Rec.release(); s->top16Count.release();
+  s->pairA.release(); s->pairB.release(); s->slotCount.release(); s->slotBase.release(); s->part0.release(); s->sortedCode16.release(); s->slotHist2.release(); s->top16Rec.release(); s->top16Count.release();
   s->osStatus.release(); s->keysA.release(); s->idsA.release(); s->rect.release(); s->partHist.release(); s->blockCount.release();
   s->rec.release(); s->recGut.release(); s->pairKey0.release(); s->pairVal0.release(); s->pairKey1.release(); s->pairVal1.release();
   s->sortedRect.release(); s->splatOffset.release(); s->chunkStart.release();
@@ -839,7 +840,7 @@ int mgs_scene_memory_usage(MgsScene s, uint64_t* sceneBytes, uint64_t* workingBy
   {
     uint64_t b = 0;
     auto add = [&](auto& buf) { b += (uint64_t)buf.n * sizeof(*buf.p); };
-    add(s->pairA); add(s->pairB); add(s->slotCount); add(s->slotBase); add(s->part0); add(s->slotHist2); add(s->top16Rec); add(s->top16Count); add(s->osStatus); add(s->keysA); add(s->idsA); add(s->rect);
+    add(s->pairA); add(s->pairB); add(s->slotCount); add(s->slotBase); add(s->part0); add(s->sortedCode16); add(s->slotHist2); add(s->top16Rec); add(s->top16Count); add(s->osStatus); add(s->keysA); add(s->idsA); add(s->rect);
     add(s->partHist); add(s->blockCount); add(s->sortedRect); add(s->splatOffset); add(s->chunkStart);
     add(s->dbinMasks); add(s->fstate); add(s->surfDepth); add(s->surfId); add(s->surfNormal); add(s->accum); add(s->rec); add(s->recGut);
     add(s->pairKey0); add(s->pairVal0); add(s->pairKey1); add(s->pairVal1); add(s->ranges); add(s->image);
@@ -1242,6 +1243,7 @@ static int sizeWorkingSet(MgsScene s)
   if((rc = s->pairA.ensure(total))) return rc;
   if((rc = s->pairB.ensure(std::max<uint64_t>(total, parts * (uint64_t)kOsSlot)))) return rc;  // whole slots
   if((rc = s->slotCount.ensure(parts))) return rc;
+  if((rc = s->sortedCode16.ensure(total))) return rc;
   if((rc = s->slotBase.ensure(parts + 1))) return rc;
   if((rc = s->part0.ensure(((size_t)osSortMaxParts((uint32_t)total) + 1) * (1 + kOsWin)))) return rc;
   if((rc = s->idsA.ensure(total))) return rc;
@@ -1476,6 +1478,37 @@ static void mapIdsToStorage(MgsScene s, uint32_t* ids, size_t n)
 }
 
 // ------------------------------------------------------------------------------------------------
+// coarse bins (the default): stable multi-split straight into the per-bin lists, no records, no pair sort; MGS_DIRECT_BIN=0
+// forces the record + pair-sort path of frames with more than 256 bins
+static const bool kDirectBin = [] { const char* e = std::getenv("MGS_DIRECT_BIN"); return e ? std::atoi(e) != 0 : true; }();
+
+// The bin rectangles ride through the key sort as codes in the id word's spare bits (kernels_common.h: rideEncode) when the
+// frame bins directly and the GPU sorts: as many of the shapes 1x1, 2x1, 1x2, 2x2 as fit the spare bits (at most 16).
+// MGS_RECT_RIDE=0: k_dbin_count gathers every rectangle by id instead (A/B).
+static const bool kRectRide = [] { const char* e = std::getenv("MGS_RECT_RIDE"); return e ? std::atoi(e) != 0 : true; }();
+static void chooseRide(MgsScene s, FrameConst& F, bool cpuMode)
+{
+  F.rideShift = F.rideShapes = 0;
+  F.rideEscape = 0;
+  if(!kRectRide || cpuMode || !kDirectBin || !directBinningSupported(F.binsX, F.binsY) || s->d->totalSplats == 0)
+    return;
+  int idBits = 1;
+  while(idBits < 32 && (1ull << idBits) < (uint64_t)s->d->totalSplats)
+    ++idBits;
+  const int codeBits = std::min(32 - idBits, 16);
+  const int bx = F.binsX, by = F.binsY, nb = bx * by;
+  const int codes[4] = {nb, nb + (bx - 1) * by, nb + (bx - 1) * by + bx * (by - 1), nb + (bx - 1) * by + bx * (by - 1) + (bx - 1) * (by - 1)};
+  for(int shapes = 4; shapes >= 1; --shapes)
+    if(codeBits >= 1 && codes[shapes - 1] + 1 <= (1 << codeBits))
+    {
+      F.rideShift  = idBits;
+      F.rideShapes = shapes;
+      F.rideEscape = (1u << codeBits) - 1u;
+      return;
+    }
+}
+
+
 static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
 {
   if(p->width <= 0 || p->height <= 0 || p->width > 8192 || p->height > 8192)
@@ -1567,6 +1600,7 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
   F.temporalSampling = p->temporal_sampling ? 1 : 0;
   F.kernelDegree     = p->kernel_degree;
   F.normalMethod     = p->normal_method;
+  chooseRide(s, F, p->sort_mode == MGS_SORT_CPU_ASYNC);
   if(p->camera_model == MGS_CAMERA_FISHEYE && p->pipeline == MGS_PIPELINE_3DGUT)
   {  // gaussian_splatting.cpp:1239-1244: frameInfo.focal is the fisheye focal only for the 3DGUT pipelines; a fisheye camera on
      // the 3DGS pipelines keeps the pinhole focal (and dist.comp's fisheye cull then runs on that)
@@ -1666,15 +1700,12 @@ static int pairSortBits(int nTiles)
   return ((bits + 7) / 8) * 8;
 }
 
-// coarse bins (the default): stable multi-split straight into the per-bin lists, no records, no pair sort; MGS_DIRECT_BIN=0
-// forces the record + pair-sort path of frames with more than 256 bins
-static const bool kDirectBin = [] { const char* e = std::getenv("MGS_DIRECT_BIN"); return e ? std::atoi(e) != 0 : true; }();
 
 // pass elision of the key sort (sort_plan.h): on by default, MGS_SORT_REMAP=0 keeps the four plain passes
 static const bool kRemap = [] { const char* e = std::getenv("MGS_SORT_REMAP"); return e ? std::atoi(e) != 0 : true; }();
 
 // the frame's key sort (k_osort.hip): slots of the project kernel -> sorted ids in idsA (keys in keysA when wanted)
-static void keySort(MgsScene s, hipStream_t st, bool wantKeys, bool allowRemap)
+static void keySort(MgsScene s, hipStream_t st, bool wantKeys, bool allowRemap, const FrameConst* ride = nullptr)
 {
   OsLaunch L{};
   L.pairs0       = s->pairB.p;
@@ -1697,6 +1728,15 @@ static void keySort(MgsScene s, hipStream_t st, bool wantKeys, bool allowRemap)
   L.status       = s->osStatus.p;
   L.ctr          = s->ctr.p;
   L.allowRemap   = allowRemap;
+  if(ride != nullptr && ride->rideShift != 0 && !wantKeys)
+  {
+    int codeBits = 0;
+    while((1u << codeBits) - 1u < ride->rideEscape)
+      ++codeBits;
+    L.rideShift = (uint32_t)ride->rideShift;
+    L.rideInfo  = (uint32_t)ride->rideShapes | ((uint32_t)codeBits << 8);
+    L.outCode16 = s->sortedCode16.p;
+  }
   launchOsSort(st, L);
 }
 
@@ -1997,7 +2037,7 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
                     s->slotHist2.p, s->top16Rec.p, cpuMode ? nullptr : s->top16Count.p, &s->plans.p->os);
     if(withEvents) HIPCHK(hipEventRecord(fev[1], st));
     if(!cpuMode)
-      keySort(s, st, false, kRemap);
+      keySort(s, st, false, kRemap, &F);
     else
     {
       rc = cpuSortStep(s, p, p->cpu_sort_blocking != 0);
@@ -2018,7 +2058,7 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     const bool direct = kDirectBin && directBinningSupported(F.binsX, F.binsY);
     if(direct)
     {
-      launchDirectBinning(st, s->idsA.p, s->idsA.p, planK, s->rect.p, s->sortedRect.p, s->dbinMasks.p, s->d->totalSplats,
+      launchDirectBinning(st, s->idsA.p, s->idsA.p, planK, s->rect.p, s->sortedCode16.p, s->dbinMasks.p, s->d->totalSplats,
                           s->partHist.p, s->pStride, &planP->ghist[0][0], s->pairVal1.p, s->ranges.p, ctr, s->pairCapacity,
                           F.binsX, F.binsY);
       if(withEvents) HIPCHK(hipEventRecord(fev[3], st));
@@ -2080,7 +2120,8 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     const int32_t kv[16] = {F.width, F.height, F.stripRow0, F.stripRow1, F.binShiftX, F.binShiftY, F.partitionCull, F.alphaMode,
                             F.debugFlags & (2 | 4 | 256), F.surfaceOutputs, half, F.nInstances, F.shDegree, isoBits,
                             F.pipeline, F.stochastic | (F.dofMode << 1) | (F.temporalSampling << 2) | ((F.pipeline == 1 && F.kernelDegree != 2) ? 8 : 0) |
-                                ((F.pipeline == 1 && F.normalMethod == 1) ? 16 : 0)};  // ... and everything that selects a kernel variant
+                                ((F.pipeline == 1 && F.normalMethod == 1) ? 16 : 0) |
+                                (F.rideShift << 8) | (F.rideShapes << 16)};  // ... and everything that selects a kernel variant or a launch argument
     std::memcpy(key.v, kv, sizeof(kv));
     key.p[0] = s->image.p;
     key.p[1] = s->surfDepth.p;

@@ -39,7 +39,8 @@ __device__ __forceinline__ uint32_t emitSlot(uint32_t M, bool allSurvive, const 
                                              uint2* __restrict__ slotPairs,
                                              uint32_t* __restrict__ slotCount, uint32_t* __restrict__ slotHist2,
                                              uint32_t* __restrict__ top16Rec, uint32_t* __restrict__ top16Count, OsPlan* __restrict__ osPlan,
-                                             FrameCounters* __restrict__ ctr, uint32_t part, uint32_t idBase)
+                                             FrameCounters* __restrict__ ctr, uint32_t part, uint32_t idBase,
+                                             uint32_t rideShift = 0u, const RideCodes* codes = nullptr)
 {
   constexpr int WAVES = THREADS / 64;
   static_assert(WAVES * ITEMS == 32, "the round x wave table of scanRoundWaveCounts has 32 entries");
@@ -144,7 +145,10 @@ __device__ __forceinline__ uint32_t emitSlot(uint32_t M, bool allSurvive, const 
     if(vis[r])
     {
       const uint32_t j         = r * THREADS + t;
-      slotPairs[dst0 + pos[r]] = make_uint2(s_key[j], idBase + (uint32_t)(s_li[j] & 0x7FFFu));
+      uint32_t id = idBase + (uint32_t)(s_li[j] & 0x7FFFu);
+      if(rideShift != 0u)  // the bin rectangle's code rides through the sort above the id (kernels_common.h: rideEncode)
+        id |= codes->get(r) << rideShift;
+      slotPairs[dst0 + pos[r]] = make_uint2(s_key[j], id);
     }
   return outCount;
 }

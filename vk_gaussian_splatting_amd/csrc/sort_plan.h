@@ -75,6 +75,9 @@ struct OsLaunch
   uint32_t*       slotBase   = nullptr;  // [prjParts + 1] scratch: exclusive prefix of slotCount (k_os_prepare)
   uint32_t*       part0      = nullptr;  // [(osSortMaxParts + 1) (1 + kOsWin)] scratch: the slot that holds the first pair of every
                                          // dense partition, then the partitions' windows (k_os_prepare)
+  uint32_t        rideShift  = 0;        // frame only: the ids carry the bin rectangles' codes above bit rideShift (rideEncode) ...
+  uint32_t        rideInfo   = 0;        // ... shapes | code bits << 8, handed to the binning stage in planOut->reserved[0] ...
+  uint16_t*       outCode16  = nullptr;  // ... and the final pass writes clean ids and, here, the codes in sorted order
   uint32_t*       nOut       = nullptr;  // the frame's count of sorted pairs (== *nPtr afterwards), written by k_os_prepare
   const uint32_t* slotHist2  = nullptr;  // [partition][256]: histograms of key bits 0-7 and 8-15, two 16-bit counters per word
   const uint32_t* top16Rec   = nullptr;  // [partition][4 waves][32]: counts of key >> 16 per producer wave (slot_emit.h)
