@@ -75,4 +75,12 @@ for pose, (eye, (w, h)) in enumerate(views):
         p.strip_row_begin, p.strip_row_end = strip
         scene.render(p)
         hh.update(np.ascontiguousarray(scene.download_frame(p)).tobytes())
+# the 3DGUT front end hands over to the same sort (its own project kernel)
+eye = synth.orbit_pose(9)
+V, P = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, 960, 540)
+p = capi.default_params(960, 540)
+capi.set_camera(p, V, P, eye)
+p.pipeline = capi.PIPELINE_3DGUT
+scene.render(p)
+hh.update(np.ascontiguousarray(scene.download_frame(p)).tobytes())
 print("FRAMES_SHA1", hh.hexdigest())

@@ -141,21 +141,24 @@ def test_radix_sort_depth_like_keys_with_outliers(scene_small, ob):
 
 def test_key_sort_variants_are_bit_identical_to_the_stable_sort():
     """the sort kernels under their build-time knobs (libmgs reads them once per process, hence the child interpreter): the
-    frame's key sort with the pass elision (default), with four plain passes (MGS_SORT_REMAP=0), and the stand-alone sorts on
-    the generic reduce-then-scan kernels instead of the key sort's (MGS_RAW_SORT=generic).  Sizes around the partition and
+    frame's key sort with the pass elision (default), with four plain passes (MGS_SORT_REMAP=0), the stand-alone sorts on
+    the generic reduce-then-scan kernels instead of the key sort's (MGS_RAW_SORT=generic), and without the bin rectangles'
+    ride through the sort (MGS_RECT_RIDE=0).  Sizes around the partition and
     look-back group boundaries, distributions with giant runs / few values / many exponents, and whole frames — every sorted
     stream must equal the stable sort bit for bit, every frame must be the same frame"""
     import subprocess
     import sys
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_child_sort.py")
     out = {}
-    for mode, env_extra in (("default", {}), ("plain", {"MGS_SORT_REMAP": "0"}), ("generic", {"MGS_RAW_SORT": "generic"})):
+    for mode, env_extra in (("default", {}), ("plain", {"MGS_SORT_REMAP": "0"}), ("generic", {"MGS_RAW_SORT": "generic"}),
+                            ("gather", {"MGS_RECT_RIDE": "0"})):
         r = subprocess.run([sys.executable, child], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
         assert "SORTS_OK" in r.stdout, r.stdout[-3000:]
         out[mode] = [l for l in r.stdout.splitlines() if l.startswith("FRAMES_SHA1")]
         print(mode, [l for l in r.stdout.splitlines() if l.startswith("STATS")])
-    assert out["default"] and out["default"] == out["plain"] == out["generic"]
+    # (gather: the bin rectangles looked up by id instead of riding through the sort above the ids, k_osort.hip)
+    assert out["default"] and out["default"] == out["plain"] == out["generic"] == out["gather"]
 
 
 def test_upload_transform_matches_oracle_bitwise(scene_small, ob):
