@@ -36,8 +36,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_SQ_FILE = "r3_x_pmc_sq_composite.json"  # {"k_composite": {"SQ_INSTS_VALU": per-launch mean, ...}}
-PMC_FILE = "r3_x_pmc_hbm_traffic.json"  # written by tools/pmc_traffic.py from rocprofv3 --pmc passes of this command
+PMC_SQ_FILE = "r3_z_pmc_sq_composite.json"  # {"k_composite": {"SQ_INSTS_VALU": per-launch mean, ...}}
+PMC_FILE = "r3_z_pmc_hbm_traffic.json"  # written by tools/pmc_traffic.py from rocprofv3 --pmc passes of this command
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 STAGES = ["project", "sort", "bin", "pairsort", "composite", "total"]
 

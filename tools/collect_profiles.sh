@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes behind profiles/${TAG}_* (run on the GPU box via gpurun; results land in gpurun_out/).
-export TAG=${TAG:-r3_x}; export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-/root/repo}; cd /tmp; rm -rf /tmp/pf /tmp/pw /tmp/psq /tmp/ps1 /tmp/ps3
+export TAG=${TAG:-r3_z}; export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-/root/repo}; cd /tmp; rm -rf /tmp/pf /tmp/pw /tmp/psq /tmp/ps1 /tmp/ps3
 CMD="python $R/bench.py --steps 24 --warmup 4 --no-cpu-baseline --inflight 1"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -- $CMD > /tmp/l1 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -- $CMD > /tmp/l2 2>&1
