@@ -403,7 +403,8 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
                                                    const uint32_t* __restrict__ binHist, uint32_t pStride,
                                                    const uint32_t* __restrict__ binTotal, uint32_t* __restrict__ binList,
                                                    uint2* __restrict__ ranges, FrameCounters* __restrict__ ctr,
-                                                   uint32_t capacity, int binsX, int binsY, uint32_t* __restrict__ binOrder)
+                                                   uint32_t capacity, int binsX, int binsY, uint32_t* __restrict__ binOrder,
+                                                   const uint16_t* __restrict__ sortedCode16)
 {
   __shared__ uint64_t s_col[4][kDbRounds][kDbMaxDim], s_row[4][kDbRounds][kDbMaxDim];  // masks of every round
   __shared__ uint32_t s_cnt[4][256];  // per-wave counts, then per-wave write cursors
@@ -439,6 +440,13 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
     for(int i = 0; i < 4; ++i)
       bt[i] = (4 * lane + i < nb) ? binTotal[4 * lane + i] : 0u;
   }
+  // the splats' own rectangles, where they rode through the key sort as codes (k_dbin_count has the story): lane == splat for the
+  // walk below
+  const uint32_t ride = plan->reserved[0];
+  uint32_t       code[kDbRounds];
+#pragma unroll
+  for(int i = 0; i < kDbRounds; ++i)
+    code[i] = ride != 0u ? (uint32_t)sortedCode16[min(e0 + i * 64u, n - 1u)] : 0u;
   {
     const int       S   = binsX + binsY;
     const uint64_t* mIn = maskBuf + ((size_t)chunk * 4 + w) * kDbRounds * S;
@@ -546,6 +554,61 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
   if(wrapped)
     return;
 
+  if(staged && ride != 0u)
+  {
+    // The rectangles are known per splat: most splats cover 1-4 bins (the coded shapes), so LANE == SPLAT places its few entries
+    // directly — position = the bin's cursor + the splats before it in this round's mask of the bin —, and only the splats with
+    // larger rectangles (escape code) are found by LANE == BIN walking the bits of its mask.  (Walking every bit that way, below,
+    // keeps 2-3 % of the lanes busy: the trip count of a round is the population of its densest bin.)  Cursors live in LDS,
+    // advanced by the bin lanes once per round, between two wave barriers.  (Cursor-free — every entry summing the bin's
+    // population over the wave's earlier rounds itself — was measured: no faster, the bin lanes run anyway because nearly every
+    // wave holds an escape.)
+    const uint32_t escape = (1u << (ride >> 8)) - 1u;
+    const uint64_t ltMask = (1ull << lane) - 1ull;
+    for(int i = 0; i < kDbRounds; ++i)
+    {
+      const bool     valid = e0 + (uint32_t)i * 64u < n;
+      const bool     coded = valid && code[i] != escape;
+      const uint32_t idx   = wbase + (uint32_t)i * 64u + (uint32_t)lane;
+      if(coded)
+      {
+        const uint32_t r  = rideDecode(code[i], binsX, binsY);
+        const uint32_t x0 = r & 255u, y0 = (r >> 8) & 255u, dx = ((r >> 16) & 255u) - x0, dy = (r >> 24) - y0;
+#pragma unroll
+        for(uint32_t ky = 0; ky < 2u; ++ky)
+#pragma unroll
+          for(uint32_t kx = 0; kx < 2u; ++kx)
+            if(kx <= dx && ky <= dy)
+            {
+              const uint32_t b   = (y0 + ky) * (uint32_t)binsX + x0 + kx;
+              const uint64_t m   = s_col[w][i][x0 + kx] & s_row[w][i][y0 + ky];
+              s_stage[s_cnt[w][b] + (uint32_t)__popcll(m & ltMask)] = (b << 16) | idx;
+            }
+      }
+      const uint64_t escM = __ballot(valid && !coded);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for(int j = 0; j < 4; ++j)
+        if(j * 64 < nb)
+        {
+          const uint64_t m    = L.on[j] ? (s_col[w][i][L.bx[j]] & s_row[w][i][L.by[j]]) : 0ull;
+          uint64_t       me   = m & escM;
+          const uint32_t run  = s_cnt[w][lane + 64 * j];
+          const uint32_t btag = (uint32_t)(lane + 64 * j) << 16;
+          while(__ballot(me != 0ull) != 0ull)
+            if(me != 0ull)
+            {
+              const uint32_t bit = (uint32_t)__builtin_ctzll(me);
+              s_stage[run + (uint32_t)__popcll(m & ((1ull << bit) - 1ull))] = btag | (wbase + (uint32_t)i * 64u + bit);
+              me &= me - 1ull;
+            }
+          if(L.on[j])
+            s_cnt[w][lane + 64 * j] = run + (uint32_t)__popcll(m);
+        }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  else
   // lane == bin: walk the set bits of its mask (low word, then high word), appending to its own list
 #pragma unroll
   for(int j = 0; j < 4; ++j)
@@ -1205,7 +1268,7 @@ void launchDirectBinning(hipStream_t stream, const uint32_t* idsX, const uint32_
   }
 #endif
   hipLaunchKernelGGL(k_dbin_emit, dim3(maxChunks), dim3(256), 0, stream, idsX, idsY, planKeys, maskBuf, binHist, pStride,
-                     binTotal, binList, ranges, ctr, capacity, binsX, binsY, binTotal + 256);
+                     binTotal, binList, ranges, ctr, capacity, binsX, binsY, binTotal + 256, sortedCode16);
 #ifdef MGS_DB_TRACE
   if(tracePath)
   {
