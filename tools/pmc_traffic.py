@@ -5,7 +5,7 @@ half their bytes, so reads are doubled; other access widths and WRITE_SIZE are u
 2*FETCH_SIZE + WRITE_SIZE an upper estimate for kernels that also issue narrower loads (k_project's 4-byte centre loads)."""
 import csv, glob, json, sys, collections
 
-STAGE = {"project": ["k_project", "k_partition_cull"], "sort": ["k_sort_", "k_os_"], "bin": ["k_dbin_", "k_bin_"], "composite": ["k_composite"]}
+STAGE = {"project": ["k_project"], "sort": ["k_sort_", "k_os_"], "bin": ["k_dbin_", "k_bin_"], "composite": ["k_composite"]}
 
 
 def per_kernel(d, counter):

@@ -1,6 +1,6 @@
 """how much of the key pass a strip still runs: frustum survivors / sorted splats per strip against the full frame, and the number
-of 2048-splat partitions k_partition_cull lets through (debug: reads the skip flags back through mgs_debug? -> derived from the
-survivor counts of the sort-only hook)"""
+of 2048-splat partitions the partition test (partition_cull.h) lets through (derived from the survivor counts of the sort-only
+hook)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -65,7 +65,7 @@ struct FrameConst
   int32_t  nInstances;
   uint32_t totalSplats;
   uint32_t totalPartitions;  // project-kernel partitions
-  int32_t  partitionCull;    // 1: k_partition_cull fills the skip flags this frame
+  int32_t  partitionCull;    // 1: the project kernels test their partition as a whole first (partition_cull.h)
   int32_t  debugFlags;       // MGS_DEBUG_* bits
   int32_t  sizeCulling;      // dist.comp.slang:93-134
   float    sizeCullingMinPixels;

@@ -918,7 +918,7 @@ void launchOsSort(hipStream_t stream, const OsLaunch& L)
 {
   if(L.maxElems == 0)
     return;
-  const bool     frame    = L.pairs0 != nullptr;  // the project kernels' dense pairs + their histograms / records
+  const bool     frame    = L.pairs0 != nullptr;  // the project kernels' slots of pairs + their histograms / records
   const uint32_t maxParts = osSortMaxParts(L.maxElems);
   const uint32_t sWords   = (uint32_t)osSortStatusWords(maxParts);
   // Three sets of look-back words: pass 0 uses set 0, pass 1 set 1, pass 2 set 2, pass 3 set 1 again.  Every set is zero when its
@@ -967,7 +967,7 @@ void launchOsSort(hipStream_t stream, const OsLaunch& L)
     a.pass    = pass;
     a.dstKeys = L.outKeys;
     a.dstVals = L.outVals;
-    // pass 0 -> A, 1 -> B, 2 -> A (or the result), 3 -> the result.  A frame's pass 0 reads the dense pairs, which live in B.
+    // pass 0 -> A, 1 -> B, 2 -> A (or the result), 3 -> the result.  A frame's pass 0 gathers from the project kernels' slots, which live in B.
     a.srcPairs  = (pass == 0) ? L.pairs0 : ((pass & 1) ? L.pairA : L.pairB);
     a.dstPairs  = (pass & 1) ? L.pairB : L.pairA;
     a.slotBase  = L.slotBase;

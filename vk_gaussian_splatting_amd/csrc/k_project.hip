@@ -10,10 +10,12 @@
 //   * the reference runs dist in id order and the mesh shader in SORTED order, so its 232 B/splat
 //     attribute gather is uncoalesced; here the gather happens before the sort, in id order, and the
 //     sort only moves 8-byte (key,id) pairs.  The 32-byte projected record (SplatRec) is indexed by global id.
-//   * survivors are compacted per 2048-splat partition into a fixed slot region (ascending id, so
-//     the order is deterministic); the radix sort's first pass consumes the slots directly — there
-//     is no global atomic append and no inter-workgroup chain — together with the partition's
-//     low-byte histogram, which is built here while the keys are on chip.
+//   * survivors are compacted per 2048-splat partition into the partition's own slot (ascending id, so
+//     the order is deterministic); the radix sort's first pass gathers dense partitions from the slots
+//     through the prefix of their counts — there is no global atomic append and no inter-workgroup
+//     chain (slot_emit.h) — and gets the partition's two low-digit histograms, built here while the
+//     keys are on chip.
+//   * the partition as a whole is tested first, by the workgroup itself (partition_cull.h).
 //   * splats that can never produce a fragment (alpha cull, lambda2<=0, clipped by z, footprint
 //     outside the strip) are dropped BEFORE the sort.
 //   * the 180-byte SH record (62 % of a splat's bytes) is not read here: shading is deferred.
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
 #endif
   const bool identityFast = (pflag & 4u) != 0u && I.modelIsIdentity != 0u;
   // strips (multi-GPU): a splat whose centre lies further from this device's rows than the partition's footprint bound R
-  // (k_partition_cull; valid for every splat of the partition) cannot reach them — dropped here, before the projection.
+  // (partition_cull.h; valid for every splat of the partition) cannot reach them — dropped here, before the projection.
   // The exact footprint-vs-strip test of phase 2 would reject it anyway: the sorted set is unchanged.
   const bool  stripPre = FULL && A.f.partitionCull && (A.f.stripRow1 - A.f.stripRow0) < A.f.tilesY;
   const float stripR   = stripPre ? partRadius : 3.0e38f;
