@@ -1065,6 +1065,16 @@ def test_rccl_strip_exchange_inside_libmgs_single_rank(scene_small):
         scene.set_strip_rows([0, 45])
         scene.render_gathered(p)
         assert np.array_equal(scene.download_frame(p).view(np.uint16), want)
+        # a sort-only frame in between leaves no frame behind: the gathered render that follows must not reuse anything of it
+        # (the idle-rank shortcut looked at "have a frame" alone), nor may a frame of another size
+        scene.sort_keys(p)
+        scene.render_gathered(p)
+        assert np.array_equal(scene.download_frame(p).view(np.uint16), want)
+        p2, *_ = camera(7, 640, 360)
+        scene.render(p2)
+        scene.set_strip_rows([0, 45])
+        scene.render_gathered(p)
+        assert np.array_equal(scene.download_frame(p).view(np.uint16), want)
     finally:
         scene.comm_destroy()
     with pytest.raises(mgs.MgsError):
