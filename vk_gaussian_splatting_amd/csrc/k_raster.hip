@@ -237,6 +237,12 @@ constexpr int kDbChunk  = 256 * kDbRounds;   // sorted splats per workgroup
 constexpr int kDbStage  = MGS_DB_STAGE;      // list entries staged in LDS per chunk so that the appends are coalesced
 constexpr int kDbMaxDim = 32;
 
+// v_writelane_b32: a wave-uniform value into ONE lane's register
+__device__ __forceinline__ void writeLane(uint32_t& dst, uint32_t value, uint32_t lane)
+{
+  asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(dst) : "s"(value), "s"(lane) : "m0");  // one SGPR per VALU op: the lane select goes through m0
+}
+
 // column / row hit masks of one round of 64 rects.  Lane b < binsX ends up holding the mask of column b, lane binsX + b the
 // mask of row b (the layout of maskBuf): each ballot is kept by ONE lane through a select — no exec juggling, no branch, one
 // LDS write at the end instead of one per ballot.  (A third fewer instructions than lane-0 stores per ballot; the kernel's
@@ -249,17 +255,21 @@ __device__ __forceinline__ uint64_t rectMasks(uint32_t r, bool valid, int binsX,
   const uint32_t x0 = r & 255u, y0 = (r >> 8) & 255u, dx = ((r >> 16) & 255u) - x0, dy = (r >> 24) - y0;
   const bool     ok = (int)dx >= 0 && (int)dy >= 0;
   const uint32_t ux = ok ? dx : 0u, nx0 = ok ? x0 : 0xFFFFu;  // rejected: b - nx0 wraps far above ux
-  uint64_t       mine = 0ull;
+  // (v_writelane: the ballot is a scalar pair, lane b's registers take it directly — no compare, no select)
+  uint32_t mlo = 0u, mhi = 0u;
   for(int b = 0; b < binsX; ++b)
   {
     const uint64_t m = __ballot((uint32_t)b - nx0 <= ux);
-    mine             = (lane == b) ? m : mine;
+    writeLane(mlo, (uint32_t)m, (uint32_t)b);
+    writeLane(mhi, (uint32_t)(m >> 32), (uint32_t)b);
   }
   for(int b = 0; b < binsY; ++b)
   {
     const uint64_t m = __ballot((uint32_t)b - y0 <= dy);
-    mine             = (lane == binsX + b) ? m : mine;
+    writeLane(mlo, (uint32_t)m, (uint32_t)(binsX + b));
+    writeLane(mhi, (uint32_t)(m >> 32), (uint32_t)(binsX + b));
   }
+  const uint64_t mine = ((uint64_t)mhi << 32) | mlo;
   if(lane < binsX)
     s_col[lane] = mine;
   else if(lane < binsX + binsY)
