@@ -341,19 +341,13 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
   // into 64 different sectors.  Pitch 7 quads: conflict-free 16-byte LDS accesses.
   __shared__ float4   s_grec[4][64 * 7];
   __shared__ uint32_t s_ggid[4][64];
-  static_assert(kGutItems == 8, "RideCodes holds eight rounds");
-  RideCodes      codes;
-  const uint32_t rideShift = (uint32_t)A.f.rideShift;
-#pragma unroll 1
-  for(uint32_t j0 = 0; j0 < (uint32_t)kGutPart; j0 += kGutThreads)
-  {  // always eight rounds (the codes' slots are counted from the last one); a round behind the survivors only shifts them
-    uint32_t code = 0u;
-    if(j0 >= Mv)
-    {
-      codes.push(code);
-      continue;
-    }
-    const uint32_t j     = j0 + t;
+  // the bin rectangles' codes for the hand-over (kernels_common.h: rideEncode): in LDS here — this kernel runs at 169 VGPRs
+  // and three workgroups per CU either way, and k_project's register chain cost it 60 us
+  __shared__ uint16_t s_code[kGutPart];
+  const uint32_t      rideShift = (uint32_t)A.f.rideShift;
+  for(uint32_t j0 = 0; j0 < Mv; j0 += kGutThreads)
+  {
+    const uint32_t j = j0 + t;
     uint32_t       gidOk = 0xFFFFFFFFu;
     if(j < Mv)
     {
@@ -372,7 +366,7 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
         dst[5]      = make_float4(r.r, r.g, r.b, r.a);
         rect[gidOk] = rc;
         if(rideShift != 0u)
-          code = rideEncode(rc, A.f.binsX, A.f.binsY, A.f.rideShapes, A.f.rideEscape);
+          s_code[j] = (uint16_t)rideEncode(rc, A.f.binsX, A.f.binsY, A.f.rideShapes, A.f.rideEscape);  // own entry only
         s_li[j] |= 0x8000u;
       }
     }
@@ -387,12 +381,11 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
         reinterpret_cast<float4*>(rec + g)[pt] = s_grec[w][rr * 7 + pt];
     }
     __builtin_amdgcn_wave_barrier();
-    codes.push(code);
   }
   __syncthreads();
   // second ordered compaction into the partition's slot + what the key sort needs up front (slot_emit.h)
   emitSlot<kGutThreads, kGutItems>(Mv, false, s_li, s_key, s_cnt, s_base, s_hist2, slotPairs, slotCount, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
-                                   I.globalOffset + local0, rideShift, &codes);
+                                   I.globalOffset + local0, rideShift, nullptr, s_code);
 }
 
 // world-space ray direction of the pixel whose centre is (pcx, pcy) (threedgut_raster.frag.slang:101-111); false: outside the

@@ -352,16 +352,10 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
     static_assert(kPrjItems == 8, "RideCodes holds eight rounds");
     RideCodes      codes;
     const uint32_t rideShift = (uint32_t)A.f.rideShift;
-#pragma unroll 1
-    for(uint32_t j0 = 0; j0 < (uint32_t)kPrjPart; j0 += kPrjThreads)
-    {  // always eight rounds (the codes' slots are counted from the last one); a round behind the survivors only shifts them
-      uint32_t code = 0u;
-      if(j0 >= M)
-      {
-        codes.push(code);
-        continue;
-      }
-      const uint32_t j     = j0 + t;
+    for(uint32_t j0 = 0; j0 < M; j0 += kPrjThreads)
+    {
+      uint32_t       code = 0u;
+      const uint32_t j    = j0 + t;
       uint32_t       gidOk = 0xFFFFFFFFu;
       SplatFetch     nxt;
       uint32_t       liNxt = 0;
@@ -402,6 +396,9 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
       liCur = liNxt;
       codes.push(code);
     }
+    // the codes' slots are counted from the LAST of eight rounds: the rounds behind the survivors only shift
+    for(uint32_t j0 = (M + kPrjThreads - 1u) / kPrjThreads * kPrjThreads; j0 < (uint32_t)kPrjPart; j0 += kPrjThreads)
+      codes.push(0u);
     // ---- second ordered compaction straight into the partition's slot region (slot_emit.h) ----
     __syncthreads();
     MGS_PRJ_STAMP(4)

@@ -40,7 +40,8 @@ __device__ __forceinline__ uint32_t emitSlot(uint32_t M, bool allSurvive, const 
                                              uint32_t* __restrict__ slotCount, uint32_t* __restrict__ slotHist2,
                                              uint32_t* __restrict__ top16Rec, uint32_t* __restrict__ top16Count, OsPlan* __restrict__ osPlan,
                                              FrameCounters* __restrict__ ctr, uint32_t part, uint32_t idBase,
-                                             uint32_t rideShift = 0u, const RideCodes* codes = nullptr)
+                                             uint32_t rideShift = 0u, const RideCodes* codes = nullptr,
+                                             const uint16_t* s_code = nullptr /* [2048] in LDS, instead of `codes` */)
 {
   constexpr int WAVES = THREADS / 64;
   static_assert(WAVES * ITEMS == 32, "the round x wave table of scanRoundWaveCounts has 32 entries");
@@ -147,7 +148,7 @@ __device__ __forceinline__ uint32_t emitSlot(uint32_t M, bool allSurvive, const 
       const uint32_t j         = r * THREADS + t;
       uint32_t id = idBase + (uint32_t)(s_li[j] & 0x7FFFu);
       if(rideShift != 0u)  // the bin rectangle's code rides through the sort above the id (kernels_common.h: rideEncode)
-        id |= codes->get(r) << rideShift;
+        id |= (s_code != nullptr ? (uint32_t)s_code[j] : codes->get(r)) << rideShift;
       slotPairs[dst0 + pos[r]] = make_uint2(s_key[j], id);
     }
   return outCount;
