@@ -151,14 +151,15 @@ def test_key_sort_variants_are_bit_identical_to_the_stable_sort():
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_child_sort.py")
     out = {}
     for mode, env_extra in (("default", {}), ("plain", {"MGS_SORT_REMAP": "0"}), ("generic", {"MGS_RAW_SORT": "generic"}),
-                            ("gather", {"MGS_RECT_RIDE": "0"})):
+                            ("gather", {"MGS_RECT_RIDE": "0"}), ("nohistory", {"MGS_BIN_HISTORY": "0"})):
         r = subprocess.run([sys.executable, child], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
         assert "SORTS_OK" in r.stdout, r.stdout[-3000:]
         out[mode] = [l for l in r.stdout.splitlines() if l.startswith("FRAMES_SHA1")]
         print(mode, [l for l in r.stdout.splitlines() if l.startswith("STATS")])
     # (gather: the bin rectangles looked up by id instead of riding through the sort above the ids, k_osort.hip)
-    assert out["default"] and out["default"] == out["plain"] == out["generic"] == out["gather"]
+    # nohistory: the compositor's bin order from the list lengths instead of the previous frame's region times (scheduling only)
+    assert out["default"] and out["default"] == out["plain"] == out["generic"] == out["gather"] == out["nohistory"]
 
 
 def test_upload_transform_matches_oracle_bitwise(scene_small, ob):

@@ -123,6 +123,7 @@ struct CompositeArgs
 #endif
   float   depthIsoThreshold;
   int32_t shOnly;             // SHOW_SH_ONLY (mesh.slang:205-207): base colour 0.5
+  uint32_t* binCost;          // [256] per bin: the longest region of this frame (100 MHz ticks) -> the NEXT frame's bin order
   struct Inst
   {
     const void*   sh;

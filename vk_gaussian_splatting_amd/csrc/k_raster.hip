@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
                                                    const uint32_t* __restrict__ binTotal, uint32_t* __restrict__ binList,
                                                    uint2* __restrict__ ranges, FrameCounters* __restrict__ ctr,
                                                    uint32_t capacity, int binsX, int binsY, uint32_t* __restrict__ binOrder,
-                                                   const uint16_t* __restrict__ sortedCode16)
+                                                   const uint16_t* __restrict__ sortedCode16, uint32_t* __restrict__ binCost)
 {
   __shared__ uint64_t s_col[4][kDbRounds][kDbMaxDim], s_row[4][kDbRounds][kDbMaxDim];  // masks of every round
   __shared__ uint32_t s_cnt[4][256];  // per-wave counts, then per-wave write cursors
@@ -536,15 +536,27 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
   {
     // longest list first: the compositor hands its workgroups out in this bin order, so the regions with the most
     // to blend start early instead of forming the kernel's tail (binOrder[rank] = bin; ties by bin index)
+    // The order: by how long the bin's slowest region took in the PREVIOUS frame of this context (k_composite leaves it in
+    // binCost; consumed and cleared here) — the regions that never saturate are the long ones, and they are the same from one
+    // frame of a sequence to the next; scheduling only, the frame does not depend on it.  Without a history (first frame, the
+    // frame before was not composited by k_composite): longest list first.
     __shared__ uint32_t s_tot[256];
     const uint32_t btot = (t < nb) ? binTotal[t] : 0u;
-    s_tot[t] = btot;
+    uint32_t       cost = 0u;
+    if(binCost != nullptr && t < nb)
+    {
+      cost       = binCost[t];
+      binCost[t] = 0u;
+    }
+    const bool     history = __syncthreads_or(cost != 0u) != 0;
+    const uint32_t sortKey = history ? cost : btot;
+    s_tot[t] = sortKey;
     __syncthreads();
     if(t < nb)
     {
       uint32_t rank = 0;
       for(int u = 0; u < nb; ++u)
-        rank += (s_tot[u] > btot || (s_tot[u] == btot && u < t)) ? 1u : 0u;
+        rank += (s_tot[u] > sortKey || (s_tot[u] == sortKey && u < t)) ? 1u : 0u;
       binOrder[rank] = (uint32_t)t;
     }
     if(t == 0)
@@ -769,6 +781,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
                                                    const FrameArgs* __restrict__ Ap, float4* __restrict__ outNormal)
 {
   uint32_t statStaged = 0, statScanned = 0;
+  const uint64_t costT0 = wall_clock64();  // this region's duration feeds the next frame's bin order (F.binCost)
 #ifdef MGS_CMP_TRACE  // debug build (tools/cmp_trace.py): per-workgroup wall-clock stamps, 100 MHz
   const uint64_t traceT0 = wall_clock64();
   uint64_t       traceA = 0, traceS = 0, traceB = 0, traceLast;  // time spent in stage A / shading / blending
@@ -1190,6 +1203,10 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
   {  // frame statistics (mgs_frame_stats): two fire-and-forget adds per workgroup
     atomicAdd(&ctr->stagedSlots[blockIdx.x & 7], statStaged);
     atomicAdd(&ctr->scannedSlots[blockIdx.x & 7], statScanned);
+    // the bin's longest region, for the next frame of this context: regions that never saturate take twice as long as the
+    // others, and starting them late is the kernel's tail; which ones they are is the same from one frame to the next
+    if(F.binCost != nullptr)
+      atomicMax(&F.binCost[bin], (uint32_t)(wall_clock64() - costT0) + 1u);
   }
   const v2f aout = early ? (v2f){1.0f - T.x, 1.0f - T.y} : asum;
 #pragma unroll
@@ -1256,7 +1273,7 @@ bool directBinningSupported(int binsX, int binsY)
 void launchDirectBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
                          const uint32_t* rect, const uint16_t* sortedCode16, uint64_t* maskBuf, uint32_t maxSplats, uint32_t* binHist, uint32_t pStride,
                          uint32_t* binTotal, uint32_t* binList, uint2* ranges, FrameCounters* ctr, uint32_t capacity,
-                         int binsX, int binsY)
+                         int binsX, int binsY, uint32_t* binCost)
 {
   const uint32_t maxChunks = (maxSplats + kDbChunk - 1) / kDbChunk;
   if(maxChunks == 0)
@@ -1278,7 +1295,7 @@ void launchDirectBinning(hipStream_t stream, const uint32_t* idsX, const uint32_
   }
 #endif
   hipLaunchKernelGGL(k_dbin_emit, dim3(maxChunks), dim3(256), 0, stream, idsX, idsY, planKeys, maskBuf, binHist, pStride,
-                     binTotal, binList, ranges, ctr, capacity, binsX, binsY, binTotal + 256, sortedCode16);
+                     binTotal, binList, ranges, ctr, capacity, binsX, binsY, binTotal + 256, sortedCode16, binCost);
 #ifdef MGS_DB_TRACE
   if(tracePath)
   {
@@ -1303,7 +1320,7 @@ void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* 
 void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
                      const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, int halfOut,
                      int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId,
-                     const void* instTable, const FrameArgs* dArgs, float4* outNormal)
+                     const void* instTable, const FrameArgs* dArgs, float4* outNormal, uint32_t* binCost)
 {
   const FrameConst& F = A.f;
   if(F.stripRow1 <= F.stripRow0)
@@ -1325,6 +1342,7 @@ void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges
   C.nInstances = F.nInstances; C.shDegree = F.shDegree; C.looseMask = (F.debugFlags & 256) ? 1 : 0;
   C.depthIsoThreshold = F.depthIsoThreshold;
   C.shOnly     = (F.debugFlags & 2) ? 1 : 0;
+  C.binCost    = binCost;
   for(int i = 0; i < F.nInstances && i < kMaxInlineInstances; ++i)
   {
     C.inst[i].sh           = A.inst[i].sh;

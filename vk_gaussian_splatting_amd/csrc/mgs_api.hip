@@ -44,13 +44,13 @@ bool directBinningSupported(int binsX, int binsY);
 void launchDirectBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
                          const uint32_t* rect, const uint16_t* sortedCode16, uint64_t* maskBuf, uint32_t maxSplats, uint32_t* binHist, uint32_t pStride,
                          uint32_t* binTotal, uint32_t* binList, uint2* ranges, FrameCounters* ctr, uint32_t capacity,
-                         int binsX, int binsY);
+                         int binsX, int binsY, uint32_t* binCost);
 void launchTileRanges(hipStream_t stream, const uint32_t* keyX, const uint32_t* keyY, const SortPlan* planPairs,
                       uint2* ranges);
 void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges, const uint32_t* valX,
                      const uint32_t* valY, const SortPlan* planPairs, const SplatRec* rec, void* image, int halfOut,
                      int shFormat, FrameCounters* ctr, float* outDepth, uint32_t* outSplatId, const void* instTable, const FrameArgs* dArgs,
-                     float4* outNormal);
+                     float4* outNormal, uint32_t* binCost);
 void launchProjectGut(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, int shFormat, FrameCounters* ctr,
                       uint2* slotPairs, uint32_t* slotCount, GutRec* rec, uint32_t* rect,
                       uint32_t* slotHist2, uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan);
@@ -289,6 +289,7 @@ struct MgsScene_t
   DevBuf<uint32_t>      slotHist2, top16Rec, top16Count, osStatus;  // what the key sort needs besides (k_osort.hip)
   DevBuf<uint32_t>      slotCount, slotBase, part0;  // pairs per slot; their exclusive prefix; first slot of every sort partition
   DevBuf<uint16_t>      sortedCode16;                // the bin rectangles' codes in sorted order (they ride through the key sort)
+  DevBuf<uint32_t>      binCost;                     // [256] per bin: its slowest region in the last frame -> the next frame's bin order
   DevBuf<uint32_t>      keysA, idsA;  // the sorted ids (and, for the sort-only hook, the sorted keys)
   DevBuf<uint32_t>      rect, partHist, blockCount;
   DevBuf<uint32_t>      sortedRect, splatOffset, chunkStart;
@@ -733,7 +734,7 @@ void mgs_scene_destroy(MgsScene s)
     auto& h = s->d->handles;
     h.erase(std::remove(h.begin(), h.end(), s), h.end());
   }
-  s->pairA.release(); s->pairB.release(); s->slotCount.release(); s->slotBase.release(); s->part0.release(); s->sortedCode16.release(); s->slotHist2.release(); s->top16Rec.release(); s->top16Count.release();
+  s->pairA.release(); s->pairB.release(); s->slotCount.release(); s->slotBase.release(); s->part0.release(); s->sortedCode16.release(); s->binCost.release(); s->slotHist2.release(); s->top16Rec.release(); s->top16Count.release();
   s->osStatus.release(); s->keysA.release(); s->idsA.release(); s->rect.release(); s->partHist.release(); s->blockCount.release();
   s->rec.release(); s->recGut.release(); s->pairKey0.release(); s->pairVal0.release(); s->pairKey1.release(); s->pairVal1.release();
   s->sortedRect.release(); s->splatOffset.release(); s->chunkStart.release();
@@ -840,7 +841,7 @@ int mgs_scene_memory_usage(MgsScene s, uint64_t* sceneBytes, uint64_t* workingBy
   {
     uint64_t b = 0;
     auto add = [&](auto& buf) { b += (uint64_t)buf.n * sizeof(*buf.p); };
-    add(s->pairA); add(s->pairB); add(s->slotCount); add(s->slotBase); add(s->part0); add(s->sortedCode16); add(s->slotHist2); add(s->top16Rec); add(s->top16Count); add(s->osStatus); add(s->keysA); add(s->idsA); add(s->rect);
+    add(s->pairA); add(s->pairB); add(s->slotCount); add(s->slotBase); add(s->part0); add(s->sortedCode16); add(s->binCost); add(s->slotHist2); add(s->top16Rec); add(s->top16Count); add(s->osStatus); add(s->keysA); add(s->idsA); add(s->rect);
     add(s->partHist); add(s->blockCount); add(s->sortedRect); add(s->splatOffset); add(s->chunkStart);
     add(s->dbinMasks); add(s->fstate); add(s->surfDepth); add(s->surfId); add(s->surfNormal); add(s->accum); add(s->rec); add(s->recGut);
     add(s->pairKey0); add(s->pairVal0); add(s->pairKey1); add(s->pairVal1); add(s->ranges); add(s->image);
@@ -1244,6 +1245,8 @@ static int sizeWorkingSet(MgsScene s)
   if((rc = s->pairB.ensure(std::max<uint64_t>(total, parts * (uint64_t)kOsSlot)))) return rc;  // whole slots
   if((rc = s->slotCount.ensure(parts))) return rc;
   if((rc = s->sortedCode16.ensure(total))) return rc;
+  if((rc = s->binCost.ensure(256))) return rc;
+  HIPCHK(hipMemset(s->binCost.p, 0, 256 * 4));
   if((rc = s->slotBase.ensure(parts + 1))) return rc;
   if((rc = s->part0.ensure(((size_t)osSortMaxParts((uint32_t)total) + 1) * (1 + kOsWin)))) return rc;
   if((rc = s->idsA.ensure(total))) return rc;
@@ -1701,6 +1704,9 @@ static int pairSortBits(int nTiles)
 }
 
 
+// the compositor's bin order from the previous frame's region times (k_dbin_emit); MGS_BIN_HISTORY=0: longest list first (A/B)
+static const bool kBinHistory = [] { const char* e = std::getenv("MGS_BIN_HISTORY"); return e ? std::atoi(e) != 0 : true; }();
+
 // pass elision of the key sort (sort_plan.h): on by default, MGS_SORT_REMAP=0 keeps the four plain passes
 static const bool kRemap = [] { const char* e = std::getenv("MGS_SORT_REMAP"); return e ? std::atoi(e) != 0 : true; }();
 
@@ -2060,7 +2066,7 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     {
       launchDirectBinning(st, s->idsA.p, s->idsA.p, planK, s->rect.p, s->sortedCode16.p, s->dbinMasks.p, s->d->totalSplats,
                           s->partHist.p, s->pStride, &planP->ghist[0][0], s->pairVal1.p, s->ranges.p, ctr, s->pairCapacity,
-                          F.binsX, F.binsY);
+                          F.binsX, F.binsY, kBinHistory ? s->binCost.p : nullptr);
       if(withEvents) HIPCHK(hipEventRecord(fev[3], st));
     }
     else
@@ -2098,7 +2104,7 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     else
       launchComposite(st, A, s->ranges.p, s->pairVal1.p, s->pairVal0.p, planP, s->rec.p, s->image.p, half, s->d->shFormat, ctr,
                       F.surfaceOutputs ? s->surfDepth.p : nullptr, F.surfaceOutputs ? s->surfId.p : nullptr, s->d->compInst.p,
-                      s->dArgs.p, F.surfaceOutputs ? s->surfNormal.p : nullptr);
+                      s->dArgs.p, F.surfaceOutputs ? s->surfNormal.p : nullptr, kBinHistory ? s->binCost.p : nullptr);
     if(F.temporalSampling)
       hipLaunchKernelGGL(k_post_accumulate, dim3(2048), dim3(256), 0, st, s->dArgs.p, s->accum.p, s->image.p, half);
     if(withEvents) HIPCHK(hipEventRecord(fev[5], st));
