@@ -685,7 +685,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
 #pragma unroll
       for(int b = 0; b < 8; ++b)
       {
-        const uint32_t x   = (uint32_t)((int32_t)(d << (31 - b)) >> 31);
+        uint32_t x = (uint32_t)((int32_t)(d << (31 - b)) >> 31);
+        asm volatile("" : "+v"(x));  // the ballot compares x itself: left alone the compiler re-derives it from d (a shift per bit)
         const uint64_t bal = __ballot(x != 0u);
         mlo &= ~((uint32_t)bal ^ x);
         mhi &= ~((uint32_t)(bal >> 32) ^ x);
