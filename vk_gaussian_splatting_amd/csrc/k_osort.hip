@@ -688,8 +688,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
         uint32_t x = (uint32_t)((int32_t)(d << (31 - b)) >> 31);
         asm volatile("" : "+v"(x));  // the ballot compares x itself: left alone the compiler re-derives it from d (a shift per bit)
         const uint64_t bal = __ballot(x != 0u);
-        mlo &= ~((uint32_t)bal ^ x);
-        mhi &= ~((uint32_t)(bal >> 32) ^ x);
+        // m & ~(bal ^ x) in one v_bitop3 per half (truth table 0x90: a & !(b ^ c))
+        mlo = __builtin_amdgcn_bitop3_b32(mlo, (uint32_t)bal, x, 0x90);
+        mhi = __builtin_amdgcn_bitop3_b32(mhi, (uint32_t)(bal >> 32), x, 0x90);
       }
       const uint32_t lower = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
       const uint32_t cnt   = (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
