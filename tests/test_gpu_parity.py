@@ -724,6 +724,28 @@ def test_determinism_and_empty_view(scene_small):
     assert not scene.download_frame(p).any()
 
 
+def test_frames_do_not_depend_on_what_was_rendered_before(scene_small):
+    """the compositor takes its bins in the order of the previous frame's slowest regions (k_dbin_emit / k_composite: scheduling
+    only): a frame must be the same frame whatever its context rendered before — another pose, another size, a strip, nothing"""
+    scene, _ = scene_small
+    ctx = scene.frame_context()
+    frames = {}
+    for pose in (3, 11, 29):
+        p, *_ = camera(pose, 800, 448)
+        ctx.render(p)                      # a fresh context: no history for the first one
+        frames[pose] = ctx.download_frame(p).view(np.uint16).copy()
+    for pose, before in ((11, 29), (3, 11), (29, 3), (3, 3)):
+        pb, *_ = camera(before, 1280, 720)
+        scene.render(pb)                   # history from another size
+        pb2, *_ = camera(before, 800, 448)
+        pb2.strip_row_begin, pb2.strip_row_end = 4, 9
+        scene.render(pb2)                  # ... and from a strip
+        p, *_ = camera(pose, 800, 448)
+        scene.render(p)
+        assert np.array_equal(scene.download_frame(p).view(np.uint16), frames[pose]), (pose, before)
+    ctx.close()
+
+
 def test_cpu_async_sort_mode(scene_small, ob):
     """config[0] plumbing: CPU depth key + sort (SplatSorterAsync semantics), cull at raster"""
     scene, sc = scene_small
