@@ -297,8 +297,7 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
       return;
     }
   }
-  for(int i = threadIdx.x; i < 256; i += kGutThreads)
-    s_hist2[i] = 0u;
+  // (s_hist2: the hand-over's small tables, slot_emit.h)
   uint32_t key[kGutItems];
   uint64_t bal[kGutItems];
   bool     vis[kGutItems];
@@ -384,8 +383,19 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
   }
   __syncthreads();
   // second ordered compaction into the partition's slot + what the key sort needs up front (slot_emit.h)
-  emitSlot<kGutThreads, kGutItems>(Mv, false, s_li, s_key, s_cnt, s_base, s_hist2, slotPairs, slotCount, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
-                                   I.globalOffset + local0, rideShift, nullptr, s_code);
+  // (the record staging area is free now: 16 KB of it hold the grouped slot, 2 KB behind them the per-wave digit counts)
+  EmitLds E;
+  E.li    = s_li;
+  E.key   = s_key;
+  E.code  = rideShift != 0u ? s_code : nullptr;
+  E.stage = reinterpret_cast<uint2*>(&s_grec[0][0]);
+  E.whist = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(&s_grec[0][0]) + 16384);
+  E.hist1 = s_hist2;
+  E.start = reinterpret_cast<uint16_t*>(s_hist2 + 128);
+  E.cnt   = s_cnt;
+  static_assert(sizeof(s_grec) >= 16384 + 2048, "the hand-over's stage and counters live in the record staging area");
+  emitSlot<kGutThreads, kGutItems>(Mv, false, E, slotPairs, slotCount, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
+                                   I.globalOffset + local0, rideShift);
 }
 
 // world-space ray direction of the pixel whose centre is (pcx, pcy) (threedgut_raster.frag.slang:101-111); false: outside the

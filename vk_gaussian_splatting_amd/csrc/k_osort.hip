@@ -114,9 +114,15 @@ __device__ uint64_t* g_osPrepTrace = nullptr;  // [reduce workgroup][8]
 #define MGS_OS_STAMP(i)
 #endif
 // ---------------------------------------------------------------------------------------------------------------------
-// (b) prepare: the digit totals of all passes from what the producer left.
-// Grid: reduce workgroups of 1024 threads, 32 slots each .  A reduce workgroup
-//   * sums its slots' two-digit histograms into plan->total[0..1] (<= 512 atomics, one per non-empty bin);
+// (b) prepare: the digit totals of all passes and the tables of the virtual pass 0, from what the producer left.
+// Grid: reduce workgroups of 1024 threads, one per CHUNK of 32 slots.  A reduce workgroup
+//   * turns its slots' digit-0 group counts (slot_emit.h) into the chunk's part of the virtual pass 0: per digit-0 value d the
+//     chunk's total (chunkSum[chunk][d]) and, per slot, how many pairs of value d the chunk's earlier slots hold together with
+//     where the slot's group of d starts inside the slot (runTab[d][slot], 16 + 16 bits) — and adds the totals to
+//     plan->total[0];  the pair that a stable pass on bits 0-7 would put at position x of its output is then found from
+//     D[d] (scan of the totals), the prefix of chunkSum[.][d] and one runTab row segment, all of which the sort's first
+//     kernel reads for just the part of the order it owns (k_os_pass<3>).  Nothing here waits for another workgroup;
+//   * sums its slots' histograms of key bits 8-15 into plan->total[1] (<= 256 atomics, one per non-empty bin);
 //   * folds its slots' key >> 16 records (slot_emit.h: one 32-word record per producer wave: counts of the values lo..lo+24)
 //     in an LDS table and adds each occurring value ONCE to the 64 K-entry count table.  The producers do not touch that
 //     table themselves: thousands of partitions hold the same handful of values, and that many atomics on a few addresses
@@ -125,15 +131,11 @@ __device__ uint64_t* g_osPrepTrace = nullptr;  // [reduce workgroup][8]
 // The workgroup that finishes last (arrival counter) then owns the occurring range of the table: at most 256 values within a
 // span < 4096 -> pass 2 sorts on their rank and the table gives that pass's totals; otherwise plain digits for passes 2 and 3.
 // It clears what it read, so the table is clean for the next sort of this context.
-// One more workgroup (the last of the grid) works on the side: it turns the slots' counts into their positions in the dense
-// order the passes sort — slotBase[] = exclusive prefix of slotCount[]; part0[q] = the slot that holds pair 4096 q, where the
-// gather of dense partition q starts (k_os_pass); part0's second half, the partitions' WINDOWS: for the first kOsWin slots
-// from part0[q] on, where the slot starts relative to pair 4096 q (0x7FFFFFFF behind the last slot that starts inside the
-// partition) — what pass 0 needs to find every pair's slot with one load — and the frame's count of sorted pairs.
-__global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict__ slotHist2, const uint32_t* __restrict__ top16Rec, uint32_t prjParts,
+// One more workgroup (the last of the grid) sums the slots' counts: the frame's number of sorted pairs.
+__global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict__ slotHist, const uint32_t* __restrict__ top16Rec, uint32_t prjParts,
                                                      uint32_t* __restrict__ top16Count, OsPlan* __restrict__ plan, const uint32_t* __restrict__ nPtr,
                                                      int allowRemap, uint32_t reduceWgs, const uint32_t* __restrict__ slotCount,
-                                                     uint32_t* __restrict__ slotBase, uint32_t* part0, uint32_t winOffset,
+                                                     uint32_t* __restrict__ chunkSum, uint32_t* __restrict__ runTab,
                                                      uint32_t* __restrict__ nOut)
 {
   const int t = threadIdx.x, lane = laneId(), w = t >> 6;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
   if(t < 8) trc[t] = 0;
   MGS_OS_STAMP(0)
 #endif
-  if(slotHist2 == nullptr)
+  if(slotHist == nullptr)
   {  // uniform input (stand-alone sort): k_os_hist has the totals
     if(blockIdx.x == 0 && t == 0)
       plan->n = *nPtr;
@@ -150,81 +152,22 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
   }
   __shared__ uint32_t s_tab[2048];
   if(blockIdx.x == reduceWgs)
-  {  // thread t owns `per` consecutive slots (<= 4 up to 8.4 M splats: their counts stay in registers)
+  {
     __shared__ uint32_t s_scan[16];
-    const uint32_t per = (prjParts + 1023u) / 1024u, s0 = (uint32_t)t * per, s1 = min(prjParts, s0 + per);
-    uint32_t       cnt[4] = {0u, 0u, 0u, 0u};
-    uint32_t       sum = 0;
-    if(per <= 4u)
-    {
-#pragma unroll
-      for(uint32_t j = 0; j < 4u; ++j)
-        if(j < per && s0 + j < s1)
-          cnt[j] = slotCount[s0 + j];
-      sum = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-    }
-    else
-      for(uint32_t q = s0; q < s1; ++q)
-        sum += slotCount[q];
-    auto pick = [&](uint32_t j) { return j == 0u ? cnt[0] : (j == 1u ? cnt[1] : (j == 2u ? cnt[2] : cnt[3])); };  // no scratch
+    uint32_t sum = 0;
+    for(uint32_t q = t; q < prjParts; q += 1024u)
+      sum += slotCount[q];
     const uint32_t inc = waveInclusiveScan(sum);
     if(lane == 63)
       s_scan[w] = inc;
     __syncthreads();
-    uint32_t base = inc - sum, total = 0;
-    for(int q = 0; q < 16; ++q)
-    {
-      if(q < w) base += s_scan[q];
-      total += s_scan[q];
-    }
-    const uint32_t osParts = (uint32_t)(((uint64_t)total + kOsPart - 1u) / kOsPart);
-    const bool     inLds   = osParts <= 2048u;  // part0 is needed again below: kept in LDS when it fits
-    int32_t*       win     = reinterpret_cast<int32_t*>(part0 + winOffset);
-    for(uint32_t i = t; i < osParts * kOsWin; i += 1024u)
-      win[i] = 0x7FFFFFFF;
-    const uint32_t base0 = base;
-    for(uint32_t q = s0; q < s1; ++q)
-    {
-      const uint32_t c = per <= 4u ? pick(q - s0) : slotCount[q];
-      slotBase[q]      = base;
-      if(c)
-      {  // at most one multiple of 4096 in [base, base + c): c <= 2048
-        const uint32_t d = (base + kOsPart - 1u) / kOsPart;
-        if((uint64_t)d * kOsPart < (uint64_t)base + c)
-        {
-          part0[d] = q;
-          if(inLds)
-            s_tab[d] = q;
-        }
-      }
-      base += c;
-    }
     if(t == 0)
     {
-      slotBase[prjParts] = total;
-      plan->n            = total;
-      *nOut              = total;
-    }
-    // the windows need part0 complete.  From LDS behind a barrier; when it does not fit, from memory: behind a fence and with
-    // agent-scope loads (the stores went through this CU's L1 to the L2, a plain load could still hit a stale L1 line)
-    if(!inLds)
-      __threadfence();
-    __syncthreads();
-    base = base0;
-    for(uint32_t q = s0; q < s1; ++q)
-    {
-      const uint32_t c = per <= 4u ? pick(q - s0) : slotCount[q];
-      if(base < total)
-      {  // a slot belongs to the window of every partition it has pairs in; an empty one to the partition its successor starts in
-        const uint32_t d0 = base / kOsPart, d1 = c ? (base + c - 1u) / kOsPart : d0;
-        for(uint32_t d = d0; d <= d1; ++d)
-        {
-          const uint32_t k = q - (inLds ? s_tab[d] : ldAgent(&part0[d]));
-          if(k < kOsWin)
-            win[d * kOsWin + k] = (int32_t)(base - d * kOsPart);
-        }
-      }
-      base += c;
+      uint32_t total = 0;
+      for(int q = 0; q < 16; ++q)
+        total += s_scan[q];
+      plan->n = total;
+      *nOut   = total;
     }
     return;
   }
@@ -245,15 +188,21 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
     recHdr             = rp[31];
     recC               = *reinterpret_cast<const uint4*>(rp + recJ0);
   }
-  {  // two-digit histograms, two 16-bit counters per word: thread = (quarter of the slots, packed column)
-    const uint32_t col = t & 255u, quarter = t >> 8;
-    uint32_t       lo16 = 0, hi16 = 0;
+  {  // the slots' rows: thread = (packed column c: digits 2 c and 2 c + 1, group j of four consecutive slots)
+    __shared__ uint32_t s_grp[8][256];
+    const uint32_t c = (uint32_t)t & 127u, j = (uint32_t)t >> 7;
+    uint32_t       w0[4], w1[4], w2[4];
 #pragma unroll
-    for(uint32_t q = quarter; q < 32u; q += 4u)
+    for(int i = 0; i < 4; ++i)
     {
-      const uint32_t v = (slot0 + q < prjParts) ? slotHist2[(size_t)min(slot0 + q, prjParts - 1u) * 256u + col] : 0u;
-      lo16 += v & 0xFFFFu;
-      hi16 += v >> 16;
+      const uint32_t  sl  = slot0 + 4u * j + (uint32_t)i;
+      const uint32_t* row = slotHist + (size_t)min(sl, prjParts - 1u) * kSlotHistWords;
+      const bool      ok  = sl < prjParts;
+      w0[i]               = row[c];
+      w1[i]               = row[128u + c];
+      w2[i]               = row[256u + c];
+      if(!ok)
+        w0[i] = w1[i] = w2[i] = 0u;
     }
     s_tab[t]         = 0u;
     s_tab[t + 1024u] = 0u;
@@ -264,16 +213,51 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
       s_lo = 0xFFFFu;
       s_hi = 0u;
     }
+    uint32_t pLo[4], pHi[4], sLo = 0, sHi = 0, lo1 = 0, hi1 = 0;
+#pragma unroll
+    for(int i = 0; i < 4; ++i)
+    {
+      pLo[i] = sLo;
+      pHi[i] = sHi;
+      sLo += w0[i] & 0xFFFFu;
+      sHi += w0[i] >> 16;
+      lo1 += w1[i] & 0xFFFFu;
+      hi1 += w1[i] >> 16;
+    }
+    s_grp[j][2u * c]      = sLo;
+    s_grp[j][2u * c + 1u] = sHi;
     __syncthreads();
-    // packed column c holds bins 2 (c & 127) and 2 (c & 127) + 1 of digit c >> 7
-    const uint32_t bin0 = (col >> 7) * 256u + (col & 127u) * 2u;
-    if(lo16)
-      atomicAdd(&s_part[bin0], lo16);
-    if(hi16)
-      atomicAdd(&s_part[bin0 + 1u], hi16);
+    if(lo1)
+      atomicAdd(&s_part[256u + 2u * c], lo1);
+    if(hi1)
+      atomicAdd(&s_part[256u + 2u * c + 1u], hi1);
+    uint32_t bLo = 0, bHi = 0;
+#pragma unroll
+    for(uint32_t q = 0; q < 7u; ++q)
+      if(q < j)
+      {
+        bLo += s_grp[q][2u * c];
+        bHi += s_grp[q][2u * c + 1u];
+      }
+    if(j == 7u)
+    {  // the chunk's totals of digits 2 c and 2 c + 1
+      const uint32_t tLo = bLo + sLo, tHi = bHi + sHi;
+      *reinterpret_cast<uint2*>(&chunkSum[(size_t)blockIdx.x * 256u + 2u * c]) = make_uint2(tLo, tHi);
+      if(tLo)
+        atomicAdd(&plan->total[0][2u * c], tLo);
+      if(tHi)
+        atomicAdd(&plan->total[0][2u * c + 1u], tHi);
+    }
+    // (pairs of the value in the chunk's earlier slots: <= 31 x 2048, 16 bits) | (start of the value's group in its slot: <= 2048) << 16
+    const size_t spad = (size_t)reduceWgs * kOsChunk, col = (size_t)slot0 + 4u * j;
+    *reinterpret_cast<uint4*>(&runTab[(size_t)(2u * c) * spad + col]) =
+        make_uint4((bLo + pLo[0]) | (w2[0] << 16), (bLo + pLo[1]) | (w2[1] << 16), (bLo + pLo[2]) | (w2[2] << 16), (bLo + pLo[3]) | (w2[3] << 16));
+    *reinterpret_cast<uint4*>(&runTab[(size_t)(2u * c + 1u) * spad + col]) =
+        make_uint4((bHi + pHi[0]) | (w2[0] & 0xFFFF0000u), (bHi + pHi[1]) | (w2[1] & 0xFFFF0000u), (bHi + pHi[2]) | (w2[2] & 0xFFFF0000u),
+                   (bHi + pHi[3]) | (w2[3] & 0xFFFF0000u));
     __syncthreads();
-    if(t < 512 && s_part[t])
-      atomicAdd(&plan->total[t >> 8][t & 255u], s_part[t]);
+    if(t >= 256 && t < 512 && s_part[t])
+      atomicAdd(&plan->total[1][t & 255u], s_part[t]);
   }
   MGS_OS_STAMP(1)
   // key >> 16 records of the 32 slots x 4 producer waves: header word 31 = lo | span << 16 (0xFFFFFFFF: nothing to fold)
@@ -301,7 +285,7 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
   for(uint32_t b = t; b < 2048u; b += 1024u)
     if(s_tab[b])
       atomicAdd(&top16Count[s_lo + b], s_tab[b]);
-  if(t == 0 && s_hi >= s_lo && s_lo != 0xFFFFu)
+  if(t == 0 && s_hi >= s_lo)  // (s_lo = 0xFFFF, s_hi = 0 is the empty state: 0xFFFF itself is a legal value of key >> 16)
   {  // occurring range over all workgroups (the plan is zeroed per sort: both as maxima)
     atomicMax(&plan->top16MinInv, 0x10000u - s_lo);
     atomicMax(&plan->top16MaxP1, s_hi + 1u);
@@ -425,19 +409,26 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// (c) one pass.  IN: 0 dense pairs (the output of the pass before), 1 the project kernels' slots (pass 0 of a frame: dense
-// partition p = pairs [4096 p, 4096 p + count) of the concatenation of the slots, gathered through slotBase / part0),
-// 2 split key / value arrays (pass 0 of the stand-alone sort).
+// (c) one pass.  IN: 0 dense pairs (the output of the pass before); 2 split key / value arrays (pass 0 of the stand-alone sort);
+// 3 the project kernels' slots, read in the order a stable pass on key bits 0-7 WOULD have left them in ("virtual pass 0": the
+// first kernel of a frame's sort sorts on bits 8-15).  Dense partition p = positions [4096 p, 4096 p + count) of that order.
+// Position x holds a pair of digit-0 value d = the one with D[d] <= x < D[d + 1] (D = exclusive scan of plan->total[0]); within
+// d the slots follow each other, each with its group of d (slot_emit.h), so with c = the chunk of 32 slots and s the slot that
+// x - D[d] falls into: x = D[d] + (sum of chunkSum[c'][d], c' < c) + runTab[d][s].low16 + i, and the pair is entry
+// runTab[d][s].high16 + i of slot s.  The workgroup expands exactly the runs that overlap its partition into a 4096-entry
+// source table in LDS (one prefix scan over the chunks per digit value it touches — usually one or two —, then one coalesced
+// read of the runTab segment) and gathers: loads of <= 8-byte runs of ~6 pairs instead of round 3's contiguous reads, but
+// everything else of a pass 0 — ranking, look-back, re-order, scatter, 67 MB of traffic — is not done at all.
 struct OsPassArgs
 {
 #ifdef MGS_OS_TRACE
   uint64_t* trace;  // [partition][8]
 #endif
   const uint2*    srcPairs;
-  const uint32_t* slotBase;  // IN 1: [slots + 1] exclusive prefix of the slots' counts
-  const uint32_t* part0;     // IN 1: [partitions] the slot holding the first pair of every dense partition, and at winOffset ...
-  uint32_t        winOffset; // ... [partitions][kOsWin]: where the first kOsWin slots from there on start, relative to the partition
-  uint32_t        slots;
+  const uint32_t* chunkSum;  // IN 3: [chunks][256]
+  const uint32_t* runTab;    // IN 3: [256][32 chunks]
+  uint32_t        chunks;
+  uint32_t        srcLimit;  // IN 3: the last valid pair index (a corrupted table must not turn into a wild read)
   // the bin rectangles' codes ride above the ids (kernels_common.h: rideEncode); the final pass of a frame separates them:
   // clean ids for everybody, the codes in sorted order for the binning stage
   uint32_t        rideShift;   // bits of the id proper; 0 = nothing rides
@@ -482,15 +473,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
 #endif
   const uint32_t p = blockIdx.x;  // partitions in dispatch order (header: why no ticket)
   const uint32_t n = *a.nPtr;
-  // IN 1: what locates this partition's pairs in the project kernels' slots (below) is fetched first of all: the pairs' own
-  // loads depend on it, and its round trip passes behind the set-up
-  [[maybe_unused]] int32_t  winMine  = 0;
-  [[maybe_unused]] uint32_t winFirst = 0;
-  if constexpr(IN == 1)
-  {
-    winMine  = reinterpret_cast<const int32_t*>(a.part0 + a.winOffset)[(size_t)p * kOsWin + (lane & (kOsWin - 1))];
-    winFirst = a.part0[p];
-  }
   // clear look-back words for a later pass (stream order: nobody reads them any more)
   for(uint32_t i = blockIdx.x * kThreads + t; i < a.zWords; i += gridDim.x * kThreads)
     a.zStatus[i] = 0u;
@@ -529,99 +511,120 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
   const uint32_t wofs   = w * 64u * rounds;
   uint32_t       key[kKpt], val[kKpt];
   MGS_OS_STAMP(1)
-  // IN 1: the slots that hold this partition's pairs.  Pair idx of the partition is pair idx - w[i] of slot first + i, where
-  // w[i] = slotBase[first + i] - 4096 p (<= 0 for i = 0) and i is the last slot that starts at or before idx (slots that are
-  // empty share their start with their successor and lose the comparison).  Usually the window is a handful of slots and
-  // k_os_prepare's table has all of it: one 32-byte load per wave, the search is seven compares.  A longer window (a strip of a
-  // multi-GPU frame leaves most slots nearly empty) is read from slotBase into s_pair (unused until the re-order; a barrier lies
-  // between) and searched there.
-  [[maybe_unused]] int32_t* s_win = reinterpret_cast<int32_t*>(s_pair);
-  [[maybe_unused]] uint32_t winLen = 0;
-  [[maybe_unused]] int32_t  wq[kOsWin];
-  [[maybe_unused]] bool     winShort = false;
-  if constexpr(IN == 1)
+  // IN 3: the source table of the virtual pass 0 (header of OsPassArgs).  s_pair is not in use before the re-order:
+  // its first half holds the table, its second half the chunk prefixes of the digit value being expanded.
+  [[maybe_unused]] uint32_t srcAt[IN == 3 ? kKpt : 1];
+  if constexpr(IN == 3)
   {
-    const uint32_t start = p * kOsPart, end = start + count;
-#pragma unroll
-    for(int k = 0; k < (int)kOsWin; ++k)
-      wq[k] = __builtin_amdgcn_readlane(winMine, k);
-    winShort = wq[kOsWin - 1] >= (int32_t)count;  // the table reaches the partition's end (0x7FFFFFFF behind the last slot)
-    if(!winShort)
-    {
-      if(t == 0)
-        s_tmp[4] = 0xFFFFFFFFu;
-      __syncthreads();
-      for(uint32_t c0 = 0; c0 < 2u * kOsPart; c0 += kThreads)
-      {  // (a table of 8192 slots is 32 KB == s_pair; a partition of 4096 pairs that needs more slots than that takes the
-         // slow path below)
-        const uint32_t i = c0 + (uint32_t)t, sl = winFirst + i;
-        const uint32_t b = sl <= a.slots ? a.slotBase[sl] : 0xFFFFFFFFu;
-        s_win[i]         = (int32_t)(b - start);
-        if(b >= end)
-          atomicMin(&s_tmp[4], i);
-        if(__syncthreads_or(b >= end ? 1 : 0))
-          break;
-      }
-      winLen = s_tmp[4];  // 0xFFFFFFFF: not within the table
-    }
-  }
-  // IN 1: where every pair of the partition lies, computed for all of them BEFORE the first load is issued (the three ways to
-  // find the slot are branches; loads behind a branch each wait for their own arrival)
-  [[maybe_unused]] uint32_t srcAt[IN == 1 ? kKpt : 1];
-  if constexpr(IN == 1)
-  {
-    if(winShort)
-    {
-#pragma unroll
-      for(int i = 0; i < kKpt; ++i)
+    uint32_t* s_src = reinterpret_cast<uint32_t*>(s_pair);  // [4096] pair index (slot * 2048 + entry) of every position of the partition
+    uint32_t* s_cp  = s_src + kOsPart;                      // [kCpTile + 1] exclusive prefix of chunkSum[.][d] over a tile of chunks
+    constexpr uint32_t kCpTile = 2048;                      // chunks per tile (8 per thread)
+    const uint32_t a0 = p * kOsPart, e0 = a0 + count;
+    // D: thread t == digit-0 value t
+    const uint32_t tot0 = plan->total[0][t];
+    const uint32_t Dt   = scan256(tot0, s_tmp);
+    s_cnt[t]            = Dt;  // (s_cnt is free until the scatter)
+    if(tot0 != 0u && Dt <= a0 && a0 < Dt + tot0)
+      s_tmp[5] = (uint32_t)t;  // the value the partition starts in (a0 < n: exactly one thread)
+    __syncthreads();
+    const uint32_t spad = a.chunks * kOsChunk;
+    for(uint32_t d = s_tmp[5]; d < 256u; ++d)
+    {  // uniform: the digit-0 values whose range [Dd, De) overlaps [a0, e0)
+      const uint32_t Dd = s_cnt[d], De = d < 255u ? s_cnt[d + 1u] : n;
+      if(Dd >= e0)
+        break;
+      if(De <= a0 || De == Dd)
+        continue;
+      uint32_t carry = Dd;  // position of the first pair of value d in the tile's first chunk
+      for(uint32_t c0 = 0; c0 < a.chunks && carry < e0; c0 += kCpTile)
       {
-        const uint32_t idx = min(wofs + (uint32_t)i * 64u + lane, count - 1u);
-        uint32_t       lo  = 0;
-        int32_t        wl  = wq[0];
+        // prefix over the tile's chunks: thread t owns 8 consecutive ones
+        uint32_t cs[8], sum = 0;
 #pragma unroll
-        for(int k = 1; k < (int)kOsWin; ++k)
+        for(int k = 0; k < 8; ++k)
         {
-          const bool in = wq[k] <= (int32_t)idx;
-          lo            = in ? (uint32_t)k : lo;
-          wl            = in ? wq[k] : wl;
+          const uint32_t c = c0 + 8u * (uint32_t)t + (uint32_t)k;
+          cs[k]            = c < a.chunks ? a.chunkSum[(size_t)c * 256u + d] : 0u;
         }
-        srcAt[i] = lo * kOsSlot + (idx - (uint32_t)wl);
+#pragma unroll
+        for(int k = 0; k < 8; ++k)
+          sum += cs[k];
+        const uint32_t ex = scan256(sum, s_tmp);  // exclusive over the threads (two barriers: the table below is not read before)
+        uint32_t       run = ex;
+#pragma unroll
+        for(int k = 0; k < 8; ++k)
+        {
+          s_cp[8 * t + k] = run;
+          run += cs[k];
+        }
+        if(t == kThreads - 1)
+          s_cp[kCpTile] = run;  // the tile's total
+        if(t == 0)
+        {
+          s_tmp[6] = 0xFFFFFFFFu;  // first / last chunk of the tile with pairs inside [a0, e0)
+          s_tmp[7] = 0u;
+        }
+        __syncthreads();
+        {
+          uint32_t r2 = ex;
+#pragma unroll
+          for(int k = 0; k < 8; ++k)
+          {
+            const uint32_t lo = carry + r2, hi = lo + cs[k];
+            if(cs[k] != 0u && lo < e0 && hi > a0)
+            {
+              atomicMin(&s_tmp[6], 8u * (uint32_t)t + (uint32_t)k);
+              atomicMax(&s_tmp[7], 8u * (uint32_t)t + (uint32_t)k + 1u);
+            }
+            r2 += cs[k];
+          }
+        }
+        __syncthreads();
+        const uint32_t cA = s_tmp[6], cB = s_tmp[7];  // [cA, cB) relative to the tile; cB == 0: none
+        const uint32_t tileTotal = s_cp[kCpTile];
+        if(cB != 0u)
+        {
+          const uint32_t entries = (cB - cA) * kOsChunk;
+          const uint32_t* row    = a.runTab + (size_t)d * spad + (size_t)(c0 + cA) * kOsChunk;
+          for(uint32_t i0 = 0; i0 < entries; i0 += kThreads)
+          {  // lane == run: 32 consecutive lanes hold a chunk's 32 slots
+            const uint32_t i   = i0 + (uint32_t)t;
+            const uint32_t ic  = min(i, entries - 1u);
+            const uint32_t v   = row[ic];
+            const uint32_t cl  = cA + ic / kOsChunk;  // chunk within the tile
+            const uint32_t inC = v & 0xFFFFu;
+            const uint32_t nxt = (uint32_t)__shfl_down((int)inC, 1, 64);
+            const uint32_t len = ((ic & (kOsChunk - 1u)) == kOsChunk - 1u ? s_cp[cl + 1u] - s_cp[cl] : nxt) - inC;
+            const uint32_t R   = carry + s_cp[cl] + inC;  // position of the run's first pair
+            uint32_t       lo  = max(R, a0), hi = min(R + len, e0);
+            if(i >= entries || hi <= lo)
+              lo = hi = 0u;
+            const uint32_t src = ((c0 + cl) * kOsChunk + (ic & (kOsChunk - 1u))) * kOsSlot + (v >> 16);  // the run's first pair
+            // short runs (the rule: ~6 pairs) are written by their lane; long ones by the wave together
+            const bool     big = hi - lo > 16u;
+            if(!big)
+              for(uint32_t x = lo; x < hi; ++x)
+                s_src[x - a0] = src + (x - R);
+            uint64_t bm = __ballot(big);
+            while(bm != 0ull)
+            {
+              const int      l   = (int)__builtin_ctzll(bm);
+              bm &= bm - 1ull;
+              const uint32_t loL = (uint32_t)__builtin_amdgcn_readlane((int)lo, l), hiL = (uint32_t)__builtin_amdgcn_readlane((int)hi, l);
+              const uint32_t dl  = (uint32_t)__builtin_amdgcn_readlane((int)(src - R), l);
+              for(uint32_t x = loL + (uint32_t)lane; x < hiL; x += 64u)
+                s_src[x - a0] = dl + x;
+            }
+          }
+        }
+        carry += tileTotal;
+        __syncthreads();  // s_cp / s_tmp are rewritten by the next tile or digit value
       }
     }
-    else if(winLen != 0xFFFFFFFFu)
-    {
-      for(int i = 0; i < kKpt; ++i)
-      {
-        const uint32_t idx = min(wofs + (uint32_t)i * 64u + lane, count - 1u);
-        uint32_t       lo = 0, hi = winLen;  // s_win[lo] <= idx < s_win[hi] throughout
-        while(hi - lo > 1u)
-        {
-          const uint32_t mid = (lo + hi) >> 1;
-          if(s_win[mid] <= (int32_t)idx)
-            lo = mid;
-          else
-            hi = mid;
-        }
-        srcAt[i] = lo * kOsSlot + (idx - (uint32_t)s_win[lo]);
-      }
-    }
-    else
-    {  // more than 8192 slots for 4096 pairs: search the prefix array itself
-      for(int i = 0; i < kKpt; ++i)
-      {
-        const uint32_t e  = p * kOsPart + min(wofs + (uint32_t)i * 64u + lane, count - 1u);
-        uint32_t       lo = 0, hi = a.slots - winFirst;
-        while(hi - lo > 1u)
-        {
-          const uint32_t mid = (lo + hi) >> 1;
-          if(a.slotBase[winFirst + mid] <= e)
-            lo = mid;
-          else
-            hi = mid;
-        }
-        srcAt[i] = lo * kOsSlot + (e - a.slotBase[winFirst + lo]);
-      }
-    }
+    __syncthreads();
+#pragma unroll
+    for(int i = 0; i < kKpt; ++i)
+      srcAt[i] = min(s_src[min(wofs + (uint32_t)i * 64u + lane, count - 1u)], a.srcLimit);
   }
   // clamped, not predicated: a predicated load becomes a branch + wait and serialises the fetches
 #pragma unroll
@@ -639,7 +642,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
       }
       else
       {
-        const uint2 kv = IN == 1 ? a.srcPairs[(size_t)winFirst * kOsSlot + srcAt[IN == 1 ? i : 0]] : a.srcPairs[(size_t)p * kOsPart + idx];
+        const uint2 kv = IN == 3 ? a.srcPairs[srcAt[IN == 3 ? i : 0]] : a.srcPairs[(size_t)p * kOsPart + idx];
         key[i] = kv.x;
         val[i] = kv.y;
       }
@@ -918,8 +921,8 @@ void launchOsSortClearPlan(hipStream_t stream, OsPlan* plan)
 
 void launchOsSort(hipStream_t stream, const OsLaunch& L)
 {
-  if(L.maxElems == 0)
-    return;
+  if(L.maxElems == 0 || (uint64_t)L.maxElems >= kOsMaxPairs)
+    return;  // (the callers reject / re-route 2^30 pairs and more: a prefix would wrap inside its status word)
   const bool     frame    = L.pairs0 != nullptr;  // the project kernels' slots of pairs + their histograms / records
   const uint32_t maxParts = osSortMaxParts(L.maxElems);
   const uint32_t sWords   = (uint32_t)osSortStatusWords(maxParts);
@@ -947,11 +950,11 @@ void launchOsSort(hipStream_t stream, const OsLaunch& L)
 #endif
   if(!frame)
     hipLaunchKernelGGL(k_os_hist, dim3(std::min<uint32_t>((L.maxElems + 2047u) / 2048u, 1024u)), dim3(256), 0, stream, L.keys0, L.nPtr, L.plan);
-  const uint32_t reduceWgs = frame ? (L.prjParts + 31u) / 32u : 0u;
-  hipLaunchKernelGGL(k_os_prepare, dim3(reduceWgs + 1u), dim3(1024), 0, stream, frame ? L.slotHist2 : nullptr, L.top16Rec, L.prjParts,
-                     L.top16Count, L.plan, L.nPtr, (frame && L.allowRemap) ? 1 : 0, reduceWgs, L.slotCount, L.slotBase, L.part0, maxParts + 1u,
-                     L.nOut);
-  for(int pass = 0; pass < 4; ++pass)
+  const uint32_t reduceWgs = frame ? osSortChunks(L.prjParts) : 0u;
+  hipLaunchKernelGGL(k_os_prepare, dim3(reduceWgs + 1u), dim3(1024), 0, stream, frame ? L.slotHist : nullptr, L.top16Rec, L.prjParts,
+                     L.top16Count, L.plan, L.nPtr, (frame && L.allowRemap) ? 1 : 0, reduceWgs, L.slotCount, L.chunkSum, L.runTab, L.nOut);
+  // A frame's sort starts at pass 1: its pass 0 is virtual (slot_emit.h, OsPassArgs).
+  for(int pass = frame ? 1 : 0; pass < 4; ++pass)
   {
     OsPassArgs a{};
 #ifdef MGS_OS_TRACE
@@ -959,23 +962,43 @@ void launchOsSort(hipStream_t stream, const OsLaunch& L)
 #endif
     a.plan    = L.plan;
     a.planOut = L.planOut;
-    const int set = pass == 3 ? 1 : pass;
+    // look-back words.  Stand-alone sort: pass 0 uses set 0, 1 -> 1, 2 -> 2, 3 -> 1 again; pass 0 clears sets 1 and 2 (whatever the
+    // previous sort left there, whether its pass 3 ran or not), pass 1 clears set 0 for the next sort, pass 2 clears set 1 for
+    // pass 3.  Frame: pass 1 uses set 0 and clears sets 1 and 2, pass 2 uses set 1 and clears set 0, pass 3 uses set 2.
+    const int set = frame ? pass - 1 : (pass == 3 ? 1 : pass);
     a.status  = st[set];
     a.gstatus = gOf(st[set]);
-    a.zStatus = pass == 1 ? st[0] : st[1];
-    a.zWords  = pass == 0 ? 2u * sWords : (pass == 3 ? 0u : sWords);
+    if(frame)
+    {
+      a.zStatus = pass == 1 ? st[1] : st[0];
+      a.zWords  = pass == 1 ? 2u * sWords : (pass == 2 ? sWords : 0u);
+    }
+    else
+    {
+      a.zStatus = pass == 1 ? st[0] : st[1];
+      a.zWords  = pass == 0 ? 2u * sWords : (pass == 3 ? 0u : sWords);
+    }
     a.nPtr    = L.nPtr;
     a.ctr     = L.ctr;
     a.pass    = pass;
     a.dstKeys = L.outKeys;
     a.dstVals = L.outVals;
-    // pass 0 -> A, 1 -> B, 2 -> A (or the result), 3 -> the result.  A frame's pass 0 gathers from the project kernels' slots, which live in B.
-    a.srcPairs  = (pass == 0) ? L.pairs0 : ((pass & 1) ? L.pairA : L.pairB);
-    a.dstPairs  = (pass & 1) ? L.pairB : L.pairA;
-    a.slotBase  = L.slotBase;
-    a.part0     = L.part0;
-    a.winOffset = maxParts + 1u;
-    a.slots     = L.prjParts;
+    // stand-alone: pass 0 -> A, 1 -> B, 2 -> A, 3 -> the result.  Frame: pass 1 reads the project kernels' slots, which live in B,
+    // -> A, 2 -> B (or the result), 3 -> the result.
+    if(frame)
+    {
+      a.srcPairs = pass == 1 ? L.pairs0 : (pass == 2 ? L.pairA : L.pairB);
+      a.dstPairs = pass == 1 ? L.pairA : L.pairB;
+    }
+    else
+    {
+      a.srcPairs = (pass & 1) ? L.pairA : L.pairB;
+      a.dstPairs = (pass & 1) ? L.pairB : L.pairA;
+    }
+    a.chunkSum  = L.chunkSum;
+    a.runTab    = L.runTab;
+    a.chunks    = reduceWgs;
+    a.srcLimit  = L.prjParts * kOsSlot - 1u;
     a.rideShift = frame ? L.rideShift : 0u;
     a.rideInfo  = L.rideInfo;
     a.dstCode16 = L.outCode16;
@@ -986,10 +1009,10 @@ void launchOsSort(hipStream_t stream, const OsLaunch& L)
     const uint32_t grid = maxParts;
     if(grid == 0)
       continue;
-    if(pass == 0 && !frame)
+    if(pass == 0)
       hipLaunchKernelGGL((k_os_pass<2, false>), dim3(grid), dim3(kThreads), 0, stream, a);
-    else if(pass == 0)
-      hipLaunchKernelGGL((k_os_pass<1, false>), dim3(grid), dim3(kThreads), 0, stream, a);
+    else if(pass == 1 && frame)
+      hipLaunchKernelGGL((k_os_pass<3, false>), dim3(grid), dim3(kThreads), 0, stream, a);
     else if(pass == 2 && frame)
       hipLaunchKernelGGL((k_os_pass<0, true>), dim3(grid), dim3(kThreads), 0, stream, a);
     else

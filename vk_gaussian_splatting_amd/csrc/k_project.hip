@@ -209,12 +209,26 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   if(threadIdx.x < 8) trc[threadIdx.x] = 0;
   MGS_PRJ_STAMP(0)
 #endif
-  __shared__ uint32_t s_hist2[256];  // 2 x 256 sixteen-bit counters: the survivors by key bits 0-7 and 8-15 (slot_emit.h)
-  __shared__ float4   s_rec[FULL ? kPrjWaves : 1][FULL ? 64 * 3 : 1];  // per wave: 64 records at a 48-byte pitch
-  __shared__ uint16_t s_li[kPrjPart];   // bit 15: survived phase 2
-  __shared__ uint32_t s_key[kPrjPart];
+  // One block of LDS, carved by hand, because the hand-over re-uses it (slot_emit.h: EmitLds):
+  //   [0, 12 K)  s_rec   per wave: 64 records at a 48-byte pitch (phase 2)  | hand-over: the codes [0, 4 K), the per-wave digit
+  //   [12, 16 K) s_li    bit 15: survived phase 2                           | counts [4 K, 6 K), then — [0, 16 K) — the slot itself
+  //   [16, 24 K) s_key
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[12288 + 4096 + 8192];
+  float4(*s_rec)[64 * 3] = reinterpret_cast<float4(*)[64 * 3]>(s_raw);
+  uint16_t* s_li         = reinterpret_cast<uint16_t*>(s_raw + 12288);
+  uint32_t* s_key        = reinterpret_cast<uint32_t*>(s_raw + 16384);
+  __shared__ uint32_t s_small[256];  // hand-over: counts of key bits 8-15 [128 words], starts of the digit-0 groups [256 x 16 bit]
   __shared__ uint32_t s_cnt[32];
   __shared__ uint32_t s_base[33];
+  EmitLds E;
+  E.li    = s_li;
+  E.key   = s_key;
+  E.code  = reinterpret_cast<const uint16_t*>(s_raw);
+  E.whist = reinterpret_cast<uint16_t*>(s_raw + 4096);
+  E.hist1 = s_small;
+  E.start = reinterpret_cast<uint16_t*>(s_small + 128);
+  E.stage = reinterpret_cast<uint2*>(s_raw);
+  E.cnt   = s_cnt;
 
   const int      t = threadIdx.x, lane = laneId(), w = t >> 6;
   const uint32_t part = blockIdx.x;
@@ -246,8 +260,6 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
     emitEmptySlot<kPrjThreads>(slotCount, slotHist2, top16Rec, part);
     return;
   }
-  for(int i = threadIdx.x; i < 256; i += kPrjThreads)
-    s_hist2[i] = 0u;  // ordered before its first use by the barriers of phase 1
   uint32_t key[kPrjItems];
   uint64_t bal[kPrjItems];
   bool     vis[kPrjItems];
@@ -329,8 +341,8 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   if constexpr(!FULL)
   {
     // sort-only hook: survivors of the dist stage, exactly dist.comp.slang's (key, id) stream
-    emitSlot<kPrjThreads, kPrjItems>(M, true, s_li, s_key, s_cnt, s_base, s_hist2, slotPairs, slotCount, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
-                                     I.globalOffset + local0);
+    E.code = nullptr;
+    emitSlot<kPrjThreads, kPrjItems>(M, true, E, slotPairs, slotCount, slotHist2, top16Rec, top16Count, osPlan, ctr, part, I.globalOffset + local0);
     return;
   }
   else
@@ -399,11 +411,18 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
     // the codes' slots are counted from the LAST of eight rounds: the rounds behind the survivors only shift
     for(uint32_t j0 = (M + kPrjThreads - 1u) / kPrjThreads * kPrjThreads; j0 < (uint32_t)kPrjPart; j0 += kPrjThreads)
       codes.push(0u);
-    // ---- second ordered compaction straight into the partition's slot region (slot_emit.h) ----
-    __syncthreads();
+    // ---- the survivors, grouped by the low byte of their keys, into the partition's slot (slot_emit.h) ----
+    __syncthreads();  // phase 2 is over: s_rec is free
     MGS_PRJ_STAMP(4)
-    const uint32_t outCount = emitSlot<kPrjThreads, kPrjItems>(M, false, s_li, s_key, s_cnt, s_base, s_hist2, slotPairs, slotCount, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
-                                                               I.globalOffset + local0, rideShift, &codes);
+    if(rideShift != 0u)
+    {  // the codes leave their registers for the hand-over, which deals the candidates out anew (wave-contiguous)
+      uint16_t* s_code = reinterpret_cast<uint16_t*>(s_raw);
+#pragma unroll
+      for(int r = 0; r < kPrjItems; ++r)
+        s_code[r * kPrjThreads + t] = (uint16_t)codes.get(r);
+    }
+    const uint32_t outCount = emitSlot<kPrjThreads, kPrjItems>(M, false, E, slotPairs, slotCount, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
+                                                               I.globalOffset + local0, rideShift);
     (void)outCount;
 #ifdef MGS_PRJ_TRACE
     MGS_PRJ_STAMP(5)

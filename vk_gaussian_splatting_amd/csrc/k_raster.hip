@@ -1097,8 +1097,10 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
           const float4 a1 = s_a[j], b1 = s_b[j], c1 = s_c[j];
           const v2f    s1 = lx * b1.x + (ly * b1.y + a1.x), u1 = lx * b1.z + (ly * b1.w + a1.y);
           const v2f    q  = s1 * s1 + u1 * u1;  // == (A/2) * log2 e of frag.slang:236
-          if(!early && waveSat)
-          {  // saturated wave in MGS_ALPHA_SUM mode: the fragment only adds its alpha
+          if(!early && !surf && waveSat)
+          {  // saturated wave in MGS_ALPHA_SUM mode: the fragment only adds its alpha.  (Not with surface outputs: the depth /
+             // id pick fires when T crosses depth_iso_threshold, which may lie below 1e-4 — T has to keep falling there, as in
+             // the reference, the oracle and the default mode's full path.)
             if(noGauss)
             {
               asum.x += (q.x <= a1.z) ? 1.0f : 0.0f;
@@ -1186,7 +1188,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
     const int allFlag = __syncthreads_and((early ? waveDone : waveSat) ? 1 : 0);
     MGS_TRACE_PHASE(traceB)
     const bool allDone = early && allFlag != 0;
-    allSat             = !early && allFlag != 0;
+    allSat             = !early && !surf && allFlag != 0;  // (surface outputs: the records' depth and normal stay needed)
     if(allDone || hi <= range.x)
       break;
   }

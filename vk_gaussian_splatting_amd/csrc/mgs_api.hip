@@ -287,7 +287,7 @@ struct MgsScene_t
   DevBuf<uint2>         pairA, pairB;  // ping-pong of the key sort; the project kernels leave their (key, id) pairs in B, one
                                        // slot of 2048 entries per partition
   DevBuf<uint32_t>      slotHist2, top16Rec, top16Count, osStatus;  // what the key sort needs besides (k_osort.hip)
-  DevBuf<uint32_t>      slotCount, slotBase, part0;  // pairs per slot; their exclusive prefix; first slot of every sort partition
+  DevBuf<uint32_t>      slotCount, chunkSum, runTab;  // pairs per slot; the tables of the sort's virtual pass 0 (k_os_prepare)
   DevBuf<uint16_t>      sortedCode16;                // the bin rectangles' codes in sorted order (they ride through the key sort)
   DevBuf<uint32_t>      binCost;                     // [256] per bin: its slowest region in the last frame -> the next frame's bin order
   DevBuf<uint32_t>      keysA, idsA;  // the sorted ids (and, for the sort-only hook, the sorted keys)
@@ -296,7 +296,14 @@ struct MgsScene_t
   DevBuf<uint64_t>      dbinMasks;
   DevBuf<FrameState>    fstate;      // counters + plans + this frame's constants: one block, one upload per frame (FrameState)
   DevView<FrameArgs>    dArgs;       // = &fstate->args
-  std::vector<uint8_t>  hostFrame;   // the upload's source: zeros for counters and plans, then the constants
+  // the upload's source: zeros for counters and plans, then the constants.  Pinned, a ring of four guarded by events: the copy
+  // is asynchronous for real (nothing is staged behind the caller's back), and a buffer is rewritten only after the copy
+  // that read it has completed — with several frames in flight a late read would hand one frame the constants of another
+  static constexpr int kUpRing = 4;
+  uint8_t*              upBuf[kUpRing] = {};
+  hipEvent_t            upEv[kUpRing]  = {};
+  bool                  upBusy[kUpRing] = {};
+  uint32_t              upNext = 0;
   struct GraphKey
   {
     int32_t v[16];
@@ -734,7 +741,7 @@ void mgs_scene_destroy(MgsScene s)
     auto& h = s->d->handles;
     h.erase(std::remove(h.begin(), h.end(), s), h.end());
   }
-  s->pairA.release(); s->pairB.release(); s->slotCount.release(); s->slotBase.release(); s->part0.release(); s->sortedCode16.release(); s->binCost.release(); s->slotHist2.release(); s->top16Rec.release(); s->top16Count.release();
+  s->pairA.release(); s->pairB.release(); s->slotCount.release(); s->chunkSum.release(); s->runTab.release(); s->sortedCode16.release(); s->binCost.release(); s->slotHist2.release(); s->top16Rec.release(); s->top16Count.release();
   s->osStatus.release(); s->keysA.release(); s->idsA.release(); s->rect.release(); s->partHist.release(); s->blockCount.release();
   s->rec.release(); s->recGut.release(); s->pairKey0.release(); s->pairVal0.release(); s->pairKey1.release(); s->pairVal1.release();
   s->sortedRect.release(); s->splatOffset.release(); s->chunkStart.release();
@@ -746,6 +753,12 @@ void mgs_scene_destroy(MgsScene s)
   s->rsPairA.release(); s->rsPairB.release(); s->rsStatus.release(); s->rsOsPlan.release();
   if(s->hCtr) (void)hipHostFree(s->hCtr);
   if(s->hPlans) (void)hipHostFree(s->hPlans);
+  for(int k = 0; k < MgsScene_t::kUpRing; ++k)
+    if(s->upBuf[k])
+    {
+      (void)hipHostFree(s->upBuf[k]);
+      (void)hipEventDestroy(s->upEv[k]);
+    }
   if(s->evReady)
   {
     for(auto& e : s->ev)
@@ -841,7 +854,7 @@ int mgs_scene_memory_usage(MgsScene s, uint64_t* sceneBytes, uint64_t* workingBy
   {
     uint64_t b = 0;
     auto add = [&](auto& buf) { b += (uint64_t)buf.n * sizeof(*buf.p); };
-    add(s->pairA); add(s->pairB); add(s->slotCount); add(s->slotBase); add(s->part0); add(s->sortedCode16); add(s->binCost); add(s->slotHist2); add(s->top16Rec); add(s->top16Count); add(s->osStatus); add(s->keysA); add(s->idsA); add(s->rect);
+    add(s->pairA); add(s->pairB); add(s->slotCount); add(s->chunkSum); add(s->runTab); add(s->sortedCode16); add(s->binCost); add(s->slotHist2); add(s->top16Rec); add(s->top16Count); add(s->osStatus); add(s->keysA); add(s->idsA); add(s->rect);
     add(s->partHist); add(s->blockCount); add(s->sortedRect); add(s->splatOffset); add(s->chunkStart);
     add(s->dbinMasks); add(s->fstate); add(s->surfDepth); add(s->surfId); add(s->surfNormal); add(s->accum); add(s->rec); add(s->recGut);
     add(s->pairKey0); add(s->pairVal0); add(s->pairKey1); add(s->pairVal1); add(s->ranges); add(s->image);
@@ -888,9 +901,9 @@ static int mgs_instance_add_impl(MgsScene s, MgsSplatSet set, const float m[16],
   for(const auto& I : s->d->instances)
     total += s->d->sets[I.set].host->size();
   total += set->data->size();
-  if(total > 0xFFFFFFFFull)
-  {
-    setError("mgs_instance_add: more than 2^32 global splats (ids are u32, like the reference)");
+  if(total >= kOsMaxPairs)
+  {  // the reference's ids are u32; this build's key sort carries 30-bit digit prefixes in its look-back words (k_osort.hip)
+    setError("mgs_instance_add: 2^30 or more global splats (the key sort's look-back words hold 30-bit prefixes)");
     return MGS_ERR_UNSUPPORTED;
   }
   Instance I;
@@ -980,17 +993,31 @@ static int ensureFrameState(MgsScene s)
 }
 
 // A frame's first operation on its stream: counters and plans to zero, this frame's constants behind them, in one upload
-// (pageable source: staged by the runtime before the call returns).
+// from the handle's ring of pinned buffers (a buffer is reused four uploads later, after its copy's event).
 static int uploadFrameState(MgsScene s, const FrameArgs& A, hipStream_t st)
 {
   int rc = ensureFrameState(s);
   if(rc)
     return rc;
   const size_t head = offsetof(FrameState, args), used = offsetof(FrameArgs, inst) + (size_t)A.f.nInstances * sizeof(InstanceConst);
-  if(s->hostFrame.size() < head + sizeof(FrameArgs))
-    s->hostFrame.assign(head + sizeof(FrameArgs), 0);  // the head stays zero for good
-  std::memcpy(s->hostFrame.data() + head, &A, used);
-  HIPCHK(hipMemcpyAsync(s->fstate.p, s->hostFrame.data(), head + used, hipMemcpyHostToDevice, st));
+  const int    k    = (int)(s->upNext++ % MgsScene_t::kUpRing);
+  if(!s->upBuf[k])
+  {
+    if(hipHostMalloc((void**)&s->upBuf[k], head + sizeof(FrameArgs)) != hipSuccess || hipEventCreateWithFlags(&s->upEv[k], hipEventDisableTiming) != hipSuccess)
+    {
+      if(s->upBuf[k]) (void)hipHostFree(s->upBuf[k]);
+      s->upBuf[k] = nullptr;
+      setError("frame: pinned allocation for the per-frame upload failed");
+      return MGS_ERR_OOM;
+    }
+    std::memset(s->upBuf[k], 0, head);  // the head stays zero for good
+  }
+  if(s->upBusy[k])
+    HIPCHK(hipEventSynchronize(s->upEv[k]));
+  std::memcpy(s->upBuf[k] + head, &A, used);
+  HIPCHK(hipMemcpyAsync(s->fstate.p, s->upBuf[k], head + used, hipMemcpyHostToDevice, st));
+  HIPCHK(hipEventRecord(s->upEv[k], st));
+  s->upBusy[k] = true;
   return MGS_OK;
 }
 
@@ -1229,7 +1256,7 @@ static int sizeWorkingSet(MgsScene s)
   s->graphs.clear();
   const uint64_t total = s->d->totalSplats, parts = s->d->totalParts;
   int rc = MGS_OK;
-  if((rc = s->slotHist2.ensure((size_t)parts * 256u))) return rc;
+  if((rc = s->slotHist2.ensure((size_t)parts * kSlotHistWords))) return rc;
   if((rc = s->top16Rec.ensure((size_t)parts * 128u))) return rc;
   // occurrences of key >> 16: the sort's prepare kernel consumes and clears it every frame; zeroed here as well, so that a
   // frame that died between the two kernels cannot leak counts into the next scene
@@ -1247,8 +1274,8 @@ static int sizeWorkingSet(MgsScene s)
   if((rc = s->sortedCode16.ensure(total))) return rc;
   if((rc = s->binCost.ensure(256))) return rc;
   HIPCHK(hipMemset(s->binCost.p, 0, 256 * 4));
-  if((rc = s->slotBase.ensure(parts + 1))) return rc;
-  if((rc = s->part0.ensure(((size_t)osSortMaxParts((uint32_t)total) + 1) * (1 + kOsWin)))) return rc;
+  if((rc = s->chunkSum.ensure((size_t)osSortChunks(parts) * 256u))) return rc;
+  if((rc = s->runTab.ensure((size_t)osSortChunks(parts) * kOsChunk * 256u))) return rc;
   if((rc = s->idsA.ensure(total))) return rc;
   if((rc = s->rect.ensure(total))) return rc;
   if((rc = s->rec.ensure(total))) return rc;
@@ -1542,6 +1569,14 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
   // bins: lists are built per (16<<shift)-pixel bin; the compositor culls per 16x16 tile on chip.
   // Default 256x128 px (MGS_BIN_SHIFT="x,y" overrides, x 1..5, y 0..5; measured sweep in DESIGN.md §3.3).
   int bsx = 4, bsy = 3;  // 256x128 px
+  // MGS_ALPHA_SUM has no early termination: every region walks its bin's WHOLE list, and the walk (the cull of stage A) is what
+  // that mode pays for — 64 regions re-scanning a 256x128-px bin's list.  Smaller bins there, as small as the direct binning
+  // allows (<= 256 bins): 128x64 px at 1080p = 255 bins; composite 6.6 -> 3.8 ms, binning +0.05 ms (profiles/r4_a_alpha_sum_sweep.log)
+  if(p->alpha_mode == MGS_ALPHA_SUM && p->sort_mode != MGS_SORT_STOCHASTIC)
+  {
+    bsx = 3;
+    bsy = 2;
+  }
   if(const char* e = std::getenv("MGS_BIN_SHIFT"))
     std::sscanf(e, "%d,%d", &bsx, &bsy);
   else
@@ -1717,10 +1752,10 @@ static void keySort(MgsScene s, hipStream_t st, bool wantKeys, bool allowRemap, 
   L.pairs0       = s->pairB.p;
   L.prjParts     = s->d->totalParts;
   L.slotCount    = s->slotCount.p;
-  L.slotBase     = s->slotBase.p;
-  L.part0        = s->part0.p;
+  L.chunkSum     = s->chunkSum.p;
+  L.runTab       = s->runTab.p;
   L.nOut         = &s->ctr.p->sortedCount;
-  L.slotHist2    = s->slotHist2.p;
+  L.slotHist     = s->slotHist2.p;
   L.top16Rec     = s->top16Rec.p;
   L.top16Count   = s->top16Count.p;
   L.nPtr         = &s->ctr.p->sortedCount;
@@ -2261,6 +2296,11 @@ int mgs_frame_stats(MgsScene s, MgsFrameOut* out)
   {
     setError("frame: tile-pair capacity exceeded (raise MGS_PAIR_CAPACITY); frame is incomplete");
     return MGS_ERR_OVERFLOW;
+  }
+  if(out->error_flags & kErrSpinTimeout)
+  {  // a look-back wait of the key sort ran into its bound (k_osort.hip): the sorted order, hence the frame, is not to be trusted
+    setError("frame: a look-back wait of the key sort gave up (kErrSpinTimeout); the frame is invalid");
+    return MGS_ERR_DEVICE;
   }
   return MGS_OK;
 }
@@ -2806,6 +2846,11 @@ int mgs_sort_keys(MgsScene s, const MgsFrameParams* p, MgsSortOut* out)
   out->key_ms = ms;
   HIPCHK(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
   out->sort_ms = ms;
+  if(s->hCtr->errorFlags & kErrSpinTimeout)
+  {
+    setError("mgs_sort_keys: a look-back wait of the key sort gave up (kErrSpinTimeout); the order is invalid");
+    return MGS_ERR_DEVICE;
+  }
   out->count   = s->hCtr->sortedCount;
   out->passes  = s->hPlans->keys.passesRun;
   out->reserved[0] = s->hPlans->os.remapOn;     // pass 2 sorted on the rank of key >> 16
@@ -2901,7 +2946,8 @@ int mgs_radix_sort_u32(MgsScene s, void* keysDev, void* valsDev, uint32_t count,
   // the stand-alone sort tests exercises exactly what the frame uses; partial bit ranges take the generic sort (k_sort.hip).
   // MGS_RAW_SORT=generic forces the generic one for every range (A/B).
   static const bool kRawGeneric = [] { const char* e = std::getenv("MGS_RAW_SORT"); return e && std::strcmp(e, "generic") == 0; }();
-  const bool os = !kRawGeneric && beginBit == 0 && endBit == 32;
+  // (2^30 pairs or more: the look-back words of k_os_pass hold 30-bit prefixes — the generic sort has no such limit)
+  const bool os = !kRawGeneric && beginBit == 0 && endBit == 32 && (uint64_t)count < kOsMaxPairs;
   if(os)
   {
     if((rc = s->rsPairA.ensure(count))) return rc;
@@ -2941,6 +2987,7 @@ int mgs_radix_sort_u32(MgsScene s, void* keysDev, void* valsDev, uint32_t count,
     O.ctr      = s->ctr.p;
     O.status   = s->rsStatus.p;
     O.allowRemap = false;
+    HIPCHK(hipMemsetAsync(&s->ctr.p->errorFlags, 0, sizeof(uint32_t), st));  // whatever an earlier frame left there is not this sort's
     launchOsSort(st, O);
   }
   else
@@ -2963,8 +3010,16 @@ int mgs_radix_sort_u32(MgsScene s, void* keysDev, void* valsDev, uint32_t count,
   }
   HIPCHK(hipEventRecord(s->ev[7], st));
   SortPlan hp;
+  uint32_t sortFlags = 0;
   HIPCHK(hipMemcpyAsync(&hp, plan.p, sizeof(SortPlan), hipMemcpyDeviceToHost, st));
+  if(os)
+    HIPCHK(hipMemcpyAsync(&sortFlags, &s->ctr.p->errorFlags, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  if(sortFlags & kErrSpinTimeout)
+  {
+    setError("mgs_radix_sort_u32: a look-back wait gave up (kErrSpinTimeout); the caller's arrays are untouched");
+    return MGS_ERR_DEVICE;
+  }
   if(ms)
     HIPCHK(hipEventElapsedTime(ms, s->ev[6], s->ev[7]));
   if(hp.finalSel == 0)

@@ -44,8 +44,11 @@ void launchRadixSort(hipStream_t stream, const SortLaunch& s);
 // ---- the frame's key sort (k_osort.hip) -------------------------------------------------------------------------------
 constexpr uint32_t kOsPart    = 4096;  // pairs per partition (256 threads x 16)
 constexpr uint32_t kOsSlot    = 2048;  // pairs a project workgroup's slot can hold (== its partition of splats)
-constexpr uint32_t kOsWin     = 8;     // slots per sort partition whose start k_os_prepare tabulates (power of two <= 64)
+constexpr uint32_t kSlotHistWords = 384;  // what a slot leaves per partition (slot_emit.h): counts of key bits 0-7 and 8-15,
+                                          // starts of the digit-0 groups — 16-bit values, two per word
+constexpr uint32_t kOsChunk   = 32;    // slots per chunk of the virtual pass 0 (k_os_prepare: one reduce workgroup per chunk)
 constexpr uint32_t kOsGroup   = 32;    // partitions per look-back group
+constexpr uint64_t kOsMaxPairs = 1ull << 30;  // exclusive: look-back words = 2 flag bits + a 30-bit prefix (callers guard)
 constexpr uint32_t kRemapSpan = 4096;  // pass 2 of a depth-key sort indexes a 4096-entry LDS table with (key >> 16) - remapBase
 
 struct OsPlan
@@ -68,18 +71,18 @@ struct OsPlan
 struct OsLaunch
 {
   // input, exactly one of: the project kernels' slots of (key, id) pairs with their per-partition histograms and records ...
-  const uint2*    pairs0     = nullptr;  // slot p = pairs [kOsSlot p, kOsSlot p + slotCount[p]); may alias pairB (pass 0 reads it
-                                         // before pass 1 writes B)
+  const uint2*    pairs0     = nullptr;  // slot p = pairs [kOsSlot p, kOsSlot p + slotCount[p]), grouped by key bits 0-7 (slot_emit.h);
+                                         // may alias pairB (the first pass reads it, the second one is the first to write B)
   uint32_t        prjParts   = 0;        // project partitions == slots (2048 splats each)
   const uint32_t* slotCount  = nullptr;  // [prjParts] pairs in every slot
-  uint32_t*       slotBase   = nullptr;  // [prjParts + 1] scratch: exclusive prefix of slotCount (k_os_prepare)
-  uint32_t*       part0      = nullptr;  // [(osSortMaxParts + 1) (1 + kOsWin)] scratch: the slot that holds the first pair of every
-                                         // dense partition, then the partitions' windows (k_os_prepare)
+  uint32_t*       chunkSum   = nullptr;  // [osSortChunks(prjParts)][256] scratch (k_os_prepare): pairs per digit-0 value in every chunk of 32 slots
+  uint32_t*       runTab     = nullptr;  // [256][32 osSortChunks(prjParts)] scratch (k_os_prepare): per (digit-0 value, slot) the pairs of
+                                         // that value in the chunk's earlier slots | the group's start inside its slot << 16
   uint32_t        rideShift  = 0;        // frame only: the ids carry the bin rectangles' codes above bit rideShift (rideEncode) ...
   uint32_t        rideInfo   = 0;        // ... shapes | code bits << 8, handed to the binning stage in planOut->reserved[0] ...
   uint16_t*       outCode16  = nullptr;  // ... and the final pass writes clean ids and, here, the codes in sorted order
   uint32_t*       nOut       = nullptr;  // the frame's count of sorted pairs (== *nPtr afterwards), written by k_os_prepare
-  const uint32_t* slotHist2  = nullptr;  // [partition][256]: histograms of key bits 0-7 and 8-15, two 16-bit counters per word
+  const uint32_t* slotHist   = nullptr;  // [partition][kSlotHistWords] (slot_emit.h)
   const uint32_t* top16Rec   = nullptr;  // [partition][4 waves][32]: counts of key >> 16 per producer wave (slot_emit.h)
   uint32_t*       top16Count = nullptr;  // [65536] occurrences of key >> 16 (filled, consumed and cleared by k_os_prepare;
                                          // partitions that span > 24 values add their keys themselves)
@@ -108,6 +111,7 @@ struct FramePlans
 };
 
 uint32_t osSortMaxParts(uint32_t maxElems);
+inline uint32_t osSortChunks(uint32_t prjParts) { return (prjParts + kOsChunk - 1u) / kOsChunk; }
 size_t   osSortStatusWords(uint32_t maxParts);
 void     launchOsSortClearPlan(hipStream_t stream, OsPlan* plan);
 void     launchOsSort(hipStream_t stream, const OsLaunch& L);
