@@ -35,9 +35,17 @@ for pose in poses:
         last = pr[pr[:, 7] == 1]
         if len(last):
             print(f"   the last arriver's fold of the count table: {(last[0, 5] - last[0, 4]) / 100.0:.2f} us; kernel body ends at {(last[0, 5] - b0) / 100.0:.1f} us")
+    g = a[0].astype(np.int64)
+    g = g[g[:, 6] > 0]
+    if len(g):  # frames: pass 0 is virtual; its area holds the sub-stamps of pass 1's source table (k_os_pass<3>)
+        ph = np.diff(g[:, :7], axis=1) / 100.0
+        print(f"--- pose {pose} pass 1, source table of the virtual pass 0 ({len(g)} workgroups):")
+        for i, nme in enumerate(["set-up + digit totals + scan", "chunk sums (first digit value)", "chunk scan + range", "run table loads", "expansion (first digit value)", "further digit values"]):
+            v = ph[:, i][g[:, i + 1] > 0] if i < 5 else ph[:, i]
+            print(f"   {nme:34s} median {np.median(v):6.2f} us  p90 {np.percentile(v, 90):6.2f}")
     for ps in range(4):
         b = a[ps]
-        ran = b[:, 6] > 0
+        ran = (b[:, 6] > 0) & (b[:, 7] > 0)
         if not ran.any():
             print(f"--- pose {pose} pass {ps}: did not run")
             continue

@@ -109,9 +109,11 @@ __global__ __launch_bounds__(256) void k_os_hist(const uint32_t* __restrict__ ke
 
 #ifdef MGS_OS_TRACE  // debug build (tools/os_trace.py): per-workgroup wall-clock stamps (100 MHz) of the phases of every pass
 #define MGS_OS_STAMP(i) if(threadIdx.x == 0) trc[i] = wall_clock64();
+#define MGS_OS_GSTAMP(i) if(threadIdx.x == 0 && gtr[i] == 0) gtr[i] = wall_clock64();  // the virtual pass 0's table (first time only)
 __device__ uint64_t* g_osPrepTrace = nullptr;  // [reduce workgroup][8]
 #else
 #define MGS_OS_STAMP(i)
+#define MGS_OS_GSTAMP(i)
 #endif
 // ---------------------------------------------------------------------------------------------------------------------
 // (b) prepare: the digit totals of all passes and the tables of the virtual pass 0, from what the producer left.
@@ -469,10 +471,15 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
     return;  // pass 2 sorted on the rank of the top 16 bits and wrote the result
 #ifdef MGS_OS_TRACE
   __shared__ uint64_t trc[8];
+  __shared__ uint64_t gtr[8];
+  if(threadIdx.x < 8) gtr[threadIdx.x] = 0;
   MGS_OS_STAMP(0)
 #endif
   const uint32_t p = blockIdx.x;  // partitions in dispatch order (header: why no ticket)
   const uint32_t n = *a.nPtr;
+  [[maybe_unused]] uint4 tot0q = make_uint4(0u, 0u, 0u, 0u);
+  if constexpr(IN == 3)  // the virtual pass 0 starts from the digit-0 totals (lane l: values 4 l .. 4 l + 3): their round trip passes behind the set-up
+    tot0q = *reinterpret_cast<const uint4*>(&plan->total[0][4 * lane]);
   // clear look-back words for a later pass (stream order: nobody reads them any more)
   for(uint32_t i = blockIdx.x * kThreads + t; i < a.zWords; i += gridDim.x * kThreads)
     a.zStatus[i] = 0u;
@@ -511,117 +518,144 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
   const uint32_t wofs   = w * 64u * rounds;
   uint32_t       key[kKpt], val[kKpt];
   MGS_OS_STAMP(1)
-  // IN 3: the source table of the virtual pass 0 (header of OsPassArgs).  s_pair is not in use before the re-order:
-  // its first half holds the table, its second half the chunk prefixes of the digit value being expanded.
+  // IN 3: the source table of the virtual pass 0 (header of OsPassArgs).  s_pair is not in use before the re-order: its first
+  // half holds the table.  Everything that locates the runs — the digit bases D, the prefix over the chunks — is computed by
+  // EVERY WAVE FOR ITSELF (identical results, a few dozen loads each): the construction has no workgroup barrier except the
+  // one before the table is read (with block-wide scans it had nine, 8 us per digit value; profiles/r4_c_os_trace.log).
   [[maybe_unused]] uint32_t srcAt[IN == 3 ? kKpt : 1];
   if constexpr(IN == 3)
   {
-    uint32_t* s_src = reinterpret_cast<uint32_t*>(s_pair);  // [4096] pair index (slot * 2048 + entry) of every position of the partition
-    uint32_t* s_cp  = s_src + kOsPart;                      // [kCpTile + 1] exclusive prefix of chunkSum[.][d] over a tile of chunks
-    constexpr uint32_t kCpTile = 2048;                      // chunks per tile (8 per thread)
+    uint32_t* s_src = reinterpret_cast<uint32_t*>(s_pair);       // [4096] pair index (slot * 2048 + entry) of every position of the partition
+    uint32_t* s_cpw = s_src + kOsPart + (uint32_t)w * 264u;      // [257] this wave's prefix of chunkSum[.][d] over a tile of chunks
+    constexpr uint32_t kCpTile = 256;                            // chunks per tile: four per lane
     const uint32_t a0 = p * kOsPart, e0 = a0 + count;
-    // D: thread t == digit-0 value t
-    const uint32_t tot0 = plan->total[0][t];
-    const uint32_t Dt   = scan256(tot0, s_tmp);
-    s_cnt[t]            = Dt;  // (s_cnt is free until the scatter)
-    if(tot0 != 0u && Dt <= a0 && a0 < Dt + tot0)
-      s_tmp[5] = (uint32_t)t;  // the value the partition starts in (a0 < n: exactly one thread)
-    __syncthreads();
+    // D: lane l holds digit-0 values 4 l .. 4 l + 3
+    const uint32_t tk[4] = {tot0q.x, tot0q.y, tot0q.z, tot0q.w};
+    uint32_t       d     = 256u;
+    {
+      const uint32_t s4 = tk[0] + tk[1] + tk[2] + tk[3];
+      uint32_t       dq = waveInclusiveScan(s4) - s4;
+#pragma unroll
+      for(int k = 0; k < 4; ++k)
+      {
+        s_cnt[4 * lane + k] = dq;  // (s_cnt is free until the scatter; the four waves write the same values)
+        const uint64_t bk   = __ballot(tk[k] != 0u && dq <= a0 && a0 < dq + tk[k]);
+        if(bk != 0ull)
+          d = 4u * (uint32_t)__builtin_ctzll(bk) + (uint32_t)k;  // the value the partition starts in
+        dq += tk[k];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    MGS_OS_GSTAMP(0)
+    auto loadCs = [&](uint32_t dd, uint32_t c0, uint32_t cs[4]) {
+#pragma unroll
+      for(int k = 0; k < 4; ++k)
+      {
+        const uint32_t c = c0 + 4u * (uint32_t)lane + (uint32_t)k;
+        cs[k]            = (dd < 256u && c < a.chunks) ? a.chunkSum[(size_t)c * 256u + dd] : 0u;
+      }
+    };
     const uint32_t spad = a.chunks * kOsChunk;
-    for(uint32_t d = s_tmp[5]; d < 256u; ++d)
-    {  // uniform: the digit-0 values whose range [Dd, De) overlaps [a0, e0)
+    uint32_t       csN[4];
+    loadCs(d, 0u, csN);
+    while(d < 256u)
+    {  // uniform (every wave computes the same): the digit-0 values whose range [Dd, De) overlaps [a0, e0)
       const uint32_t Dd = s_cnt[d], De = d < 255u ? s_cnt[d + 1u] : n;
       if(Dd >= e0)
         break;
-      if(De <= a0 || De == Dd)
-        continue;
-      uint32_t carry = Dd;  // position of the first pair of value d in the tile's first chunk
-      for(uint32_t c0 = 0; c0 < a.chunks && carry < e0; c0 += kCpTile)
+      uint32_t cs[4] = {csN[0], csN[1], csN[2], csN[3]};
+      loadCs(De < e0 ? d + 1u : 256u, 0u, csN);  // the next value's first tile travels behind this one's expansion
+      if(De > a0 && De != Dd)
       {
-        // prefix over the tile's chunks: thread t owns 8 consecutive ones
-        uint32_t cs[8], sum = 0;
-#pragma unroll
-        for(int k = 0; k < 8; ++k)
+        uint32_t carry = Dd;  // position of the first pair of value d in the tile's first chunk
+        for(uint32_t c0 = 0;;)
         {
-          const uint32_t c = c0 + 8u * (uint32_t)t + (uint32_t)k;
-          cs[k]            = c < a.chunks ? a.chunkSum[(size_t)c * 256u + d] : 0u;
-        }
+          const uint32_t sum = cs[0] + cs[1] + cs[2] + cs[3];
+          const uint32_t inc = waveInclusiveScan(sum);
+          MGS_OS_GSTAMP(1)  // chunk sums arrived
+          const uint32_t tileTotal = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+          uint32_t       run = inc - sum, cA = kCpTile, cB = 0u;  // chunks [cA, cB) of the tile hold pairs inside [a0, e0)
 #pragma unroll
-        for(int k = 0; k < 8; ++k)
-          sum += cs[k];
-        const uint32_t ex = scan256(sum, s_tmp);  // exclusive over the threads (two barriers: the table below is not read before)
-        uint32_t       run = ex;
-#pragma unroll
-        for(int k = 0; k < 8; ++k)
-        {
-          s_cp[8 * t + k] = run;
-          run += cs[k];
-        }
-        if(t == kThreads - 1)
-          s_cp[kCpTile] = run;  // the tile's total
-        if(t == 0)
-        {
-          s_tmp[6] = 0xFFFFFFFFu;  // first / last chunk of the tile with pairs inside [a0, e0)
-          s_tmp[7] = 0u;
-        }
-        __syncthreads();
-        {
-          uint32_t r2 = ex;
-#pragma unroll
-          for(int k = 0; k < 8; ++k)
+          for(int k = 0; k < 4; ++k)
           {
-            const uint32_t lo = carry + r2, hi = lo + cs[k];
-            if(cs[k] != 0u && lo < e0 && hi > a0)
+            s_cpw[4 * lane + k] = run;
+            const uint32_t lo   = carry + run, hi = lo + cs[k];
+            const uint64_t bk   = __ballot(cs[k] != 0u && lo < e0 && hi > a0);
+            if(bk != 0ull)
             {
-              atomicMin(&s_tmp[6], 8u * (uint32_t)t + (uint32_t)k);
-              atomicMax(&s_tmp[7], 8u * (uint32_t)t + (uint32_t)k + 1u);
+              cA = min(cA, 4u * (uint32_t)__builtin_ctzll(bk) + (uint32_t)k);
+              cB = max(cB, 4u * (63u - (uint32_t)__builtin_clzll(bk)) + (uint32_t)k + 1u);
             }
-            r2 += cs[k];
+            run += cs[k];
           }
-        }
-        __syncthreads();
-        const uint32_t cA = s_tmp[6], cB = s_tmp[7];  // [cA, cB) relative to the tile; cB == 0: none
-        const uint32_t tileTotal = s_cp[kCpTile];
-        if(cB != 0u)
-        {
-          const uint32_t entries = (cB - cA) * kOsChunk;
-          const uint32_t* row    = a.runTab + (size_t)d * spad + (size_t)(c0 + cA) * kOsChunk;
-          for(uint32_t i0 = 0; i0 < entries; i0 += kThreads)
-          {  // lane == run: 32 consecutive lanes hold a chunk's 32 slots
-            const uint32_t i   = i0 + (uint32_t)t;
-            const uint32_t ic  = min(i, entries - 1u);
-            const uint32_t v   = row[ic];
-            const uint32_t cl  = cA + ic / kOsChunk;  // chunk within the tile
-            const uint32_t inC = v & 0xFFFFu;
-            const uint32_t nxt = (uint32_t)__shfl_down((int)inC, 1, 64);
-            const uint32_t len = ((ic & (kOsChunk - 1u)) == kOsChunk - 1u ? s_cp[cl + 1u] - s_cp[cl] : nxt) - inC;
-            const uint32_t R   = carry + s_cp[cl] + inC;  // position of the run's first pair
-            uint32_t       lo  = max(R, a0), hi = min(R + len, e0);
-            if(i >= entries || hi <= lo)
-              lo = hi = 0u;
-            const uint32_t src = ((c0 + cl) * kOsChunk + (ic & (kOsChunk - 1u))) * kOsSlot + (v >> 16);  // the run's first pair
-            // short runs (the rule: ~6 pairs) are written by their lane; long ones by the wave together
-            const bool     big = hi - lo > 16u;
-            if(!big)
-              for(uint32_t x = lo; x < hi; ++x)
-                s_src[x - a0] = src + (x - R);
-            uint64_t bm = __ballot(big);
-            while(bm != 0ull)
+          if(lane == 63)
+            s_cpw[kCpTile] = run;
+          __builtin_amdgcn_wave_barrier();
+          MGS_OS_GSTAMP(2)  // chunk range known
+          if(cB != 0u)
+          {
+            const uint32_t  entries = (cB - cA) * kOsChunk;
+            const uint32_t* row     = a.runTab + (size_t)d * spad + (size_t)(c0 + cA) * kOsChunk;
+            // lane == run: 32 consecutive lanes hold a chunk's 32 slots; the workgroup's 256 threads share the runs.  Four loads in
+            // flight per thread (the usual partition overlaps ~700 runs: one batch).
+            auto expand = [&](uint32_t i, uint32_t ic, uint32_t v) {
+              const uint32_t cl  = cA + ic / kOsChunk;  // chunk within the tile
+              const uint32_t inC = v & 0xFFFFu;
+              const uint32_t nxt = (uint32_t)__shfl_down((int)inC, 1, 64);
+              const uint32_t len = ((ic & (kOsChunk - 1u)) == kOsChunk - 1u ? s_cpw[cl + 1u] - s_cpw[cl] : nxt) - inC;
+              const uint32_t R   = carry + s_cpw[cl] + inC;  // position of the run's first pair
+              uint32_t       lo  = max(R, a0), hi = min(R + len, e0);
+              if(i >= entries || hi <= lo)
+                lo = hi = 0u;
+              const uint32_t src = ((c0 + cl) * kOsChunk + (ic & (kOsChunk - 1u))) * kOsSlot + (v >> 16);  // the run's first pair
+              // short runs (the rule: ~6 pairs) are written by their lane; long ones by the wave together
+              const bool     big = hi - lo > 16u;
+              if(!big)
+                for(uint32_t x = lo; x < hi; ++x)
+                  s_src[x - a0] = src + (x - R);
+              uint64_t bm = __ballot(big);
+              while(bm != 0ull)
+              {
+                const int      l   = (int)__builtin_ctzll(bm);
+                bm &= bm - 1ull;
+                const uint32_t loL = (uint32_t)__builtin_amdgcn_readlane((int)lo, l), hiL = (uint32_t)__builtin_amdgcn_readlane((int)hi, l);
+                const uint32_t dl  = (uint32_t)__builtin_amdgcn_readlane((int)(src - R), l);
+                for(uint32_t x = loL + (uint32_t)lane; x < hiL; x += 64u)
+                  s_src[x - a0] = dl + x;
+              }
+            };
+            for(uint32_t i0 = 0; i0 < entries; i0 += 4u * kThreads)
             {
-              const int      l   = (int)__builtin_ctzll(bm);
-              bm &= bm - 1ull;
-              const uint32_t loL = (uint32_t)__builtin_amdgcn_readlane((int)lo, l), hiL = (uint32_t)__builtin_amdgcn_readlane((int)hi, l);
-              const uint32_t dl  = (uint32_t)__builtin_amdgcn_readlane((int)(src - R), l);
-              for(uint32_t x = loL + (uint32_t)lane; x < hiL; x += 64u)
-                s_src[x - a0] = dl + x;
+              uint32_t vv[4];
+#pragma unroll
+              for(int k = 0; k < 4; ++k)
+                vv[k] = row[min(i0 + (uint32_t)k * kThreads + (uint32_t)t, entries - 1u)];
+#ifdef MGS_OS_TRACE
+              if(vv[0] + vv[1] + vv[2] + vv[3] == 0x12345678u) gtr[7] = 1;  // consume the loads: the stamp follows their arrival
+              MGS_OS_GSTAMP(3)
+#endif
+#pragma unroll
+              for(int k = 0; k < 4; ++k)
+              {
+                const uint32_t i = i0 + (uint32_t)k * kThreads + (uint32_t)t;
+                if(i0 + (uint32_t)k * kThreads + (uint32_t)(t & ~63) < entries)  // wave-uniform
+                  expand(i, min(i, entries - 1u), vv[k]);
+              }
             }
           }
+          carry += tileTotal;
+          c0 += kCpTile;
+          if(c0 >= a.chunks || carry >= e0)
+            break;
+          __builtin_amdgcn_wave_barrier();  // the wave's prefix table is rewritten
+          loadCs(d, c0, cs);
         }
-        carry += tileTotal;
-        __syncthreads();  // s_cp / s_tmp are rewritten by the next tile or digit value
+        MGS_OS_GSTAMP(4)  // first digit value expanded
       }
+      ++d;
     }
     __syncthreads();
+    MGS_OS_STAMP(1)  // (trace build: the table's construction counts as "table + zeroing", the gather itself as "loads")
 #pragma unroll
     for(int i = 0; i < kKpt; ++i)
       srcAt[i] = min(s_src[min(wofs + (uint32_t)i * 64u + lane, count - 1u)], a.srcLimit);
@@ -891,6 +925,14 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
     uint64_t* o = a.trace + (size_t)p * 8;
     for(int i = 0; i < 7; ++i) o[i] = trc[i];
     o[7] = ((uint64_t)count << 32) | spins;
+    if(IN == 3)
+    {  // the table's sub-stamps go where the (virtual) pass 0 would have put its own
+      uint64_t* g = a.trace - (size_t)gridDim.x * 8 + (size_t)p * 8;
+      g[0] = trc[0];
+      for(int i = 0; i < 5; ++i) g[1 + i] = gtr[i];
+      g[6] = trc[1];
+      g[7] = 0;
+    }
   }
 #endif
 }
