@@ -101,6 +101,8 @@ def main():
                     "single-stream calibration frames")
     ap.add_argument("--check-gather", action="store_true", help="N>1: verify the gathered frame == a full-frame render")
     ap.add_argument("--equal-strips", action="store_true", help="N>1: equal tile-row strips instead of cost-balanced ones")
+    ap.add_argument("--strip-bounds", default=None, help="N>1: the strip table itself, N+1 ascending tile rows \"0,r1,...,rows\" "
+                    "(equal neighbours = an empty strip): exercises ragged partitions of the exchange")
     ap.add_argument("--torch-gather", action="store_true", help="N>1: exchange the strips with torch.distributed instead of "
                     "libmgs's own RCCL call (the fallback path)")
     args = ap.parse_args()
@@ -235,7 +237,11 @@ def main():
                     scenes[c].comm_destroy()
             gather_mode = ("torch.distributed all_gather_into_tensor (RCCL)" if args.backend == "nccl"
                            else f"torch.distributed all_gather over {args.backend}, strips staged through host memory (functional check)")
-        if not args.equal_strips:
+        if args.strip_bounds:
+            bounds = [int(x) for x in args.strip_bounds.split(",")]
+            assert len(bounds) == world + 1 and bounds[0] == 0 and bounds[-1] == tiles_y and all(a <= b for a, b in zip(bounds, bounds[1:])), \
+                f"--strip-bounds needs {world + 1} ascending tile rows from 0 to {tiles_y}"
+        elif not args.equal_strips:
             # cost-balanced strips: per-tile-row list lengths of untimed full frames (every rank renders the same
             # frames, so every rank derives the same table; no exchange needed)
             cost = np.zeros(tiles_y, np.float64)

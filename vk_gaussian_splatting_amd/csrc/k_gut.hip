@@ -363,9 +363,11 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
         dst[3]      = make_float4(r.B[4], r.B[5], r.B[6], r.B[7]);
         dst[4]      = make_float4(r.B[8], r.ro[0], r.ro[1], r.ro[2]);
         dst[5]      = make_float4(r.r, r.g, r.b, r.a);
-        rect[gidOk] = rc;
+        uint32_t code = A.f.rideEscape;
         if(rideShift != 0u)
-          s_code[j] = (uint16_t)rideEncode(rc, A.f.binsX, A.f.binsY, A.f.rideShapes, A.f.rideEscape);  // own entry only
+          s_code[j] = (uint16_t)(code = rideEncode(rc, A.f.binsX, A.f.binsY, A.f.rideShapes, A.f.rideEscape));  // own entry only
+        if(rideShift == 0u || code == A.f.rideEscape)  // read back by id only where the code cannot say it (k_project.hip)
+          rect[gidOk] = rc;
         s_li[j] |= 0x8000u;
       }
     }

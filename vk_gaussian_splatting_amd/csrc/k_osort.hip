@@ -703,6 +703,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
     rd[i] = d << 16;
   }
   const uint32_t g = p / kOsGroup, m = p % kOsGroup;
+  // bits that tell the digits of this pass apart: 8, or — sorting on the rank of key >> 16 — as many as the largest rank has
+  [[maybe_unused]] const int rankBits = (REMAP && useRemap) ? 32 - __builtin_clz(plan->remapPadRank | 1u) : 8;
   MGS_OS_STAMP(2)
 
   // ---- (the look-back is software-pipelined with the rest of the pass: level 1 is issued right after the partition's own
@@ -722,6 +724,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
 #pragma unroll
       for(int b = 0; b < 8; ++b)
       {
+        if(REMAP && b >= rankBits)  // wave-uniform: the ranks of a remapped pass need ceil(log2(values)) bits — 3 for the usual 5-8
+          break;
         uint32_t x = (uint32_t)((int32_t)(d << (31 - b)) >> 31);
         asm volatile("" : "+v"(x));  // the ballot compares x itself: left alone the compiler re-derives it from d (a shift per bit)
         const uint64_t bal = __ballot(x != 0u);

@@ -240,6 +240,21 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   const uint32_t       local0 = (part - I.blockBegin) * kPrjPart;
 
   const PartitionBox pbox = partitionLoad(I, part - I.blockBegin);  // ahead of the centres (partition_cull.h)
+  // A strip of a multi-GPU frame skips most partitions (a middle strip of eight: 9 of 10): there the test runs BEFORE the
+  // centres are requested — one 32-byte round trip first instead of 24 KB of loads per workgroup that nobody looks at.  A full
+  // frame skips few, and issues the centres' loads first (the test runs behind them).
+  float      partRadius = 3.0e38f;
+  uint32_t   pflag      = 0u;
+  const bool testFirst  = A.f.partitionCull && (A.f.stripRow1 - A.f.stripRow0) < A.f.tilesY;
+  if(testFirst)
+  {
+    pflag = partitionTest(A, I, pbox, partRadius);
+    if(pflag & 1u)
+    {
+      emitEmptySlot<kPrjThreads>(slotCount, slotHist2, top16Rec, part);
+      return;
+    }
+  }
   // ---- phase 1: key + frustum cull for 8 splats per thread -------------------------------------------
   float px[kPrjItems], py[kPrjItems], pz[kPrjItems];
 #pragma unroll
@@ -253,8 +268,8 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   }
   // the partition as a whole (partition_cull.h; behind the centres' loads, which are in flight either way): bit 0 no splat of
   // it can survive the cull / reach the strip, bit 1 every centre passes the frustum test, bit 2 all centres finite
-  float          partRadius = 3.0e38f;
-  const uint32_t pflag      = A.f.partitionCull ? partitionTest(A, I, pbox, partRadius) : 0u;
+  if(!testFirst && A.f.partitionCull)
+    pflag = partitionTest(A, I, pbox, partRadius);
   if(pflag & 1u)
   {
     emitEmptySlot<kPrjThreads>(slotCount, slotHist2, top16Rec, part);
@@ -385,9 +400,12 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
           float4* dst = &s_rec[w][lane * 3];  // 48-byte pitch: conflict-free 16-byte accesses
           dst[0]      = make_float4(pr.rec.cx, pr.rec.cy, pr.rec.p1x, pr.rec.p1y);
           dst[1]      = make_float4(pr.rec.p2x, pr.rec.p2y, pr.rec.a, __uint_as_float(pr.rec.exey));
-          rect[gidOk] = pr.rect;
           if(rideShift != 0u)
             code = rideEncode(pr.rect, A.f.binsX, A.f.binsY, A.f.rideShapes, A.f.rideEscape);
+          // the rectangle by id is read back only where the code cannot say it (escape), or when nothing rides: four scattered
+          // bytes per survivor less
+          if(rideShift == 0u || code == A.f.rideEscape)
+            rect[gidOk] = pr.rect;
           s_li[j] |= 0x8000u;  // own entry only: no race
         }
       }
