@@ -482,7 +482,7 @@ def main():
                                       "min": float(st[:, 5].min()), "max": float(st[:, 5].max())},
         "value_single_frame": 1e3 / float(calib_ms[5]) if calib_ms[5] > 0 else None,  # frames/s with ONE frame in flight
         "roofline": {"bound": "hbm", "stage": dom_name,
-                     "kernels": {"project": "k_project", "sort": "k_os_prepare + 3 x k_os_pass (+ 1 that exits at once)",
+                     "kernels": {"project": "k_project", "sort": "k_os_prepare + 2 x k_os_pass (+ 1 that exits at once); pass 0 is virtual (done in k_project)",
                                  "bin": "k_dbin_count + k_dbin_scan + k_dbin_emit"}[dom_name],
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
@@ -545,6 +545,49 @@ def main():
             out["parity"] = par
         except Exception as e:  # noqa: BLE001
             out["parity"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+
+    if (rank == 0 and world == 1 and not args.ply and args.scene == "garden" and args.pipeline == 0 and args.instances == 1
+            and not args.stochastic and not args.alpha_sum and args.dof == 0.0 and args.sh_format == 0 and args.rgba_format == 0):
+        # The same workload in the reference's OTHER defaults, so that the headline cannot be mistaken for them (untimed extras,
+        # a few dozen frames each, same contexts and frames in flight as the headline):
+        #  * value_reference_alpha: MGS_ALPHA_SUM — A = sum(alpha), every fragment composited, no early termination: the blend
+        #    state of the reference's default pipeline (src/gaussian_splatting.cpp:2081-2086); the headline's alpha is 1 - T with
+        #    early termination at T < 1e-4, the reference's FRONT_TO_BACK alpha.  Colour is the same to the bit in both.
+        #  * value_uint8_storage: SH and colour stored as uint8, the reference's default storage (src/parameters.h:88-89); the
+        #    headline uses fp32 storage (the benchmark setting of SURVEY.md 8d).
+        def timed_fps(plist, steps, warm, inflight):
+            kk = max(1, min(K, inflight))
+            for i in range(warm):
+                with torch.cuda.stream(streams[i % kk]):
+                    scenes[i % kk].render(plist[i % 64])
+            fence()
+            tq = time.perf_counter()
+            for i in range(steps):
+                with torch.cuda.stream(streams[i % kk]):
+                    scenes[i % kk].render(plist[(warm + i) % 64])
+            fence()
+            return steps / (time.perf_counter() - tq)
+        try:
+            for pp in poses:
+                pp.alpha_mode = capi.ALPHA_SUM
+            out["value_reference_alpha"] = timed_fps(poses, 24, 4, K)
+            out["value_reference_alpha_single_frame"] = timed_fps(poses, 24, 4, 1)
+            for pp in poses:
+                pp.alpha_mode = capi.ALPHA_COVERAGE
+            out["value_reference_alpha_note"] = ("frames/s with alpha_mode = MGS_ALPHA_SUM (additive alpha, no early termination: the reference's "
+                                                 "default blend state, gaussian_splatting.cpp:2081-2086); `value` is alpha = 1 - T with early termination")
+        except Exception as e:  # noqa: BLE001
+            out["value_reference_alpha"] = None
+            out["value_reference_alpha_note"] = f"{type(e).__name__}: {e}"[:200]
+        try:
+            scene.commit(2, 2)  # contexts re-size their working sets at their next frame
+            out["value_uint8_storage"] = timed_fps(poses, 48, 8, K)
+            out["value_uint8_storage_single_frame"] = timed_fps(poses, 48, 8, 1)
+            out["value_uint8_storage_note"] = "frames/s with SH and colour stored as uint8 (the reference's default storage, src/parameters.h:88-89)"
+            scene.commit(args.sh_format, args.rgba_format)
+        except Exception as e:  # noqa: BLE001
+            out["value_uint8_storage"] = None
+            out["value_uint8_storage_note"] = f"{type(e).__name__}: {e}"[:200]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: restated SplatSorterAsync::innerSort on a bounded sample of the same workload

@@ -240,21 +240,6 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   const uint32_t       local0 = (part - I.blockBegin) * kPrjPart;
 
   const PartitionBox pbox = partitionLoad(I, part - I.blockBegin);  // ahead of the centres (partition_cull.h)
-  // A strip of a multi-GPU frame skips most partitions (a middle strip of eight: 9 of 10): there the test runs BEFORE the
-  // centres are requested — one 32-byte round trip first instead of 24 KB of loads per workgroup that nobody looks at.  A full
-  // frame skips few, and issues the centres' loads first (the test runs behind them).
-  float      partRadius = 3.0e38f;
-  uint32_t   pflag      = 0u;
-  const bool testFirst  = A.f.partitionCull && (A.f.stripRow1 - A.f.stripRow0) < A.f.tilesY;
-  if(testFirst)
-  {
-    pflag = partitionTest(A, I, pbox, partRadius);
-    if(pflag & 1u)
-    {
-      emitEmptySlot<kPrjThreads>(slotCount, slotHist2, top16Rec, part);
-      return;
-    }
-  }
   // ---- phase 1: key + frustum cull for 8 splats per thread -------------------------------------------
   float px[kPrjItems], py[kPrjItems], pz[kPrjItems];
 #pragma unroll
@@ -268,8 +253,11 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   }
   // the partition as a whole (partition_cull.h; behind the centres' loads, which are in flight either way): bit 0 no splat of
   // it can survive the cull / reach the strip, bit 1 every centre passes the frustum test, bit 2 all centres finite
-  if(!testFirst && A.f.partitionCull)
-    pflag = partitionTest(A, I, pbox, partRadius);
+  // (Strips: running the test BEFORE the centres are requested was measured in round 4 — a middle strip of eight skips only
+  //  14 % of the partitions, 16 size classes make a partition's cell ~200 px tall on screen — 75 -> 78 us: the other 86 % pay a
+  //  round trip for nothing.)
+  float          partRadius = 3.0e38f;
+  const uint32_t pflag      = A.f.partitionCull ? partitionTest(A, I, pbox, partRadius) : 0u;
   if(pflag & 1u)
   {
     emitEmptySlot<kPrjThreads>(slotCount, slotHist2, top16Rec, part);

@@ -982,6 +982,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
             // the other side than with the exp-then-compare order: a contribution of <= 0.4 % of one splat's colour.
             const float qCut = noGauss ? kQMax : fminf(kQMax, __log2f(fmaxf(rc * 255.0f, 1.0f)));
             s_a[pos].z       = qCut;
+            s_a[pos].w       = rc;  // the opacity once more: the saturated waves of MGS_ALPHA_SUM read s_a and s_b only
             const float qLim = qCut * 1.001f + 1e-3f;
             const float rs = 7.5f * fabsf(sb.x) + 3.5f * fabsf(sb.y), ru = 7.5f * fabsf(sb.z) + 3.5f * fabsf(sb.w);
             uint32_t    qm = 0;
@@ -1094,25 +1095,25 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
         {
           const uint32_t j = j0 + (uint32_t)__builtin_ctzll(hits);
           hits &= hits - 1ull;
-          const float4 a1 = s_a[j], b1 = s_b[j], c1 = s_c[j];
+          const float4 a1 = s_a[j], b1 = s_b[j];
           const v2f    s1 = lx * b1.x + (ly * b1.y + a1.x), u1 = lx * b1.z + (ly * b1.w + a1.y);
           const v2f    q  = s1 * s1 + u1 * u1;  // == (A/2) * log2 e of frag.slang:236
           if(!early && !surf && waveSat)
           {  // saturated wave in MGS_ALPHA_SUM mode: the fragment only adds its alpha.  (Not with surface outputs: the depth /
              // id pick fires when T crosses depth_iso_threshold, which may lie below 1e-4 — T has to keep falling there, as in
              // the reference, the oracle and the default mode's full path.)
-            if(noGauss)
+            // (the opacity rides in s_a[j].w: two LDS reads per record here instead of three; products and sum packed)
+            v2f al = {1.0f, 1.0f};
+            if(!noGauss)
             {
-              asum.x += (q.x <= a1.z) ? 1.0f : 0.0f;
-              asum.y += (q.y <= a1.z) ? 1.0f : 0.0f;
+              const v2f e = {__builtin_amdgcn_exp2f(-q.x), __builtin_amdgcn_exp2f(-q.y)};
+              al          = e * a1.w;
             }
-            else
-            {
-              asum.x += (q.x <= a1.z) ? __builtin_amdgcn_exp2f(-q.x) * c1.w : 0.0f;
-              asum.y += (q.y <= a1.z) ? __builtin_amdgcn_exp2f(-q.y) * c1.w : 0.0f;
-            }
+            const v2f ah = {(q.x <= a1.z) ? al.x : 0.0f, (q.y <= a1.z) ? al.y : 0.0f};
+            asum += ah;
             continue;
           }
+          const float4 c1 = s_c[j];
           v2f          al = {1.0f, 1.0f};
           if(!noGauss)  // frag.slang:248-254
           {
