@@ -137,6 +137,30 @@ def test_vulkan_reproducible_fixture_on_the_gpu(ob, pipeline, expected):
     scene.close()
 
 
+@pytest.mark.parametrize("case", ["u8_storage", "fisheye150_3dgut", "msaa_3dgs", "two_instances_trs"])
+def test_vulkan_reproducible_cases_on_the_gpu(ob, case):
+    """tests/golden/vkrepro/<case>/repro.vkgs through the product (project reader, loader, commit formats, instances, camera
+    model, pipeline) against the committed expected frame of the case"""
+    import json
+    import os
+    from conftest import GOLDEN
+    from vk_gaussian_splatting_amd import project
+    d = os.path.join(GOLDEN, "vkrepro", case)
+    pr = project.load_project(os.path.join(d, "repro.vkgs"))
+    cj = json.load(open(os.path.join(d, "camera.json")))
+    scene = pr.build_scene(0)
+    want = np.load(os.path.join(d, "expected_rgba16f.npy")).astype(np.float32)
+    H, W = want.shape[:2]
+    p = pr.frame_params(W, H)
+    p.ms_antialiasing = int(cj["frame"]["msAntialiasing"])  # a UI setting of the reference: not part of the project file
+    out = scene.render(p, want_stats=True)
+    img = scene.download_frame(p).astype(np.float32)
+    psnr = ob.psnr_rgb(img, want)
+    print(f"vkrepro case {case}: PSNR {psnr:.2f} dB, sorted {out.sorted_count}")
+    assert out.error_flags == 0 and psnr >= PSNR_MIN and np.abs(img[..., :3] - want[..., :3]).max() <= ABS_TOL
+    scene.close()
+
+
 def test_gut_surface_outputs_match_oracle(scene_gut, ob):
     """NEED_SURFACE_INFO in the 3DGUT pipeline (threedgut_raster.frag.slang:127-131,195-228): picked depth, the splat that set
     it, the integrated normal; the frame itself is unchanged by the side outputs.  The pick is a threshold test on T: >= 99.5 %

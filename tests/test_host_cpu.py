@@ -407,3 +407,50 @@ def test_camera_set_presets_and_project_camera_fields(tmp_path):
     (tmp_path / "gs.vkgs").write_text(json.dumps(doc))
     p = project.load_project(str(tmp_path / "gs.vkgs")).frame_params(320, 200)
     assert p.pipeline == capi.PIPELINE_3DGS and p.dof_mode == capi.DOF_DISABLED
+
+
+def test_compare_vkrepro_tool_reads_radiance_hdr(tmp_path):
+    """tools/compare_vkrepro.py (what a maintainer runs on a Vulkan box against the reference's .hdr screenshot): its RGBE reader —
+    flat and run-length encoded scanlines, as stb_image_write emits them — and its PSNR (image_compare_metric.comp.slang:116-130)"""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("compare_vkrepro", os.path.join(root, "tools", "compare_vkrepro.py"))
+    cv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cv)
+    want = np.maximum(np.load(os.path.join(root, "tests", "golden", "vkrepro", "msaa_3dgs", "expected_rgba16f.npy")).astype(np.float32), 0.0)
+    flat = str(tmp_path / "flat.hdr")
+    cv.write_hdr(flat, want)
+    a = cv.read_hdr(flat)
+    assert a.shape == want.shape[:2] + (3,) and cv.psnr_rgb(want, a)[0] > 50.0  # 8-bit mantissas
+    # the same pixels, run-length encoded per channel the way stb does (runs of equal bytes >= 3, literal spans otherwise)
+    raw = open(flat, "rb").read()
+    head_end = raw.index(b"\n", raw.index(b"\n\n") + 2) + 1
+    H, W = want.shape[:2]
+    rgbe = np.frombuffer(raw, np.uint8, offset=head_end).reshape(H, W, 4)
+    out = bytearray(raw[:head_end])
+    for y in range(H):
+        out += bytes([2, 2, W >> 8, W & 255])
+        for ch in range(4):
+            row, x = rgbe[y, :, ch], 0
+            while x < W:
+                r = 1
+                while x + r < W and r < 127 and row[x + r] == row[x]:
+                    r += 1
+                if r >= 3:
+                    out += bytes([128 + r, int(row[x])])
+                    x += r
+                else:
+                    n = 1
+                    while x + n < W and n < 128 and not (x + n + 2 < W and row[x + n] == row[x + n + 1] == row[x + n + 2]):
+                        n += 1
+                    out += bytes([n]) + row[x:x + n].tobytes()
+                    x += n
+    rle = str(tmp_path / "rle.hdr")
+    open(rle, "wb").write(bytes(out))
+    assert np.array_equal(cv.read_hdr(rle), a)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "compare_vkrepro.py"), "msaa_3dgs", rle], capture_output=True, text=True)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "compare_vkrepro.py"), "u8_storage", rle, "--flip-y"], capture_output=True, text=True)
+    assert r.returncode == 1 and "FAIL" in r.stdout  # another case, upside down: far below the bar

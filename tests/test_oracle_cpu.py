@@ -554,6 +554,36 @@ def test_vulkan_reproducible_fixture_is_what_the_oracle_renders(ob):
     assert np.array_equal(g.astype(np.float16), np.load(os.path.join(d, "expected_3dgut_rgba16f.npy")))
 
 
+def _vkrepro_generator():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_vkrepro", os.path.join(GOLDEN, "make_vkrepro.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("case", ["u8_storage", "fisheye150_3dgut", "msaa_3dgs", "two_instances_trs"])
+def test_vulkan_reproducible_cases_are_what_the_oracle_renders(ob, case):
+    """tests/golden/vkrepro/<case>/ (round 4: uint8 storage — the reference's default —, fisheye 3DGUT at 150 degrees, Mip-Splatting
+    antialiasing, two instances with translation / rotation / scale): the committed project file read back through the
+    product's reader gives the camera of camera.json, and the committed expected frame is exactly what the oracle renders from it.
+    (Expected = our oracle: unvalidated against the reference until a Vulkan box runs camera.json's reference_command.)"""
+    import json
+    from vk_gaussian_splatting_amd import project
+    gen = _vkrepro_generator()
+    d = os.path.join(GOLDEN, "vkrepro", case)
+    pr = project.load_project(os.path.join(d, "repro.vkgs"))
+    cj = json.load(open(os.path.join(d, "camera.json")))
+    assert (cj["width"], cj["height"]) == (gen.CW, gen.CH) and pr.camera.model == cj["camera_model"]
+    assert (pr.sh_format, pr.rgba_format) == (cj["frame"]["shFormat"], cj["frame"]["rgbaFormat"])
+    assert os.path.samefile(pr.splat_sets[0], os.path.join(GOLDEN, "vkrepro", "scene.ply"))
+    img, st, (V, P) = gen.render_case(case, pr)
+    assert np.allclose(np.asarray(V, np.float32).T.reshape(-1), cj["view_glm_column_major"], atol=1e-6)
+    assert np.allclose(np.asarray(P, np.float32).T.reshape(-1), cj["proj_glm_column_major"], atol=1e-6)
+    want = np.load(os.path.join(d, "expected_rgba16f.npy"))
+    assert np.array_equal(img, want) and st["fragments"] > 50_000 and float(want[..., 3].max()) > 0.5
+
+
 # ---- stochastic paths: random numbers, stochastic splats, depth of field, temporal accumulation ----------------------------
 def _np_xxhash32(x, y, z):
     M = 0xFFFFFFFF
@@ -575,6 +605,21 @@ def _np_rand(seed):
     r = (word >> 22) ^ word
     v = np.array([0x3F800000 | (r >> 9)], np.uint32).view(np.float32)[0] - np.float32(1.0)
     return float(v), prev
+
+
+def test_xxhash32_restatement_against_the_published_xxhash_library(ob):
+    """A pin from outside the three restatements: Jarzynski-Olano's xxhash32(uvec3) — what nvshaders/random.h.slang ships, absent
+    from the reference tree — is the published XXH32 of the eight bytes (x, y) with the seed word taking z's place:
+    XXH32 starts a short input at seed + PRIME32_5 + length, the shader variant at z + PRIME32_5, then both run the same two
+    word rounds and the same avalanche — so xxhash32(x, y, z) == XXH32(le32(x) || le32(y), seed = z - 8 mod 2^32).  Checked
+    against the `xxhash` wheel (Yann Collet's reference implementation behind it), including XXH32's own published vector."""
+    import struct
+    xxhash = pytest.importorskip("xxhash")
+    assert xxhash.xxh32(b"", seed=0).intdigest() == 0x02CC5D05  # the library is the real thing (xxHash's documented test vector)
+    rng = np.random.default_rng(11)
+    for x, y, z in rng.integers(0, 2**32, (500, 3), dtype=np.uint64).tolist() + [[0, 0, 0], [1919, 1079, 199], [2**32 - 1] * 3, [5, 7, 3]]:
+        want = xxhash.xxh32(struct.pack("<II", x, y), seed=(z - 8) & 0xFFFFFFFF).intdigest()
+        assert ob.xxhash32(x, y, z) == want == _np_xxhash32(x, y, z)
 
 
 def test_random_numbers_against_independent_python_restatement(ob):
