@@ -162,6 +162,23 @@ def test_key_sort_variants_are_bit_identical_to_the_stable_sort():
     assert out["default"] and out["default"] == out["plain"] == out["generic"] == out["gather"] == out["nohistory"]
 
 
+def test_key_sort_oversubscribed_by_a_co_running_kernel():
+    """The look-back of k_os_pass waits for lower-numbered workgroups and leans on the dispatcher starting a 1-D grid in index
+    order (k_osort.hip header); all partitions of a frame-sized sort are usually resident at once, which hides the question.
+    Here a second stream fills the compute units with LDS-heavy workgroups that retire at 16 different times
+    (tests/helpers/cu_hog.hip), so the passes run in instalments: 18 sorts / frames / stand-alone sorts must equal the
+    undisturbed ones bit for bit; a wait that ran into its bound must come back as an error naming kErrSpinTimeout (ADVICE r3:
+    it used to return MGS_OK) — and nothing may hang (child process under a timeout)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    if not os.path.exists(os.path.join(here, "helpers", "libcuhog.so")):
+        pytest.skip("tests/helpers/libcuhog.so not built (python __graft_entry__.py)")
+    r = subprocess.run([sys.executable, os.path.join(here, "_child_hog.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "HOG_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    print([l for l in r.stdout.splitlines() if l.startswith("HOG_OK")])
+
+
 def test_upload_transform_matches_oracle_bitwise(scene_small, ob):
     scene, sc = scene_small
     ps = ob.PreparedSet(sc)
