@@ -36,8 +36,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_SQ_FILE = "r3_z_pmc_sq_composite.json"  # {"k_composite": {"SQ_INSTS_VALU": per-launch mean, ...}}
-PMC_FILE = "r3_z_pmc_hbm_traffic.json"  # written by tools/pmc_traffic.py from rocprofv3 --pmc passes of this command
+PMC_SQ_FILE = "r4_z_pmc_sq_composite.json"  # {"k_composite": {"SQ_INSTS_VALU": per-launch mean, ...}}
+PMC_FILE = "r4_z_pmc_hbm_traffic.json"  # written by tools/pmc_traffic.py from rocprofv3 --pmc passes of this command
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 STAGES = ["project", "sort", "bin", "pairsort", "composite", "total"]
 
@@ -92,6 +92,8 @@ def main():
                     "instead of the sorted alpha blend; a secondary number, never the headline")
     ap.add_argument("--dof", type=float, default=0.0, help="3DGUT only: depth of field with this aperture (focus distance 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras of the default run (value_reference_alpha, "
+                    "value_uint8_storage): profiling passes want the headline frames only")
     ap.add_argument("--inflight", type=int, default=3, help="frames in flight per GPU (each on its own HIP stream with "
                     "its own working buffers); >1 overlaps one frame's tails/launch gaps/all-gather with the next frame")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (functional check of the N>1 path "
@@ -547,7 +549,8 @@ def main():
             out["parity"] = {"error": f"{type(e).__name__}: {e}"[:200]}
 
     if (rank == 0 and world == 1 and not args.ply and args.scene == "garden" and args.pipeline == 0 and args.instances == 1
-            and not args.stochastic and not args.alpha_sum and args.dof == 0.0 and args.sh_format == 0 and args.rgba_format == 0):
+            and not args.stochastic and not args.alpha_sum and args.dof == 0.0 and args.sh_format == 0 and args.rgba_format == 0
+            and not args.no_extras):
         # The same workload in the reference's OTHER defaults, so that the headline cannot be mistaken for them (untimed extras,
         # a few dozen frames each, same contexts and frames in flight as the headline):
         #  * value_reference_alpha: MGS_ALPHA_SUM — A = sum(alpha), every fragment composited, no early termination: the blend
@@ -557,16 +560,19 @@ def main():
         #    headline uses fp32 storage (the benchmark setting of SURVEY.md 8d).
         def timed_fps(plist, steps, warm, inflight):
             kk = max(1, min(K, inflight))
-            for i in range(warm):
-                with torch.cuda.stream(streams[i % kk]):
-                    scenes[i % kk].render(plist[i % 64])
-            fence()
-            tq = time.perf_counter()
-            for i in range(steps):
-                with torch.cuda.stream(streams[i % kk]):
-                    scenes[i % kk].render(plist[(warm + i) % 64])
-            fence()
-            return steps / (time.perf_counter() - tq)
+            best = 0.0
+            for rep in range(2):  # best of two: right after a re-commit one run in a few is hit by a one-off ~1 s stall (allocator)
+                for i in range(warm):
+                    with torch.cuda.stream(streams[i % kk]):
+                        scenes[i % kk].render(plist[i % 64])
+                fence()
+                tq = time.perf_counter()
+                for i in range(steps):
+                    with torch.cuda.stream(streams[i % kk]):
+                        scenes[i % kk].render(plist[(warm + i) % 64])
+                fence()
+                best = max(best, steps / (time.perf_counter() - tq))
+            return best
         try:
             for pp in poses:
                 pp.alpha_mode = capi.ALPHA_SUM

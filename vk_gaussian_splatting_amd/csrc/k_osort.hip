@@ -5,14 +5,19 @@
 // sort of this build (k_sort.hip) runs histogram / scan / scatter per pass.  This file is what the in-frame key sort uses
 // instead: every pass is ONE kernel — each partition publishes its digit counts, resolves its digit prefixes from the
 // partitions before it while it ranks its keys, and scatters ("onesweep" structure; the look-back is re-designed for
-// MI355X, below) — and the digit totals every pass needs up front come for free from the producer:
-//   * k_project leaves a two-digit histogram per slot (bits 0-7 and 8-15, built while the keys are on chip) and, per wave, a
-//     record of how often each value of key >> 16 occurs (a partition is a compact cell of space: 1-3 values);
-//   * k_os_prepare reduces the slot histograms to totals, folds the records into a 64 K-entry count table (one atomic per
+// MI355X, below) — and what the passes need up front comes for free from the producer:
+//   * PASS 0 IS VIRTUAL (round 4).  k_project writes its slot grouped by the key's low byte (a stable multi-split of <= 2048
+//     pairs in LDS, slot_emit.h) together with the groups' counts and starts; where a pair stands after a stable pass on
+//     bits 0-7 is then a function of those counts alone, so that pass is never run: k_os_prepare turns the counts into two
+//     small tables, and the sort's first kernel (bits 8-15) gathers its dense partitions straight from the slots in digit-0
+//     order (k_os_pass<3>).  One pass of ranking, look-back, re-order, scatter and 16 B/key of traffic less than round 3;
+//   * k_project also leaves the slot's histogram of bits 8-15 and, per wave, a record of how often each value of key >> 16
+//     occurs (a partition is a compact cell of space: 1-3 values);
+//   * k_os_prepare reduces the histograms to totals, folds the records into a 64 K-entry count table (one atomic per
 //     occurring value per 32 slots) and turns the table into the totals of the upper passes: when at
 //     most 256 values of key >> 16 occur (depth keys span one or two binades) pass 2 sorts on the RANK of key >> 16 among
 //     them — an order-preserving 8-bit digit that covers the top 16 bits — and pass 3 does not run; otherwise plain digits.
-//   => launches per sort: prepare + 3 passes (+ 1 that exits at once), against 11 for reduce-then-scan with the elision.
+//   => launches per frame sort: prepare + 2 passes (+ 1 that exits at once); round 3: prepare + 3 (+ 1); reduce-then-scan: 11.
 //
 // Look-back, re-designed: the classic chain resolves partition p from p-1, one dependent cross-CU load per hop; with all
 // ~1 000 partitions of a frame's sort resident at once that serialises (measured 1.27 us per hop, tools/micro/

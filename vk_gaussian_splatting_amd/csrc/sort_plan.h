@@ -1,6 +1,7 @@
 // sort_plan.h — device-resident plans of the radix sorts and the host-side launch descriptors.
 //   k_sort.hip   generic reduce-then-scan LSD sort (any bit range; the record-path pair sort, the stand-alone sort API)
-//   k_osort.hip  the frame's depth-key sort: single-kernel passes with an in-kernel two-level look-back
+//   k_osort.hip  the frame's depth-key sort: single-kernel passes with an in-kernel two-level look-back; its pass 0 is virtual
+//                (done by the project kernels' hand-over, slot_emit.h)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -43,7 +44,7 @@ void launchRadixSort(hipStream_t stream, const SortLaunch& s);
 
 // ---- the frame's key sort (k_osort.hip) -------------------------------------------------------------------------------
 constexpr uint32_t kOsPart    = 4096;  // pairs per partition (256 threads x 16)
-constexpr uint32_t kOsSlot    = 2048;  // pairs a project workgroup's slot can hold (== its partition of splats)
+constexpr uint32_t kOsSlot    = 2048;  // pairs a project workgroup's slot can hold (== its partition of splats): 11-bit starts
 constexpr uint32_t kSlotHistWords = 384;  // what a slot leaves per partition (slot_emit.h): counts of key bits 0-7 and 8-15,
                                           // starts of the digit-0 groups — 16-bit values, two per word
 constexpr uint32_t kOsChunk   = 32;    // slots per chunk of the virtual pass 0 (k_os_prepare: one reduce workgroup per chunk)
@@ -54,7 +55,7 @@ constexpr uint32_t kRemapSpan = 4096;  // pass 2 of a depth-key sort indexes a 4
 struct OsPlan
 {
   uint32_t total[4][256];  // digit totals of every pass, complete before pass 0 starts (pass 2: per rank when remapOn)
-  uint32_t ticket[4];      // partitions are handed out in start order
+  uint32_t reserved4[4];   // (round 3 tried a start-order ticket per pass here: measured and dropped, k_osort.hip header)
   // Pass elision for depth keys: when at most 256 values of key >> 16 occur (within a span < 4096), pass 2 sorts on the RANK
   // of key >> 16 among them — an order-preserving 8-bit digit that covers the top 16 bits at once — and pass 3 does not run.
   uint32_t remapOn, remapCount, remapBase;
