@@ -206,6 +206,69 @@ def test_depth_keys_cull_and_sort_bit_exact(scene_small, ob, pose, flip):
     assert np.array_equal(i2[np.lexsort((i2, k2))], gi[np.lexsort((gi, gk))])  # same ids inside every tie run
 
 
+@pytest.mark.parametrize("shape", ["one key", "two keys", "few splats", "camera inside", "plane + cloud"])
+def test_frame_sort_degenerate_key_distributions(ob, shape):
+    """The frame's key sort never runs its first LSD pass: the project kernels write their slots grouped by the key's low byte
+    and the sort's first kernel gathers in that order through run tables (slot_emit.h, k_osort.hip).  The stand-alone sort's
+    adversarial battery does not go through that path, so here are the frame-path degenerates: every key equal (ONE run of up to
+    2048 pairs per slot: the wave-cooperative expansion; every id a tie, resolved in storage order), two key values, a handful of
+    splats (one partition spanning hundreds of digit-0 values, most of them empty), the camera inside the cloud (hundreds of values
+    of key >> 16: slots that span more than 24 of them, plain digits in the upper passes) and a plane inside a cloud (one giant run
+    among ordinary ones).  Sorted keys and ids bit for bit vs the
+    oracle, and the frame renders without error."""
+    rng = np.random.default_rng(17)
+    W, H = 640, 480
+    eye = np.array([0.0, 0.0, 5.0], np.float32)  # looks down -z at the origin: a plane z = const has ONE view depth
+    V, P = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, W, H)
+    n = {"one key": 300_000, "two keys": 200_000, "few splats": 67, "camera inside": 400_000, "plane + cloud": 250_000}[shape]
+    sc = synth.make_scene(n, seed=31)
+    pos = sc["positions"].copy()
+    xy = rng.uniform(-1.5, 1.5, (n, 2)).astype(np.float32)
+    if shape == "one key":
+        pos = np.concatenate([xy, np.zeros((n, 1), np.float32)], axis=1)
+    elif shape == "two keys":
+        pos = np.concatenate([xy, np.where(rng.random(n) < 0.5, 0.0, -1.0).astype(np.float32)[:, None]], axis=1)
+    elif shape == "few splats":
+        pos = np.concatenate([xy * 0.3, rng.uniform(-1, 1, (n, 1)).astype(np.float32)], axis=1)
+    elif shape == "plane + cloud":
+        plane = rng.random(n) < 0.4
+        pos[plane, 2] = 0.25
+        pos[plane, :2] = xy[plane]
+    sc["positions"] = np.ascontiguousarray(pos, np.float32)
+    sc["scale"] = np.full_like(sc["scale"], -5.0)  # small splats: nearly all survive the raster front end too
+    scene = mgs.Scene(0)
+    scene.add_instance(mgs.SplatSet.from_arrays(**sc))
+    scene.commit()
+    if shape == "camera inside":
+        eye = np.array([0.05, 0.1, 0.02], np.float32)
+        V, P = mgs.camera_lookat_perspective(eye, [1, 0.2, 0.5], [0, 1, 0], 60.0, 0.1, 2000.0, W, H)
+    p = capi.default_params(W, H)
+    capi.set_camera(p, V, P, eye)
+    oks, ois = oracle_sorted_stream(ob, scene, sc, dict(view=V, proj=P, camera_pos=eye, width=W, height=H))
+    so = scene.sort_keys(p)
+    gk, gi = scene.sort_download(so.count)
+    assert so.count == oks.size and so.count > (30 if shape == "few splats" else 30_000)
+    if shape == "camera inside":  # keys on both sides of zero: slots that span far more than the 24 values a wave record holds
+        top = np.unique(gk >> 16)
+        rank_digit = top.size <= 256 and int(top[-1]) - int(top[0]) < 4095  # what k_os_prepare decides (k_osort.hip)
+        assert top.size > 100 and ((so.reserved[0] == 1 and so.passes == 3) if rank_digit else (so.reserved[0] == 0 and so.passes == 4))
+    if shape == "one key":
+        assert np.unique(gk).size == 1
+    if shape == "two keys":
+        assert np.unique(gk).size == 2
+    assert np.array_equal(gk, oks) and np.array_equal(gi, ois)
+    out = scene.render(p, want_stats=True)
+    assert out.error_flags == 0 and out.sorted_count <= so.count
+    # the same through a second pose (other digit boundaries) for the mixed cases
+    if shape in ("plane + cloud", "few splats", "camera inside"):
+        p2, V2, P2, eye2 = camera(23, W, H)
+        oks, ois = oracle_sorted_stream(ob, scene, sc, dict(view=V2, proj=P2, camera_pos=eye2, width=W, height=H))
+        so = scene.sort_keys(p2)
+        gk, gi = scene.sort_download(so.count)
+        assert np.array_equal(gk, oks) and np.array_equal(gi, ois)
+    scene.close()
+
+
 def test_size_culling_bit_exact(scene_small, ob):
     """SIZE_CULLING_MODE (dist.comp.slang:93-134): same survivors, same keys, bit for bit"""
     scene, sc = scene_small
