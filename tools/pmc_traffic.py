@@ -1,8 +1,9 @@
 """rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py -> profiles/<name>.json (per-stage HBM bytes per launch).
 usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> "<command line that was profiled>"
 Correction (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE tallies wide (16 B/lane) coalesced streaming reads at
-half their bytes, so reads are doubled; other access widths and WRITE_SIZE are uncalibrated there, which makes
-2*FETCH_SIZE + WRITE_SIZE an upper estimate for kernels that also issue narrower loads (k_project's 4-byte centre loads)."""
+half their bytes, so reads are doubled.  Round 4 calibrated the other widths (tools/micro/pmc_calib.hip,
+profiles/r4_z_pmc_calibration.json): streaming reads of 4-, 8-, 16-byte lanes and of 3 x 4 bytes at a 12-byte pitch are ALL
+tallied at exactly half, writes of 4-, 8-, 16-byte lanes and 32-byte records exactly: 2*FETCH_SIZE + WRITE_SIZE holds."""
 import csv, glob, json, sys, collections
 
 STAGE = {"project": ["k_project"], "sort": ["k_sort_", "k_os_"], "bin": ["k_dbin_", "k_bin_"], "composite": ["k_composite"]}
