@@ -245,7 +245,10 @@ typedef struct MgsFrameOut {
   uint32_t frustum_count;   /* survivors of the dist-stage cull == IndirectParams.instanceCount (shaderio.h:343-356) */
   uint32_t sorted_count;    /* elements actually sorted (after alpha/extent/off-screen rejection) */
   uint64_t tile_pairs;      /* (tile, splat) records built by the binning stage */
-  uint32_t error_flags;     /* device-side diagnostics, 0 = clean */
+  uint32_t error_flags;     /* device-side diagnostics, 0 = clean.  bit 0: a per-bin list overflowed (mgs_frame_stats returns
+                               MGS_ERR_OVERFLOW); bit 1: a bounded look-back wait of the key sort gave up — the sorted order,
+                               hence the frame, is invalid (mgs_frame_stats / mgs_sort_keys / mgs_radix_sort_u32 return
+                               MGS_ERR_DEVICE; nothing hangs) */
   uint32_t shaded_count;    /* (splat, screen region) pairs staged and shaded by the compositor (deferred SH evaluation) */
   uint64_t scanned_entries; /* bin-list entries the compositor looked at before its regions saturated */
   float    stage_ms[MGS_STAGE_COUNT]; /* valid when collect_timings; HIP-event times on the render stream */
