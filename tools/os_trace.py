@@ -28,9 +28,9 @@ for pose in poses:
     pr = pr[pr[:, 0] > 0]
     if len(pr):
         b0 = pr[:, 0].min()
-        ph = np.diff(pr[:, :5], axis=1) / 100.0
-        print(f"--- pose {pose} k_os_prepare: {len(pr)} reduce workgroups; start spread {(pr[:, 0].max() - b0) / 100.0:.1f} us; all arrived at {(pr[:, 4].max() - b0) / 100.0:.1f} us")
-        for i, n in enumerate(["zeroing + slot histograms + total atomics", "records -> LDS table -> count-table atomics", "drain (vmcnt 0) + barrier", "arrival atomic + barrier"]):
+        ph = np.diff(pr[:, :3], axis=1) / 100.0
+        print(f"--- pose {pose} k_os_prepare: {len(pr)} reduce workgroups; start spread {(pr[:, 0].max() - b0) / 100.0:.1f} us; all done at {(pr[:, 2].max() - b0) / 100.0:.1f} us")
+        for i, n in enumerate(["slot rows -> chunk tables + total atomics", "records -> LDS table -> count-table atomics"]):
             print(f"   {n:48s} median {np.median(ph[:, i]):6.2f} us  max {ph[:, i].max():6.2f}")
         last = pr[pr[:, 7] == 1]
         if len(last):

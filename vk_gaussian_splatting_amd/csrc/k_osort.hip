@@ -297,62 +297,77 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
     atomicMax(&plan->top16MinInv, 0x10000u - s_lo);
     atomicMax(&plan->top16MaxP1, s_hi + 1u);
   }
-  // ---- arrival: the last workgroup folds the table.  Every wave drains its own atomics (they are performed at the memory
-  // side, so "acknowledged" is "visible"), then one lane takes the ticket: no fence by 1024 threads ----
-  MGS_OS_STAMP(2)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  MGS_OS_STAMP(3)
-  if(t == 0)
-    s_last = (atomicAdd(&plan->arrived, 1u) == reduceWgs - 1u) ? 1u : 0u;
-  __syncthreads();
-  MGS_OS_STAMP(4)
+  // (Rounds 3 and the first half of round 4 went on here: the workgroup that arrived last — drain, arrival counter, barrier —
+  //  folded the count table into the rank table, 4 us at the end of this kernel's critical path.  The fold needs the table
+  //  complete and is needed by the SECOND sort kernel only: it now runs as one extra workgroup of the first one, beside its
+  //  partitions — foldTop16 below.)
 #ifdef MGS_OS_TRACE
-  if(t == 0 && g_osPrepTrace && !s_last)
+  MGS_OS_STAMP(2)
+  if(t == 0 && g_osPrepTrace)
     for(int i = 0; i < 8; ++i) g_osPrepTrace[(size_t)blockIdx.x * 8 + i] = trc[i];
 #endif
-  if(!s_last)
-    return;
-  const uint32_t minInv = ldAgent(&plan->top16MinInv), maxP1 = ldAgent(&plan->top16MaxP1);
+  (void)s_mm;
+  (void)s_last;
+  (void)s_tmp;
+  (void)allowRemap;
+}
+
+// The count table of key >> 16 -> what the upper passes sort on.  At most 256 occurring values within a span < 4096: the second
+// kernel sorts on their RANK (plan->remapVals, totals per rank) and is final; otherwise plain digits for passes 2 and 3 (totals of
+// bits 16-23 and 24-31).  Clears what it read: the table is clean for the next sort of this context.  One workgroup; the table is
+// complete (the kernel that filled it has ended).
+// kOsFoldWgs workgroups take part: the narrow case (the rule) is workgroup 0's alone; a wide range — up to 64 K values — is split
+// between all of them (one 256-thread workgroup walking it alone held the first sort kernel up for 50 us).
+constexpr uint32_t kOsFoldWgs = 8;
+template <int THREADS>
+__device__ __forceinline__ void foldTop16(OsPlan* __restrict__ plan, uint32_t* __restrict__ top16Count, int allowRemap, uint32_t wg,
+                                          uint32_t* s_part /*512*/, uint32_t* s_sum /*THREADS / 64*/)
+{
+  constexpr uint32_t kPer = kRemapSpan / THREADS;  // consecutive values per thread (ordered compaction)
+  const int          t = threadIdx.x, lane = laneId(), w = t >> 6;
+  const uint32_t     minInv = plan->top16MinInv, maxP1 = plan->top16MaxP1;
   if(minInv == 0u || maxP1 == 0u)
   {  // no real keys at all
-    if(t == 0)
+    if(t == 0 && wg == 0u)
       plan->remapOn = plan->remapCount = plan->remapBase = 0u;
     return;
   }
   const uint32_t vlo = 0x10000u - minInv, span = maxP1 - vlo;  // values vlo .. vlo + span - 1
+  for(int i = t; i < 512; i += THREADS)
+    s_part[i] = 0u;
   if(span <= kRemapSpan - 1u)
-  {  // thread t owns 4 consecutive values; ordered compaction by a block scan
-    uint32_t c[4], nz = 0;
+  {
+    if(wg != 0u)
+      return;
+    uint32_t c[kPer], nz = 0;
 #pragma unroll
-    for(int i = 0; i < 4; ++i)
+    for(uint32_t i = 0; i < kPer; ++i)
     {
-      const uint32_t k = (uint32_t)t * 4u + i;
-      c[i]             = k < span ? ldAgent(&top16Count[vlo + k]) : 0u;
-      if(k < span)
-        top16Count[vlo + k] = 0u;  // consumed: clean for the next sort of this context
+      const uint32_t k = (uint32_t)t * kPer + i;
+      c[i]             = k < span ? top16Count[vlo + k] : 0u;
       nz += c[i] ? 1u : 0u;
     }
+#pragma unroll
+    for(uint32_t i = 0; i < kPer; ++i)
+      if(c[i])
+        top16Count[vlo + (uint32_t)t * kPer + i] = 0u;  // consumed
     const uint32_t inc = waveInclusiveScan(nz);
     if(lane == 63)
-      s_tmp[w] = inc;
+      s_sum[w] = inc;
     __syncthreads();
     uint32_t base = 0, total = 0;
-    for(int q = 0; q < 16; ++q)
+    for(int q = 0; q < THREADS / 64; ++q)
     {
-      if(q < w) base += s_tmp[q];
-      total += s_tmp[q];
+      if(q < w) base += s_sum[q];
+      total += s_sum[q];
     }
     const bool on = allowRemap != 0 && total >= 1u && total <= 256u;
     uint32_t   run = base + inc - nz;
-    if(t < 256)
-      s_part[t] = s_part[256 + t] = 0u;
-    __syncthreads();
 #pragma unroll
-    for(int i = 0; i < 4; ++i)
+    for(uint32_t i = 0; i < kPer; ++i)
       if(c[i])
       {
-        const uint32_t v = vlo + (uint32_t)t * 4u + i;
+        const uint32_t v = vlo + (uint32_t)t * kPer + i;
         if(on)
         {
           plan->remapVals[run] = (uint16_t)v;
@@ -366,11 +381,12 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
         }
       }
     __syncthreads();
-    if(!on && t < 256)
-    {
-      plan->total[2][t] = s_part[t];
-      plan->total[3][t] = s_part[256 + t];
-    }
+    if(!on)
+      for(int i = t; i < 256; i += THREADS)
+      {
+        plan->total[2][i] = s_part[i];
+        plan->total[3][i] = s_part[256 + i];
+      }
     if(t == 0)
     {
       plan->remapOn      = on ? 1u : 0u;
@@ -378,41 +394,41 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
       plan->remapBase    = on ? vlo : 0u;
       plan->remapPadRank = on ? total - 1u : 0u;  // keys outside the table (padding) take the largest rank
     }
-#ifdef MGS_OS_TRACE
-    __syncthreads();
-    MGS_OS_STAMP(5)
-    if(t == 0 && g_osPrepTrace)
-    {
-      for(int i = 0; i < 8; ++i) g_osPrepTrace[(size_t)blockIdx.x * 8 + i] = trc[i];
-      g_osPrepTrace[(size_t)blockIdx.x * 8 + 7] = 1;  // the last arriver
-    }
-#endif
     return;
   }
-  // wide range (camera inside the cloud): plain digits of bits 16-23 and 24-31
-  if(t < 256)
-    s_part[t] = s_part[256 + t] = 0u;
+  // wide range (camera inside the cloud): plain digits of bits 16-23 and 24-31; this workgroup's share of the range, eight loads
+  // in flight per thread, the totals added to the plan's (zero when the frame starts)
   __syncthreads();
-  for(uint32_t k = t; k < span; k += 1024u)
+  const uint32_t share = (span + kOsFoldWgs - 1u) / kOsFoldWgs, k0 = wg * share, k1 = min(span, k0 + share);
+  for(uint32_t kb = k0; kb < k1; kb += 8u * THREADS)
   {
-    const uint32_t c = ldAgent(&top16Count[vlo + k]);
-    if(c)
+    uint32_t c[8];
+#pragma unroll
+    for(int i = 0; i < 8; ++i)
     {
-      const uint32_t v   = vlo + k;
-      top16Count[v]      = 0u;
-      atomicAdd(&s_part[v & 255u], c);
-      atomicAdd(&s_part[256u + (v >> 8)], c);
+      const uint32_t k = kb + (uint32_t)i * THREADS + (uint32_t)t;
+      c[i]             = k < k1 ? top16Count[vlo + k] : 0u;
     }
+#pragma unroll
+    for(int i = 0; i < 8; ++i)
+      if(c[i])
+      {
+        const uint32_t v = vlo + kb + (uint32_t)i * THREADS + (uint32_t)t;
+        top16Count[v]    = 0u;
+        atomicAdd(&s_part[v & 255u], c[i]);
+        atomicAdd(&s_part[256u + (v >> 8)], c[i]);
+      }
   }
   __syncthreads();
-  if(t < 256)
+  for(int i = t; i < 256; i += THREADS)
   {
-    plan->total[2][t] = s_part[t];
-    plan->total[3][t] = s_part[256 + t];
+    if(s_part[i])
+      atomicAdd(&plan->total[2][i], s_part[i]);
+    if(s_part[256 + i])
+      atomicAdd(&plan->total[3][i], s_part[256 + i]);
   }
-  if(t == 0)
+  if(t == 0 && wg == 0u)
     plan->remapOn = plan->remapCount = plan->remapBase = 0u;
-  (void)s_mm;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -436,6 +452,8 @@ struct OsPassArgs
   const uint32_t* runTab;    // IN 3: [256][32 chunks]
   uint32_t        chunks;
   uint32_t        srcLimit;  // IN 3: the last valid pair index (a corrupted table must not turn into a wild read)
+  uint32_t*       top16Count;  // IN 3: the grid's LAST workgroup folds the count table of key >> 16 for the kernel behind this one
+  int             allowRemap;
   // the bin rectangles' codes ride above the ids (kernels_common.h: rideEncode); the final pass of a frame separates them:
   // clean ids for everybody, the codes in sorted order for the binning stage
   uint32_t        rideShift;   // bits of the id proper; 0 = nothing rides
@@ -488,6 +506,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
   // clear look-back words for a later pass (stream order: nobody reads them any more)
   for(uint32_t i = blockIdx.x * kThreads + t; i < a.zWords; i += gridDim.x * kThreads)
     a.zStatus[i] = 0u;
+  if constexpr(IN == 3)
+    if(blockIdx.x >= gridDim.x - kOsFoldWgs)
+    {  // workgroups beyond the partitions: what the SECOND kernel sorts on (foldTop16), beside this kernel's own work
+      foldTop16<kThreads>(plan, a.top16Count, a.allowRemap, blockIdx.x - (gridDim.x - kOsFoldWgs), reinterpret_cast<uint32_t*>(s_pair), s_tmp);
+      return;
+    }
   for(int i = t; i < kWaves * 256; i += kThreads)
     (&s_whist[0][0])[i] = 0;
   const bool useRemap = REMAP && remapped;
@@ -936,7 +960,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
     o[7] = ((uint64_t)count << 32) | spins;
     if(IN == 3)
     {  // the table's sub-stamps go where the (virtual) pass 0 would have put its own
-      uint64_t* g = a.trace - (size_t)gridDim.x * 8 + (size_t)p * 8;
+      uint64_t* g = a.trace - (size_t)(gridDim.x - kOsFoldWgs) * 8 + (size_t)p * 8;  // (this kernel's grid has workgroups beyond the partitions)
       g[0] = trc[0];
       for(int i = 0; i < 5; ++i) g[1 + i] = gtr[i];
       g[6] = trc[1];
@@ -1050,6 +1074,8 @@ void launchOsSort(hipStream_t stream, const OsLaunch& L)
     a.runTab    = L.runTab;
     a.chunks    = reduceWgs;
     a.srcLimit  = L.prjParts * kOsSlot - 1u;
+    a.top16Count = L.top16Count;
+    a.allowRemap = (frame && L.allowRemap) ? 1 : 0;
     a.rideShift = frame ? L.rideShift : 0u;
     a.rideInfo  = L.rideInfo;
     a.dstCode16 = L.outCode16;
@@ -1063,7 +1089,7 @@ void launchOsSort(hipStream_t stream, const OsLaunch& L)
     if(pass == 0)
       hipLaunchKernelGGL((k_os_pass<2, false>), dim3(grid), dim3(kThreads), 0, stream, a);
     else if(pass == 1 && frame)
-      hipLaunchKernelGGL((k_os_pass<3, false>), dim3(grid), dim3(kThreads), 0, stream, a);
+      hipLaunchKernelGGL((k_os_pass<3, false>), dim3(grid + kOsFoldWgs), dim3(kThreads), 0, stream, a);  // + the workgroups that fold the count table
     else if(pass == 2 && frame)
       hipLaunchKernelGGL((k_os_pass<0, true>), dim3(grid), dim3(kThreads), 0, stream, a);
     else
