@@ -1086,10 +1086,13 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
     // with scalar bit tricks (no per-record branch) and the per-pixel discards are predicated.
     if(!waveDone)
     {
+      // (the wave's quarter bit as a scalar: derived from the thread index it was a vector register the compiler spilled and
+      //  re-loaded from scratch at the head of every 64-record chunk)
+      const uint32_t wbit = 1u << (uint32_t)__builtin_amdgcn_readfirstlane(w);
       for(uint32_t j0 = 0; j0 < fill; j0 += 64)
       {
         const uint32_t jl   = j0 + (uint32_t)lane;
-        const bool     mine = jl < fill && ((s_m[jl] >> w) & 1u);
+        const bool     mine = jl < fill && (s_m[jl] & wbit) != 0u;
         uint64_t       hits = __ballot(mine);
         while(hits != 0ull)
         {
