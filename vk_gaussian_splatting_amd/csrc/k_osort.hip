@@ -181,8 +181,7 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
   if(blockIdx.x >= reduceWgs)
     return;
   __shared__ uint32_t s_part[512];
-  __shared__ uint32_t s_lo, s_hi, s_last;
-  __shared__ uint32_t s_tmp[16], s_mm[32];
+  __shared__ uint32_t s_lo, s_hi;
   const uint32_t slot0 = blockIdx.x * 32u;
   // the records' loads go out with the histograms' (one round trip instead of three): thread t owns words j0 .. j0 + 3 of
   // record t / 8, and reads that record's header itself
@@ -299,17 +298,14 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
   }
   // (Rounds 3 and the first half of round 4 went on here: the workgroup that arrived last — drain, arrival counter, barrier —
   //  folded the count table into the rank table, 4 us at the end of this kernel's critical path.  The fold needs the table
-  //  complete and is needed by the SECOND sort kernel only: it now runs as one extra workgroup of the first one, beside its
-  //  partitions — foldTop16 below.)
+  //  complete and is needed by the SECOND sort kernel only: it now runs in workgroups beyond the partitions of the first one,
+  //  beside that kernel's own work — foldTop16 below.)
 #ifdef MGS_OS_TRACE
   MGS_OS_STAMP(2)
   if(t == 0 && g_osPrepTrace)
     for(int i = 0; i < 8; ++i) g_osPrepTrace[(size_t)blockIdx.x * 8 + i] = trc[i];
 #endif
-  (void)s_mm;
-  (void)s_last;
-  (void)s_tmp;
-  (void)allowRemap;
+  (void)allowRemap;  // (the rank digit's switch travels with the first sort kernel now: OsPassArgs::allowRemap)
 }
 
 // The count table of key >> 16 -> what the upper passes sort on.  At most 256 occurring values within a span < 4096: the second

@@ -61,7 +61,7 @@ struct OsPlan
   uint32_t remapOn, remapCount, remapBase;
   uint32_t n;               // element count (copied from the device-side counter by k_os_prepare)
   uint32_t remapPadRank;    // pass 2 when remapOn: the rank of keys outside the table (padding lanes): the largest
-  uint32_t arrived;         // reduce workgroups of k_os_prepare that are done (the last one folds the count table)
+  uint32_t arrivedUnused;   // (rounds 3-4: arrival counter of k_os_prepare's reduce workgroups; the fold moved to k_os_pass<3>)
   uint32_t top16MinInv;     // 0x10000 - (smallest occurring value of key >> 16); 0 = none   } both kept as maxima: the plan
   uint32_t top16MaxP1;      // largest occurring value + 1; 0 = none                          } starts zeroed
   uint32_t pad[4];
