@@ -213,4 +213,25 @@ def test_projected_records_match_oracle_per_splat(ob, case):
     shrink = np.sqrt(np.minimum(4.0, np.log(a255)) / 4.0)
     assert np.all(ex >= shrink * np.hypot(want[:, 2], want[:, 4]) * 0.999)
     assert np.all(ey >= shrink * np.hypot(want[:, 3], want[:, 5]) * 0.999)
+    # ... and the bin rectangle of EVERY sorted splat (the ones whose rectangle rode through the key sort as a code
+    # used to come back stale): default bins are 256 x 128 px
+    bw, bh = 256, 128
+    bxn, byn = (W + bw - 1) // bw, (H + bh - 1) // bh
+    x0b, y0b = (rect & 255).astype(np.int64), ((rect >> 8) & 255).astype(np.int64)
+    x1b, y1b = ((rect >> 16) & 255).astype(np.int64), (rect >> 24).astype(np.int64)
+    assert np.all(x0b <= x1b) and np.all(y0b <= y1b) and np.all(x1b < bxn) and np.all(y1b < byn)
+    exw, eyw = shrink * np.hypot(want[:, 2], want[:, 4]) * 0.999, shrink * np.hypot(want[:, 3], want[:, 5]) * 0.999
+    fx0, fx1 = np.ceil(want[:, 0] - exw - 0.5), np.floor(want[:, 0] + exw - 0.5)
+    fy0, fy1 = np.ceil(want[:, 1] - eyw - 0.5), np.floor(want[:, 1] + eyw - 0.5)
+    vis = (fx1 >= fx0) & (fy1 >= fy0) & (fx1 >= 0) & (fx0 <= W - 1) & (fy1 >= 0) & (fy0 <= H - 1)
+    assert vis.sum() > 0.9 * ids.size
+    cx0, cx1 = np.clip(fx0, 0, W - 1), np.clip(fx1, 0, W - 1)
+    cy0, cy1 = np.clip(fy0, 0, H - 1), np.clip(fy1, 0, H - 1)
+    assert np.all((x0b * bw <= cx0)[vis]) and np.all(((x1b + 1) * bw > cx1)[vis])
+    assert np.all((y0b * bh <= cy0)[vis]) and np.all(((y1b + 1) * bh > cy1)[vis])
+    # tight as well: the rectangle is the box of the kernel's own (fp16-rounded-up) extents at most
+    gx0, gx1 = np.clip(np.ceil(got[:, 0] - ex - 0.5), 0, W - 1), np.clip(np.floor(got[:, 0] + ex - 0.5), 0, W - 1)
+    gy0, gy1 = np.clip(np.ceil(got[:, 1] - ey - 0.5), 0, H - 1), np.clip(np.floor(got[:, 1] + ey - 0.5), 0, H - 1)
+    assert np.all((x0b >= gx0 // bw)[vis]) and np.all((x1b <= gx1 // bw)[vis])
+    assert np.all((y0b >= gy0 // bh)[vis]) and np.all((y1b <= gy1 // bh)[vis])
     scene.close()

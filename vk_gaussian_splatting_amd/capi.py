@@ -69,6 +69,8 @@ class SortOut(C.Structure):
 
 
 def lib_path():
+    if os.environ.get("MGS_LIB"):  # experiments: a variant build of the same library (tools/build_variant.sh); never a fallback
+        return os.path.abspath(os.environ["MGS_LIB"])
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmgs.so")
 
 

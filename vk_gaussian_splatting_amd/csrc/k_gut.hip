@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
                                                              GutRec* __restrict__ rec, uint32_t* __restrict__ rect,
                                                              uint32_t* __restrict__ slotHist2,
                                                              uint32_t* __restrict__ top16Rec, uint32_t* __restrict__ top16Count,
-                                                             OsPlan* __restrict__ osPlan)
+                                                             OsPlan* __restrict__ osPlan, const uint32_t* __restrict__ order)
 {
   const FrameArgs& A = *Ap;
   __shared__ uint32_t s_hist2[256];  // 2 x 256 sixteen-bit counters (slot_emit.h)
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
   __shared__ uint32_t s_cnt[32];
   __shared__ uint32_t s_base[33];
   const int      t = threadIdx.x, lane = laneId(), w = t >> 6;
-  const uint32_t part = blockIdx.x;
+  const uint32_t part = order != nullptr ? order[blockIdx.x] : blockIdx.x;  // fullest slot of the previous frame first (k_project.hip)
   int            k    = 0;
   for(int i = 1; i < A.f.nInstances; ++i)
     if(part >= A.inst[i].blockBegin)
@@ -1014,13 +1014,13 @@ __global__ __launch_bounds__(256) void k_composite_gut2(const FrameArgs* __restr
 // ---------------------------------------------------------------------------------------------
 void launchProjectGut(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, int shFormat, FrameCounters* ctr,
                       uint2* slotPairs, uint32_t* slotCount, GutRec* rec, uint32_t* rect,
-                      uint32_t* slotHist2, uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan)
+                      uint32_t* slotHist2, uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan, const uint32_t* order)
 {
   (void)shFormat;
   if(args.f.totalPartitions == 0)
     return;
   hipLaunchKernelGGL(k_project_gut, dim3(args.f.totalPartitions), dim3(kGutThreads), 0, stream, dArgs, ctr, slotPairs, slotCount, rec, rect,
-                     slotHist2, top16Rec, top16Count, osPlan);
+                     slotHist2, top16Rec, top16Count, osPlan, order);
 }
 
 void launchCompositeGut(hipStream_t stream, const FrameArgs& A, const FrameArgs* dArgs, const uint2* ranges, const uint32_t* valX,

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
                                                      uint32_t* __restrict__ top16Count, OsPlan* __restrict__ plan, const uint32_t* __restrict__ nPtr,
                                                      int allowRemap, uint32_t reduceWgs, const uint32_t* __restrict__ slotCount,
                                                      uint32_t* __restrict__ chunkSum, uint32_t* __restrict__ runTab,
-                                                     uint32_t* __restrict__ nOut)
+                                                     uint32_t* __restrict__ nOut, uint32_t* __restrict__ orderOut)
 {
   const int t = threadIdx.x, lane = laneId(), w = t >> 6;
 #ifdef MGS_OS_TRACE
@@ -175,6 +175,33 @@ __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict_
         total += s_scan[q];
       plan->n = total;
       *nOut   = total;
+    }
+    if(orderOut != nullptr)
+    {  // The NEXT frame's dispatch order of the project kernel's partitions: fullest slot first (round 5).  That kernel runs
+       // 1.85 residency waves of workgroups that take 19 .. 80 us each in storage order, and a third of its span was a draining
+       // tail (profiles/r4_z_prj_trace.log); a partition's cost follows its survivor count, which hardly changes from one frame of
+       // a sequence to the next.  Scheduling only: slots are per partition, the frame does not depend on the order.  A counting
+       // sort on count / 64 (33 classes), the order inside a class is whatever the atomics give.
+      __shared__ uint32_t s_cls[40];
+      if(t < 40)
+        s_cls[t] = 0u;
+      __syncthreads();
+      for(uint32_t q = t; q < prjParts; q += 1024u)
+        atomicAdd(&s_cls[32u - min(slotCount[q] >> 6, 32u)], 1u);
+      __syncthreads();
+      if(t == 0)
+      {
+        uint32_t run = 0;
+        for(int c = 0; c < 33; ++c)
+        {
+          const uint32_t v = s_cls[c];
+          s_cls[c]         = run;
+          run += v;
+        }
+      }
+      __syncthreads();
+      for(uint32_t q = t; q < prjParts; q += 1024u)
+        orderOut[atomicAdd(&s_cls[32u - min(slotCount[q] >> 6, 32u)], 1u)] = q;
     }
     return;
   }
@@ -473,8 +500,11 @@ struct OsPassArgs
   int             finalMode;  // 0 writes pairs; 1 writes the result; 2 writes the result iff the plan says remap (pass 2)
 };
 
+#ifndef MGS_OS_WAVES
+#define MGS_OS_WAVES 4
+#endif
 template <int IN, bool REMAP>
-__global__ __launch_bounds__(kThreads, 4) void k_os_pass(const OsPassArgs a)
+__global__ __launch_bounds__(kThreads, MGS_OS_WAVES) void k_os_pass(const OsPassArgs a)
 {
   __shared__ uint2    s_pair[kOsPart];       // 32 KB: the partition's pairs ordered by digit
   __shared__ uint16_t s_whist[kWaves][256];  //  2 KB: per wave digit counts -> offsets
@@ -1023,7 +1053,7 @@ void launchOsSort(hipStream_t stream, const OsLaunch& L)
     hipLaunchKernelGGL(k_os_hist, dim3(std::min<uint32_t>((L.maxElems + 2047u) / 2048u, 1024u)), dim3(256), 0, stream, L.keys0, L.nPtr, L.plan);
   const uint32_t reduceWgs = frame ? osSortChunks(L.prjParts) : 0u;
   hipLaunchKernelGGL(k_os_prepare, dim3(reduceWgs + 1u), dim3(1024), 0, stream, frame ? L.slotHist : nullptr, L.top16Rec, L.prjParts,
-                     L.top16Count, L.plan, L.nPtr, (frame && L.allowRemap) ? 1 : 0, reduceWgs, L.slotCount, L.chunkSum, L.runTab, L.nOut);
+                     L.top16Count, L.plan, L.nPtr, (frame && L.allowRemap) ? 1 : 0, reduceWgs, L.slotCount, L.chunkSum, L.runTab, L.nOut, L.prjOrderOut);
   // A frame's sort starts at pass 1: its pass 0 is virtual (slot_emit.h, OsPassArgs).
   for(int pass = frame ? 1 : 0; pass < 4; ++pass)
   {

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
                                                          SplatRec* __restrict__ rec, uint32_t* __restrict__ rect,
                                                          uint32_t* __restrict__ slotHist2,
                                                          uint32_t* __restrict__ top16Rec, uint32_t* __restrict__ top16Count,
-                                                         OsPlan* __restrict__ osPlan)
+                                                         OsPlan* __restrict__ osPlan, const uint32_t* __restrict__ order)
 {
   const FrameArgs& A = *Ap;  // frame constants live in device memory (same pointer every frame: graph-replayable)
 #ifdef MGS_PRJ_TRACE
@@ -231,7 +231,8 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   E.cnt   = s_cnt;
 
   const int      t = threadIdx.x, lane = laneId(), w = t >> 6;
-  const uint32_t part = blockIdx.x;
+  // partitions are dispatched fullest slot of the PREVIOUS frame first (k_os_prepare leaves the order; scheduling only)
+  const uint32_t part = order != nullptr ? order[blockIdx.x] : blockIdx.x;
   int            k    = 0;
   for(int i = 1; i < A.f.nInstances; ++i)  // instances own consecutive partition ranges
     if(part >= A.inst[i].blockBegin)
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
     MGS_PRJ_STAMP(5)
     if(threadIdx.x == 0 && g_prjTrace)
     {
-      uint64_t* o = g_prjTrace + (size_t)blockIdx.x * 8;
+      uint64_t* o = g_prjTrace + (size_t)blockIdx.x * 8;  // (dispatch order)
       for(int i = 0; i < 6; ++i) o[i] = trc[i];
       o[6] = M;
       o[7] = outCount;
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
 // host-callable launcher
 void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full, FrameCounters* ctr, uint2* slotPairs,
                    uint32_t* slotCount, SplatRec* rec, uint32_t* rect, uint32_t* slotHist2,
-                   uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan)
+                   uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan, const uint32_t* order)
 {
   const dim3 grid(args.f.totalPartitions), block(kPrjThreads);
   if(args.f.totalPartitions == 0)
@@ -469,7 +470,7 @@ void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* d
 #endif
 #define MGS_LAUNCH(FULLV)                                                                                                \
   hipLaunchKernelGGL((k_project<FULLV>), grid, block, 0, stream, dArgs, ctr, slotPairs, slotCount, rec, rect, slotHist2, \
-                     top16Rec, top16Count, osPlan)
+                     top16Rec, top16Count, osPlan, order)
   if(full)
     MGS_LAUNCH(true);
   else

@@ -34,7 +34,7 @@ namespace mgs {
 // kernels_*.hip
 void launchProject(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, bool full, FrameCounters* ctr, uint2* slotPairs,
                    uint32_t* slotCount, SplatRec* rec, uint32_t* rect, uint32_t* slotHist2,
-                   uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan);
+                   uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan, const uint32_t* order);
 void launchFrameInit(hipStream_t stream, uint2* ranges, uint32_t nTiles);
 void launchBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
                    const uint32_t* rect, uint32_t* blockCount, uint32_t maxBlocks, FrameCounters* ctr, uint32_t* sortedRect,
@@ -53,7 +53,7 @@ void launchComposite(hipStream_t stream, const FrameArgs& A, const uint2* ranges
                      float4* outNormal, uint32_t* binCost);
 void launchProjectGut(hipStream_t stream, const FrameArgs& args, const FrameArgs* dArgs, int shFormat, FrameCounters* ctr,
                       uint2* slotPairs, uint32_t* slotCount, GutRec* rec, uint32_t* rect,
-                      uint32_t* slotHist2, uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan);
+                      uint32_t* slotHist2, uint32_t* top16Rec, uint32_t* top16Count, OsPlan* osPlan, const uint32_t* order);
 void launchCompositeGut(hipStream_t stream, const FrameArgs& A, const FrameArgs* dArgs, const uint2* ranges, const uint32_t* valX,
                         const uint32_t* valY, const SortPlan* planPairs, const GutRec* rec, void* image, int halfOut,
                         FrameCounters* ctr, int shFormat, float* outDepth, uint32_t* outSplatId, float4* outNormal);
@@ -287,6 +287,7 @@ struct MgsScene_t
   DevBuf<uint2>         pairA, pairB;  // ping-pong of the key sort; the project kernels leave their (key, id) pairs in B, one
                                        // slot of 2048 entries per partition
   DevBuf<uint32_t>      slotHist2, top16Rec, top16Count, osStatus;  // what the key sort needs besides (k_osort.hip)
+  DevBuf<uint32_t>      prjOrder;                    // [parts] dispatch order of the project kernels' partitions (identity until a key sort has run)
   DevBuf<uint32_t>      slotCount, chunkSum, runTab;  // pairs per slot; the tables of the sort's virtual pass 0 (k_os_prepare)
   DevBuf<uint16_t>      sortedCode16;                // the bin rectangles' codes in sorted order (they ride through the key sort)
   DevBuf<uint32_t>      binCost;                     // [256] per bin: its slowest region in the last frame -> the next frame's bin order
@@ -339,6 +340,7 @@ struct MgsScene_t
   // last frame
   MgsFrameParams lastParams{};
   bool           haveFrame = false, lastTimed = false, lastWasSortOnly = false;
+  int            lastRide[5] = {0, 0, 0, 0, 0};  // the last frame's rideShift, code bits, binsX, binsY, 1 if the GPU key sort ran (mgs_frame_download_projected)
   bool           lastListsPartial = false;  // the last frame came from mgs_render_gathered: its bin lists cover this rank's rows only
   size_t         imageBytes = 0, imageRowBytes = 0;
   MgsSortOut     lastSort{};
@@ -741,7 +743,7 @@ void mgs_scene_destroy(MgsScene s)
     auto& h = s->d->handles;
     h.erase(std::remove(h.begin(), h.end(), s), h.end());
   }
-  s->pairA.release(); s->pairB.release(); s->slotCount.release(); s->chunkSum.release(); s->runTab.release(); s->sortedCode16.release(); s->binCost.release(); s->slotHist2.release(); s->top16Rec.release(); s->top16Count.release();
+  s->pairA.release(); s->prjOrder.release(); s->pairB.release(); s->slotCount.release(); s->chunkSum.release(); s->runTab.release(); s->sortedCode16.release(); s->binCost.release(); s->slotHist2.release(); s->top16Rec.release(); s->top16Count.release();
   s->osStatus.release(); s->keysA.release(); s->idsA.release(); s->rect.release(); s->partHist.release(); s->blockCount.release();
   s->rec.release(); s->recGut.release(); s->pairKey0.release(); s->pairVal0.release(); s->pairKey1.release(); s->pairVal1.release();
   s->sortedRect.release(); s->splatOffset.release(); s->chunkStart.release();
@@ -854,7 +856,7 @@ int mgs_scene_memory_usage(MgsScene s, uint64_t* sceneBytes, uint64_t* workingBy
   {
     uint64_t b = 0;
     auto add = [&](auto& buf) { b += (uint64_t)buf.n * sizeof(*buf.p); };
-    add(s->pairA); add(s->pairB); add(s->slotCount); add(s->chunkSum); add(s->runTab); add(s->sortedCode16); add(s->binCost); add(s->slotHist2); add(s->top16Rec); add(s->top16Count); add(s->osStatus); add(s->keysA); add(s->idsA); add(s->rect);
+    add(s->pairA); add(s->pairB); add(s->prjOrder); add(s->slotCount); add(s->chunkSum); add(s->runTab); add(s->sortedCode16); add(s->binCost); add(s->slotHist2); add(s->top16Rec); add(s->top16Count); add(s->osStatus); add(s->keysA); add(s->idsA); add(s->rect);
     add(s->partHist); add(s->blockCount); add(s->sortedRect); add(s->splatOffset); add(s->chunkStart);
     add(s->dbinMasks); add(s->fstate); add(s->surfDepth); add(s->surfId); add(s->surfNormal); add(s->accum); add(s->rec); add(s->recGut);
     add(s->pairKey0); add(s->pairVal0); add(s->pairKey1); add(s->pairVal1); add(s->ranges); add(s->image);
@@ -1271,6 +1273,14 @@ static int sizeWorkingSet(MgsScene s)
   if((rc = s->pairA.ensure(total))) return rc;
   if((rc = s->pairB.ensure(std::max<uint64_t>(total, parts * (uint64_t)kOsSlot)))) return rc;  // whole slots
   if((rc = s->slotCount.ensure(parts))) return rc;
+  {  // the partitions' dispatch order starts as the identity; every key sort leaves the next frame's (always a permutation)
+    if((rc = s->prjOrder.ensure(std::max<uint64_t>(parts, 1)))) return rc;
+    std::vector<uint32_t> iota(parts);
+    for(uint32_t i = 0; i < (uint32_t)parts; ++i)
+      iota[i] = i;
+    if(parts)
+      HIPCHK(hipMemcpy(s->prjOrder.p, iota.data(), (size_t)parts * 4, hipMemcpyHostToDevice));
+  }
   if((rc = s->sortedCode16.ensure(total))) return rc;
   if((rc = s->binCost.ensure(256))) return rc;
   HIPCHK(hipMemset(s->binCost.p, 0, 256 * 4));
@@ -1745,6 +1755,10 @@ static const bool kBinHistory = [] { const char* e = std::getenv("MGS_BIN_HISTOR
 // pass elision of the key sort (sort_plan.h): on by default, MGS_SORT_REMAP=0 keeps the four plain passes
 static const bool kRemap = [] { const char* e = std::getenv("MGS_SORT_REMAP"); return e ? std::atoi(e) != 0 : true; }();
 
+// the project kernels' partitions are dispatched fullest slot of the previous frame first (k_os_prepare writes the order,
+// k_project reads it; scheduling only); MGS_PRJ_ORDER=0: storage order (A/B)
+static const bool kPrjOrder = [] { const char* e = std::getenv("MGS_PRJ_ORDER"); return e ? std::atoi(e) != 0 : true; }();
+
 // the frame's key sort (k_osort.hip): slots of the project kernel -> sorted ids in idsA (keys in keysA when wanted)
 static void keySort(MgsScene s, hipStream_t st, bool wantKeys, bool allowRemap, const FrameConst* ride = nullptr)
 {
@@ -1755,6 +1769,7 @@ static void keySort(MgsScene s, hipStream_t st, bool wantKeys, bool allowRemap, 
   L.chunkSum     = s->chunkSum.p;
   L.runTab       = s->runTab.p;
   L.nOut         = &s->ctr.p->sortedCount;
+  L.prjOrderOut  = kPrjOrder ? s->prjOrder.p : nullptr;
   L.slotHist     = s->slotHist2.p;
   L.top16Rec     = s->top16Rec.p;
   L.top16Count   = s->top16Count.p;
@@ -2072,10 +2087,10 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
       hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, st, s->rect.p, 1u, s->d->totalSplats);
     if(gut)
       launchProjectGut(st, A, s->dArgs.p, s->d->shFormat, ctr, s->pairB.p, s->slotCount.p, s->recGut.p, s->rect.p,
-                       s->slotHist2.p, s->top16Rec.p, cpuMode ? nullptr : s->top16Count.p, &s->plans.p->os);
+                       s->slotHist2.p, s->top16Rec.p, cpuMode ? nullptr : s->top16Count.p, &s->plans.p->os, kPrjOrder ? s->prjOrder.p : nullptr);
     else
       launchProject(st, A, s->dArgs.p, true, ctr, s->pairB.p, s->slotCount.p, s->rec.p, s->rect.p,
-                    s->slotHist2.p, s->top16Rec.p, cpuMode ? nullptr : s->top16Count.p, &s->plans.p->os);
+                    s->slotHist2.p, s->top16Rec.p, cpuMode ? nullptr : s->top16Count.p, &s->plans.p->os, kPrjOrder ? s->prjOrder.p : nullptr);
     if(withEvents) HIPCHK(hipEventRecord(fev[1], st));
     if(!cpuMode)
       keySort(s, st, false, kRemap, &F);
@@ -2211,6 +2226,13 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
   s->lastTimed       = timed;
   s->lastWasSortOnly = false;
   s->lastListsPartial = false;
+  {
+    int codeBits = 0;
+    while(F.rideShift != 0 && (1u << codeBits) - 1u < F.rideEscape)
+      ++codeBits;
+    const int lr[5] = {F.rideShift, codeBits, F.binsX, F.binsY, cpuModeOuter ? 0 : 1};
+    std::memcpy(s->lastRide, lr, sizeof(lr));
+  }
   if(timed)
     ++s->frameIndex;
   if(out)
@@ -2748,6 +2770,33 @@ static int mgs_frame_download_projected_impl(MgsScene s, const uint32_t* ids, si
   std::vector<uint32_t> rect(s->d->totalSplats);
   HIPCHK(hipMemcpy(rec.data(), s->rec.p, (size_t)s->d->totalSplats * sizeof(SplatRec), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(rect.data(), s->rect.p, (size_t)s->d->totalSplats * 4, hipMemcpyDeviceToHost));
+  if(rectOut && s->lastRide[0] != 0 && s->lastRide[4] != 0)
+  {  // the rectangles rode through the key sort as codes (kernels_common.h: rideEncode): rect[id] holds the escapes only, the
+     // others are rebuilt from the code at the id's sorted position (they used to come back stale)
+    FrameCounters c;
+    HIPCHK(hipMemcpy(&c, s->ctr.p, sizeof(c), hipMemcpyDeviceToHost));
+    const uint32_t        n = std::min<uint32_t>(c.sortedCount, (uint32_t)s->d->totalSplats);
+    std::vector<uint32_t> sortedIds(n);
+    std::vector<uint16_t> codes(n);
+    if(n)
+    {
+      HIPCHK(hipMemcpy(sortedIds.data(), s->idsA.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(codes.data(), s->sortedCode16.p, (size_t)n * 2, hipMemcpyDeviceToHost));
+    }
+    const int      bx = s->lastRide[2], by = s->lastRide[3], nb = bx * by;
+    const uint32_t escape = (1u << s->lastRide[1]) - 1u;
+    const uint32_t base[4] = {0u, (uint32_t)nb, (uint32_t)(nb + (bx - 1) * by), (uint32_t)(nb + (bx - 1) * by + bx * (by - 1))};
+    for(uint32_t e = 0; e < n; ++e)
+    {
+      const uint32_t code = codes[e];
+      if(code == escape || sortedIds[e] >= rect.size())
+        continue;
+      const uint32_t shape = code >= base[3] ? 3u : (code >= base[2] ? 2u : (code >= base[1] ? 1u : 0u));
+      const uint32_t r = code - base[shape], dx = shape & 1u, dy = shape >> 1, wS = (uint32_t)bx - dx;
+      const uint32_t y0 = r / wS, x0 = r - y0 * wS;
+      rect[sortedIds[e]] = x0 | (y0 << 8) | ((x0 + dx) << 16) | ((y0 + dy) << 24);
+    }
+  }
   for(size_t i = 0; i < count; ++i)
   {
     const SplatRec& r = rec[sid[i]];
@@ -2832,7 +2881,7 @@ int mgs_sort_keys(MgsScene s, const MgsFrameParams* p, MgsSortOut* out)
   if((rc = uploadFrameState(s, A, st))) return rc;
   HIPCHK(hipEventRecord(s->ev[0], st));
   launchProject(st, A, s->dArgs.p, false, s->ctr.p, s->pairB.p, s->slotCount.p, s->rec.p, s->rect.p,
-                s->slotHist2.p, s->top16Rec.p, s->top16Count.p, &s->plans.p->os);
+                s->slotHist2.p, s->top16Rec.p, s->top16Count.p, &s->plans.p->os, kPrjOrder ? s->prjOrder.p : nullptr);
   HIPCHK(hipEventRecord(s->ev[1], st));
   if((rc = s->keysA.ensure(s->d->totalSplats))) return rc;  // the hook returns the sorted keys too
   keySort(s, st, true, kRemap);

@@ -43,7 +43,10 @@ void launchSortClearPlan(hipStream_t stream, SortPlan* plan);
 void launchRadixSort(hipStream_t stream, const SortLaunch& s);
 
 // ---- the frame's key sort (k_osort.hip) -------------------------------------------------------------------------------
-constexpr uint32_t kOsPart    = 4096;  // pairs per partition (256 threads x 16)
+#ifndef MGS_OS_PART
+#define MGS_OS_PART 4096
+#endif
+constexpr uint32_t kOsPart    = MGS_OS_PART;  // pairs per partition (256 threads x 16)
 constexpr uint32_t kOsSlot    = 2048;  // pairs a project workgroup's slot can hold (== its partition of splats): 11-bit starts
 constexpr uint32_t kSlotHistWords = 384;  // what a slot leaves per partition (slot_emit.h): counts of key bits 0-7 and 8-15,
                                           // starts of the digit-0 groups — 16-bit values, two per word
@@ -82,6 +85,7 @@ struct OsLaunch
   uint32_t        rideShift  = 0;        // frame only: the ids carry the bin rectangles' codes above bit rideShift (rideEncode) ...
   uint32_t        rideInfo   = 0;        // ... shapes | code bits << 8, handed to the binning stage in planOut->reserved[0] ...
   uint16_t*       outCode16  = nullptr;  // ... and the final pass writes clean ids and, here, the codes in sorted order
+  uint32_t*       prjOrderOut = nullptr; // [prjParts] the next frame's dispatch order of the project kernel: fullest slot first (k_os_prepare)
   uint32_t*       nOut       = nullptr;  // the frame's count of sorted pairs (== *nPtr afterwards), written by k_os_prepare
   const uint32_t* slotHist   = nullptr;  // [partition][kSlotHistWords] (slot_emit.h)
   const uint32_t* top16Rec   = nullptr;  // [partition][4 waves][32]: counts of key >> 16 per producer wave (slot_emit.h)
