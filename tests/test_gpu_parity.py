@@ -142,8 +142,10 @@ def test_radix_sort_depth_like_keys_with_outliers(scene_small, ob):
 def test_key_sort_variants_are_bit_identical_to_the_stable_sort():
     """the sort kernels under their build-time knobs (libmgs reads them once per process, hence the child interpreter): the
     frame's key sort with the pass elision (default), with four plain passes (MGS_SORT_REMAP=0), the stand-alone sorts on
-    the generic reduce-then-scan kernels instead of the key sort's (MGS_RAW_SORT=generic), and without the bin rectangles'
-    ride through the sort (MGS_RECT_RIDE=0).  Sizes around the partition and
+    the generic reduce-then-scan kernels instead of the key sort's (MGS_RAW_SORT=generic), without the bin rectangles'
+    ride through the sort (MGS_RECT_RIDE=0), with the codes split between the key's low byte and the id's spare bits as scenes
+    beyond 8 M splats have them (MGS_RIDE_SPLIT=2), and with the project kernel's partitions in storage order instead of
+    fullest-slot-first (MGS_PRJ_ORDER=0).  Sizes around the partition and
     look-back group boundaries, distributions with giant runs / few values / many exponents, and whole frames — every sorted
     stream must equal the stable sort bit for bit, every frame must be the same frame"""
     import subprocess
@@ -151,7 +153,8 @@ def test_key_sort_variants_are_bit_identical_to_the_stable_sort():
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_child_sort.py")
     out = {}
     for mode, env_extra in (("default", {}), ("plain", {"MGS_SORT_REMAP": "0"}), ("generic", {"MGS_RAW_SORT": "generic"}),
-                            ("gather", {"MGS_RECT_RIDE": "0"}), ("nohistory", {"MGS_BIN_HISTORY": "0"})):
+                            ("gather", {"MGS_RECT_RIDE": "0"}), ("nohistory", {"MGS_BIN_HISTORY": "0"}),
+                            ("split", {"MGS_RIDE_SPLIT": "2"}), ("storageorder", {"MGS_PRJ_ORDER": "0"})):
         r = subprocess.run([sys.executable, child], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
         assert "SORTS_OK" in r.stdout, r.stdout[-3000:]
@@ -160,6 +163,7 @@ def test_key_sort_variants_are_bit_identical_to_the_stable_sort():
     # (gather: the bin rectangles looked up by id instead of riding through the sort above the ids, k_osort.hip)
     # nohistory: the compositor's bin order from the list lengths instead of the previous frame's region times (scheduling only)
     assert out["default"] and out["default"] == out["plain"] == out["generic"] == out["gather"] == out["nohistory"]
+    assert out["default"] == out["split"] == out["storageorder"]
 
 
 def test_key_sort_oversubscribed_by_a_co_running_kernel():

@@ -96,6 +96,8 @@ struct FrameConst
   int32_t  rideShift;              // bits the ids need; 0 = no ride
   int32_t  rideShapes;             // how many of the shapes 1x1, 2x1, 1x2, 2x2 have codes
   uint32_t rideEscape;             // the code of every other rectangle: (1 << code bits) - 1
+  int32_t  rideSplit;              // 1: the id word's spare bits do not hold the whole code (> 8 M splats): its low 8 bits travel in the
+                                   // key's low byte — dead weight once the slot is grouped by it (slot_emit.h) —, the rest above the id
 };
 
 struct FrameArgs

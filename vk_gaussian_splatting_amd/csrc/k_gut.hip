@@ -397,7 +397,7 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
   E.cnt   = s_cnt;
   static_assert(sizeof(s_grec) >= 16384 + 2048, "the hand-over's stage and counters live in the record staging area");
   emitSlot<kGutThreads, kGutItems>(Mv, false, E, slotPairs, slotCount, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
-                                   I.globalOffset + local0, rideShift);
+                                   I.globalOffset + local0, rideShift | (A.f.rideSplit ? 0x100u : 0u));
 }
 
 // world-space ray direction of the pixel whose centre is (pcx, pcy) (threedgut_raster.frag.slang:101-111); false: outside the

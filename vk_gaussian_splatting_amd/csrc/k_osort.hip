@@ -480,6 +480,7 @@ struct OsPassArgs
   // the bin rectangles' codes ride above the ids (kernels_common.h: rideEncode); the final pass of a frame separates them:
   // clean ids for everybody, the codes in sorted order for the binning stage
   uint32_t        rideShift;   // bits of the id proper; 0 = nothing rides
+  uint32_t        rideSplit;   // 1: the code's low 8 bits lie in the key's low byte, the rest above the id (slot_emit.h)
   uint32_t        rideInfo;    // what planOut->reserved[0] tells k_dbin_count: shapes | code bits << 8
   uint16_t*       dstCode16;
   const uint32_t* srcKeys;
@@ -963,7 +964,7 @@ __global__ __launch_bounds__(kThreads, MGS_OS_WAVES) void k_os_pass(const OsPass
         if(finalOut && a.rideShift != 0u)
         {
           a.dstVals[dst]   = kv.y & ((1u << a.rideShift) - 1u);
-          a.dstCode16[dst] = (uint16_t)(kv.y >> a.rideShift);
+          a.dstCode16[dst] = a.rideSplit ? (uint16_t)((kv.x & 255u) | ((kv.y >> a.rideShift) << 8)) : (uint16_t)(kv.y >> a.rideShift);
         }
         else if(finalOut)
         {
@@ -1104,6 +1105,7 @@ void launchOsSort(hipStream_t stream, const OsLaunch& L)
     a.allowRemap = (frame && L.allowRemap) ? 1 : 0;
     a.rideShift = frame ? L.rideShift : 0u;
     a.rideInfo  = L.rideInfo;
+    a.rideSplit = frame ? L.rideSplit : 0u;
     a.dstCode16 = L.outCode16;
     a.srcKeys   = L.keys0;
     a.srcVals   = L.vals0;

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
         s_code[r * kPrjThreads + t] = (uint16_t)codes.get(r);
     }
     const uint32_t outCount = emitSlot<kPrjThreads, kPrjItems>(M, false, E, slotPairs, slotCount, slotHist2, top16Rec, top16Count, osPlan, ctr, part,
-                                                               I.globalOffset + local0, rideShift);
+                                                               I.globalOffset + local0, rideShift | (A.f.rideSplit ? 0x100u : 0u));
     (void)outCount;
 #ifdef MGS_PRJ_TRACE
     MGS_PRJ_STAMP(5)

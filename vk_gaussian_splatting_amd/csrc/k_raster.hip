@@ -765,40 +765,6 @@ constexpr int kCmpCap     = MGS_CMP_CAP;                // LDS batch capacity (r
 constexpr int kCmpGo      = MGS_CMP_GO;                // blend as soon as this many records are staged (<= kCmpCap-256)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// Touch-prefetch for the deferred shading (round 5): a staged record's colour, centre and SH record are requested the moment
-// stage A accepts it, so that the shading phase — one thread per record, five dependent round trips to HBM (colour + centre, then
-// the 192-byte SH record in four groups) — finds them in the XCD's L2.  The request is an LDS-DMA load (global_load_lds_dword:
-// no destination VGPR, so nothing has to stay live and no register can be overwritten late); its four bytes land in a junk
-// row of LDS that nobody reads.
-#ifndef MGS_CMP_PREFETCH
-#define MGS_CMP_PREFETCH 1
-#endif
-__device__ __forceinline__ void touchGlobal(const void* p, uint32_t* ldsJunk)
-{
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p, (__attribute__((address_space(3))) void*)ldsJunk, 4, 0, 0);
-}
-template <int SHF>
-__device__ __forceinline__ void shadePrefetch(const CompositeArgs& F, uint32_t gid, uint32_t* ldsJunk)
-{
-  constexpr uint32_t recBytes = SHF == 0 ? 192u : (SHF == 1 ? 96u : 48u);
-  CompositeArgs::Inst I = F.inst[0];
-  for(int i = 1; i < F.nInstances; ++i)
-    if(gid >= F.inst[i].globalOffset)
-      I = F.inst[i];
-  const uint32_t li = gid - I.globalOffset;
-  touchGlobal(&I.rgba[li], ldsJunk);
-  touchGlobal(&I.centers[3 * (size_t)li], ldsJunk);
-  if(I.sh != nullptr && min(I.shDegree, F.shDegree) > 0)
-  {
-    const char* r = reinterpret_cast<const char*>(I.sh) + (size_t)li * recBytes;
-    touchGlobal(r, ldsJunk);
-    if(recBytes > 64u)
-      touchGlobal(r + 64, ldsJunk);
-    if(recBytes > 128u)
-      touchGlobal(r + 128, ldsJunk);
-  }
-}
-
 // MODE bit 0: additive alpha (no early-out), bit 1: DISABLE_OPACITY_GAUSSIAN, bit 2: surface side outputs,
 // bit 3: stochastic splats (frag.slang:265-290: a fragment is accepted with probability alpha and written opaque; the
 // depth test keeps the nearest accepted one == the first accepted one of the nearest-first list); SHF: SH storage format
@@ -833,7 +799,6 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
   __shared__ float4   s_n[surf_lds(MODE) ? kCmpCap : 1];  // world normal of the record (surface outputs only)
   __shared__ uint32_t s_wc[2][kCmpEntries][4];
   __shared__ uint8_t  s_m[kCmpCap];  // which of the 4 quarters (waves) the record's footprint touches
-  __shared__ uint32_t s_junk[64];    // where the touch-prefetches of the shading phase land (never read)
 
   const int t = threadIdx.x, lane = laneId(), w = t >> 6;
   // regions are 32-px columns x 16-px rows ("tile pairs"); binShiftX >= 1, so a pair never straddles two bins.
@@ -1034,13 +999,6 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
           base += m;
           used = k + 1;
         }
-      }
-      if(MGS_CMP_PREFETCH && !allSat && F.nInstances <= kMaxInlineInstances)
-      {  // behind the round's last LDS access: the accepted entries' shading inputs start their way to the L2
-#pragma unroll
-        for(int k = 0; k < kCmpEntries; ++k)
-          if(k < used && ok[k])
-            shadePrefetch<SHF>(F, g[k], s_junk);
       }
       statStaged += base - fill;
       fill                    = base;

@@ -1528,17 +1528,42 @@ static const bool kDirectBin = [] { const char* e = std::getenv("MGS_DIRECT_BIN"
 static const bool kRectRide = [] { const char* e = std::getenv("MGS_RECT_RIDE"); return e ? std::atoi(e) != 0 : true; }();
 static void chooseRide(MgsScene s, FrameConst& F, bool cpuMode)
 {
-  F.rideShift = F.rideShapes = 0;
+  F.rideShift = F.rideShapes = F.rideSplit = 0;
   F.rideEscape = 0;
   if(!kRectRide || cpuMode || !kDirectBin || !directBinningSupported(F.binsX, F.binsY) || s->d->totalSplats == 0)
     return;
   int idBits = 1;
   while(idBits < 32 && (1ull << idBits) < (uint64_t)s->d->totalSplats)
     ++idBits;
-  const int codeBits = std::min(32 - idBits, 16);
   const int bx = F.binsX, by = F.binsY, nb = bx * by;
   const int codes[4] = {nb, nb + (bx - 1) * by, nb + (bx - 1) * by + bx * (by - 1), nb + (bx - 1) * by + bx * (by - 1) + (bx - 1) * (by - 1)};
-  for(int shapes = 4; shapes >= 1; --shapes)
+  // Where the id word's spare bits hold all four shapes the code rides there whole.  Otherwise (round 5; 8 garden instances
+  // need 26 id bits) it is split: its low 8 bits replace the KEY's low byte in the slot — the slot is grouped by that byte, so
+  // the sort never looks at it again (slot_emit.h) — and only the rest rides above the id: 8 + spare bits.  MGS_RIDE_SPLIT=0:
+  // as before (fewer shapes, or the gather by id); =2: always split (tests: small scenes take the split path too).
+  static const int kSplitMode = [] { const char* e = std::getenv("MGS_RIDE_SPLIT"); return e ? std::atoi(e) : 1; }();
+  const bool kSplit = kSplitMode != 0;
+  const int  spare  = 32 - idBits;
+  for(int pass = kSplitMode == 2 ? 1 : 0; pass < 2; ++pass)
+  {
+    const bool split    = pass == 1;
+    const int  codeBits = std::min(split ? spare + 8 : spare, 16);
+    if(split && (!kSplit || spare < 1))
+      break;
+    for(int shapes = 4; shapes >= (split ? 1 : 4); --shapes)
+      if(codeBits >= 1 && codes[shapes - 1] + 1 <= (1 << codeBits))
+      {
+        F.rideShift  = idBits;
+        F.rideShapes = shapes;
+        F.rideEscape = (1u << codeBits) - 1u;
+        F.rideSplit  = split ? 1 : 0;
+        return;
+      }
+  }
+  if(kSplit)
+    return;
+  const int codeBits = std::min(spare, 16);
+  for(int shapes = 3; shapes >= 1; --shapes)
     if(codeBits >= 1 && codes[shapes - 1] + 1 <= (1 << codeBits))
     {
       F.rideShift  = idBits;
@@ -1790,6 +1815,7 @@ static void keySort(MgsScene s, hipStream_t st, bool wantKeys, bool allowRemap, 
     while((1u << codeBits) - 1u < ride->rideEscape)
       ++codeBits;
     L.rideShift = (uint32_t)ride->rideShift;
+    L.rideSplit = (uint32_t)ride->rideSplit;
     L.rideInfo  = (uint32_t)ride->rideShapes | ((uint32_t)codeBits << 8);
     L.outCode16 = s->sortedCode16.p;
   }
@@ -2177,7 +2203,7 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
                             F.debugFlags & (2 | 4 | 256), F.surfaceOutputs, half, F.nInstances, F.shDegree, isoBits,
                             F.pipeline, F.stochastic | (F.dofMode << 1) | (F.temporalSampling << 2) | ((F.pipeline == 1 && F.kernelDegree != 2) ? 8 : 0) |
                                 ((F.pipeline == 1 && F.normalMethod == 1) ? 16 : 0) |
-                                (F.rideShift << 8) | (F.rideShapes << 16)};  // ... and everything that selects a kernel variant or a launch argument
+                                (F.rideShift << 8) | (F.rideShapes << 16) | (F.rideSplit << 24)};  // ... and everything that selects a kernel variant or a launch argument
     std::memcpy(key.v, kv, sizeof(kv));
     key.p[0] = s->image.p;
     key.p[1] = s->surfDepth.p;

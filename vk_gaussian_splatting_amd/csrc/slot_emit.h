@@ -98,9 +98,20 @@ __device__ __forceinline__ uint32_t emitSlot(uint32_t M, bool allSurvive, const 
     const bool     vis = (j < M) && (allSurvive || (liw & 0x8000u));
     key[r]             = S.key[j];
     idc[r]             = idBase + (liw & 0x7FFFu);
-    if(rideShift != 0u)  // the bin rectangle's code rides through the sort above the id (kernels_common.h: rideEncode)
-      idc[r] |= (uint32_t)S.code[j] << rideShift;
     rd[r]              = 0u;
+    if(rideShift != 0u)
+    {  // the bin rectangle's code rides through the sort above the id (kernels_common.h: rideEncode) ...
+      const uint32_t code = S.code[j];
+      if(rideShift & 0x100u)
+      {  // ... or, when the id leaves too few bits (bit 8 of rideShift: FrameConst::rideSplit), split: the low byte takes the
+         // place of the KEY's low byte when the pair is staged — the slot is grouped by that byte, the group says it, and no
+         // later pass looks at it again — and waits in the top byte of rd[r] until then
+        idc[r] |= (code >> 8) << (rideShift & 31u);
+        rd[r] = code << 24;
+      }
+      else
+        idc[r] |= code << rideShift;
+    }
     const uint64_t act = __ballot(vis);
     if(act == 0ull)  // wave-uniform
       continue;
@@ -111,7 +122,7 @@ __device__ __forceinline__ uint32_t emitSlot(uint32_t M, bool allSurvive, const 
     uint32_t pre = 0u;
     if(vis)
       pre = S.whist[w * 256 + d];
-    rd[r] = (d << 16) | (pre + lower);
+    rd[r] |= (d << 16) | (pre + lower);
     __builtin_amdgcn_wave_barrier();  // every lane of the group has read `pre` before the leader bumps it
     if(vis && lower == 0u)
       S.whist[w * 256 + d] = (uint16_t)(pre + cnt);
@@ -169,8 +180,8 @@ __device__ __forceinline__ uint32_t emitSlot(uint32_t M, bool allSurvive, const 
 #pragma unroll
   for(int r = 0; r < ITEMS; ++r)
   {
-    const uint32_t d = rd[r] >> 16;
-    rd[r]            = (uint32_t)S.start[d] + (uint32_t)S.whist[w * 256 + d] + (rd[r] & 0xFFFFu);
+    const uint32_t d = (rd[r] >> 16) & 255u;
+    rd[r]            = (rd[r] & 0xFF000000u) | ((uint32_t)S.start[d] + (uint32_t)S.whist[w * 256 + d] + (rd[r] & 0xFFFFu));
   }
   // ---- this wave's record of key >> 16: counts of lo .. lo + 24 in words 0-24, header in word 31 ----
   uint32_t lo, hi;
@@ -230,7 +241,7 @@ __device__ __forceinline__ uint32_t emitSlot(uint32_t M, bool allSurvive, const 
 #pragma unroll
   for(int r = 0; r < ITEMS; ++r)
     if((vmask >> r) & 1u)
-      S.stage[rd[r]] = make_uint2(key[r], idc[r]);
+      S.stage[rd[r] & 0xFFFFu] = make_uint2((rideShift & 0x100u) ? ((key[r] & 0xFFFFFF00u) | (rd[r] >> 24)) : key[r], idc[r]);
   __syncthreads();
   uint2* dst = slotPairs + (size_t)part * (size_t)kOsSlot;
   for(uint32_t i = t; i < outCount; i += THREADS)

@@ -83,6 +83,7 @@ struct OsLaunch
   uint32_t*       runTab     = nullptr;  // [256][32 osSortChunks(prjParts)] scratch (k_os_prepare): per (digit-0 value, slot) the pairs of
                                          // that value in the chunk's earlier slots | the group's start inside its slot << 16
   uint32_t        rideShift  = 0;        // frame only: the ids carry the bin rectangles' codes above bit rideShift (rideEncode) ...
+  uint32_t        rideSplit  = 0;        // ... (1: split between the key's low byte and the id's spare bits, FrameConst::rideSplit) ...
   uint32_t        rideInfo   = 0;        // ... shapes | code bits << 8, handed to the binning stage in planOut->reserved[0] ...
   uint16_t*       outCode16  = nullptr;  // ... and the final pass writes clean ids and, here, the codes in sorted order
   uint32_t*       prjOrderOut = nullptr; // [prjParts] the next frame's dispatch order of the project kernel: fullest slot first (k_os_prepare)
