@@ -87,12 +87,24 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   const float  tx = MV[0] * px + MV[4] * py + MV[8] * pz + MV[12];
   const float  ty = MV[1] * px + MV[5] * py + MV[9] * pz + MV[13];
   const float  tz = MV[2] * px + MV[6] * py + MV[10] * pz + MV[14];
-  const float  tw = MV[3] * px + MV[7] * py + MV[11] * pz + MV[15];
   const float* P  = F.proj;
-  const float  cx = P[0] * tx + P[4] * ty + P[8] * tz + P[12] * tw;
-  const float  cy = P[1] * tx + P[5] * ty + P[9] * tz + P[13] * tw;
-  const float  cz = P[2] * tx + P[6] * ty + P[10] * tz + P[14] * tw;
-  const float  cw = P[3] * tx + P[7] * ty + P[11] * tz + P[15] * tw;
+  float        tw, cx, cy, cz, cw;
+  if(F.perspAffine && (I.modelIsIdentity | I.modelIsAffine))
+  {  // the same products without the matrices' exact zeros (FrameConst::perspAffine): 7 instead of 20 multiply-adds
+    tw = 1.0f;
+    cx = P[0] * tx + P[8] * tz;
+    cy = P[5] * ty + P[9] * tz;
+    cz = P[10] * tz + P[14];
+    cw = P[11] * tz;
+  }
+  else
+  {
+    tw = MV[3] * px + MV[7] * py + MV[11] * pz + MV[15];
+    cx = P[0] * tx + P[4] * ty + P[8] * tz + P[12] * tw;
+    cy = P[1] * tx + P[5] * ty + P[9] * tz + P[13] * tw;
+    cz = P[2] * tx + P[6] * ty + P[10] * tz + P[14] * tw;
+    cw = P[3] * tx + P[7] * ty + P[11] * tz + P[15] * tw;
+  }
   if(F.cullMode == 2)
   {  // FRUSTUM_CULLING_AT_RASTER, mesh.slang:181-190
     const float c = (1.0f + F.frustumDilation) * cw;
@@ -139,7 +151,7 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   if(F.debugFlags & 1)  // POINT_CLOUD_MODE, threedgs.h.slang:108-110
     ev1 = ev2 = 0.2f;
   float       e1x = (fabsf(b) < 0.001f) ? 1.0f : b, e1y = ev1 - a;
-  const float el  = rsqrtf(e1x * e1x + e1y * e1y);
+  const float el  = __builtin_amdgcn_rsqf(e1x * e1x + e1y * e1y);  // (1-ulp hardware instruction, like fastRcp / fastSqrt)
   e1x *= el;
   e1y *= el;
   const float kSqrt8 = 2.8284271247461903f;
@@ -153,7 +165,7 @@ __device__ __forceinline__ bool projectSplat(const FrameConst& F, const Instance
   const bool  noGauss = (F.debugFlags & 4) != 0;  // DISABLE_OPACITY_GAUSSIAN: alpha == 1 inside the ellipse
   const float a255    = col.w * 255.0f;
   ok                  = ok && (noGauss || a255 > 1.0f);
-  const float qmax    = noGauss ? 4.0f : fminf(4.0f, __logf(fmaxf(a255, 1.0f)) + 1e-3f);
+  const float qmax    = noGauss ? 4.0f : fminf(4.0f, __builtin_amdgcn_logf(fmaxf(a255, 1.0f)) * 0.6931471805599453f + 1e-3f);  // v_log_f32 (log2) * ln 2: the argument is >= 1, no denormal handling needed
   const float shrink = fastSqrt(qmax * 0.25f) * 1.0005f;
   const float ex = shrink * fastSqrt(b1x * b1x + b2x * b2x) + 0.01f;
   const float ey = shrink * fastSqrt(b1y * b1y + b2y * b2y) + 0.01f;
@@ -272,6 +284,9 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   MGS_PRJ_STAMP(1)
 #endif
   const bool identityFast = (pflag & 4u) != 0u && I.modelIsIdentity != 0u;
+  // affine model and view, perspective projection, finite and moderate coordinates: w stays exactly 1 through M and V and the
+  // products with the matrices' zeros can be dropped without changing a bit (kernels_common.h: mulMat4ExactAffineW1 / mulPersp...)
+  const bool w1Fast = (pflag & 12u) == 12u && A.f.perspAffine != 0 && (I.modelIsIdentity != 0u || I.modelIsAffine != 0u);
   // strips (multi-GPU): a splat whose centre lies further from this device's rows than the partition's footprint bound R
   // (partition_cull.h; valid for every splat of the partition) cannot reach them — dropped here, before the projection.
   // The exact footprint-vs-strip test of phase 2 would reject it anyway: the sorted set is unchanged.
@@ -292,20 +307,40 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
       wp[2] = pz[it] + 0.0f;
       wp[3] = 1.0f;
     }
+    else if(w1Fast)
+    {
+      mulMat4ExactAffineW1(I.model, px[it], py[it], pz[it], wp);  // dist.comp.slang:58
+      wp[3] = 1.0f;
+    }
     else
       mulMat4Exact(I.model, px[it], py[it], pz[it], 1.0f, wp);  // dist.comp.slang:58
-    mulMat4Exact(A.f.view, wp[0], wp[1], wp[2], wp[3], vp);   // :58
+    if(w1Fast)
+    {
+      mulMat4ExactAffineW1(A.f.view, wp[0], wp[1], wp[2], vp);   // :58
+      vp[3] = 1.0f;
+    }
+    else
+      mulMat4Exact(A.f.view, wp[0], wp[1], wp[2], wp[3], vp);   // :58
     bool  v = li < I.count;
     float nz;
     if(insideFast)
     {  // every centre of this partition passes :71-73 (all 8 corners of its box do, with margin, and the tests are linear
        // in the point): only clip z and w — the key — are needed
-      mulMat4ExactZW(A.f.proj, vp[0], vp[1], vp[2], vp[3], cp[2], cp[3]);
+      if(w1Fast)
+        mulPerspExactW1ZW(A.f.proj, vp[2], cp[2], cp[3]);
+      else
+        mulMat4ExactZW(A.f.proj, vp[0], vp[1], vp[2], vp[3], cp[2], cp[3]);
       nz = divExact(cp[2], cp[3]);
     }
     else
     {
-      mulMat4Exact(A.f.proj, vp[0], vp[1], vp[2], vp[3], cp);   // :60
+      if(w1Fast)
+      {
+        mulPerspExactW1XY(A.f.proj, vp[0], vp[1], vp[2], cp[0], cp[1]);
+        mulPerspExactW1ZW(A.f.proj, vp[2], cp[2], cp[3]);
+      }
+      else
+        mulMat4Exact(A.f.proj, vp[0], vp[1], vp[2], vp[3], cp);   // :60
       const float nx = divExact(cp[0], cp[3]), ny = divExact(cp[1], cp[3]);  // :61
       nz             = divExact(cp[2], cp[3]);
       if(A.f.cullMode == 1 && distStageCulled(A.f, nx, ny, nz, vp[0], vp[1], vp[2]))  // :64-91, pinhole box or fisheye validity

@@ -135,6 +135,54 @@ __device__ __forceinline__ void mulMat4Exact(const float* m, float x, float y, f
   }
 }
 
+// Shortcuts of mulMat4Exact that are BIT-IDENTICAL to it under conditions the host and the partition test establish (round 5;
+// a wave64 VALU instruction holds its SIMD for four cycles, tools/micro/valu_rate.hip, and phase 1 of the project kernel is a
+// quarter of its instructions):
+//  * mulMat4ExactAffineW1: the matrix's last row is (+0, +0, +0, 1) and w == 1.0f exactly.  Then 1 * m[12 + r] == m[12 + r] (the
+//    product is exact) and out[3] == ((x*0 + y*0) + z*0) + 1 == 1.0f for finite x, y, z (a sum of zeros of either sign plus one).
+//  * mulPerspExactW1: P has the perspective pattern P[1] = P[2] = P[3] = P[4] = P[6] = P[7] = P[12] = P[13] = P[15] = +0,
+//    P[14] != 0, and w == 1.0f.  Every dropped product is a zero of either sign; adding such a zero to a nonzero term returns
+//    the term, and where all terms of a row vanish the full evaluation ends in "+ (1 * +0)", which yields +0 — the explicit
+//    "+ 0.0f" below does the same (it is not an identity: -0 + 0 = +0).  Row 2 ends in "+ P[14]", which absorbs any zero.
+//    Finite inputs only (Inf * 0 would be NaN in the full product): FrameConst::perspAffine bounds the matrices' magnitudes and
+//    the partition test (bit 3) the coordinates', so that no intermediate can overflow.
+__device__ __forceinline__ void mulMat4ExactAffineW1(const float* m, float x, float y, float z, float out[3])
+{
+#pragma clang fp contract(off)
+#pragma unroll
+  for(int r = 0; r < 3; ++r)
+  {
+    const float a = x * m[r];
+    const float b = y * m[4 + r];
+    const float c = z * m[8 + r];
+    out[r]        = ((a + b) + c) + m[12 + r];
+  }
+}
+__device__ __forceinline__ void mulPerspExactW1XY(const float* P, float x, float y, float z, float& ox, float& oy)
+{
+#pragma clang fp contract(off)
+  {
+    const float a = x * P[0], c = z * P[8];
+    ox            = (a + c) + 0.0f;
+  }
+  {
+    const float b = y * P[5], c = z * P[9];
+    oy            = (b + c) + 0.0f;
+  }
+}
+__device__ __forceinline__ void mulPerspExactW1ZW(const float* P, float z, float& oz, float& ow)
+{
+#pragma clang fp contract(off)
+  {
+    const float c = z * P[10];
+    oz            = c + P[14];
+  }
+  {
+    const float c = z * P[11];
+    ow            = c + 0.0f;
+  }
+}
+
 // rows 2 and 3 of mulMat4Exact only (clip z and w): what the depth key needs when the frustum test is known to pass
 __device__ __forceinline__ void mulMat4ExactZW(const float* m, float x, float y, float z, float w, float& oz, float& ow)
 {

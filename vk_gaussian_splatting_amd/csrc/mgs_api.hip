@@ -1585,6 +1585,20 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
   FrameConst& F = A.f;
   std::memcpy(F.view, p->view, sizeof(F.view));
   std::memcpy(F.proj, p->proj, sizeof(F.proj));
+  {  // affine view + perspective projection, bit patterns and magnitudes checked: the project kernels may drop the products with
+     // the exact zeros (kernels_common.h: mulMat4ExactAffineW1 / mulPerspExactW1*).  MGS_EXACT_SHORTCUTS=0: never (A/B).
+    static const bool kShort = [] { const char* e = std::getenv("MGS_EXACT_SHORTCUTS"); return e ? std::atoi(e) != 0 : true; }();
+    const float vrow[4] = {p->view[3], p->view[7], p->view[11], p->view[15]}, want[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+    bool        ok      = kShort && std::memcmp(vrow, want, sizeof(want)) == 0;
+    static const int kZero[9] = {1, 2, 3, 4, 6, 7, 12, 13, 15};
+    const float      zero     = 0.0f;
+    for(int q = 0; q < 9 && ok; ++q)
+      ok = std::memcmp(&p->proj[kZero[q]], &zero, 4) == 0;  // +0 bitwise
+    ok = ok && p->proj[14] != 0.0f;
+    for(int q = 0; q < 16 && ok; ++q)
+      ok = std::fabs(p->view[q]) < 1.0995e12f && std::fabs(p->proj[q]) < 1.0995e12f;  // 2^40; false for NaN
+    F.perspAffine = ok ? 1 : 0;
+  }
   F.focal[0] = p->proj[0] * 0.5f * (float)p->width;   // gaussian_splatting.cpp:1248-1250
   F.focal[1] = p->proj[5] * 0.5f * (float)p->height;
   F.width    = p->width;
@@ -1754,6 +1768,13 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
     {
       static const float kId[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
       C.modelIsIdentity = std::memcmp(I.M, kId, sizeof(kId)) == 0 ? 1u : 0u;  // bitwise (+0 only)
+      {  // last row bitwise (+0, +0, +0, 1), moderate entries: w stays exactly 1 through M (kernels_common.h: mulMat4ExactAffineW1)
+        const float    row[4] = {0.0f, 0.0f, 0.0f, 1.0f}, got[4] = {I.M[3], I.M[7], I.M[11], I.M[15]};
+        bool           ok     = std::memcmp(row, got, sizeof(row)) == 0;
+        for(int q = 0; q < 16 && ok; ++q)
+          ok = std::fabs(I.M[q]) < 1.0995e12f;  // also false for NaN
+        C.modelIsAffine = ok ? 1u : 0u;
+      }
     }
     C.globalOffset = offset;
     C.blockBegin   = block;
