@@ -472,7 +472,12 @@ def main():
                    f"{world} tile-row strips of every frame ({'equal' if args.equal_strips else 'cost-balanced'} rows {bounds}) + strip exchange: {gather_mode}"},
         "alternate_frames": alt_out,
         "this_rank_strip_rows": list(my_rows) if world > 1 else None,
+        "gather_mode": gather_mode,  # which exchange ran (N > 1): libmgs's own RCCL call, or the torch.distributed fallback — never silent
         "sorted_gsplats_per_s": (Vs / (sort_ms * 1e-3)) / 1e9 if sort_ms > 0 else None,
+        "sorted_gsplats_per_s_note": ("sorted pairs / time of the frame's sort stage (k_os_prepare + the two sort kernels + the launch that exits). "
+                                      "EXCLUDED: the depth keys and the sort's first LSD pass, which the project kernel does while the keys are on chip "
+                                      "(its hand-over groups each slot by the key's low byte: ~15 % of k_project's instructions); "
+                                      "key_plus_sort_gsplats_per_s is depth key + cull + whole sort end to end"),
         "sorted_gsplats_per_s_in_frame_aggregate": Vs_all * fps / 1e9,  # all ranks' sorted elements x frames/s
         "visible_splats": {"frustum": Vf, "sorted": Vs, "tile_pairs": D, "shaded": shaded, "list_entries_scanned": scanned},
         "stage_ms": {STAGES[j]: float(stage_ms[j]) for j in range(6)},
@@ -578,22 +583,45 @@ def main():
                 pp.alpha_mode = capi.ALPHA_SUM
             out["value_reference_alpha"] = timed_fps(poses, 24, 4, K)
             out["value_reference_alpha_single_frame"] = timed_fps(poses, 24, 4, 1)
-            for pp in poses:
-                pp.alpha_mode = capi.ALPHA_COVERAGE
             out["value_reference_alpha_note"] = ("frames/s with alpha_mode = MGS_ALPHA_SUM (additive alpha, no early termination: the reference's "
                                                  "default blend state, gaussian_splatting.cpp:2081-2086); `value` is alpha = 1 - T with early termination")
         except Exception as e:  # noqa: BLE001
             out["value_reference_alpha"] = None
             out["value_reference_alpha_note"] = f"{type(e).__name__}: {e}"[:200]
+        finally:  # (whatever happened, what follows runs in the headline's mode again)
+            for pp in poses:
+                pp.alpha_mode = capi.ALPHA_COVERAGE
         try:
             scene.commit(2, 2)  # contexts re-size their working sets at their next frame
             out["value_uint8_storage"] = timed_fps(poses, 48, 8, K)
             out["value_uint8_storage_single_frame"] = timed_fps(poses, 48, 8, 1)
             out["value_uint8_storage_note"] = "frames/s with SH and colour stored as uint8 (the reference's default storage, src/parameters.h:88-89)"
-            scene.commit(args.sh_format, args.rgba_format)
         except Exception as e:  # noqa: BLE001
             out["value_uint8_storage"] = None
             out["value_uint8_storage_note"] = f"{type(e).__name__}: {e}"[:200]
+        finally:
+            try:
+                scene.commit(args.sh_format, args.rgba_format)
+            except Exception:  # noqa: BLE001
+                pass
+
+    if rank == 0 and world == 1 and args.pipeline == 0 and not args.stochastic:
+        # depth key + cull + sort end to end (mgs_sort_keys: k_project<false>, then the whole key sort), the like-for-like GPU figure
+        # beside cpu_baseline, which times depth key + sort on the host (sorted_gsplats_per_s is the sort stage alone)
+        try:
+            best, cnt = None, 0
+            for i in range(6):
+                so = scenes[0].sort_keys(poses[i % 64])
+                tms = float(so.key_ms) + float(so.sort_ms)
+                if i >= 2 and tms > 0 and (best is None or tms < best):
+                    best, cnt = tms, int(so.count)
+            out["key_plus_sort_gsplats_per_s"] = (cnt / (best * 1e-3) / 1e9) if best else None
+            out["key_plus_sort_ms"] = best
+            out["key_plus_sort_note"] = ("mgs_sort_keys end to end on this workload: depth key + dist-stage cull over all splats (k_project<false>) + the key sort of the "
+                                         "survivors; sorted pairs / time (best of four)")
+        except Exception as e:  # noqa: BLE001
+            out["key_plus_sort_gsplats_per_s"] = None
+            out["key_plus_sort_note"] = f"{type(e).__name__}: {e}"[:200]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: restated SplatSorterAsync::innerSort on a bounded sample of the same workload

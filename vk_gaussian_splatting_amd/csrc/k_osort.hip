@@ -135,10 +135,12 @@ __device__ uint64_t* g_osPrepTrace = nullptr;  // [reduce workgroup][8]
 //     table themselves: thousands of partitions hold the same handful of values, and that many atomics on a few addresses
 //     serialise (measured: 0.13 -> 0.55 ms for k_project).  Partitions that span more than 24 values (a cell around the
 //     camera) are the exception: their keys are spread over many addresses and were added one by one.
-// The workgroup that finishes last (arrival counter) then owns the occurring range of the table: at most 256 values within a
-// span < 4096 -> pass 2 sorts on their rank and the table gives that pass's totals; otherwise plain digits for passes 2 and 3.
-// It clears what it read, so the table is clean for the next sort of this context.
-// One more workgroup (the last of the grid) sums the slots' counts: the frame's number of sorted pairs.
+// Turning the count table into what the upper passes sort on (at most 256 values within a span < 4096 -> pass 2 sorts on their
+// rank; otherwise plain digits for passes 2 and 3) is NOT done here any more: the table is complete when this kernel ends and
+// its fold is needed by the second sort kernel only, so workgroups beyond the partitions of the FIRST sort kernel do it (foldTop16
+// below; rounds 3-4a had the reduce workgroup that arrived last do it here, 4 us at the end of this kernel's critical path).
+// One more workgroup (the last of the grid) sums the slots' counts — the frame's number of sorted pairs — and leaves the project
+// kernel's dispatch order for the NEXT frame, fullest slot first (round 5).
 __global__ __launch_bounds__(1024) void k_os_prepare(const uint32_t* __restrict__ slotHist, const uint32_t* __restrict__ top16Rec, uint32_t prjParts,
                                                      uint32_t* __restrict__ top16Count, OsPlan* __restrict__ plan, const uint32_t* __restrict__ nPtr,
                                                      int allowRemap, uint32_t reduceWgs, const uint32_t* __restrict__ slotCount,

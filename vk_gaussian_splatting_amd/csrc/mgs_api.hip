@@ -905,7 +905,10 @@ static int mgs_instance_add_impl(MgsScene s, MgsSplatSet set, const float m[16],
   total += set->data->size();
   if(total >= kOsMaxPairs)
   {  // the reference's ids are u32; this build's key sort carries 30-bit digit prefixes in its look-back words (k_osort.hip)
-    setError("mgs_instance_add: 2^30 or more global splats (the key sort's look-back words hold 30-bit prefixes)");
+    // (ADVICE r4 asked for the generic sort as a fall-back here instead.  Not built: a scene that large cannot be resident — 2^30
+    //  splats are >= 107 GB of splat data in the smallest storage formats plus >= 200 B per splat of working set per frame in
+    //  flight, beyond the 288 GB of one MI355X — so the limit that binds first is memory, and this one is never the reason.)
+    setError("mgs_instance_add: 2^30 or more global splats (the key sort's look-back words hold 30-bit prefixes; such a scene would not fit 288 GB either)");
     return MGS_ERR_UNSUPPORTED;
   }
   Instance I;
