@@ -154,7 +154,8 @@ def test_key_sort_variants_are_bit_identical_to_the_stable_sort():
     out = {}
     for mode, env_extra in (("default", {}), ("plain", {"MGS_SORT_REMAP": "0"}), ("generic", {"MGS_RAW_SORT": "generic"}),
                             ("gather", {"MGS_RECT_RIDE": "0"}), ("nohistory", {"MGS_BIN_HISTORY": "0"}),
-                            ("split", {"MGS_RIDE_SPLIT": "2"}), ("storageorder", {"MGS_PRJ_ORDER": "0"})):
+                            ("split", {"MGS_RIDE_SPLIT": "2"}), ("storageorder", {"MGS_PRJ_ORDER": "0"}),
+                            ("fullproducts", {"MGS_EXACT_SHORTCUTS": "0"})):
         r = subprocess.run([sys.executable, child], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
         assert "SORTS_OK" in r.stdout, r.stdout[-3000:]
@@ -164,6 +165,8 @@ def test_key_sort_variants_are_bit_identical_to_the_stable_sort():
     # nohistory: the compositor's bin order from the list lengths instead of the previous frame's region times (scheduling only)
     assert out["default"] and out["default"] == out["plain"] == out["generic"] == out["gather"] == out["nohistory"]
     assert out["default"] == out["split"] == out["storageorder"]
+    # fullproducts: P*V*M without the exact shortcuts of round 5 (products with exact zeros dropped): the same frames to the bit
+    assert out["default"] == out["fullproducts"]
 
 
 def test_key_sort_oversubscribed_by_a_co_running_kernel():
@@ -456,6 +459,49 @@ def test_multi_instance_unified_sort_and_golden_frame(ob):
                                                         height=120), transforms=(None, M))
     oimg, _ = ob.render(ob.make_frame(g["view"], g["proj"], g["eye"], 160, 120, target_fp16=1), inst, order=order)
     assert ob.psnr_rgb(img2, oimg) >= PSNR_MIN
+    scene.close()
+
+
+@pytest.mark.parametrize("case", ["off-centre projection", "projective model", "negative zero in P", "sheared view row", "far coordinates"])
+def test_exact_matrix_shortcuts_and_their_fallbacks_bit_exact(ob, case):
+    """k_project drops the products with the matrices' exact zeros when view / model are affine and the projection has the
+    perspective pattern (kernels_common.h: mulMat4ExactAffineW1 / mulPerspExactW1*, round 5) — bit-identical to the oracle's full
+    products by construction.  Here: a projection with P[0][2], P[1][2] != 0 (an off-centre frustum keeps those terms), and the
+    inputs that must switch the shortcuts OFF — a model matrix with a projective last row, a -0 where the pattern wants +0, a view
+    matrix whose last row is not (0,0,0,1), coordinates beyond 2^60 — each against the oracle's (key, id) stream, bit for bit."""
+    n = 30_000
+    sc = synth.make_scene(n, seed=91)
+    M = None
+    W, H = 320, 240
+    eye = synth.orbit_pose(9)
+    V, P = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, W, H)
+    if case == "off-centre projection":
+        P[0, 2], P[1, 2] = 0.13, -0.07
+    elif case == "projective model":
+        M, _ = mgs.compute_transform([1.1, 0.9, 1.0], [5.0, 20.0, -10.0], [0.3, -0.1, 0.2])
+        M[3, 2] = 1.0e-3  # w = 1 + 1e-3 z: not affine
+    elif case == "negative zero in P":
+        P[3, 0] = -0.0
+        M, _ = mgs.compute_transform([1.0, 1.0, 1.0], [0.0, 33.0, 0.0], [0.1, 0.0, 0.0])
+    elif case == "sheared view row":
+        V = V.copy()
+        V[3, 1] = 1.0e-4
+    elif case == "far coordinates":
+        sc = {k: v.copy() for k, v in sc.items()}
+        sc["positions"][: n // 2] *= np.float32(3.0e18)  # beyond 2^60: the partitions holding them take the full products
+    ss = mgs.SplatSet.from_arrays(**sc)
+    scene = mgs.Scene(0)
+    scene.add_instance(ss, M)
+    scene.commit()
+    p = capi.default_params(W, H)
+    capi.set_camera(p, V, P, eye)
+    oks, ois = oracle_sorted_stream(ob, scene, sc, dict(view=V, proj=P, camera_pos=eye, width=W, height=H), transforms=(M,))
+    so = scene.sort_keys(p)
+    gk, gi = scene.sort_download(so.count)
+    assert so.count == oks.size and so.count > (2000 if case != "far coordinates" else 500)
+    assert np.array_equal(gk, oks) and np.array_equal(gi, ois)
+    out = scene.render(p, want_stats=True)  # the frame path takes the same decisions
+    assert out.error_flags == 0 and out.frustum_count == oks.size
     scene.close()
 
 
