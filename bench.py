@@ -36,8 +36,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_SQ_FILE = "r4_z_pmc_sq_composite.json"  # {"k_composite": {"SQ_INSTS_VALU": per-launch mean, ...}}
-PMC_FILE = "r4_z_pmc_hbm_traffic.json"  # written by tools/pmc_traffic.py from rocprofv3 --pmc passes of this command
+PMC_SQ_FILE = "r5_z_pmc_sq_composite.json"  # {"k_composite": {"SQ_INSTS_VALU": per-launch mean, ...}}
+PMC_FILE = "r5_z_pmc_hbm_traffic.json"  # written by tools/pmc_traffic.py from rocprofv3 --pmc passes of this command
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 STAGES = ["project", "sort", "bin", "pairsort", "composite", "total"]
 
@@ -45,7 +45,10 @@ STAGES = ["project", "sort", "bin", "pairsort", "composite", "total"]
 def composite_roofline(ms, alg_bytes, world, N, args):
     """k_composite is bound by fp32 VALU issue, not by HBM.  Its fraction is the VALU-busy fraction of the SIMDs over the
     kernel's duration: SQ_ACTIVE_INST_VALU (quad-cycles, summed over the chip; committed rocprofv3 --pmc pass of this
-    command) x 4 / (launch duration x 2.4 GHz x 1024 SIMDs) — a counter ratio, no assumed issue rate."""
+    command) x 4 / (launch duration x 2.4 GHz x 1024 SIMDs) — a counter ratio, no assumed issue rate.  Calibrated in round 5
+    (tools/micro/valu_rate.hip, profiles/r5_valu_rate.log): the counter advances 1.00 quad-cycle per plain wave64 VALU instruction
+    and 2.00 per transcendental, and such an instruction really holds its SIMD for four cycles; 2.4 GHz is the nominal clock —
+    under a VALU-dense load the chip ran at 2.13 GHz (GRBM_GUI_ACTIVE), so the fraction at the real clock is up to 1.13x this."""
     out = {"bound": "valu", "unit": "fraction of SIMD cycles issuing VALU", "peak": 1.0, "launch_ms": float(ms), "achieved": None,
            "frac": None, "hbm_algorithmic_bytes_per_launch": float(alg_bytes),
            "hbm_achieved_GBps": (alg_bytes / (ms * 1e-3)) / 1e9 if ms > 0 else None}
@@ -58,6 +61,8 @@ def composite_roofline(ms, alg_bytes, world, N, args):
             out["valu_insts_per_launch"] = pj["k_composite"]["SQ_INSTS_VALU"]
             out["achieved"] = busy / (ms * 1e-3 * 2.4e9 * 1024)
             out["frac"] = out["achieved"]
+            out["clock_note"] = ("2.4 GHz nominal; at the 2.13 GHz the chip sustains under VALU-dense load (profiles/r5_valu_rate.log) the busy "
+                                 "fraction is 1.13x `frac`")
             out["valu_source"] = f"profiles/{PMC_SQ_FILE} (committed rocprofv3 --pmc pass of `bench.py --inflight 1`; the duration is this run's)"
     except Exception:
         pass
