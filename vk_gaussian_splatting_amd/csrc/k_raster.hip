@@ -236,6 +236,7 @@ constexpr int kDbRounds = MGS_DB_ROUNDS;     // rounds of 64 splats per wave
 constexpr int kDbChunk  = 256 * kDbRounds;   // sorted splats per workgroup
 constexpr int kDbStage  = MGS_DB_STAGE;      // list entries staged in LDS per chunk so that the appends are coalesced
 constexpr int kDbMaxDim = 32;
+constexpr int kDbMaxSum = 40;  // binsX + binsY of a frame the direct binning takes (each <= 32, product <= 256: 32 + 8)
 
 // v_writelane_b32: a wave-uniform value into ONE lane's register
 __device__ __forceinline__ void writeLane(uint32_t& dst, uint32_t value, uint32_t lane)
@@ -416,10 +417,14 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
                                                    uint32_t capacity, int binsX, int binsY, uint32_t* __restrict__ binOrder,
                                                    const uint16_t* __restrict__ sortedCode16, uint32_t* __restrict__ binCost)
 {
-  __shared__ uint64_t s_col[4][kDbRounds][kDbMaxDim], s_row[4][kDbRounds][kDbMaxDim];  // masks of every round
+  // LDS diet (round 5): this kernel's residency is set by its LDS — 32 KB were 5 workgroups per CU, and 3 KB more cost a fifth of
+  // them and 9 us (seen by accident) — so: column and row masks share one row of binsX + binsY <= 40 words per (wave, round)
+  // (8 -> 5 KB), a staged entry is a 16-bit position + an 8-bit bin in two arrays (12 -> 9 KB), the bin ranking borrows the stage.
+  __shared__ uint64_t s_msk[4][kDbRounds][kDbMaxSum];  // masks of every round: columns [0, binsX), rows [binsX, binsX + binsY)
   __shared__ uint32_t s_cnt[4][256];  // per-wave counts, then per-wave write cursors
   __shared__ uint32_t s_ids[kDbChunk];
-  __shared__ uint32_t s_stage[kDbStage];  // (bin << 16) | position inside the chunk
+  __shared__ __attribute__((aligned(16))) uint16_t s_spos[kDbStage];  // staged entry: position inside the chunk ...
+  __shared__ uint8_t  s_sbin[kDbStage];                              // ... and its bin
   __shared__ uint32_t s_gdst[256], s_loc[256];
   __shared__ uint32_t s_tmp[4], s_tmp64[2];
   const uint32_t n      = plan->n;
@@ -471,10 +476,7 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
     for(int i = 0; i < kDbRounds; ++i)
       if(lane < S)
       {
-        if(lane < binsX)
-          s_col[w][i][lane] = mk[i];
-        else
-          s_row[w][i][lane - binsX] = mk[i];
+        s_msk[w][i][lane] = mk[i];  // (the masks arrive in this order: maskBuf holds columns, then rows)
       }
   }
   __builtin_amdgcn_wave_barrier();
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
     for(int j = 0; j < 4; ++j)
       if(j * 64 < nb)
       {
-        const uint64_t m = L.on[j] ? (s_col[w][i][L.bx[j]] & s_row[w][i][L.by[j]]) : 0ull;
+        const uint64_t m = L.on[j] ? (s_msk[w][i][L.bx[j]] & s_msk[w][i][binsX + L.by[j]]) : 0ull;
         cnt[j] += (uint32_t)__popcll(m);
       }
 #pragma unroll
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
     // binCost; consumed and cleared here) — the regions that never saturate are the long ones, and they are the same from one
     // frame of a sequence to the next; scheduling only, the frame does not depend on it.  Without a history (first frame, the
     // frame before was not composited by k_composite): longest list first.
-    __shared__ uint32_t s_tot[256];
+    uint32_t*      s_tot = reinterpret_cast<uint32_t*>(s_spos);  // [256] (the stage is filled only after this block)
     const uint32_t btot = (t < nb) ? binTotal[t] : 0u;
     uint32_t       cost = 0u;
     if(binCost != nullptr && t < nb)
@@ -603,8 +605,10 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
             if(kx <= dx && ky <= dy)
             {
               const uint32_t b   = (y0 + ky) * (uint32_t)binsX + x0 + kx;
-              const uint64_t m   = s_col[w][i][x0 + kx] & s_row[w][i][y0 + ky];
-              s_stage[s_cnt[w][b] + (uint32_t)__popcll(m & ltMask)] = (b << 16) | idx;
+              const uint64_t m   = s_msk[w][i][x0 + kx] & s_msk[w][i][(uint32_t)binsX + y0 + ky];
+              const uint32_t at = s_cnt[w][b] + (uint32_t)__popcll(m & ltMask);
+              s_spos[at]        = (uint16_t)idx;
+              s_sbin[at]        = (uint8_t)b;
             }
       }
       const uint64_t escM = __ballot(valid && !coded);
@@ -613,15 +617,17 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
       for(int j = 0; j < 4; ++j)
         if(j * 64 < nb)
         {
-          const uint64_t m    = L.on[j] ? (s_col[w][i][L.bx[j]] & s_row[w][i][L.by[j]]) : 0ull;
+          const uint64_t m    = L.on[j] ? (s_msk[w][i][L.bx[j]] & s_msk[w][i][binsX + L.by[j]]) : 0ull;
           uint64_t       me   = m & escM;
           const uint32_t run  = s_cnt[w][lane + 64 * j];
-          const uint32_t btag = (uint32_t)(lane + 64 * j) << 16;
+          const uint8_t  btag = (uint8_t)(lane + 64 * j);
           while(__ballot(me != 0ull) != 0ull)
             if(me != 0ull)
             {
               const uint32_t bit = (uint32_t)__builtin_ctzll(me);
-              s_stage[run + (uint32_t)__popcll(m & ((1ull << bit) - 1ull))] = btag | (wbase + (uint32_t)i * 64u + bit);
+              const uint32_t at  = run + (uint32_t)__popcll(m & ((1ull << bit) - 1ull));
+              s_spos[at]         = (uint16_t)(wbase + (uint32_t)i * 64u + bit);
+              s_sbin[at]         = btag;
               me &= me - 1ull;
             }
           if(L.on[j])
@@ -637,10 +643,10 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
     if(j * 64 < nb)
     {
       uint32_t       run  = s_cnt[w][lane + 64 * j];
-      const uint32_t btag = (uint32_t)(lane + 64 * j) << 16;
+      const uint8_t  btag = (uint8_t)(lane + 64 * j);
       for(int i = 0; i < kDbRounds; ++i)
       {
-        const uint64_t m = L.on[j] ? (s_col[w][i][L.bx[j]] & s_row[w][i][L.by[j]]) : 0ull;
+        const uint64_t m = L.on[j] ? (s_msk[w][i][L.bx[j]] & s_msk[w][i][binsX + L.by[j]]) : 0ull;
 #pragma unroll
         for(int h = 0; h < 2; ++h)
         {
@@ -651,7 +657,8 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
             while(__ballot(mh != 0u) != 0ull)
               if(mh != 0u)
               {
-                s_stage[run++] = btag | (pos0 + (uint32_t)__builtin_ctz(mh));
+                s_spos[run]   = (uint16_t)(pos0 + (uint32_t)__builtin_ctz(mh));
+                s_sbin[run++] = btag;
                 mh &= mh - 1u;
               }
           }
@@ -676,11 +683,10 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
   MGS_DB_STAMP(3)
   for(uint32_t i = t; i < P; i += 256)
   {
-    const uint32_t v   = s_stage[i];
-    const uint32_t b   = v >> 16;
+    const uint32_t b   = s_sbin[i];
     const uint32_t dst = s_gdst[b] + (i - s_loc[b]);
     if(dst < capacity)
-      binList[dst] = s_ids[v & 0xFFFFu];
+      binList[dst] = s_ids[s_spos[i]];
   }
 #ifdef MGS_DB_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1273,7 +1279,7 @@ void launchBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* ids
 
 bool directBinningSupported(int binsX, int binsY)
 {
-  return binsX <= kDbMaxDim && binsY <= kDbMaxDim && binsX * binsY <= 256;
+  return binsX <= kDbMaxDim && binsY <= kDbMaxDim && binsX * binsY <= 256 && binsX + binsY <= kDbMaxSum;
 }
 
 void launchDirectBinning(hipStream_t stream, const uint32_t* idsX, const uint32_t* idsY, const SortPlan* planKeys,
