@@ -332,7 +332,7 @@ __global__ __launch_bounds__(kGutThreads) void k_project_gut(const FrameArgs* __
     }
   __syncthreads();
   if(t == 0 && Mv)
-    atomicAdd(&ctr->frustumCount, Mv);
+    atomicAdd(&frameStatSlotFromOs(osPlan, part)[2], Mv);  // (sort_plan.h: 32 slots on 32 lines, not the counters' one line)
   // ---- 3DGUT front end over the survivors ----
   // The 96-byte records leave through LDS (as k_project's do): every lane builds one record, then the wave stores its 64 records
   // six lanes per record, so that a store instruction covers whole sectors wherever neighbouring ids both survive (a wave's
@@ -712,8 +712,9 @@ __global__ __launch_bounds__(256) void k_composite_gut(const FrameArgs* __restri
   }
   if(t == 0)
   {
-    atomicAdd(&ctr->scannedSlots[blockIdx.x & 7], statScanned);
-    atomicAdd(&ctr->stagedSlots[blockIdx.x & 7], statStaged);
+    uint32_t* stat = frameStatSlot(plan, blockIdx.x >> 3);  // (sort_plan.h: one 128-byte line per slot)
+    atomicAdd(&stat[1], statScanned);
+    atomicAdd(&stat[0], statStaged);
   }
   if(!inside)
     return;
@@ -981,8 +982,9 @@ __global__ __launch_bounds__(256) void k_composite_gut2(const FrameArgs* __restr
   }
   if(t == 0)
   {
-    atomicAdd(&ctr->scannedSlots[blockIdx.x & 7], statScanned);
-    atomicAdd(&ctr->stagedSlots[blockIdx.x & 7], statStaged);
+    uint32_t* stat = frameStatSlot(plan, blockIdx.x >> 3);  // (sort_plan.h: one 128-byte line per slot)
+    atomicAdd(&stat[1], statScanned);
+    atomicAdd(&stat[0], statStaged);
   }
 #pragma unroll
   for(int h = 0; h < 2; ++h)

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
     }
   __syncthreads();
   if(t == 0 && M)
-    atomicAdd(&ctr->frustumCount, M);
+    atomicAdd(&frameStatSlotFromOs(osPlan, part)[2], M);  // (sort_plan.h: 32 slots on 32 lines, not the counters' one line)
 
   MGS_PRJ_STAMP(3)
   if constexpr(!FULL)

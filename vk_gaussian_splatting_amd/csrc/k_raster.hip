@@ -1213,8 +1213,9 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
 #endif
   if(t == 0)
   {  // frame statistics (mgs_frame_stats): two fire-and-forget adds per workgroup
-    atomicAdd(&ctr->stagedSlots[blockIdx.x & 7], statStaged);
-    atomicAdd(&ctr->scannedSlots[blockIdx.x & 7], statScanned);
+    uint32_t* stat = frameStatSlot(plan, blockIdx.x >> 3);  // (sort_plan.h: one 128-byte line per slot)
+    atomicAdd(&stat[0], statStaged);
+    atomicAdd(&stat[1], statScanned);
     // the bin's longest region, for the next frame of this context: regions that never saturate take twice as long as the
     // others, and starting them late is the kernel's tail; which ones they are is the same from one frame to the next
     if(F.binCost != nullptr)

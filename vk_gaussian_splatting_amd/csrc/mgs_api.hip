@@ -2353,11 +2353,13 @@ int mgs_frame_stats(MgsScene s, MgsFrameOut* out)
   out->error_flags   = s->hCtr->errorFlags;
   out->shaded_count  = 0;
   out->scanned_entries = 0;
-  for(int i = 0; i < 8; ++i)
-  {
-    out->shaded_count += s->hCtr->stagedSlots[i];
-    out->scanned_entries += s->hCtr->scannedSlots[i];
-  }
+  for(uint32_t i = 0; i < kFrameStatSlots; ++i)
+    {  // (sort_plan.h: frameStatSlot — the kernels' counts live in the keys plan's histogram rows, one 128-byte line per slot; after
+       //  mgs_sort_keys the plans were fetched by that call)
+      out->frustum_count += (&s->hPlans->keys.ghist[0][0])[32u * i + 2u];
+      out->shaded_count += (&s->hPlans->keys.ghist[0][0])[32u * i];
+      out->scanned_entries += (&s->hPlans->keys.ghist[0][0])[32u * i + 1u];
+    }
   if(s->lastTimed && !s->lastWasSortOnly)
   {
     int rc = mgs_timings_query(s, 0, out->stage_ms);

@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdint>
 
 #include "device_types.h"
@@ -115,6 +116,27 @@ struct FramePlans
   SortPlan pairs;  // the record path's pair sort / the direct binning's per-bin totals
   OsPlan   os;     // the key sort's own plan
 };
+
+static_assert(offsetof(FramePlans, pairs) == sizeof(SortPlan) && offsetof(FramePlans, os) == 2 * sizeof(SortPlan),
+              "frameStatSlot: the keys plan sits right before the pairs plan, the key sort's plan right behind it");
+// The compositors' frame statistics (staged records, scanned list entries; mgs_frame_stats): every region adds its two counts
+// with fire-and-forget atomics.  Rounds 1-4 kept 8 + 8 words for them in the frame counters — ONE 128-byte line; at 4K that is
+// 33 K atomics on one line, and the line's atomic unit (~90 per microsecond) was what the compositor's tail waited for (round 5
+// ablation: composite 361 -> 331 us at 4K, 118 -> 114 at 1080p without them).  Now 32 slots, one per 128-byte line of the KEYS
+// plan's histogram rows, which a frame's key sort does not use and the frame's upload zeroes: word 0 staged, word 1 scanned.
+constexpr uint32_t kFrameStatSlots = 32;
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t* frameStatSlot(const SortPlan* planPairs /* &FramePlans::pairs */, uint32_t slot)
+{
+  return const_cast<uint32_t*>(&(planPairs - 1)->ghist[0][0]) + 32u * (slot & (kFrameStatSlots - 1u));
+}
+// the same slots from the project kernels, which hold &FramePlans::os: word 2 = survivors of the dist-stage cull (one add per
+// partition: 22.8 K of them at configs[4] were 23 us of the frame counters' line)
+__device__ __forceinline__ uint32_t* frameStatSlotFromOs(const OsPlan* osPlan /* &FramePlans::os */, uint32_t slot)
+{
+  return frameStatSlot(reinterpret_cast<const SortPlan*>(osPlan) - 1, slot);
+}
+#endif
 
 uint32_t osSortMaxParts(uint32_t maxElems);
 inline uint32_t osSortChunks(uint32_t prjParts) { return (prjParts + kOsChunk - 1u) / kOsChunk; }
