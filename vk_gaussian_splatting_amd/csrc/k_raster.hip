@@ -805,6 +805,9 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
   __shared__ float4   s_n[surf_lds(MODE) ? kCmpCap : 1];  // world normal of the record (surface outputs only)
   __shared__ uint32_t s_wc[2][kCmpEntries][4];
   __shared__ uint8_t  s_m[kCmpCap];  // which of the 4 quarters (waves) the record's footprint touches
+  // MGS_ALPHA_SUM without surface outputs: s_a = (k1, k2, log2 opacity, cutoff term) feeds the saturated waves' two-quad walk
+  // (below); the unsaturated walk's fragment cutoff lives here instead
+  __shared__ float    s_t[((MODE & 1) != 0 && !surf_lds(MODE)) ? kCmpCap : 1];
 
   const int t = threadIdx.x, lane = laneId(), w = t >> 6;
   // regions are 32-px columns x 16-px rows ("tile pairs"); binShiftX >= 1, so a pair never straddles two bins.
@@ -851,6 +854,8 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
   constexpr bool noGauss = (MODE & 2) != 0;
   constexpr bool surf    = (MODE & 4) != 0;  // FTB side outputs: picked depth + the splat that set it (frag.slang:320-349)
   constexpr bool stoch   = (MODE & 8) != 0;
+  constexpr bool sumWalk = !early && !surf;  // saturated waves only sum alpha (s_a layout: see s_t)
+  constexpr float kSumBig = 1073741824.0f;   // 2^30: (log2 alpha - cutoff) * 2^30, clamped to [0, 1], is the fragment's 0 / 1 weight
   // frag.slang:271: seed = xxhash32(uint3(fragCoord.xy, frameSampleId)); the sample id changes every frame: read through
   // the per-frame constants, not the by-value arguments a captured graph freezes
   uint32_t seedPx0 = 0u, seedPx1 = 0u;
@@ -970,7 +975,8 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
             // two instructions per pixel pair instead of three, and small operands (no 1000-px coordinates in the products)
             const float rx = a[k].x - bcx, ry = a[k].y - bcy;
             s_a[pos]       = make_float4(-(rx * sb.x + ry * sb.y), -(rx * sb.z + ry * sb.w), 0.0f, 0.0f);  // .z: the fragment cutoff, below
-            s_b[pos]           = sb;
+            // (saturated Σα walk: the y terms of (s, u) are ONE packed fma when p1y, p2y are neighbours — as k1, k2 are)
+            s_b[pos]           = sumWalk ? make_float4(sb.x, sb.z, sb.y, sb.w) : sb;
             s_c[pos]           = make_float4(0.f, 0.f, 0.f, al[k]);  // rgb: shading phase
             s_g[pos]           = g[k];
             // quarter (qx,qy): pixel centres x in [bcx-15.5,bcx-0.5] / [bcx+0.5,bcx+15.5], y in [bcy-7.5,bcy-0.5] / [bcy+0.5,bcy+7.5].
@@ -987,8 +993,19 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
             // quarter of the blend loop's instructions.)  A fragment whose alpha is within rounding of 1/255 may fall on
             // the other side than with the exp-then-compare order: a contribution of <= 0.4 % of one splat's colour.
             const float qCut = noGauss ? kQMax : fminf(kQMax, __log2f(fmaxf(rc * 255.0f, 1.0f)));
-            s_a[pos].z       = qCut;
-            s_a[pos].w       = rc;  // the opacity once more: the saturated waves of MGS_ALPHA_SUM read s_a and s_b only
+            if constexpr(sumWalk)
+            {  // saturated waves: alpha = 2^(l2a - q), kept iff q <= qCut  <=>  l2a - q >= l2a - qCut =: c, evaluated as
+               // clamp((l2a - q) * 2^30 - c * 2^30) in {0, 1}
+              const float l2a = noGauss ? 0.0f : __log2f(fmaxf(rc, 1.0e-30f));
+              s_a[pos].z      = l2a;
+              s_a[pos].w      = (qCut - l2a) * kSumBig;
+              s_t[pos]        = qCut;
+            }
+            else
+            {
+              s_a[pos].z = qCut;
+              s_a[pos].w = rc;
+            }
             const float qLim = qCut * 1.001f + 1e-3f;
             const float rs = 7.5f * fabsf(sb.x) + 3.5f * fabsf(sb.y), ru = 7.5f * fabsf(sb.z) + 3.5f * fabsf(sb.w);
             uint32_t    qm = 0;
@@ -1095,33 +1112,22 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
       // (the wave's quarter bit as a scalar: derived from the thread index it was a vector register the compiler spilled and
       //  re-loaded from scratch at the head of every 64-record chunk)
       const uint32_t wbit = 1u << (uint32_t)__builtin_amdgcn_readfirstlane(w);
+      const v2f      sumBig2 = {kSumBig, kSumBig};
       for(uint32_t j0 = 0; j0 < fill; j0 += 64)
       {
         const uint32_t jl   = j0 + (uint32_t)lane;
         const bool     mine = jl < fill && (s_m[jl] & wbit) != 0u;
         uint64_t       hits = __ballot(mine);
-        while(hits != 0ull)
+        // MGS_ALPHA_SUM: a saturated wave walks its hits in a loop of its own (below); the switch happens per record
+        while(hits != 0ull && !(sumWalk && waveSat))
         {
           const uint32_t j = j0 + (uint32_t)__builtin_ctzll(hits);
           hits &= hits - 1ull;
-          const float4 a1 = s_a[j], b1 = s_b[j];
+          const float4 a1 = s_a[j], b0 = s_b[j];
+          const float4 b1 = sumWalk ? make_float4(b0.x, b0.z, b0.y, b0.w) : b0;  // (p1x, p1y, p2x, p2y)
           const v2f    s1 = lx * b1.x + (ly * b1.y + a1.x), u1 = lx * b1.z + (ly * b1.w + a1.y);
           const v2f    q  = s1 * s1 + u1 * u1;  // == (A/2) * log2 e of frag.slang:236
-          if(!early && !surf && waveSat)
-          {  // saturated wave in MGS_ALPHA_SUM mode: the fragment only adds its alpha.  (Not with surface outputs: the depth /
-             // id pick fires when T crosses depth_iso_threshold, which may lie below 1e-4 — T has to keep falling there, as in
-             // the reference, the oracle and the default mode's full path.)
-            // (the opacity rides in s_a[j].w: two LDS reads per record here instead of three; products and sum packed)
-            v2f al = {1.0f, 1.0f};
-            if(!noGauss)
-            {
-              const v2f e = {__builtin_amdgcn_exp2f(-q.x), __builtin_amdgcn_exp2f(-q.y)};
-              al          = e * a1.w;
-            }
-            const v2f ah = {(q.x <= a1.z) ? al.x : 0.0f, (q.y <= a1.z) ? al.y : 0.0f};
-            asum += ah;
-            continue;
-          }
+          const float  qc = sumWalk ? s_t[j] : a1.z;
           const float4 c1 = s_c[j];
           v2f          al = {1.0f, 1.0f};
           if(!noGauss)  // frag.slang:248-254
@@ -1136,8 +1142,8 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
 #else
           // no test of T: a saturated pixel of a live wave keeps taking fragments (each weighs < 1e-4) until the WAVE retires,
           // which is checked per record and depends only on the sequence of records — the same in a strip and in the full frame
-          ah.x = (q.x <= a1.z) ? al.x : 0.0f;
-          ah.y = (q.y <= a1.z) ? al.y : 0.0f;
+          ah.x = (q.x <= qc) ? al.x : 0.0f;
+          ah.y = (q.y <= qc) ? al.y : 0.0f;
 #endif
           if constexpr(stoch)
           {  // frag.slang:272-276: seed = xxhash32(uint3(seed, splatId, primitiveID)); accept iff rand(seed) < opacity.
@@ -1186,6 +1192,37 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
           }
           if(!early && __ballot(T.x >= 1.0e-4f || T.y >= 1.0e-4f) == 0ull)
             waveSat = true;
+        }
+        if constexpr(sumWalk)
+        {
+          // Saturated wave in MGS_ALPHA_SUM mode: the fragment only adds its alpha.  (Not with surface outputs: the depth / id
+          // pick fires when T crosses depth_iso_threshold, which may lie below 1e-4 — T has to keep falling there, as in the
+          // reference, the oracle and the default mode's full path.)  Two LDS quads per record; the opacity is folded into the
+          // exponent (nq = log2 a - q, alpha = 2^nq) and the fragment rule (q <= qCut) is one packed fma with the clamp
+          // modifier instead of two compares + two selects: seven packed fmas and two v_exp per record and 128 pixels — this
+          // walk IS bound by VALU issue.
+          // (the hit mask is wave-uniform; said explicitly, or the walk's bit tricks land on the vector unit)
+          uint64_t hs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(hits >> 32)) << 32)
+                        | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)hits);
+          while(hs != 0ull)
+          {
+            const uint32_t j = j0 + (uint32_t)__builtin_ctzll(hs);
+            hs &= hs - 1ull;
+            const float4 a1 = s_a[j], b1 = s_b[j];  // (k1, k2, log2 a, cutoff term), (p1x, p2x, p1y, p2y)
+            const v2f    k12 = {a1.x, a1.y}, py12 = {b1.z, b1.w}, zw = {a1.z, a1.w};
+            const v2f    yt  = ly * py12 + k12;
+            const v2f    s1 = lx * b1.x + yt.x, u1 = lx * b1.y + yt.y;
+            const v2f    nq = -(u1 * u1) + (-(s1 * s1) + a1.z);
+            v2f          m;
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,1] clamp" : "=v"(m) : "v"(nq), "s"(sumBig2), "v"(zw));
+            if(noGauss)
+              asum += m;
+            else
+            {
+              const v2f e = {__builtin_amdgcn_exp2f(nq.x), __builtin_amdgcn_exp2f(nq.y)};
+              asum        = e * m + asum;
+            }
+          }
         }
         if(waveDone)
           break;
