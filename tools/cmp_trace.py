@@ -19,6 +19,8 @@ def run(pose):
   V, P = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, W, H)
   p = capi.default_params(W, H)
   capi.set_camera(p, V, P, eye)
+  if os.environ.get("ALPHA_SUM"):   # trace the additive-alpha mode (MGS_ALPHA_SUM) instead of the default
+      p.alpha_mode = capi.ALPHA_SUM
   for _ in range(4):
       scene.render(p, want_stats=True)
   path = os.environ["MGS_CMP_TRACE_FILE"]

@@ -775,6 +775,19 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // bit 3: stochastic splats (frag.slang:265-290: a fragment is accepted with probability alpha and written opaque; the
 // depth test keeps the nearest accepted one == the first accepted one of the nearest-first list); SHF: SH storage format
 constexpr bool surf_lds(int mode) { return (mode & 4) != 0; }
+constexpr bool sum_walk(int mode) { return (mode & 1) != 0 && (mode & 4) == 0; }  // MGS_ALPHA_SUM without surface outputs
+#ifndef MGS_SUM_ENTRIES
+#define MGS_SUM_ENTRIES MGS_CMP_ENTRIES
+#endif
+#ifndef MGS_SUM_CAP
+#define MGS_SUM_CAP 448  // (sweep, garden-sized frame: 288/32 2.89 ms, 352/96 2.82, 416/160 2.80, 448/192 2.79 — 25.6 KB, still 6 workgroups
+#endif                   //  per CU —, 544/288 2.77, 672/416 and beyond lose more to the residency than the longer batches gain)
+#ifndef MGS_SUM_GO
+#define MGS_SUM_GO 192
+#endif
+#ifndef MGS_SUM_UNROLL
+#define MGS_SUM_UNROLL 2
+#endif
 #ifndef MGS_CMP_WAVES
 #define MGS_CMP_WAVES 6
 #endif
@@ -786,6 +799,10 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
                                                    float* __restrict__ outDepth, uint32_t* __restrict__ outSplatId,
                                                    const FrameArgs* __restrict__ Ap, float4* __restrict__ outNormal)
 {
+  // batch geometry: the additive-alpha mode (every fragment of a region's whole list is composited) has its own
+  constexpr int cEnt = sum_walk(MODE) ? MGS_SUM_ENTRIES : kCmpEntries, cRound = 256 * cEnt;
+  constexpr int cCap = sum_walk(MODE) ? MGS_SUM_CAP : kCmpCap, cGo = sum_walk(MODE) ? MGS_SUM_GO : kCmpGo;
+  static_assert(cGo <= cCap - 256, "sub-group 0 of a stage-A round must always fit");
   uint32_t statStaged = 0, statScanned = 0;
   const uint64_t costT0 = wall_clock64();  // this region's duration feeds the next frame's bin order (F.binCost)
 #ifdef MGS_CMP_TRACE  // debug build (tools/cmp_trace.py): per-workgroup wall-clock stamps, 100 MHz
@@ -797,17 +814,17 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
 #else
 #define MGS_TRACE_PHASE(acc)
 #endif
-  __shared__ float4   s_a[kCmpCap];  // k1, k2 (centre terms of d.p1, d.p2), fragment cutoff, -
-  __shared__ float4   s_b[kCmpCap];  // p1, p2 (scaled by sqrt(log2 e))
-  __shared__ float4   s_c[kCmpCap];  // r, g, b, a
-  __shared__ uint32_t s_g[kCmpCap];  // global id: what the deferred shading needs
-  __shared__ float    s_z[surf_lds(MODE) ? kCmpCap : 1];  // fragCoord.z of the record (surface outputs only)
-  __shared__ float4   s_n[surf_lds(MODE) ? kCmpCap : 1];  // world normal of the record (surface outputs only)
-  __shared__ uint32_t s_wc[2][kCmpEntries][4];
-  __shared__ uint8_t  s_m[kCmpCap];  // which of the 4 quarters (waves) the record's footprint touches
+  __shared__ float4   s_a[cCap];  // k1, k2 (centre terms of d.p1, d.p2), fragment cutoff, -
+  __shared__ float4   s_b[cCap];  // p1, p2 (scaled by sqrt(log2 e))
+  __shared__ float4   s_c[cCap];  // r, g, b, a
+  __shared__ uint32_t s_g[cCap];  // global id: what the deferred shading needs
+  __shared__ float    s_z[surf_lds(MODE) ? cCap : 1];  // fragCoord.z of the record (surface outputs only)
+  __shared__ float4   s_n[surf_lds(MODE) ? cCap : 1];  // world normal of the record (surface outputs only)
+  __shared__ uint32_t s_wc[2][cEnt][4];
+  __shared__ uint8_t  s_m[cCap];  // which of the 4 quarters (waves) the record's footprint touches
   // MGS_ALPHA_SUM without surface outputs: s_a = (k1, k2, log2 opacity, cutoff term) feeds the saturated waves' two-quad walk
   // (below); the unsaturated walk's fragment cutoff lives here instead
-  __shared__ float    s_t[((MODE & 1) != 0 && !surf_lds(MODE)) ? kCmpCap : 1];
+  __shared__ float    s_t[sum_walk(MODE) ? cCap : 1];
 
   const int t = threadIdx.x, lane = laneId(), w = t >> 6;
   // regions are 32-px columns x 16-px rows ("tile pairs"); binShiftX >= 1, so a pair never straddles two bins.
@@ -854,7 +871,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
   constexpr bool noGauss = (MODE & 2) != 0;
   constexpr bool surf    = (MODE & 4) != 0;  // FTB side outputs: picked depth + the splat that set it (frag.slang:320-349)
   constexpr bool stoch   = (MODE & 8) != 0;
-  constexpr bool sumWalk = !early && !surf;  // saturated waves only sum alpha (s_a layout: see s_t)
+  constexpr bool sumWalk = sum_walk(MODE);  // saturated waves only sum alpha (s_a layout: see s_t)
   constexpr float kSumBig = 1073741824.0f;   // 2^30: (log2 alpha - cutoff) * 2^30, clamped to [0, 1], is the fragment's 0 / 1 weight
   // frag.slang:271: seed = xxhash32(uint3(fragCoord.xy, frameSampleId)); the sample id changes every frame: read through
   // the per-frame constants, not the by-value arguments a captured graph freezes
@@ -889,38 +906,38 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
   uint32_t hi   = range.y;
   uint32_t fill = 0;  // records currently in the LDS batch
   int      rnd  = 0;
-  uint32_t gNext[kCmpEntries];
+  uint32_t gNext[cEnt];
   bool     prefValid = false;
 #pragma unroll
-  for(int k = 0; k < kCmpEntries; ++k)
+  for(int k = 0; k < cEnt; ++k)
     gNext[k] = 0u;
   for(;;)
   {
     // ---- stage A: scan list entries (nearest first) until enough records are staged or the list ends ----
     // A round looks at up to 1024 entries as 4 sub-groups of 256 (k-th sub-group = entries k*256+t).  The
-    // sub-groups are accepted in order while they fit into the batch; since fill < kCmpGo <= cap-256 on
+    // sub-groups are accepted in order while they fit into the batch; since fill < cGo <= cap-256 on
     // entry, sub-group 0 always fits, so every round makes progress and the batch can never overflow.
     // The ids of the NEXT round are fetched before this round's barrier (one dependent trip instead of two).
-    while(hi > range.x && fill < (uint32_t)kCmpGo)
+    while(hi > range.x && fill < (uint32_t)cGo)
     {
 #ifdef MGS_CMP_TRACE
       ++traceRounds;
 #endif
       const uint32_t avail = hi - range.x;
-      uint32_t       g[kCmpEntries];
-      float4         a[kCmpEntries], pb[kCmpEntries];  // (cx, cy, ex, ey), (p1, p2)
-      float          al[kCmpEntries];                  // opacity
-      bool           ok[kCmpEntries];
-      uint64_t       bal[kCmpEntries];
+      uint32_t       g[cEnt];
+      float4         a[cEnt], pb[cEnt];  // (cx, cy, ex, ey), (p1, p2)
+      float          al[cEnt];                  // opacity
+      bool           ok[cEnt];
+      uint64_t       bal[cEnt];
 #pragma unroll
-      for(int k = 0; k < kCmpEntries; ++k)
+      for(int k = 0; k < cEnt; ++k)
       {
         const uint32_t e = k * 256u + (uint32_t)t;  // e-th nearest remaining entry
         ok[k]            = e < avail;
         g[k]             = prefValid ? gNext[k] : (ok[k] ? vals[hi - 1u - e] : 0u);
       }
 #pragma unroll
-      for(int k = 0; k < kCmpEntries; ++k)
+      for(int k = 0; k < cEnt; ++k)
       {  // the whole 32-byte record (half a sector): centre + p1 | p2 + opacity + fp16 extents
         const float4* r  = reinterpret_cast<const float4*>(rec + g[k]);
         const float4  r0 = ok[k] ? r[0] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -933,17 +950,17 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
       }
       // speculative prefetch of the next round's ids (valid if this round is consumed completely)
       {
-        const uint32_t hiN = hi - min(avail, (uint32_t)kCmpRound);
+        const uint32_t hiN = hi - min(avail, (uint32_t)cRound);
         const uint32_t avN = hiN - range.x;
 #pragma unroll
-        for(int k = 0; k < kCmpEntries; ++k)
+        for(int k = 0; k < cEnt; ++k)
         {
           const uint32_t e = k * 256u + (uint32_t)t;
           gNext[k]         = (e < avN) ? vals[hiN - 1u - e] : 0u;
         }
       }
 #pragma unroll
-      for(int k = 0; k < kCmpEntries; ++k)
+      for(int k = 0; k < cEnt; ++k)
       {
         // pixel centres of the region span bcx +- 15.5, bcy +- 7.5
         ok[k]  = ok[k] && fabsf(a[k].x - bcx) <= a[k].z + 15.5f && fabsf(a[k].y - bcy) <= a[k].w + 7.5f;
@@ -957,10 +974,10 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
       uint32_t base = fill;
       int      used = 0;  // sub-groups consumed
 #pragma unroll
-      for(int k = 0; k < kCmpEntries; ++k)
+      for(int k = 0; k < cEnt; ++k)
       {
         const uint32_t m = cnt[k][0] + cnt[k][1] + cnt[k][2] + cnt[k][3];
-        if(used == k && base + m <= (uint32_t)kCmpCap)
+        if(used == k && base + m <= (uint32_t)cCap)
         {
           uint32_t wb = 0;
           if(w > 0) wb += cnt[k][0];
@@ -997,9 +1014,23 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
             {  // saturated waves: alpha = 2^(l2a - q), kept iff q <= qCut  <=>  l2a - q >= l2a - qCut =: c, evaluated as
                // clamp((l2a - q) * 2^30 - c * 2^30) in {0, 1}
               const float l2a = noGauss ? 0.0f : __log2f(fmaxf(rc, 1.0e-30f));
-              s_a[pos].z      = l2a;
-              s_a[pos].w      = (qCut - l2a) * kSumBig;
-              s_t[pos]        = qCut;
+              const float tb  = (qCut - l2a) * kSumBig;
+              if(allSat)
+              {  // every wave of the region is saturated: this batch is only ever summed, by the polynomial walk (stage B) —
+                 // nq = l2a - q as a quadratic in the pixel's offset (lx, ly) from the region centre,
+                 // q = (lx p1x + ly p1y + k1)^2 + (lx p2x + ly p2y + k2)^2:
+                 // nq = (nA lx + (nB ly + nD)) lx + ((nC ly + nE) ly + F'), coefficients per record, computed here once
+                const float k1 = -(rx * sb.x + ry * sb.y), k2 = -(rx * sb.z + ry * sb.w);
+                s_a[pos] = make_float4(-2.0f * (sb.x * sb.y + sb.z * sb.w), -(sb.y * sb.y + sb.w * sb.w),
+                                       -2.0f * (k1 * sb.x + k2 * sb.z), -2.0f * (k1 * sb.y + k2 * sb.w));
+                s_b[pos] = make_float4(-(sb.x * sb.x + sb.z * sb.z), l2a - (k1 * k1 + k2 * k2), tb, 0.0f);
+              }
+              else
+              {
+                s_a[pos].z = l2a;
+                s_a[pos].w = tb;
+                s_t[pos]   = qCut;
+              }
             }
             else
             {
@@ -1027,9 +1058,9 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
       fill                    = base;
       const uint32_t consumed = min(avail, (uint32_t)used * 256u);
       statScanned += consumed;
-      prefValid               = (used == kCmpEntries);
+      prefValid               = (used == cEnt);
       hi -= consumed;
-      if(used < kCmpEntries)
+      if(used < cEnt)
         break;  // batch full: blend, then rescan the unconsumed sub-groups
     }
     __syncthreads();
@@ -1118,6 +1149,49 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
         const uint32_t jl   = j0 + (uint32_t)lane;
         const bool     mine = jl < fill && (s_m[jl] & wbit) != 0u;
         uint64_t       hits = __ballot(mine);
+        if constexpr(sumWalk)
+        {
+          if(allSat)
+          {  // the batch was staged for the polynomial walk (stage A): 5 packed fmas, one plain one, two v_exp per record
+            uint64_t hs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(hits >> 32)) << 32)
+                          | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)hits);
+            auto polyTerm = [&](uint32_t j, v2f& m, v2f& e) {
+              const float4 a1 = s_a[j], b1 = s_b[j];  // (nB, nC, nD, nE), (nA, F', cutoff term, -)
+              const v2f    bc = {a1.x, a1.y}, de = {a1.z, a1.w}, tz = {b1.z, b1.w};
+              const v2f    hg = ly * bc + de;          // (nB ly + nD, nC ly + nE)
+              const float  g  = hg.y * ly + b1.y;
+              const v2f    nq = (lx * b1.x + hg.x) * lx + g;
+              asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,1,0] clamp" : "=v"(m) : "v"(nq), "s"(sumBig2), "v"(tz));
+              if(noGauss)
+                e = (v2f){1.0f, 1.0f};
+              else
+                e = (v2f){__builtin_amdgcn_exp2f(nq.x), __builtin_amdgcn_exp2f(nq.y)};
+            };
+#if MGS_SUM_UNROLL == 2
+            while((hs & (hs - 1ull)) != 0ull)
+            {
+              const uint32_t ja = j0 + (uint32_t)__builtin_ctzll(hs);
+              hs &= hs - 1ull;
+              const uint32_t jb = j0 + (uint32_t)__builtin_ctzll(hs);
+              hs &= hs - 1ull;
+              v2f ma, ea, mb, eb;
+              polyTerm(ja, ma, ea);
+              polyTerm(jb, mb, eb);
+              asum = ea * ma + asum;
+              asum = eb * mb + asum;
+            }
+#endif
+            while(hs != 0ull)
+            {
+              const uint32_t j = j0 + (uint32_t)__builtin_ctzll(hs);
+              hs &= hs - 1ull;
+              v2f m, e;
+              polyTerm(j, m, e);
+              asum = e * m + asum;
+            }
+            continue;
+          }
+        }
         // MGS_ALPHA_SUM: a saturated wave walks its hits in a loop of its own (below); the switch happens per record
         while(hits != 0ull && !(sumWalk && waveSat))
         {
@@ -1204,24 +1278,42 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
           // (the hit mask is wave-uniform; said explicitly, or the walk's bit tricks land on the vector unit)
           uint64_t hs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(hits >> 32)) << 32)
                         | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)hits);
-          while(hs != 0ull)
-          {
-            const uint32_t j = j0 + (uint32_t)__builtin_ctzll(hs);
-            hs &= hs - 1ull;
+          // one record's fragments for this lane's two pixels: weight m in {0, 1} (the fragment rule) and alpha e
+          auto sumTerm = [&](uint32_t j, v2f& m, v2f& e) {
             const float4 a1 = s_a[j], b1 = s_b[j];  // (k1, k2, log2 a, cutoff term), (p1x, p2x, p1y, p2y)
             const v2f    k12 = {a1.x, a1.y}, py12 = {b1.z, b1.w}, zw = {a1.z, a1.w};
             const v2f    yt  = ly * py12 + k12;
             const v2f    s1 = lx * b1.x + yt.x, u1 = lx * b1.y + yt.y;
             const v2f    nq = -(u1 * u1) + (-(s1 * s1) + a1.z);
-            v2f          m;
             asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,1] clamp" : "=v"(m) : "v"(nq), "s"(sumBig2), "v"(zw));
             if(noGauss)
-              asum += m;
+              e = (v2f){1.0f, 1.0f};
             else
-            {
-              const v2f e = {__builtin_amdgcn_exp2f(nq.x), __builtin_amdgcn_exp2f(nq.y)};
-              asum        = e * m + asum;
-            }
+              e = (v2f){__builtin_amdgcn_exp2f(nq.x), __builtin_amdgcn_exp2f(nq.y)};
+          };
+#if MGS_SUM_UNROLL == 2
+          // two records per trip: two independent chains (LDS round trip, six dependent packed fmas, v_exp) in flight per wave;
+          // the sums are added in list order, as in the one-record form
+          while((hs & (hs - 1ull)) != 0ull)
+          {
+            const uint32_t ja = j0 + (uint32_t)__builtin_ctzll(hs);
+            hs &= hs - 1ull;
+            const uint32_t jb = j0 + (uint32_t)__builtin_ctzll(hs);
+            hs &= hs - 1ull;
+            v2f ma, ea, mb, eb;
+            sumTerm(ja, ma, ea);
+            sumTerm(jb, mb, eb);
+            asum = ea * ma + asum;
+            asum = eb * mb + asum;
+          }
+#endif
+          while(hs != 0ull)
+          {
+            const uint32_t j = j0 + (uint32_t)__builtin_ctzll(hs);
+            hs &= hs - 1ull;
+            v2f m, e;
+            sumTerm(j, m, e);
+            asum = e * m + asum;
           }
         }
         if(waveDone)
