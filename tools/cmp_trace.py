@@ -11,6 +11,8 @@ from vk_gaussian_splatting_amd import capi, synth
 poses = [int(x) for x in sys.argv[1:]] or [0]
 W, H = 1920, 1080
 sc = synth.make_scene(5_830_000, seed=1)
+if os.environ.get("SCENE") == "fog":   # bench.py --scene fog: regions that never saturate
+    sc["opacity"] = (sc["opacity"] - 2.5).astype(np.float32)
 scene = mgs.Scene(0)
 scene.add_instance(mgs.SplatSet.from_arrays(**sc))
 scene.commit()

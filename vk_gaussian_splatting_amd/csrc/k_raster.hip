@@ -785,6 +785,15 @@ constexpr bool sum_walk(int mode) { return (mode & 1) != 0 && (mode & 4) == 0; }
 #ifndef MGS_SUM_GO
 #define MGS_SUM_GO 192
 #endif
+// MGS_CMP_FOLD: the blend walk's fragment alpha as 2^(log2 a - q) with the fragment rule as one packed fma + clamp (17 instead of
+// 23 vector instructions per record and wave)
+#ifndef MGS_CMP_FOLD
+#define MGS_CMP_FOLD 1
+#endif
+#ifdef MGS_CMP_EXACT_PRED
+#undef MGS_CMP_FOLD
+#define MGS_CMP_FOLD 0
+#endif
 #ifndef MGS_SUM_UNROLL
 #define MGS_SUM_UNROLL 2
 #endif
@@ -824,7 +833,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
   __shared__ uint8_t  s_m[cCap];  // which of the 4 quarters (waves) the record's footprint touches
   // MGS_ALPHA_SUM without surface outputs: s_a = (k1, k2, log2 opacity, cutoff term) feeds the saturated waves' two-quad walk
   // (below); the unsaturated walk's fragment cutoff lives here instead
-  __shared__ float    s_t[sum_walk(MODE) ? cCap : 1];
+  __shared__ float    s_t[(sum_walk(MODE) && MGS_CMP_FOLD == 0) ? cCap : 1];
 
   const int t = threadIdx.x, lane = laneId(), w = t >> 6;
   // regions are 32-px columns x 16-px rows ("tile pairs"); binShiftX >= 1, so a pair never straddles two bins.
@@ -871,7 +880,8 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
   constexpr bool noGauss = (MODE & 2) != 0;
   constexpr bool surf    = (MODE & 4) != 0;  // FTB side outputs: picked depth + the splat that set it (frag.slang:320-349)
   constexpr bool stoch   = (MODE & 8) != 0;
-  constexpr bool sumWalk = sum_walk(MODE);  // saturated waves only sum alpha (s_a layout: see s_t)
+  constexpr bool sumWalk = sum_walk(MODE);
+  constexpr bool fold    = MGS_CMP_FOLD != 0;  // s_a = (k1, k2, log2 a, cutoff term), s_b = (p1x, p2x, p1y, p2y)  // saturated waves only sum alpha (s_a layout: see s_t)
   constexpr float kSumBig = 1073741824.0f;   // 2^30: (log2 alpha - cutoff) * 2^30, clamped to [0, 1], is the fragment's 0 / 1 weight
   // frag.slang:271: seed = xxhash32(uint3(fragCoord.xy, frameSampleId)); the sample id changes every frame: read through
   // the per-frame constants, not the by-value arguments a captured graph freezes
@@ -985,70 +995,14 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
           if(w > 2) wb += cnt[k][2];
           if(ok[k])
           {
+            // the survivor's record goes to its place in the batch as it is (centre + extents | p1, p2 | opacity | id); what the
+            // blend walk reads is computed from it by finishRecord below, once per STAGED record and on dense lanes — here,
+            // under the survivors' predicate, the arithmetic ran for every round of 64 entries (a quarter of which survive)
             const uint32_t pos = base + wb + lanesBelow(bal[k]);
-            const float4   sb  = make_float4(pb[k].x * kSqrtLog2e, pb[k].y * kSqrtLog2e, pb[k].z * kSqrtLog2e, pb[k].w * kSqrtLog2e);
-            // (s, u) = (d.p1, d.p2) with d = pixel - centre, rewritten around the region centre: s = lx*p1x + (ly*p1y + k1),
-            // k1 = -((cx - bcx)*p1x + (cy - bcy)*p1y), lx/ly = the pixel relative to the region centre (|.| <= 15.5):
-            // two instructions per pixel pair instead of three, and small operands (no 1000-px coordinates in the products)
-            const float rx = a[k].x - bcx, ry = a[k].y - bcy;
-            s_a[pos]       = make_float4(-(rx * sb.x + ry * sb.y), -(rx * sb.z + ry * sb.w), 0.0f, 0.0f);  // .z: the fragment cutoff, below
-            // (saturated Σα walk: the y terms of (s, u) are ONE packed fma when p1y, p2y are neighbours — as k1, k2 are)
-            s_b[pos]           = sumWalk ? make_float4(sb.x, sb.z, sb.y, sb.w) : sb;
+            s_a[pos]           = a[k];
+            s_b[pos]           = pb[k];
             s_c[pos]           = make_float4(0.f, 0.f, 0.f, al[k]);  // rgb: shading phase
             s_g[pos]           = g[k];
-            // quarter (qx,qy): pixel centres x in [bcx-15.5,bcx-0.5] / [bcx+0.5,bcx+15.5], y in [bcy-7.5,bcy-0.5] / [bcy+0.5,bcy+7.5].
-            // Footprint box first, then a bound in the ellipse's own frame: over the quarter (centre m, half
-            // extents 7.5 x 3.5) s = d.p1 stays within |s_m| -+ (7.5|p1x| + 3.5|p1y|), likewise u = d.p2, so
-            // q >= max(0,|s_m|-rs)^2 + max(0,|u_m|-ru)^2; a quarter whose bound exceeds what the alpha
-            // threshold lets through (a 2^-q > 1/255) cannot receive a fragment.  43 % of the wave-level
-            // evaluations were empty before this test (corner overlaps of slanted ellipses).
-            const bool  xl = a[k].x - a[k].z <= bcx - 0.5f, xr = a[k].x + a[k].z >= bcx + 0.5f;
-            const bool  yt = a[k].y - a[k].w <= bcy - 0.5f, yb = a[k].y + a[k].w >= bcy + 0.5f;
-            const float rc = al[k];
-            // Fragment rule of frag.slang:242-262 — discard A > 8 (q > kQMax here), discard alpha <= 1/255 — as ONE compare per
-            // pixel: alpha = a 2^-q > 1/255  <=>  q < log2(255 a).  (Two compares + the saturation test per pixel were a
-            // quarter of the blend loop's instructions.)  A fragment whose alpha is within rounding of 1/255 may fall on
-            // the other side than with the exp-then-compare order: a contribution of <= 0.4 % of one splat's colour.
-            const float qCut = noGauss ? kQMax : fminf(kQMax, __log2f(fmaxf(rc * 255.0f, 1.0f)));
-            if constexpr(sumWalk)
-            {  // saturated waves: alpha = 2^(l2a - q), kept iff q <= qCut  <=>  l2a - q >= l2a - qCut =: c, evaluated as
-               // clamp((l2a - q) * 2^30 - c * 2^30) in {0, 1}
-              const float l2a = noGauss ? 0.0f : __log2f(fmaxf(rc, 1.0e-30f));
-              const float tb  = (qCut - l2a) * kSumBig;
-              if(allSat)
-              {  // every wave of the region is saturated: this batch is only ever summed, by the polynomial walk (stage B) —
-                 // nq = l2a - q as a quadratic in the pixel's offset (lx, ly) from the region centre,
-                 // q = (lx p1x + ly p1y + k1)^2 + (lx p2x + ly p2y + k2)^2:
-                 // nq = (nA lx + (nB ly + nD)) lx + ((nC ly + nE) ly + F'), coefficients per record, computed here once
-                const float k1 = -(rx * sb.x + ry * sb.y), k2 = -(rx * sb.z + ry * sb.w);
-                s_a[pos] = make_float4(-2.0f * (sb.x * sb.y + sb.z * sb.w), -(sb.y * sb.y + sb.w * sb.w),
-                                       -2.0f * (k1 * sb.x + k2 * sb.z), -2.0f * (k1 * sb.y + k2 * sb.w));
-                s_b[pos] = make_float4(-(sb.x * sb.x + sb.z * sb.z), l2a - (k1 * k1 + k2 * k2), tb, 0.0f);
-              }
-              else
-              {
-                s_a[pos].z = l2a;
-                s_a[pos].w = tb;
-                s_t[pos]   = qCut;
-              }
-            }
-            else
-            {
-              s_a[pos].z = qCut;
-              s_a[pos].w = rc;
-            }
-            const float qLim = qCut * 1.001f + 1e-3f;
-            const float rs = 7.5f * fabsf(sb.x) + 3.5f * fabsf(sb.y), ru = 7.5f * fabsf(sb.z) + 3.5f * fabsf(sb.w);
-            uint32_t    qm = 0;
-#pragma unroll
-            for(int qd = 0; qd < 4; ++qd)
-            {
-              const float mx = bcx + ((qd & 1) ? 8.0f : -8.0f) - a[k].x, my = bcy + ((qd & 2) ? 4.0f : -4.0f) - a[k].y;
-              const float ds = fmaxf(fabsf(mx * sb.x + my * sb.y) - rs, 0.0f), du = fmaxf(fabsf(mx * sb.z + my * sb.w) - ru, 0.0f);
-              const bool  box = ((qd & 1) ? xr : xl) && ((qd & 2) ? yb : yt);
-              qm |= (box && (ds * ds + du * du <= qLim || F.looseMask)) ? (1u << qd) : 0u;
-            }
-            s_m[pos] = (uint8_t)qm;
           }
           base += m;
           used = k + 1;
@@ -1068,8 +1022,78 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
     // ---- shading: the SH sum of the staged splats (mesh.slang:243), one thread per record ---------------------
     // Deferred from the projection: only splats that reach an unsaturated region are ever shaded (a quarter of
     // the frustum survivors on the garden-sized bench), and their 192-byte SH records are the bulk of a splat.
-    for(uint32_t j = t; j < fill && !allSat; j += 256)
+    // ---- finish the staged records (dense lanes, one thread per record): the blend walk's operands and the quarter masks ----
+    auto finishRecord = [&](uint32_t pos) {
+      const float4 ak = s_a[pos], pbk = s_b[pos];  // (cx, cy, ex, ey), (p1, p2)
+      const float  alk = s_c[pos].w;
+        const float4   sb  = make_float4(pbk.x * kSqrtLog2e, pbk.y * kSqrtLog2e, pbk.z * kSqrtLog2e, pbk.w * kSqrtLog2e);
+        // (s, u) = (d.p1, d.p2) with d = pixel - centre, rewritten around the region centre: s = lx*p1x + (ly*p1y + k1),
+        // k1 = -((cx - bcx)*p1x + (cy - bcy)*p1y), lx/ly = the pixel relative to the region centre (|.| <= 15.5):
+        // two instructions per pixel pair instead of three, and small operands (no 1000-px coordinates in the products)
+        const float rx = ak.x - bcx, ry = ak.y - bcy;
+        s_a[pos]       = make_float4(-(rx * sb.x + ry * sb.y), -(rx * sb.z + ry * sb.w), 0.0f, 0.0f);  // .z: the fragment cutoff, below
+        // (saturated Σα walk: the y terms of (s, u) are ONE packed fma when p1y, p2y are neighbours — as k1, k2 are)
+        s_b[pos]           = (sumWalk || fold) ? make_float4(sb.x, sb.z, sb.y, sb.w) : sb;
+        // quarter (qx,qy): pixel centres x in [bcx-15.5,bcx-0.5] / [bcx+0.5,bcx+15.5], y in [bcy-7.5,bcy-0.5] / [bcy+0.5,bcy+7.5].
+        // Footprint box first, then a bound in the ellipse's own frame: over the quarter (centre m, half
+        // extents 7.5 x 3.5) s = d.p1 stays within |s_m| -+ (7.5|p1x| + 3.5|p1y|), likewise u = d.p2, so
+        // q >= max(0,|s_m|-rs)^2 + max(0,|u_m|-ru)^2; a quarter whose bound exceeds what the alpha
+        // threshold lets through (a 2^-q > 1/255) cannot receive a fragment.  43 % of the wave-level
+        // evaluations were empty before this test (corner overlaps of slanted ellipses).
+        const bool  xl = ak.x - ak.z <= bcx - 0.5f, xr = ak.x + ak.z >= bcx + 0.5f;
+        const bool  yt = ak.y - ak.w <= bcy - 0.5f, yb = ak.y + ak.w >= bcy + 0.5f;
+        const float rc = alk;
+        // Fragment rule of frag.slang:242-262 — discard A > 8 (q > kQMax here), discard alpha <= 1/255 — as ONE compare per
+        // pixel: alpha = a 2^-q > 1/255  <=>  q < log2(255 a).  (Two compares + the saturation test per pixel were a
+        // quarter of the blend loop's instructions.)  A fragment whose alpha is within rounding of 1/255 may fall on
+        // the other side than with the exp-then-compare order: a contribution of <= 0.4 % of one splat's colour.
+        const float qCut = noGauss ? kQMax : fminf(kQMax, __log2f(fmaxf(rc * 255.0f, 1.0f)));
+        if constexpr(sumWalk || fold)
+        {  // saturated waves: alpha = 2^(l2a - q), kept iff q <= qCut  <=>  l2a - q >= l2a - qCut =: c, evaluated as
+           // clamp((l2a - q) * 2^30 - c * 2^30) in {0, 1}
+          const float l2a = noGauss ? 0.0f : __log2f(fmaxf(rc, 1.0e-30f));
+          const float tb  = (qCut - l2a) * kSumBig;
+          if(sumWalk && allSat)
+          {  // every wave of the region is saturated: this batch is only ever summed, by the polynomial walk (stage B) —
+             // nq = l2a - q as a quadratic in the pixel's offset (lx, ly) from the region centre,
+             // q = (lx p1x + ly p1y + k1)^2 + (lx p2x + ly p2y + k2)^2:
+             // nq = (nA lx + (nB ly + nD)) lx + ((nC ly + nE) ly + F'), coefficients per record, computed here once
+            const float k1 = -(rx * sb.x + ry * sb.y), k2 = -(rx * sb.z + ry * sb.w);
+            s_a[pos] = make_float4(-2.0f * (sb.x * sb.y + sb.z * sb.w), -(sb.y * sb.y + sb.w * sb.w),
+                                   -2.0f * (k1 * sb.x + k2 * sb.z), -2.0f * (k1 * sb.y + k2 * sb.w));
+            s_b[pos] = make_float4(-(sb.x * sb.x + sb.z * sb.z), l2a - (k1 * k1 + k2 * k2), tb, 0.0f);
+          }
+          else
+          {
+            s_a[pos].z = l2a;
+            s_a[pos].w = tb;
+            if constexpr(!fold)
+              s_t[pos] = qCut;
+          }
+        }
+        else
+        {
+          s_a[pos].z = qCut;
+          s_a[pos].w = rc;
+        }
+        const float qLim = qCut * 1.001f + 1e-3f;
+        const float rs = 7.5f * fabsf(sb.x) + 3.5f * fabsf(sb.y), ru = 7.5f * fabsf(sb.z) + 3.5f * fabsf(sb.w);
+        uint32_t    qm = 0;
+#pragma unroll
+        for(int qd = 0; qd < 4; ++qd)
+        {
+          const float mx = bcx + ((qd & 1) ? 8.0f : -8.0f) - ak.x, my = bcy + ((qd & 2) ? 4.0f : -4.0f) - ak.y;
+          const float ds = fmaxf(fabsf(mx * sb.x + my * sb.y) - rs, 0.0f), du = fmaxf(fabsf(mx * sb.z + my * sb.w) - ru, 0.0f);
+          const bool  box = ((qd & 1) ? xr : xl) && ((qd & 2) ? yb : yt);
+          qm |= (box && (ds * ds + du * du <= qLim || F.looseMask)) ? (1u << qd) : 0u;
+        }
+        s_m[pos] = (uint8_t)qm;
+    };
+    for(uint32_t j = t; j < fill; j += 256)
     {
+      finishRecord(j);
+      if(allSat)
+        continue;  // (a region whose four waves are saturated sums alpha only: nothing to shade)
       const uint32_t gid = s_g[j];
       CompositeArgs::Inst I = F.inst[0];
       int                 instIdx = 0;
@@ -1155,8 +1179,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
           {  // the batch was staged for the polynomial walk (stage A): 5 packed fmas, one plain one, two v_exp per record
             uint64_t hs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(hits >> 32)) << 32)
                           | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)hits);
-            auto polyTerm = [&](uint32_t j, v2f& m, v2f& e) {
-              const float4 a1 = s_a[j], b1 = s_b[j];  // (nB, nC, nD, nE), (nA, F', cutoff term, -)
+            auto polyTerm = [&](const float4 a1, const float4 b1, v2f& m, v2f& e) {  // (nB, nC, nD, nE), (nA, F', cutoff term, -)
               const v2f    bc = {a1.x, a1.y}, de = {a1.z, a1.w}, tz = {b1.z, b1.w};
               const v2f    hg = ly * bc + de;          // (nB ly + nD, nC ly + nE)
               const float  g  = hg.y * ly + b1.y;
@@ -1167,18 +1190,27 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
               else
                 e = (v2f){__builtin_amdgcn_exp2f(nq.x), __builtin_amdgcn_exp2f(nq.y)};
             };
-#if MGS_SUM_UNROLL == 2
-            while((hs & (hs - 1ull)) != 0ull)
+#if MGS_SUM_UNROLL >= 2
+            // several records per trip, their LDS quads requested together: the walk of ONE wave is a latency chain per record
+            // (LDS round trip, four dependent packed fmas, v_exp), and the region with the longest list is the kernel's span
+            while(__builtin_popcountll(hs) >= MGS_SUM_UNROLL)
             {
-              const uint32_t ja = j0 + (uint32_t)__builtin_ctzll(hs);
-              hs &= hs - 1ull;
-              const uint32_t jb = j0 + (uint32_t)__builtin_ctzll(hs);
-              hs &= hs - 1ull;
-              v2f ma, ea, mb, eb;
-              polyTerm(ja, ma, ea);
-              polyTerm(jb, mb, eb);
-              asum = ea * ma + asum;
-              asum = eb * mb + asum;
+              float4 qa[MGS_SUM_UNROLL], qb[MGS_SUM_UNROLL];
+#pragma unroll
+              for(int u = 0; u < MGS_SUM_UNROLL; ++u)
+              {
+                const uint32_t j = j0 + (uint32_t)__builtin_ctzll(hs);
+                hs &= hs - 1ull;
+                qa[u] = s_a[j];
+                qb[u] = s_b[j];
+              }
+              v2f mm[MGS_SUM_UNROLL], ee[MGS_SUM_UNROLL];
+#pragma unroll
+              for(int u = 0; u < MGS_SUM_UNROLL; ++u)
+                polyTerm(qa[u], qb[u], mm[u], ee[u]);
+#pragma unroll
+              for(int u = 0; u < MGS_SUM_UNROLL; ++u)
+                asum = ee[u] * mm[u] + asum;  // in list order
             }
 #endif
             while(hs != 0ull)
@@ -1186,7 +1218,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
               const uint32_t j = j0 + (uint32_t)__builtin_ctzll(hs);
               hs &= hs - 1ull;
               v2f m, e;
-              polyTerm(j, m, e);
+              polyTerm(s_a[j], s_b[j], m, e);
               asum = e * m + asum;
             }
             continue;
@@ -1197,6 +1229,33 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
         {
           const uint32_t j = j0 + (uint32_t)__builtin_ctzll(hits);
           hits &= hits - 1ull;
+#if MGS_CMP_FOLD
+          // alpha = a 2^-q as 2^(log2 a - q); the fragment rule of frag.slang:242-262 (discard A > 8, discard alpha <= 1/255: one
+          // cutoff per record, stage A) as clamp((log2 a - q) * 2^30 + cutoff term) in {0, 1} — a packed fma instead of two
+          // compares and two selects; the y terms of (s, u) packed.  No test of T: a saturated pixel of a live wave keeps taking
+          // fragments (each weighs < 1e-4) until the WAVE retires, which is checked per record and depends only on the
+          // sequence of records — the same in a strip and in the full frame
+          const float4 a1 = s_a[j], b1 = s_b[j];  // (k1, k2, log2 a, cutoff term), (p1x, p2x, p1y, p2y)
+          const v2f    k12 = {a1.x, a1.y}, py12 = {b1.z, b1.w}, zw = {a1.z, a1.w};
+          const v2f    yt  = ly * py12 + k12;
+          const v2f    s1 = lx * b1.x + yt.x, u1 = lx * b1.y + yt.y;
+          const v2f    nq = -(u1 * u1) + (-(s1 * s1) + a1.z);  // log2 alpha;  q == (A/2) * log2 e of frag.slang:236
+          float4       c1 = s_c[j];
+          {  // keep (b, a) a register pair: the whole quad in one ds_read_b128 (4 LDS cycles; the b96 the compiler picks when
+             // .w is unused takes 8) and blue broadcast through op_sel instead of a move
+            v2f czw = {c1.z, c1.w};
+            asm("" : "+v"(czw));
+            c1.z = czw.x;
+            c1.w = czw.y;
+          }
+          v2f          ah;
+          asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,1] clamp" : "=v"(ah) : "v"(nq), "s"(sumBig2), "v"(zw));
+          if(!noGauss)  // frag.slang:248-254
+          {
+            const v2f e = {__builtin_amdgcn_exp2f(nq.x), __builtin_amdgcn_exp2f(nq.y)};
+            ah          = e * ah;
+          }
+#else
           const float4 a1 = s_a[j], b0 = s_b[j];
           const float4 b1 = sumWalk ? make_float4(b0.x, b0.z, b0.y, b0.w) : b0;  // (p1x, p1y, p2x, p2y)
           const v2f    s1 = lx * b1.x + (ly * b1.y + a1.x), u1 = lx * b1.z + (ly * b1.w + a1.y);
@@ -1218,6 +1277,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
           // which is checked per record and depends only on the sequence of records — the same in a strip and in the full frame
           ah.x = (q.x <= qc) ? al.x : 0.0f;
           ah.y = (q.y <= qc) ? al.y : 0.0f;
+#endif
 #endif
           if constexpr(stoch)
           {  // frag.slang:272-276: seed = xxhash32(uint3(seed, splatId, primitiveID)); accept iff rand(seed) < opacity.
