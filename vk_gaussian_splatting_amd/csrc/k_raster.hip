@@ -794,6 +794,9 @@ constexpr bool sum_walk(int mode) { return (mode & 1) != 0 && (mode & 4) == 0; }
 #undef MGS_CMP_FOLD
 #define MGS_CMP_FOLD 0
 #endif
+#ifndef MGS_SUM_POLY  // 0: A/B — batches of an all-saturated region are walked in the (s, u) form as well
+#define MGS_SUM_POLY 1
+#endif
 #ifndef MGS_SUM_UNROLL
 #define MGS_SUM_UNROLL 2
 #endif
@@ -1053,7 +1056,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
            // clamp((l2a - q) * 2^30 - c * 2^30) in {0, 1}
           const float l2a = noGauss ? 0.0f : __log2f(fmaxf(rc, 1.0e-30f));
           const float tb  = (qCut - l2a) * kSumBig;
-          if(sumWalk && allSat)
+          if(sumWalk && MGS_SUM_POLY && allSat)
           {  // every wave of the region is saturated: this batch is only ever summed, by the polynomial walk (stage B) —
              // nq = l2a - q as a quadratic in the pixel's offset (lx, ly) from the region centre,
              // q = (lx p1x + ly p1y + k1)^2 + (lx p2x + ly p2y + k2)^2:
@@ -1175,7 +1178,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
         uint64_t       hits = __ballot(mine);
         if constexpr(sumWalk)
         {
-          if(allSat)
+          if(MGS_SUM_POLY && allSat)
           {  // the batch was staged for the polynomial walk (stage A): 5 packed fmas, one plain one, two v_exp per record
             uint64_t hs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(hits >> 32)) << 32)
                           | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)hits);
