@@ -1004,7 +1004,9 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
             const uint32_t pos = base + wb + lanesBelow(bal[k]);
             s_a[pos]           = a[k];
             s_b[pos]           = pb[k];
-            s_c[pos]           = make_float4(0.f, 0.f, 0.f, al[k]);  // rgb: shading phase
+            // (the opacity alone, a 4-byte LDS store: a 16-byte one costs the wave 13 cycles of the LDS path however few of its lanes
+            //  are survivors — composite -3 us; rgb is the shading phase's)
+            reinterpret_cast<float*>(&s_c[pos])[3] = al[k];
             s_g[pos]           = g[k];
           }
           base += m;
