@@ -750,12 +750,18 @@ __global__ void k_tile_ranges(const uint32_t* __restrict__ keyX, const uint32_t*
 // the fine culling on chip:
 //   stage A  every thread fetches 2 list entries (id -> the 32-byte record: centre, p1, p2, opacity, fp16 extents),
 //            tests the footprint against the workgroup's region, and the survivors are compacted
-//            IN ORDER (ballot + mbcnt) into an LDS batch together with the rest of their record;
-//   stage B  each wave walks the batch, skips splats that miss its quarter, and blends front-to-back:
-//            q=(d.p1)^2+(d.p2)^2 (== A/2, frag.slang:236), discard q>4, alpha=a*exp(-q), discard <=1/255.
-//            (p1, p2 are pre-scaled by sqrt(log2 e) when staged, so the exponential is a bare v_exp_f32.)
-// A wave retires when all 128 pixels have T < 1e-4; the workgroup stops fetching when all 4 have
-// (not in MGS_ALPHA_SUM mode, where the reference's additive alpha must see every fragment).
+//            IN ORDER (ballot + mbcnt) into an LDS batch, their records as they are;
+//   finish   one thread per STAGED record (dense lanes, at the head of the shading loop) turns it into the blend walk's operands:
+//            axes scaled by sqrt(log2 e) (the exponential is then a bare v_exp_f32), centre terms around the region centre,
+//            log2 of the opacity, the fragment rule's cutoff term, the mask of the quarters its ellipse can reach;
+//   shading  colour + SH of the staged records (deferred from the projection: a sixth of the sorted splats are ever staged);
+//   stage B  each wave walks the batch, skips records that miss its quarter, and blends front-to-back:
+//            q=(d.p1)^2+(d.p2)^2 (== A/2, frag.slang:236), alpha = 2^(log2 a - q), discard q>4 and alpha<=1/255 (one cutoff per
+//            record, applied as a packed fma with the clamp modifier).
+// A wave retires when all 128 pixels have T < 1e-4; the workgroup stops fetching when all 4 have.  In MGS_ALPHA_SUM mode, where the
+// reference's additive alpha must see every fragment, a saturated wave goes on SUMMING alpha (a walk of its own: two LDS quads,
+// seven packed fmas, two v_exp per record), and the batches staged after all four are saturated are staged and walked as a
+// quadratic in the pixel offset.
 #ifndef MGS_CMP_ENTRIES
 #define MGS_CMP_ENTRIES 2
 #endif
