@@ -37,7 +37,9 @@ def run(pose):
         f"(= {dur.sum() / end.max():.1f} workgroups resident on average; 256 CUs x 6 = 1536 slots)")
   print("duration us percentiles 10/50/90/99/max:", np.percentile(dur, [10, 50, 90, 99, 100]).round(1))
   print("start us percentiles 10/50/90/99/max:", np.percentile(start, [10, 50, 90, 99, 100]).round(1))
-  it, rounds, scanned, staged = a[:, 4], a[:, 5], a[:, 2], a[:, 3]
+  it, rounds, scanned, staged = a[:, 4] & 0xFFFFFFFF, a[:, 5], a[:, 2], a[:, 3]
+  needed = a[:, 4] >> 32   # staged (= shaded) records up to the one at which the region's last wave retired
+  print(f"staged {int(staged.sum())}, of which needed before the region retired {int(needed.sum())} ({needed.sum() / max(staged.sum(), 1):.2f}); per region needed/staged p10/50/90:", np.percentile(needed / np.maximum(staged, 1), [10, 50, 90]).round(2))
   ok = it > 0
   print("iterations per workgroup 50/90/99/max:", np.percentile(it, [50, 90, 99, 100]), " stage-A rounds:", np.percentile(rounds, [50, 90, 99, 100]))
   print("us per iteration (median over workgroups with >= 4 iterations):", np.median(dur[it >= 4] / it[it >= 4]).round(2),

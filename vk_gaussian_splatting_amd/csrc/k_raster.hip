@@ -826,7 +826,8 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
 #ifdef MGS_CMP_TRACE  // debug build (tools/cmp_trace.py): per-workgroup wall-clock stamps, 100 MHz
   const uint64_t traceT0 = wall_clock64();
   uint64_t       traceA = 0, traceS = 0, traceB = 0, traceLast;  // time spent in stage A / shading / blending
-  uint32_t       traceIters = 0, traceRounds = 0;
+  uint32_t       traceIters = 0, traceRounds = 0, traceNeed = 0, traceNeeded = 0;
+  __shared__ uint32_t s_traceNeed;
   traceLast = traceT0;
 #define MGS_TRACE_PHASE(acc) { const uint64_t now_ = wall_clock64(); acc += now_ - traceLast; traceLast = now_; }
 #else
@@ -1333,6 +1334,9 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
           if(early && __ballot(T.x >= tMin || T.y >= tMin) == 0ull)
           {
             waveDone = true;
+#ifdef MGS_CMP_TRACE
+            traceNeed = j + 1u;  // this wave needed the batch's records up to here
+#endif
             break;
           }
           if(!early && __ballot(T.x >= 1.0e-4f || T.y >= 1.0e-4f) == 0ull)
@@ -1391,10 +1395,20 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
           break;
       }
     }
-    fill = 0;
 #ifdef MGS_CMP_TRACE
+    {  // how many of the batch's (shaded) records did the region need?  max over the waves that blended this batch
+      if(!waveDone)
+        traceNeed = fill;
+      if(t == 0) s_traceNeed = 0u;
+      __syncthreads();
+      if(lane == 0 && traceNeed) atomicMax(&s_traceNeed, traceNeed);
+      __syncthreads();
+      traceNeeded += s_traceNeed;
+      traceNeed = 0u;
+    }
     ++traceIters;
 #endif
+    fill = 0;
     const int allFlag = __syncthreads_and((early ? waveDone : waveSat) ? 1 : 0);
     MGS_TRACE_PHASE(traceB)
     const bool allDone = early && allFlag != 0;
@@ -1407,7 +1421,7 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
   if(t == 0 && F.trace)
   {
     uint64_t* o = F.trace + (size_t)blockIdx.x * 10;
-    o[0] = traceT0; o[1] = wall_clock64(); o[2] = statScanned; o[3] = statStaged; o[4] = traceIters; o[5] = traceRounds;
+    o[0] = traceT0; o[1] = wall_clock64(); o[2] = statScanned; o[3] = statStaged; o[4] = traceIters | ((uint64_t)traceNeeded << 32); o[5] = traceRounds;
     o[6] = traceA; o[7] = traceS; o[8] = traceB; o[9] = ((uint64_t)range.y - range.x) | ((uint64_t)(ty * colsX + cx2) << 32);
   }
 #endif
