@@ -300,12 +300,65 @@ __device__ __forceinline__ LaneBins laneBins(int binsX, int nb)
   return L;
 }
 
+// The same masks by a bit-matrix transpose (round 5, third session): a lane's rectangle IS a row of the (splat x bin-column / bin-row)
+// bit matrix — columns x0..x1 in bits [0, binsX), rows y0..y1 in bits [binsX, binsX + binsY) — and the masks are its columns.
+// Five butterfly stages (partner's word by DPP for lane distances 1, 2, 8, by ds_swizzle for 4 and 16; v_alignbit + v_bfi)
+// transpose the 32 x 32 blocks of both wave halves at once, one ds_bpermute brings the upper half's word to lane b: ~25 vector
+// instructions per round of 64 splats, whatever binsX + binsY is, where the ballots cost (binsX + binsY) x 7 (compare, ballot
+// into an SGPR pair, two v_writelane through m0) — 119 at 1080p, 224 at 4K — in one dependent chain.  Needs binsX + binsY <= 32.
+struct TransposeConst
+{
+  uint32_t keep[5];  // the bits a lane keeps at stage k (distance 1 << k): those whose index has bit k like the lane's own
+  uint32_t rot[5];   // v_alignbit shift that brings the partner's other bits under the complement of keep
+};
+__device__ __forceinline__ TransposeConst transposeConst()
+{
+  TransposeConst C;
+  const uint32_t lowMask[5] = {0x55555555u, 0x33333333u, 0x0F0F0F0Fu, 0x00FF00FFu, 0x0000FFFFu};
+  const uint32_t lane = (uint32_t)laneId();
+#pragma unroll
+  for(int k = 0; k < 5; ++k)
+  {
+    const bool up = (lane >> k) & 1u;
+    C.keep[k]     = up ? ~lowMask[k] : lowMask[k];
+    C.rot[k]      = up ? (1u << k) : 32u - (1u << k);  // rotate right by d (upper lane) / left by d (lower lane)
+  }
+  return C;
+}
+template <int N>
+__device__ __forceinline__ void transposeWords(uint32_t (&x)[N], const TransposeConst& C)
+{
+#define MGS_TR_STAGE(K, PARTNER)                                                                        \
+  _Pragma("unroll") for(int i = 0; i < N; ++i)                                                          \
+  {                                                                                                     \
+    const uint32_t p = (uint32_t)(PARTNER);                                                             \
+    const uint32_t r = __builtin_amdgcn_alignbit(p, p, C.rot[K]);                                       \
+    x[i]             = (C.keep[K] & x[i]) | (~C.keep[K] & r);                                           \
+  }
+  MGS_TR_STAGE(0, __builtin_amdgcn_update_dpp(0, (int)x[i], 0xB1, 0xF, 0xF, true))   // quad_perm [1,0,3,2]: lane ^ 1
+  MGS_TR_STAGE(1, __builtin_amdgcn_update_dpp(0, (int)x[i], 0x4E, 0xF, 0xF, true))   // quad_perm [2,3,0,1]: lane ^ 2
+  MGS_TR_STAGE(2, __builtin_amdgcn_ds_swizzle((int)x[i], (4 << 10) | 0x1F))          // BITMASK_PERM xor 4
+  MGS_TR_STAGE(3, __builtin_amdgcn_update_dpp(0, (int)x[i], 0x128, 0xF, 0xF, true))  // row_ror:8 = lane ^ 8 within a row of 16
+  MGS_TR_STAGE(4, __builtin_amdgcn_ds_swizzle((int)x[i], (16 << 10) | 0x1F))         // BITMASK_PERM xor 16
+#undef MGS_TR_STAGE
+}
+// a lane's row of the bit matrix: bins columns x0..x1 | bin rows y0..y1 << binsX (empty for an invalid / inverted rectangle)
+__device__ __forceinline__ uint32_t rectWord(uint32_t r, bool valid, int binsX, uint32_t colAll, uint32_t rowAll)
+{
+  const uint32_t x0 = r & 255u, y0 = (r >> 8) & 255u, dx = ((r >> 16) & 255u) - x0, dy = (r >> 24) - y0;
+  const bool     ok = valid && (int)dx >= 0 && (int)dy >= 0;
+  const uint32_t cb = (((2u << (dx & 31u)) - 1u) << (x0 & 31u)) & colAll;
+  const uint32_t rb = (((2u << (dy & 31u)) - 1u) << (y0 & 31u)) & rowAll;
+  return ok ? (cb | (rb << binsX)) : 0u;
+}
+
 __global__ __launch_bounds__(256) void k_dbin_count(const uint32_t* __restrict__ idsX, const uint32_t* __restrict__ idsY,
                                                     const SortPlan* __restrict__ plan, const uint32_t* __restrict__ rect,
                                                     const uint16_t* __restrict__ sortedCode16, uint64_t* __restrict__ maskBuf,
-                                                    uint32_t* __restrict__ binHist, uint32_t pStride, int binsX, int binsY)
+                                                    uint32_t* __restrict__ binHist, uint32_t pStride, int binsX, int binsY, int transpose)
 {
   __shared__ uint64_t s_col[4][kDbMaxDim], s_row[4][kDbMaxDim];
+  __shared__ uint64_t s_msk[4][kDbRounds][32];  // transpose path: the rounds' masks, columns then rows (binsX + binsY <= 32)
   __shared__ uint32_t s_cnt[4][256];
   const uint32_t n      = plan->n;
   const uint32_t chunks = (n + kDbChunk - 1) / kDbChunk;
@@ -345,6 +398,39 @@ __global__ __launch_bounds__(256) void k_dbin_count(const uint32_t* __restrict__
   // the masks of every round are kept for k_dbin_emit (17 x 8 B per round instead of re-reading 64 rects and
   // redoing the ballots): maskBuf[((chunk*4 + wave)*rounds + round)*S + {column masks, row masks}]
   uint64_t* mOut = maskBuf + ((size_t)blockIdx.x * 4 + w) * kDbRounds * S;
+  if(S <= 32 && transpose != 0)
+  {  // masks by transpose (above): the four rounds' butterflies are independent and interleave
+    const TransposeConst C      = transposeConst();
+    const uint32_t       colAll = (1u << binsX) - 1u, rowAll = (1u << binsY) - 1u;  // (binsX, binsY <= 31 here)
+    uint32_t             x[kDbRounds];
+#pragma unroll
+    for(int i = 0; i < kDbRounds; ++i)
+      x[i] = rectWord(r[i], e0 + i * 64u < n, binsX, colAll, rowAll);
+    transposeWords(x, C);
+    const int up = ((lane + 32) & 63) << 2;
+#pragma unroll
+    for(int i = 0; i < kDbRounds; ++i)
+    {
+      const uint32_t hi   = (uint32_t)__builtin_amdgcn_ds_bpermute(up, (int)x[i]);  // lane b: the word of lane 32 + b
+      const uint64_t mine = ((uint64_t)hi << 32) | x[i];
+      if(lane < S)
+      {
+        s_msk[w][i][lane] = mine;
+        mOut[i * S + lane] = mine;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for(int i = 0; i < kDbRounds; ++i)
+#pragma unroll
+      for(int j = 0; j < 4; ++j)
+        if(j * 64 < nb)
+        {
+          const uint64_t m = L.on[j] ? (s_msk[w][i][L.bx[j]] & s_msk[w][i][binsX + L.by[j]]) : 0ull;
+          cnt[j] += (uint32_t)__popcll(m);
+        }
+  }
+  else
 #pragma unroll
   for(int i = 0; i < kDbRounds; ++i)
   {
@@ -1505,8 +1591,10 @@ void launchDirectBinning(hipStream_t stream, const uint32_t* idsX, const uint32_
   const uint32_t maxChunks = (maxSplats + kDbChunk - 1) / kDbChunk;
   if(maxChunks == 0)
     return;
+  // MGS_DB_TRANSPOSE=0: the rounds' masks by ballots everywhere (A/B switch of the transpose path; the masks are the same)
+  static const int kTranspose = [] { const char* e = std::getenv("MGS_DB_TRANSPOSE"); return e ? std::atoi(e) : 1; }();
   hipLaunchKernelGGL(k_dbin_count, dim3(maxChunks), dim3(256), 0, stream, idsX, idsY, planKeys, rect, sortedCode16, maskBuf,
-                     binHist, pStride, binsX, binsY);
+                     binHist, pStride, binsX, binsY, kTranspose);
   hipLaunchKernelGGL(k_dbin_scan, dim3(binsX * binsY), dim3(256), 0, stream, planKeys, binHist, pStride, binTotal);
 #ifdef MGS_DB_TRACE
   static uint64_t* traceBuf = nullptr;
