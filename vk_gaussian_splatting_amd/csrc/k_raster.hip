@@ -236,6 +236,10 @@ constexpr int kDbRounds = MGS_DB_ROUNDS;     // rounds of 64 splats per wave
 constexpr int kDbChunk  = 256 * kDbRounds;   // sorted splats per workgroup
 constexpr int kDbStage  = MGS_DB_STAGE;      // list entries staged in LDS per chunk so that the appends are coalesced
 constexpr int kDbMaxDim = 32;
+#ifndef MGS_DB_CNT_MUL
+#define MGS_DB_CNT_MUL 1
+#endif
+constexpr int kDbCntMul = MGS_DB_CNT_MUL;  // chunks counted per workgroup of k_dbin_count
 constexpr int kDbMaxSum = 40;  // binsX + binsY of a frame the direct binning takes (each <= 32, product <= 256: 32 + 8)
 
 // v_writelane_b32: a wave-uniform value into ONE lane's register
@@ -362,97 +366,125 @@ __global__ __launch_bounds__(256) void k_dbin_count(const uint32_t* __restrict__
   __shared__ uint32_t s_cnt[4][256];
   const uint32_t n      = plan->n;
   const uint32_t chunks = (n + kDbChunk - 1) / kDbChunk;
-  if(blockIdx.x >= chunks)
+  // a workgroup counts kDbCntMul consecutive chunks (k_dbin_emit's unit stays one chunk): the kernel is a chain of dependent round
+  // trips per workgroup (plan -> codes + ids -> the escapes' rectangles -> masks), so with every chunk's loads in flight at once
+  // the grid passes through the chip in one residency wave instead of two
+  const uint32_t chunk0 = blockIdx.x * (uint32_t)kDbCntMul;
+  if(chunk0 >= chunks)
     return;
   const int       t = threadIdx.x, lane = laneId(), w = t >> 6;
   const uint32_t* ids = plan->finalSel ? idsY : idsX;
-  const uint32_t  e0  = blockIdx.x * (uint32_t)kDbChunk + (uint32_t)w * (kDbRounds * 64) + (uint32_t)lane;
-  uint32_t        r[kDbRounds];
+  uint32_t        r[kDbCntMul][kDbRounds];
   const uint32_t  ride = plan->reserved[0];
+  const uint32_t  eW   = (uint32_t)w * (kDbRounds * 64) + (uint32_t)lane;
   if(ride != 0u)
   {  // the rectangles rode through the key sort as codes above the ids and lie in sorted order (kernels_common.h: rideEncode);
-    // only the escapes — splats over more than 2 x 2 bins — are looked up by id
+    // only the escapes — splats over more than 2 x 2 bins — are looked up by id.  The ids are requested beside the codes
+    // (coalesced, 4 B per splat): an escape's rectangle is two dependent trips away, not three
     const uint32_t escape = (1u << (ride >> 8)) - 1u;
-    uint32_t       v[kDbRounds];
+    uint32_t       v[kDbCntMul][kDbRounds], id[kDbCntMul][kDbRounds];
 #pragma unroll
-    for(int i = 0; i < kDbRounds; ++i)
-      v[i] = sortedCode16[min(e0 + i * 64u, n - 1u)];
+    for(int c = 0; c < kDbCntMul; ++c)
 #pragma unroll
-    for(int i = 0; i < kDbRounds; ++i)
-      r[i] = (v[i] == escape) ? rect[ids[min(e0 + i * 64u, n - 1u)]] : rideDecode(v[i], binsX, binsY);
+      for(int i = 0; i < kDbRounds; ++i)
+      {
+        const uint32_t e = min((chunk0 + c) * (uint32_t)kDbChunk + eW + i * 64u, n - 1u);
+        v[c][i]          = sortedCode16[e];
+        id[c][i]         = ids[e];
+      }
+#pragma unroll
+    for(int c = 0; c < kDbCntMul; ++c)
+#pragma unroll
+      for(int i = 0; i < kDbRounds; ++i)
+        r[c][i] = (v[c][i] == escape) ? rect[id[c][i]] : rideDecode(v[c][i], binsX, binsY);
   }
   else
   {
-    uint32_t id[kDbRounds];
+    uint32_t id[kDbCntMul][kDbRounds];
 #pragma unroll
-    for(int i = 0; i < kDbRounds; ++i)
-      id[i] = ids[min(e0 + i * 64u, n - 1u)];  // clamped, not predicated: all loads in flight
+    for(int c = 0; c < kDbCntMul; ++c)
 #pragma unroll
-    for(int i = 0; i < kDbRounds; ++i)
-      r[i] = rect[id[i]];  // one random gather per splat: 4.2 M of them run at ~120 G/s (L2-miss sectors), 35 us, wherever they
-                           // are issued (moving them into the sort's final pass was measured twice: +36 us there for -16 us here)
+      for(int i = 0; i < kDbRounds; ++i)
+        id[c][i] = ids[min((chunk0 + c) * (uint32_t)kDbChunk + eW + i * 64u, n - 1u)];  // clamped, not predicated: all loads in flight
+#pragma unroll
+    for(int c = 0; c < kDbCntMul; ++c)
+#pragma unroll
+      for(int i = 0; i < kDbRounds; ++i)
+        r[c][i] = rect[id[c][i]];  // one random gather per splat: 4.2 M of them run at ~120 G/s (L2-miss sectors), 35 us, wherever
+                                   // they are issued (moving them into the sort's final pass was measured twice: +36 us there for -16 us here)
   }
-  const int      nb = binsX * binsY, S = binsX + binsY;
-  const LaneBins L  = laneBins(binsX, nb);
-  uint32_t       cnt[4] = {0u, 0u, 0u, 0u};
-  // the masks of every round are kept for k_dbin_emit (17 x 8 B per round instead of re-reading 64 rects and
-  // redoing the ballots): maskBuf[((chunk*4 + wave)*rounds + round)*S + {column masks, row masks}]
-  uint64_t* mOut = maskBuf + ((size_t)blockIdx.x * 4 + w) * kDbRounds * S;
-  if(S <= 32 && transpose != 0)
-  {  // masks by transpose (above): the four rounds' butterflies are independent and interleave
-    const TransposeConst C      = transposeConst();
-    const uint32_t       colAll = (1u << binsX) - 1u, rowAll = (1u << binsY) - 1u;  // (binsX, binsY <= 31 here)
-    uint32_t             x[kDbRounds];
+  const int            nb = binsX * binsY, S = binsX + binsY;
+  const LaneBins       L  = laneBins(binsX, nb);
+  const bool           viaTranspose = S <= 32 && transpose != 0;
+  const TransposeConst C  = transposeConst();
 #pragma unroll
-    for(int i = 0; i < kDbRounds; ++i)
-      x[i] = rectWord(r[i], e0 + i * 64u < n, binsX, colAll, rowAll);
-    transposeWords(x, C);
-    const int up = ((lane + 32) & 63) << 2;
+  for(int c = 0; c < kDbCntMul; ++c)
+  {
+    const uint32_t chunk = chunk0 + (uint32_t)c;
+    if(chunk >= chunks)
+      break;
+    const uint32_t e0     = chunk * (uint32_t)kDbChunk + eW;
+    uint32_t       cnt[4] = {0u, 0u, 0u, 0u};
+    // the masks of every round are kept for k_dbin_emit (binsX + binsY words of 8 B per round instead of re-reading 64 rects and
+    // redoing the masks): maskBuf[((chunk*4 + wave)*rounds + round)*S + {column masks, row masks}]
+    uint64_t* mOut = maskBuf + ((size_t)chunk * 4 + w) * kDbRounds * S;
+    if(viaTranspose)
+    {  // masks by transpose (above): the four rounds' butterflies are independent and interleave
+      const uint32_t colAll = (1u << binsX) - 1u, rowAll = (1u << binsY) - 1u;  // (binsX, binsY <= 31 here)
+      uint32_t       x[kDbRounds];
+#pragma unroll
+      for(int i = 0; i < kDbRounds; ++i)
+        x[i] = rectWord(r[c][i], e0 + i * 64u < n, binsX, colAll, rowAll);
+      transposeWords(x, C);
+      const int up = ((lane + 32) & 63) << 2;
+#pragma unroll
+      for(int i = 0; i < kDbRounds; ++i)
+      {
+        const uint32_t hi   = (uint32_t)__builtin_amdgcn_ds_bpermute(up, (int)x[i]);  // lane b: the word of lane 32 + b
+        const uint64_t mine = ((uint64_t)hi << 32) | x[i];
+        if(lane < S)
+        {
+          s_msk[w][i][lane] = mine;
+          mOut[i * S + lane] = mine;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for(int i = 0; i < kDbRounds; ++i)
+#pragma unroll
+        for(int j = 0; j < 4; ++j)
+          if(j * 64 < nb)
+          {
+            const uint64_t m = L.on[j] ? (s_msk[w][i][L.bx[j]] & s_msk[w][i][binsX + L.by[j]]) : 0ull;
+            cnt[j] += (uint32_t)__popcll(m);
+          }
+    }
+    else
 #pragma unroll
     for(int i = 0; i < kDbRounds; ++i)
     {
-      const uint32_t hi   = (uint32_t)__builtin_amdgcn_ds_bpermute(up, (int)x[i]);  // lane b: the word of lane 32 + b
-      const uint64_t mine = ((uint64_t)hi << 32) | x[i];
+      const uint64_t mine = rectMasks(r[c][i], e0 + i * 64u < n, binsX, binsY, s_col[w], s_row[w]);
+      __builtin_amdgcn_wave_barrier();
       if(lane < S)
-      {
-        s_msk[w][i][lane] = mine;
         mOut[i * S + lane] = mine;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for(int i = 0; i < kDbRounds; ++i)
 #pragma unroll
       for(int j = 0; j < 4; ++j)
         if(j * 64 < nb)
         {
-          const uint64_t m = L.on[j] ? (s_msk[w][i][L.bx[j]] & s_msk[w][i][binsX + L.by[j]]) : 0ull;
+          const uint64_t m = L.on[j] ? (s_col[w][L.bx[j]] & s_row[w][L.by[j]]) : 0ull;
           cnt[j] += (uint32_t)__popcll(m);
         }
-  }
-  else
-#pragma unroll
-  for(int i = 0; i < kDbRounds; ++i)
-  {
-    const uint64_t mine = rectMasks(r[i], e0 + i * 64u < n, binsX, binsY, s_col[w], s_row[w]);
-    __builtin_amdgcn_wave_barrier();
-    if(lane < S)
-      mOut[i * S + lane] = mine;
+      __builtin_amdgcn_wave_barrier();
+    }
 #pragma unroll
     for(int j = 0; j < 4; ++j)
-      if(j * 64 < nb)
-      {
-        const uint64_t m = L.on[j] ? (s_col[w][L.bx[j]] & s_row[w][L.by[j]]) : 0ull;
-        cnt[j] += (uint32_t)__popcll(m);
-      }
-    __builtin_amdgcn_wave_barrier();
+      s_cnt[w][lane + 64 * j] = cnt[j];
+    __syncthreads();
+    if(t < nb)
+      binHist[(size_t)t * pStride + chunk] = s_cnt[0][t] + s_cnt[1][t] + s_cnt[2][t] + s_cnt[3][t];
+    if(c + 1 < kDbCntMul)
+      __syncthreads();  // s_cnt (and a wave's s_msk rows) are written again for the next chunk
   }
-#pragma unroll
-  for(int j = 0; j < 4; ++j)
-    s_cnt[w][lane + 64 * j] = cnt[j];
-  __syncthreads();
-  if(t < nb)
-    binHist[(size_t)t * pStride + blockIdx.x] = s_cnt[0][t] + s_cnt[1][t] + s_cnt[2][t] + s_cnt[3][t];
 }
 
 __global__ __launch_bounds__(256) void k_dbin_scan(const SortPlan* __restrict__ plan, uint32_t* __restrict__ binHist,
@@ -566,6 +598,9 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
       }
   }
   __builtin_amdgcn_wave_barrier();
+  // pop[j]: the populations of bin lane + 64 j's mask in the wave's rounds, 8 bits each (<= 64) — the cursors advance by them below
+  uint32_t pop[4] = {0u, 0u, 0u, 0u};
+  static_assert(kDbRounds <= 4, "pop[] packs one byte per round");
 #pragma unroll
   for(int i = 0; i < kDbRounds; ++i)
 #pragma unroll
@@ -573,7 +608,9 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
       if(j * 64 < nb)
       {
         const uint64_t m = L.on[j] ? (s_msk[w][i][L.bx[j]] & s_msk[w][i][binsX + L.by[j]]) : 0ull;
-        cnt[j] += (uint32_t)__popcll(m);
+        const uint32_t c = (uint32_t)__popcll(m);
+        cnt[j] += c;
+        pop[j] |= c << (8 * i);
       }
 #pragma unroll
   for(int j = 0; j < 4; ++j)
@@ -609,7 +646,7 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
   const uint64_t D64     = ((uint64_t)s_tmp64[1] << 16) + s_tmp64[0];
   const bool     wrapped = D64 > 0xFFFFFFFFull;  // bin bases are meaningless: emit nothing, report the overflow
   const bool     staged  = P <= (uint32_t)kDbStage;
-  const uint32_t gdst    = binBase + ((t < nb) ? binHist[(size_t)t * pStride + chunk] : 0u);
+  const uint32_t gdst    = binBase + ((t < nb) ? binHist[(size_t)t * pStride + chunk] : 0u);  // (requested here, not at the kernel's head: 256 strided loads beside the ids and masks cost 1.5 us — measured)
   __syncthreads();  // everybody has read its base: s_gdst is overwritten
   s_gdst[t] = gdst;
   s_loc[t]  = local;
@@ -674,7 +711,16 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
     // population over the wave's earlier rounds itself — was measured: no faster, the bin lanes run anyway because nearly every
     // wave holds an escape.)
     const uint32_t escape = (1u << (ride >> 8)) - 1u;
-    const uint64_t ltMask = (1ull << lane) - 1ull;
+    // (round 5, third session: the kernel is bound by VALU issue — 14 M instructions, 26 of its 37 us — so the placement was put on
+    //  a diet: a coded splat's two column and two row masks are read once instead of per bin, its rank in a bin's mask is
+    //  v_mbcnt_lo / hi instead of and + popcount on both halves, the bin lanes keep their cursors in registers and advance them by
+    //  the populations the counting above already found, and a round without escapes does not touch its bin masks again)
+    uint32_t run[4];
+#pragma unroll
+    for(int j = 0; j < 4; ++j)
+      run[j] = s_cnt[w][lane + 64 * j];
+    const uint32_t xLast = (uint32_t)binsX - 1u, yLast = (uint32_t)(binsX + binsY) - 1u;
+#pragma unroll
     for(int i = 0; i < kDbRounds; ++i)
     {
       const bool     valid = e0 + (uint32_t)i * 64u < n;
@@ -684,15 +730,18 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
       {
         const uint32_t r  = rideDecode(code[i], binsX, binsY);
         const uint32_t x0 = r & 255u, y0 = (r >> 8) & 255u, dx = ((r >> 16) & 255u) - x0, dy = (r >> 24) - y0;
+        const uint64_t cm[2] = {s_msk[w][i][x0], s_msk[w][i][min(x0 + 1u, xLast)]};
+        const uint64_t rm[2] = {s_msk[w][i][(uint32_t)binsX + y0], s_msk[w][i][min((uint32_t)binsX + y0 + 1u, yLast)]};
+        const uint32_t b0    = y0 * (uint32_t)binsX + x0;
 #pragma unroll
         for(uint32_t ky = 0; ky < 2u; ++ky)
 #pragma unroll
           for(uint32_t kx = 0; kx < 2u; ++kx)
             if(kx <= dx && ky <= dy)
             {
-              const uint32_t b   = (y0 + ky) * (uint32_t)binsX + x0 + kx;
-              const uint64_t m   = s_msk[w][i][x0 + kx] & s_msk[w][i][(uint32_t)binsX + y0 + ky];
-              const uint32_t at = s_cnt[w][b] + (uint32_t)__popcll(m & ltMask);
+              const uint32_t b  = b0 + ky * (uint32_t)binsX + kx;
+              const uint64_t m  = cm[kx] & rm[ky];
+              const uint32_t at = s_cnt[w][b] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
               s_spos[at]        = (uint16_t)idx;
               s_sbin[at]        = (uint8_t)b;
             }
@@ -703,21 +752,24 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
       for(int j = 0; j < 4; ++j)
         if(j * 64 < nb)
         {
-          const uint64_t m    = L.on[j] ? (s_msk[w][i][L.bx[j]] & s_msk[w][i][binsX + L.by[j]]) : 0ull;
-          uint64_t       me   = m & escM;
-          const uint32_t run  = s_cnt[w][lane + 64 * j];
-          const uint8_t  btag = (uint8_t)(lane + 64 * j);
-          while(__ballot(me != 0ull) != 0ull)
-            if(me != 0ull)
-            {
-              const uint32_t bit = (uint32_t)__builtin_ctzll(me);
-              const uint32_t at  = run + (uint32_t)__popcll(m & ((1ull << bit) - 1ull));
-              s_spos[at]         = (uint16_t)(wbase + (uint32_t)i * 64u + bit);
-              s_sbin[at]         = btag;
-              me &= me - 1ull;
-            }
-          if(L.on[j])
-            s_cnt[w][lane + 64 * j] = run + (uint32_t)__popcll(m);
+          if(escM != 0ull)  // wave-uniform
+          {
+            const uint64_t m    = L.on[j] ? (s_msk[w][i][L.bx[j]] & s_msk[w][i][binsX + L.by[j]]) : 0ull;
+            uint64_t       me   = m & escM;
+            const uint8_t  btag = (uint8_t)(lane + 64 * j);
+            while(__ballot(me != 0ull) != 0ull)
+              if(me != 0ull)
+              {
+                const uint32_t bit = (uint32_t)__builtin_ctzll(me);
+                const uint32_t at  = run[j] + (uint32_t)__popcll(m & ((1ull << bit) - 1ull));
+                s_spos[at]         = (uint16_t)(wbase + (uint32_t)i * 64u + bit);
+                s_sbin[at]         = btag;
+                me &= me - 1ull;
+              }
+          }
+          run[j] += (pop[j] >> (8 * i)) & 255u;
+          if(L.on[j] && i + 1 < kDbRounds)
+            s_cnt[w][lane + 64 * j] = run[j];
         }
       __builtin_amdgcn_wave_barrier();
     }
@@ -1593,7 +1645,7 @@ void launchDirectBinning(hipStream_t stream, const uint32_t* idsX, const uint32_
     return;
   // MGS_DB_TRANSPOSE=0: the rounds' masks by ballots everywhere (A/B switch of the transpose path; the masks are the same)
   static const int kTranspose = [] { const char* e = std::getenv("MGS_DB_TRANSPOSE"); return e ? std::atoi(e) : 1; }();
-  hipLaunchKernelGGL(k_dbin_count, dim3(maxChunks), dim3(256), 0, stream, idsX, idsY, planKeys, rect, sortedCode16, maskBuf,
+  hipLaunchKernelGGL(k_dbin_count, dim3((maxChunks + kDbCntMul - 1) / kDbCntMul), dim3(256), 0, stream, idsX, idsY, planKeys, rect, sortedCode16, maskBuf,
                      binHist, pStride, binsX, binsY, kTranspose);
   hipLaunchKernelGGL(k_dbin_scan, dim3(binsX * binsY), dim3(256), 0, stream, planKeys, binHist, pStride, binTotal);
 #ifdef MGS_DB_TRACE
