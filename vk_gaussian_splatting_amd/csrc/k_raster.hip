@@ -382,6 +382,8 @@ __global__ __launch_bounds__(256) void k_dbin_count(const uint32_t* __restrict__
     // only the escapes — splats over more than 2 x 2 bins — are looked up by id.  The ids are requested beside the codes
     // (coalesced, 4 B per splat): an escape's rectangle is two dependent trips away, not three
     const uint32_t escape = (1u << (ride >> 8)) - 1u;
+    RideDecoder    dec    = rideDecoder(binsX, binsY);
+    asm volatile("" : "+s"(dec.i0), "+s"(dec.i1));  // made once: left alone the compiler repeats the uniform divisions per decode
     uint32_t       v[kDbCntMul][kDbRounds], id[kDbCntMul][kDbRounds];
 #pragma unroll
     for(int c = 0; c < kDbCntMul; ++c)
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(256) void k_dbin_count(const uint32_t* __restrict__
     for(int c = 0; c < kDbCntMul; ++c)
 #pragma unroll
       for(int i = 0; i < kDbRounds; ++i)
-        r[c][i] = (v[c][i] == escape) ? rect[id[c][i]] : rideDecode(v[c][i], binsX, binsY);
+        r[c][i] = (v[c][i] == escape) ? rect[id[c][i]] : rideDecode(v[c][i], dec);
   }
   else
   {
@@ -719,6 +721,8 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
 #pragma unroll
     for(int j = 0; j < 4; ++j)
       run[j] = s_cnt[w][lane + 64 * j];
+    RideDecoder dec = rideDecoder(binsX, binsY);
+    asm volatile("" : "+s"(dec.i0), "+s"(dec.i1));  // (made once, see k_dbin_count)
     const uint32_t xLast = (uint32_t)binsX - 1u, yLast = (uint32_t)(binsX + binsY) - 1u;
 #pragma unroll
     for(int i = 0; i < kDbRounds; ++i)
@@ -728,7 +732,7 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
       const uint32_t idx   = wbase + (uint32_t)i * 64u + (uint32_t)lane;
       if(coded)
       {
-        const uint32_t r  = rideDecode(code[i], binsX, binsY);
+        const uint32_t r  = rideDecode(code[i], dec);
         const uint32_t x0 = r & 255u, y0 = (r >> 8) & 255u, dx = ((r >> 16) & 255u) - x0, dy = (r >> 24) - y0;
         const uint64_t cm[2] = {s_msk[w][i][x0], s_msk[w][i][min(x0 + 1u, xLast)]};
         const uint64_t rm[2] = {s_msk[w][i][(uint32_t)binsX + y0], s_msk[w][i][min((uint32_t)binsX + y0 + 1u, yLast)]};

@@ -81,13 +81,34 @@ __device__ __forceinline__ uint32_t rideEncode(uint32_t rect, int binsX, int bin
     return escape;
   return rideBase(shape, binsX, binsY) + y0 * (uint32_t)(binsX - (int)dx) + x0;
 }
-__device__ __forceinline__ uint32_t rideDecode(uint32_t code, int binsX, int binsY)
+// branch-free, no division (round 5, third session: hipcc expands __fdividef to the full IEEE sequence and the shape selection
+// to exec-mask branches — 36 vector instructions per decode, four decodes per wave in k_dbin_count and in k_dbin_emit, both bound
+// by VALU issue): the thresholds are nested, so the base and the shape follow from three compares; y0 = r / wS by a 16-bit
+// reciprocal, exact for r < 1024 and wS <= 32 (error r / 65536 < 1 / wS; tests/test_ride_code.py walks every grid).  The
+// wave-uniform part is made once per kernel (RideDecoder).
+struct RideDecoder
 {
-  const uint32_t b1 = rideBase(1, binsX, binsY), b2 = rideBase(2, binsX, binsY), b3 = rideBase(3, binsX, binsY);
-  const uint32_t shape = code >= b3 ? 3u : (code >= b2 ? 2u : (code >= b1 ? 1u : 0u));
-  const uint32_t r  = code - (shape == 3u ? b3 : (shape == 2u ? b2 : (shape == 1u ? b1 : 0u)));
-  const uint32_t dx = shape & 1u, dy = shape >> 1, wS = (uint32_t)binsX - dx;
-  const uint32_t y0 = (uint32_t)__fdividef((float)r + 0.5f, (float)wS);  // r < 1024, wS <= 32: exact
+  uint32_t b1, b2, b3, w0, w1, i0, i1;
+};
+__device__ __forceinline__ RideDecoder rideDecoder(int binsX, int binsY)
+{
+  RideDecoder D;
+  D.b1 = rideBase(1, binsX, binsY);
+  D.b2 = rideBase(2, binsX, binsY);
+  D.b3 = rideBase(3, binsX, binsY);
+  D.w0 = (uint32_t)binsX;
+  D.w1 = (uint32_t)max(binsX - 1, 1);
+  D.i0 = (65536u + D.w0 - 1u) / D.w0;
+  D.i1 = (65536u + D.w1 - 1u) / D.w1;
+  return D;
+}
+__device__ __forceinline__ uint32_t rideDecode(uint32_t code, const RideDecoder& D)
+{
+  const bool     c1 = code >= D.b1, c2 = code >= D.b2, c3 = code >= D.b3;
+  const uint32_t r  = code - (c3 ? D.b3 : (c2 ? D.b2 : (c1 ? D.b1 : 0u)));
+  const uint32_t dy = c2 ? 1u : 0u, dx = (c3 || (c1 && !c2)) ? 1u : 0u;
+  const uint32_t wS = dx ? D.w1 : D.w0;
+  const uint32_t y0 = (r * (dx ? D.i1 : D.i0)) >> 16;
   const uint32_t x0 = r - y0 * wS;
   return x0 | (y0 << 8) | ((x0 + dx) << 16) | ((y0 + dy) << 24);
 }
