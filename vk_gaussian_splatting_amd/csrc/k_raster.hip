@@ -752,6 +752,9 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
       }
       const uint64_t escM = __ballot(valid && !coded);
       __builtin_amdgcn_wave_barrier();
+      // (The escapes one after the other in a SCALAR loop — bin lane b takes escape e iff bit e of its mask is set, one-hot and
+      //  below-mask as scalar pairs, no per-lane ctz / 64-bit shifts — was measured: bin 64.6 -> 67.4 us, 4K 91.8 -> 94.5: a round
+      //  holds more escapes than its fullest bin takes trips.)
 #pragma unroll
       for(int j = 0; j < 4; ++j)
         if(j * 64 < nb)
