@@ -17,8 +17,9 @@ off).  The throughput partition (alternate frames: rank r renders poses r, r+N, 
 the same run and reported in the secondary `alternate_frames` object.
 
 The JSON line also carries
-  roofline      — SURVEY.md 8d's algorithmic bytes of the longest HBM-bound stage (project / sort / bin, chosen by measured
-                  single-stream time) / its HIP-event duration; roofline_project, roofline_sort, roofline_bin, roofline_frame
+  roofline      — the LONGEST stage of the frame by measured single-stream time: SURVEY.md 8d's algorithmic bytes / its HIP-event
+                  duration, its PMC HBM bytes (`traffic`), and — when that stage is the compositor, which is not HBM-bound — its VALU
+                  issue fraction with the calibration caveat (`valu`); roofline_project, roofline_sort, roofline_bin, roofline_frame
                   (bytes actually moved) and roofline_composite (VALU) beside it
   value_single_frame — frames/s with one frame in flight (value: --inflight frames, default 3)
   cpu_baseline  — the oracle's restatement of the reference's CPU sorter (splat_sorter_async.cpp:92-141),
@@ -36,8 +37,17 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_SQ_FILE = "r5_z_pmc_sq_composite.json"  # {"k_composite": {"SQ_INSTS_VALU": per-launch mean, ...}}
-PMC_FILE = "r5_z_pmc_hbm_traffic.json"  # written by tools/pmc_traffic.py from rocprofv3 --pmc passes of this command
+
+def _first_profile(*names):
+    for n in names:
+        if os.path.exists(os.path.join(ROOT, "profiles", n)):
+            return n
+    return names[0]
+
+
+# committed rocprofv3 --pmc passes of this command (the newest round's that exists)
+PMC_SQ_FILE = _first_profile("r6_z_pmc_sq_composite.json", "r5_z_pmc_sq_composite.json")  # {"k_composite": {"SQ_INSTS_VALU": per-launch mean, ...}}
+PMC_FILE = _first_profile("r6_z_pmc_hbm_traffic.json", "r5_z_pmc_hbm_traffic.json")  # written by tools/pmc_traffic.py
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 STAGES = ["project", "sort", "bin", "pairsort", "composite", "total"]
 
@@ -61,8 +71,13 @@ def composite_roofline(ms, alg_bytes, world, N, args):
             out["valu_insts_per_launch"] = pj["k_composite"]["SQ_INSTS_VALU"]
             out["achieved"] = busy / (ms * 1e-3 * 2.4e9 * 1024)
             out["frac"] = out["achieved"]
-            out["clock_note"] = ("2.4 GHz nominal; at the 2.13 GHz the chip sustains under VALU-dense load (profiles/r5_valu_rate.log) the busy "
-                                 "fraction is 1.13x `frac`")
+            out["clock_note"] = ("`frac` is issue-slot occupancy under THIS BUILD'S calibration: SQ_ACTIVE_INST_VALU advances one quad-cycle per plain "
+                                 "wave64 VALU instruction and such an instruction holds its SIMD ~4 cycles (tools/micro/valu_rate.hip, profiles/r5_valu_rate.log: "
+                                 "v_fma_f32 540 wave-instr/SIMD/us = 70.8 TFLOP/s chip-wide, v_pk_fma_f32 428 = 112 TFLOP/s = 0.71 of the 157.3 TFLOP/s fp32 "
+                                 "vector spec; v_mov 2.8, v_fma 4.0, v_pk_fma 5.0 real cycles: 4 is an average, not a law).  MI355X_MICROARCH.md's table lists "
+                                 "2 cycles for v_fma_f32 (wave64): under that reading the fraction is `frac_if_2_cycles`.  2.4 GHz nominal; at the 2.13 GHz the "
+                                 "chip sustains under VALU-dense load the busy fraction is 1.13x `frac`")
+            out["frac_if_2_cycles"] = out["frac"] * 0.5
             out["valu_source"] = f"profiles/{PMC_SQ_FILE} (committed rocprofv3 --pmc pass of `bench.py --inflight 1`; the duration is this run's)"
     except Exception:
         pass
@@ -360,12 +375,13 @@ def main():
         pp.collect_timings = 0
         pp.strip_row_begin, pp.strip_row_end = my_rows  # N>1: this rank's strip (what the stage times describe)
         o = scene.render(pp, want_stats=True)
-        counts.append((o.frustum_count, o.sorted_count, o.tile_pairs, o.error_flags, o.shaded_count, o.scanned_entries))
+        counts.append((o.frustum_count, o.sorted_count, o.tile_pairs, o.error_flags, o.shaded_count, o.scanned_entries, o.escape_count))
         pp.collect_timings = 2 if args.stage_events else 0
         pp.strip_row_begin, pp.strip_row_end = 0, 0
     counts = np.array(counts, np.float64)
     Vf, Vs, D = counts[:, 0].mean(), counts[:, 1].mean(), counts[:, 2].mean()
     shaded, scanned = counts[:, 4].mean(), counts[:, 5].mean()
+    escapes = counts[:, 6].mean()  # sorted splats whose bin rectangle is stored / gathered by id (the others' ride as codes)
     err = int(counts[:, 3].max())
     if world > 1:
         agg = torch.tensor([Vs, D, Vf], dtype=torch.float64, device="cuda")
@@ -404,7 +420,8 @@ def main():
     alg = {
         # centres of every splat; opacity + covariance of the frustum survivors; 32-B record + rect + (key, id) of the sorted
         # ones (colour, view direction and the 180-B SH records are not touched here: shading is deferred to the compositor)
-        "project": 12 * N + (4 + 24) * Vf + (32 + 4 + 8) * Vs,
+        # (round 6: the 4-byte rectangle by id is stored for the ESCAPES only — the other rectangles ride through the sort as codes)
+        "project": 12 * N + (4 + 24) * Vf + (32 + 8) * Vs + 4 * escapes,
         "sort": 68 * Vs,
         # direct binning: ids + rect gather + sorted rect (count), sorted rect + ids + list append (emit)
         "bin": 20 * Vs + 4 * D,
@@ -435,6 +452,11 @@ def main():
         return {"bound": "hbm", "stage": STAGES[j], "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
                 "algorithmic_bytes_per_launch": alg[STAGES[j]], "launch_ms": ms}
 
+    # (round 6) `roofline` describes the LONGEST stage of the frame, whatever bounds it: when that is the compositor
+    # the object carries its SURVEY 8d byte fraction (`frac`: algorithmic bytes, mostly L2 / MALL hits), its PMC HBM bytes (`traffic`,
+    # `traffic_frac`) AND its VALU issue fraction (`valu`), with the calibration caveat in `valu.clock_note`
+    if longest == "composite":
+        dom, dom_name = 4, "composite"
     dom_ms = float(calib_ms[dom]) - (cull_ms if dom == 0 else 0.0)
     achieved = alg[dom_name] / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
     b_frame = 12 * N + Vs * (16 + 24 + 180) + 8 * Vs + 68 * Vs + 2 * 48 * Vs + 8 * Ppix
@@ -484,7 +506,7 @@ def main():
                                       "(its hand-over groups each slot by the key's low byte: ~15 % of k_project's instructions); "
                                       "key_plus_sort_gsplats_per_s is depth key + cull + whole sort end to end"),
         "sorted_gsplats_per_s_in_frame_aggregate": Vs_all * fps / 1e9,  # all ranks' sorted elements x frames/s
-        "visible_splats": {"frustum": Vf, "sorted": Vs, "tile_pairs": D, "shaded": shaded, "list_entries_scanned": scanned},
+        "visible_splats": {"frustum": Vf, "sorted": Vs, "tile_pairs": D, "shaded": shaded, "list_entries_scanned": scanned, "rect_escapes": escapes},
         "stage_ms": {STAGES[j]: float(stage_ms[j]) for j in range(6)},
         "stage_ms_single_stream": {STAGES[j]: float(calib_ms[j]) for j in range(6)},
         "frame_interval_ms_percentiles": {"p50": float(np.percentile(intervals, 50)), "p95": float(np.percentile(intervals, 95)),
@@ -495,15 +517,19 @@ def main():
         "value_single_frame": 1e3 / float(calib_ms[5]) if calib_ms[5] > 0 else None,  # frames/s with ONE frame in flight
         "roofline": {"bound": "hbm", "stage": dom_name,
                      "kernels": {"project": "k_project", "sort": "k_os_prepare + 2 x k_os_pass (+ 1 that exits at once); pass 0 is virtual (done in k_project)",
-                                 "bin": "k_dbin_count + k_dbin_scan + k_dbin_emit"}[dom_name],
+                                 "bin": "k_dbin_count + k_dbin_scan + k_dbin_emit", "composite": "k_composite"}[dom_name],
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
+                     "traffic_frac": (traffic / (dom_ms * 1e-3)) / HBM_PEAK if (traffic and dom_ms > 0) else None,
+                     "actual_bound": "valu (fp32 vector issue + the serial chain per region; see `valu`)" if dom_name == "composite" else "hbm + valu (co-limited, DESIGN 3)",
+                     "valu": composite_roofline(dom_ms, alg["composite"], world, N, args) if dom_name == "composite" else None,
                      "traffic_source": (f"profiles/{PMC_FILE}: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --inflight 1` "
                                         "(2*FETCH + WRITE per launch, MI355X_MICROARCH.md HBM section); not measured in this run") if traffic else None,
                      "algorithmic_bytes_per_launch": alg[dom_name], "launch_ms": float(dom_ms),
-                     "note": f"the longest HBM-bound stage of the frame by measured single-stream time (HIP events on the untimed calibration "
-                             f"frames), SURVEY.md 8d's bytes for it; the longest stage overall is `{longest}`"
-                             + (" (fp32-VALU bound, see roofline_composite)" if longest == "composite" else "")},
+                     "note": f"the LONGEST stage of the frame by measured single-stream time (HIP events on the untimed calibration frames): `{longest}`; "
+                             "`achieved` / `frac` = SURVEY.md 8d's algorithmic bytes for it / that time, `traffic` = its HBM bytes by the PMC counters"
+                             + ("; k_composite is not an HBM kernel (its records and lists are L2 / MALL hits: traffic << algorithmic bytes) — what bounds it "
+                                "is in `valu`; the longest HBM-bound stage is in roofline_project / roofline_sort / roofline_bin" if longest == "composite" else "")},
         "roofline_project": dict(stage_roofline(0), stage_ms_incl_head=float(calib_ms[0]), head_ms=cull_ms),
         "roofline_composite": composite_roofline(calib_ms[4] if K > 1 else stage_ms[4], alg["composite"], world, N, args),
         "roofline_sort": {"bound": "hbm", "achieved": (68 * Vs / (sort_ms * 1e-3)) / 1e9 if sort_ms > 0 else None,
@@ -513,14 +539,15 @@ def main():
         "roofline_bin": stage_roofline(2),
         # the frame as a whole: the bytes this build's kernels move (sum of the per-stage algorithmic bytes; deferred shading
         # means the 180 B/splat SH stream of SURVEY.md 8d's B_frame does not exist) x frames/s; `frac_single_frame` is the same
-        # bytes over the GPU time of one frame.  The B_frame form is kept as `frac_survey_bytes`.
+        # bytes over the GPU time of one frame.  The B_frame form is kept as `survey_budget_ratio` (a budget comparison, not a fraction).
         "roofline_frame": {"bound": "hbm", "achieved": b_moved * fps / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                            "frac": b_moved * fps / HBM_PEAK if world == 1 else None,
                            "frac_single_frame": (b_moved / (frame_gpu_ms * 1e-3)) / HBM_PEAK if frame_gpu_ms > 0 else None,
                            "bytes_moved_per_frame": b_moved,
                            "survey_bytes_per_frame": b_frame,
-                           "frac_survey_bytes": b_frame * fps / HBM_PEAK if world == 1 else None,
-                           "frac_survey_bytes_single_frame": (b_frame / (frame_gpu_ms * 1e-3)) / HBM_PEAK if frame_gpu_ms > 0 else None},
+                           # (not a fraction of work done: SURVEY's B_frame counts 0.70 GB of SH per frame that deferred shading never moves)
+                           "survey_budget_ratio": b_frame * fps / HBM_PEAK if world == 1 else None,
+                           "survey_budget_ratio_single_frame": (b_frame / (frame_gpu_ms * 1e-3)) / HBM_PEAK if frame_gpu_ms > 0 else None},
         "error_flags": err,
         "setup_s": setup_s,
     }
@@ -610,7 +637,7 @@ def main():
             except Exception:  # noqa: BLE001
                 pass
 
-    if rank == 0 and world == 1 and args.pipeline == 0 and not args.stochastic:
+    if rank == 0 and world == 1 and args.pipeline == 0 and not args.stochastic and not args.no_extras:
         # depth key + cull + sort end to end (mgs_sort_keys: k_project<false>, then the whole key sort), the like-for-like GPU figure
         # beside cpu_baseline, which times depth key + sort on the host (sorted_gsplats_per_s is the sort stage alone)
         try:
@@ -623,7 +650,7 @@ def main():
             out["key_plus_sort_gsplats_per_s"] = (cnt / (best * 1e-3) / 1e9) if best else None
             out["key_plus_sort_ms"] = best
             out["key_plus_sort_note"] = ("mgs_sort_keys end to end on this workload: depth key + dist-stage cull over all splats (k_project<false>) + the key sort of the "
-                                         "survivors; sorted pairs / time (best of four)")
+                                         "survivors; sorted pairs / time, BEST of four calls (an extra: skipped with --no-extras)")
         except Exception as e:  # noqa: BLE001
             out["key_plus_sort_gsplats_per_s"] = None
             out["key_plus_sort_note"] = f"{type(e).__name__}: {e}"[:200]

@@ -25,8 +25,9 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 3 /* 2: MgsFrameParams grew the 3DGUT fields; loader, strip-exchange and debug entry points added;
-                            3: stochastic splats, depth of field, temporal accumulation (MgsFrameParams 256 -> 288 bytes) */
+#define MGS_ABI_VERSION 4 /* 2: MgsFrameParams grew the 3DGUT fields; loader, strip-exchange and debug entry points added;
+                            3: stochastic splats, depth of field, temporal accumulation (MgsFrameParams 256 -> 288 bytes);
+                            4: MgsFrameOut 80 -> 88 bytes (escape_count) */
 
 typedef enum MgsStatus {
   MGS_OK              = 0,
@@ -252,6 +253,9 @@ typedef struct MgsFrameOut {
   uint32_t shaded_count;    /* (splat, screen region) pairs staged and shaded by the compositor (deferred SH evaluation) */
   uint64_t scanned_entries; /* bin-list entries the compositor looked at before its regions saturated */
   float    stage_ms[MGS_STAGE_COUNT]; /* valid when collect_timings; HIP-event times on the render stream */
+  uint32_t escape_count;    /* sorted splats whose bin rectangle did not fit a code that rides through the key sort (more than 2 x 2
+                               bins): the only ones whose rectangle is stored and gathered by id (build-only diagnostic) */
+  uint32_t reserved0;
 } MgsFrameOut;
 
 /* GaussianSplatting::onRender -> renderHybridPipeline (src/gaussian_splatting.cpp:335,414,494):

@@ -32,7 +32,7 @@ def test_struct_layouts_match_header_sizes():
 
     import ctypes
     assert ctypes.sizeof(capi.FrameParams) == 288  # ABI 3: + dof_mode, focus_dist, aperture, frame_sample_id, temporal_sampling, kernel_degree, 2 reserved
-    assert ctypes.sizeof(capi.FrameOut) == 8 + 8 + 4 + 4 + 8 + 4 + 4 + 8 + 32
+    assert ctypes.sizeof(capi.FrameOut) == 8 + 8 + 4 + 4 + 8 + 4 + 4 + 8 + 32 + 8
     assert ctypes.sizeof(capi.SortOut) == 32
     assert ctypes.sizeof(capi.SplatSetView) == 6 * 8 + 8 + 4 + 4
 

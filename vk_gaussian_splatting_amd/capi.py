@@ -60,7 +60,7 @@ class FrameOut(C.Structure):
     _fields_ = [("rgba_device", C.c_void_p), ("rgba_bytes", C.c_uint64),
                 ("frustum_count", C.c_uint32), ("sorted_count", C.c_uint32), ("tile_pairs", C.c_uint64),
                 ("error_flags", C.c_uint32), ("shaded_count", C.c_uint32), ("scanned_entries", C.c_uint64),
-                ("stage_ms", C.c_float * 8)]
+                ("stage_ms", C.c_float * 8), ("escape_count", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class SortOut(C.Structure):

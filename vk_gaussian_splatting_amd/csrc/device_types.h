@@ -38,7 +38,7 @@ struct InstanceConst
   float        modelScale;     // largest singular value of the model 3x3 (upper bound of any length stretch)
   uint32_t     count;
   uint32_t     modelIsIdentity; // M is bitwise the identity: M*p == p + 0.0f for finite p (k_project skips the product)
-  uint32_t     modelIsAffine;   // M's last row is bitwise (+0, +0, +0, 1) and its entries are < 2^40 in magnitude (kernels_common.h: mulMat4ExactAffineW1)
+  uint32_t     modelIsAffine;   // M's last row is bitwise (+0, +0, +0, 1) and its entries are < 2^24 in magnitude (kernels_common.h: mulMat4ExactAffineW1)
   uint32_t     globalOffset;   // first global splat id of this instance
   uint32_t     blockBegin;     // first project-kernel partition of this instance
   int32_t      shDegree;       // of the splat set
@@ -98,7 +98,7 @@ struct FrameConst
   int32_t  rideShapes;             // how many of the shapes 1x1, 2x1, 1x2, 2x2 have codes
   uint32_t rideEscape;             // the code of every other rectangle: (1 << code bits) - 1
   int32_t  perspAffine;            // 1: view's last row is bitwise (+0,+0,+0,1), proj has the perspective zero pattern with P[14] != 0, all
-                                   // entries < 2^40 in magnitude: the project kernels may take the exact shortcuts of kernels_common.h
+                                   // entries < 2^24 in magnitude: the project kernels may take the exact shortcuts of kernels_common.h
   int32_t  rideSplit;              // 1: the id word's spare bits do not hold the whole code (> 8 M splats): its low 8 bits travel in the
                                    // key's low byte — dead weight once the slot is grouped by it (slot_emit.h) —, the rest above the id
 };

@@ -245,7 +245,10 @@ constexpr int kDbMaxSum = 40;  // binsX + binsY of a frame the direct binning ta
 // v_writelane_b32: a wave-uniform value into ONE lane's register
 __device__ __forceinline__ void writeLane(uint32_t& dst, uint32_t value, uint32_t lane)
 {
-  asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(dst) : "s"(value), "s"(lane) : "m0");  // one SGPR per VALU op: the lane select goes through m0
+  // one SGPR per VALU op on gfx9: the lane select goes through m0.  Round 6: m0 is an INPUT ("{m0}") that the compiler sets up and
+  // tracks itself — rounds 3-5 wrote it inside the asm and listed it as a clobber, which hipcc flags as possibly undefined; this
+  // clang has no __builtin_amdgcn_writelane.
+  asm volatile("v_writelane_b32 %0, %1, m0" : "+v"(dst) : "s"(value), "{m0}"(lane));
 }
 
 // column / row hit masks of one round of 64 rects.  Lane b < binsX ends up holding the mask of column b, lane binsX + b the
@@ -399,6 +402,16 @@ __global__ __launch_bounds__(256) void k_dbin_count(const uint32_t* __restrict__
 #pragma unroll
       for(int i = 0; i < kDbRounds; ++i)
         r[c][i] = (v[c][i] == escape) ? rect[id[c][i]] : rideDecode(v[c][i], dec);
+    // how many rectangles did NOT fit a code (MgsFrameOut::escape_count: the only rect[id] stores / gathers of the frame): one
+    // fire-and-forget atomic per wave on the frame's statistics lines (sort_plan.h: frameStatSlot, word 3)
+    uint32_t esc = 0u;
+#pragma unroll
+    for(int c = 0; c < kDbCntMul; ++c)
+#pragma unroll
+      for(int i = 0; i < kDbRounds; ++i)
+        esc += (uint32_t)__popcll(__ballot(v[c][i] == escape && (chunk0 + c) * (uint32_t)kDbChunk + eW + i * 64u < n));
+    if(lane == 0 && esc != 0u)
+      atomicAdd(const_cast<uint32_t*>(&plan->ghist[0][0]) + 32u * ((blockIdx.x * 4u + (uint32_t)w) & (kFrameStatSlots - 1u)) + 3u, esc);
   }
   else
   {
@@ -911,7 +924,7 @@ __global__ void k_tile_ranges(const uint32_t* __restrict__ keyX, const uint32_t*
 #define MGS_CMP_ENTRIES 2
 #endif
 constexpr int kCmpEntries = MGS_CMP_ENTRIES;                  // list entries per thread per stage-A round (sweep with shading in the kernel: 1/2/3/4/6 -> 0.137/0.134/0.140/0.142/0.157 ms; 4K 0.374/0.379/-/0.42/-)
-constexpr int kCmpRound   = 256 * kCmpEntries;  // 1024 entries scanned per round
+// (a stage-A round scans 256 * kCmpEntries list entries)
 #ifndef MGS_CMP_CAP
 #define MGS_CMP_CAP 288
 #endif
@@ -1244,6 +1257,11 @@ __global__ __launch_bounds__(256, MGS_CMP_WAVES) void k_composite(const Composit
           const bool  box = ((qd & 1) ? xr : xl) && ((qd & 2) ? yb : yt);
           qm |= (box && (ds * ds + du * du <= qLim || F.looseMask)) ? (1u << qd) : 0u;
         }
+        //  a record with a non-finite axis or centre takes no part: the folded fragment rule is clamp(fma) * exp2(nq), and a
+        // NaN nq would pass the clamp as 0 and then poison colour and T through 0 * NaN — the select it replaced mapped NaN to 0.
+        // k1 + k2 is non-finite whenever any of sb, rx, ry is (0 * Inf = NaN included); two instructions per STAGED record.
+        if(!(fabsf((rx * sb.x + ry * sb.y) + (rx * sb.z + ry * sb.w)) < 3.0e38f))
+          qm = 0u;
         s_m[pos] = (uint8_t)qm;
     };
     for(uint32_t j = t; j < fill; j += 256)

@@ -165,8 +165,9 @@ __device__ __forceinline__ void mulMat4Exact(const float* m, float x, float y, f
 //    P[14] != 0, and w == 1.0f.  Every dropped product is a zero of either sign; adding such a zero to a nonzero term returns
 //    the term, and where all terms of a row vanish the full evaluation ends in "+ (1 * +0)", which yields +0 — the explicit
 //    "+ 0.0f" below does the same (it is not an identity: -0 + 0 = +0).  Row 2 ends in "+ P[14]", which absorbs any zero.
-//    Finite inputs only (Inf * 0 would be NaN in the full product): FrameConst::perspAffine bounds the matrices' magnitudes and
-//    the partition test (bit 3) the coordinates', so that no intermediate can overflow.
+//    Finite inputs only (Inf * 0 would be NaN in the full product): FrameConst::perspAffine / modelIsAffine bound the
+//    matrices' entries by 2^24 and the partition test (bit 3) the coordinates by 2^40, so that every intermediate of the chain stays
+//    below 2^118 (round 6, ADVICE r5: the earlier bounds 2^40 / 2^60 allowed 2^142).
 __device__ __forceinline__ void mulMat4ExactAffineW1(const float* m, float x, float y, float z, float out[3])
 {
 #pragma clang fp contract(off)

@@ -399,7 +399,7 @@ static int guarded(const char* what, Fn&& fn) noexcept
 extern "C" {
 
 const char* mgs_last_error(void) { return lastError(); }
-const char* mgs_version(void) { return "mgs 0.3 (gfx950, ABI 3)"; }
+const char* mgs_version(void) { return "mgs 0.4 (gfx950, ABI 4)"; }
 
 static int mgs_splatset_load_impl(const char* path, MgsSplatSet* out);
 int mgs_splatset_load(const char* path, MgsSplatSet* out)
@@ -1599,7 +1599,7 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
       ok = std::memcmp(&p->proj[kZero[q]], &zero, 4) == 0;  // +0 bitwise
     ok = ok && p->proj[14] != 0.0f;
     for(int q = 0; q < 16 && ok; ++q)
-      ok = std::fabs(p->view[q]) < 1.0995e12f && std::fabs(p->proj[q]) < 1.0995e12f;  // 2^40; false for NaN
+      ok = std::fabs(p->view[q]) < 16777216.0f && std::fabs(p->proj[q]) < 16777216.0f;  // 2^24 (with |coordinate| < 2^40 and |M| < 2^24 no product of the chain P*V*M*p reaches 2^127); false for NaN
     F.perspAffine = ok ? 1 : 0;
   }
   F.focal[0] = p->proj[0] * 0.5f * (float)p->width;   // gaussian_splatting.cpp:1248-1250
@@ -1775,7 +1775,7 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
         const float    row[4] = {0.0f, 0.0f, 0.0f, 1.0f}, got[4] = {I.M[3], I.M[7], I.M[11], I.M[15]};
         bool           ok     = std::memcmp(row, got, sizeof(row)) == 0;
         for(int q = 0; q < 16 && ok; ++q)
-          ok = std::fabs(I.M[q]) < 1.0995e12f;  // also false for NaN
+          ok = std::fabs(I.M[q]) < 16777216.0f;  // 2^24; also false for NaN
         C.modelIsAffine = ok ? 1u : 0u;
       }
     }
@@ -2353,13 +2353,17 @@ int mgs_frame_stats(MgsScene s, MgsFrameOut* out)
   out->error_flags   = s->hCtr->errorFlags;
   out->shaded_count  = 0;
   out->scanned_entries = 0;
+  out->escape_count  = 0;
   for(uint32_t i = 0; i < kFrameStatSlots; ++i)
     {  // (sort_plan.h: frameStatSlot — the kernels' counts live in the keys plan's histogram rows, one 128-byte line per slot; after
        //  mgs_sort_keys the plans were fetched by that call)
       out->frustum_count += (&s->hPlans->keys.ghist[0][0])[32u * i + 2u];
       out->shaded_count += (&s->hPlans->keys.ghist[0][0])[32u * i];
       out->scanned_entries += (&s->hPlans->keys.ghist[0][0])[32u * i + 1u];
+      out->escape_count += (&s->hPlans->keys.ghist[0][0])[32u * i + 3u];
     }
+  if(!s->lastWasSortOnly && s->lastRide[0] == 0)
+    out->escape_count = out->sorted_count;  // nothing rode through the sort: every sorted splat's rectangle was stored and gathered by id
   if(s->lastTimed && !s->lastWasSortOnly)
   {
     int rc = mgs_timings_query(s, 0, out->stage_ms);

@@ -58,13 +58,14 @@ __device__ __forceinline__ PartitionBox partitionLoad(const InstanceConst& I, ui
 }
 
 // returns the partition's flags: bit 0 skip, bit 1 every centre passes the frustum test, bit 2 all centres finite, bit 3 all
-// coordinates below 2^60 in magnitude (with bit 2: no product with a matrix entry < 2^40 can overflow); R: footprint
+// coordinates below 2^40 in magnitude (with bit 2 and every entry of M, V, P below 2^24 — modelIsAffine / perspAffine — the largest
+// intermediate of P*(V*(M*p)) stays below 2^40 * (4 * 2^24)^3 = 2^118: nothing overflows, so the full evaluation never meets Inf * 0); R: footprint
 // bound of the partition's splats in pixels (strips only; 3.0e38 = unknown).  Wave-uniform result; call with all lanes active.
 __device__ __forceinline__ uint32_t partitionTest(const FrameArgs& A, const InstanceConst& I, const PartitionBox& B, float& Rout)
 {
   uint32_t     skip = 0, inside = 0;
   const float    mag    = fmaxf(fmaxf(fmaxf(fabsf(B.lo[0]), fabsf(B.lo[1])), fmaxf(fabsf(B.lo[2]), fabsf(B.hi[0]))), fmaxf(fabsf(B.hi[1]), fabsf(B.hi[2])));
-  const uint32_t finite = (B.bad == 0.0f) ? (mag < 1.152921504606847e18f ? 12u : 4u) : 0u;
+  const uint32_t finite = (B.bad == 0.0f) ? (mag < 1.099511627776e12f ? 12u : 4u) : 0u;
   Rout = 3.0e38f;
   if(B.bad != 0.0f)
     return 0u;  // non-finite data: never cull this partition
