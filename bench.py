@@ -127,6 +127,9 @@ def main():
                     "(equal neighbours = an empty strip): exercises ragged partitions of the exchange")
     ap.add_argument("--torch-gather", action="store_true", help="N>1: exchange the strips with torch.distributed instead of "
                     "libmgs's own RCCL call (the fallback path)")
+    ap.add_argument("--libmgs-gather", action="store_true", help="N>1 with --backend gloo: still exchange the strips through libmgs's own "
+                    "RCCL calls (mgs_scene_comm_init / mgs_render_gathered).  With all ranks on one GPU that needs MGS_RCCL_LIB to name the "
+                    "test double tests/helpers/libfakerccl.so (real RCCL refuses two ranks on one device)")
     args = ap.parse_args()
     if args.config == 1:
         args.splats = 1_030_000
@@ -229,7 +232,7 @@ def main():
 
     # ---- N>1: communicators + strip table --------------------------------------------------------------------
     if world > 1:
-        if args.backend == "nccl" and not args.torch_gather:
+        if (args.backend == "nccl" or args.libmgs_gather) and not args.torch_gather:
             # libmgs's own RCCL exchange: one communicator per frame context (each has its own stream).  Rank 0 makes the
             # ids; whatever happens there, every rank takes part in the broadcast (nobody is left waiting in it)
             ids = [None] * K
@@ -246,6 +249,9 @@ def main():
                 for c in range(K):
                     scenes[c].comm_init(rank, world, ids[c])
                 gather_mode = "libmgs: grouped ncclBroadcast of every rank's rows, in place in the frame buffer, on the render stream"
+                if os.environ.get("MGS_RCCL_LIB"):
+                    loaded = [ln.split()[-1] for ln in open("/proc/self/maps") if "rccl" in ln.lower() and ".so" in ln]
+                    gather_mode += f" [MGS_RCCL_LIB: {os.path.basename(os.environ['MGS_RCCL_LIB'])}, mapped: {sorted(set(os.path.basename(x) for x in loaded))}]"
             except Exception as e:  # noqa: BLE001
                 print(f"[rank {rank}] libmgs RCCL exchange unavailable ({type(e).__name__}: {e}); falling back to torch.distributed",
                       file=sys.stderr)
@@ -437,7 +443,7 @@ def main():
     hbm_stages = [0, 1, 2]
     dom = max(hbm_stages, key=lambda j: calib_ms[j] - (calib_ms[6] if j == 0 else 0.0))
     dom_name = STAGES[dom]
-    longest = STAGES[max(range(5), key=lambda j: calib_ms[j])]
+    longest = STAGES[max(range(5), key=lambda j: calib_ms[j] - (calib_ms[6] if j == 0 else 0.0))]
     # kernel duration: HIP events around the stage on an otherwise idle GPU (the untimed calibration frames).  With
     # several frames in flight the event span of a stage also contains queueing behind the other streams' kernels —
     # rocprofv3's per-kernel duration of this same command agrees with the calibration value, not with the span.

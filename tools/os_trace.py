@@ -9,16 +9,31 @@ from vk_gaussian_splatting_amd import capi, synth
 
 poses = [int(x) for x in sys.argv[1:]] or [0]
 W, H = 1920, 1080
-sc = synth.make_scene(5_830_000, seed=1)
+# round 6: OS_SPLATS / OS_INSTANCES / OS_STRIP="b e" select the workload (train-sized, configs[4], a strip of the multi-GPU partition)
+NS, NI = int(os.environ.get("OS_SPLATS", "5830000")), int(os.environ.get("OS_INSTANCES", "1"))
+STRIP = [int(x) for x in os.environ.get("OS_STRIP", "").split()] or None
+sc = synth.make_scene(NS, seed=1)
 scene = mgs.Scene(0)
-scene.add_instance(mgs.SplatSet.from_arrays(**sc))
+ss = mgs.SplatSet.from_arrays(**sc)
+for q in range(NI):
+    if NI == 1:
+        scene.add_instance(ss)
+    else:
+        cols = (NI + 1) // 2
+        M = np.eye(4, dtype=np.float32)
+        M[0, 3] = ((q % cols) - (cols - 1) / 2.0) * 12.0
+        M[2, 3] = ((q // cols) - 0.5) * 12.0
+        scene.add_instance(ss, M)
 scene.commit()
+print(f"workload: {NS} splats x {NI} instance(s), strip {STRIP}")
 names = ["table + zeroing", "loads + digits", "ranking", "publish + level-1 issue + scans + level-1 consume + level-2 issue", "LDS re-order + level-2 consume / poll", "scatter stores (drained)"]
 for pose in poses:
     eye = synth.orbit_pose(pose)
     V, P = mgs.camera_lookat_perspective(eye, [0, 0, 0], [0, 1, 0], 60.0, 0.1, 2000.0, W, H)
     p = capi.default_params(W, H)
     capi.set_camera(p, V, P, eye)
+    if STRIP:
+        p.strip_row_begin, p.strip_row_end = STRIP
     for _ in range(4):
         scene.render(p, want_stats=True)
     raw = np.fromfile(os.environ["MGS_OS_TRACE_FILE"], np.uint64)

@@ -39,6 +39,7 @@
 //
 // Pairs travel interleaved (uint2): one 8-byte access per element, digit runs of 16 elements are 128 contiguous bytes; the
 // last pass writes the ids alone (the keys are dead; the sort-only hook asks for them explicitly).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -501,7 +502,27 @@ struct OsPassArgs
   int             pass;
   int             digitMode;  // 0 plain byte `pass`; 1 pass 2: rank of key >> 16 when the plan says remap, else plain; 2 pass 3: exits when remapped
   int             finalMode;  // 0 writes pairs; 1 writes the result; 2 writes the result iff the plan says remap (pass 2)
+  // Round 6 (A/B knob, off by default): the partition size chosen ON THE DEVICE from the element count (osPartOf below) — 1024 or
+  // 2048 pairs when that many partitions still fit the grid and one residency wave of the chip, else kOsPart.
+  uint32_t        partMin;    // smallest partition size allowed (kOsPart: the fixed size of rounds 3-5; A/B)
+  uint32_t        resSlots;   // workgroups of this kernel the chip holds at once
 };
+
+// A sort of few keys used to run on few workgroups: a strip's 0.32 M keys were 78 partitions of 4096 on 256 CUs, a train-sized
+// frame's 0.74 M were 181 (64 us and 54 us, a third of a strip's frame).  The rounds of a partition adapt to its element
+// count anyway (the ragged last one), so the SAME kernel takes partitions of 1024 or 2048 pairs: every workgroup derives the size
+// from n (device-side count, identical for all) and the grid the host launched — no host-side guess, nothing in the graph key.
+// Smaller partitions are taken only while all of them are resident at once: the look-back then never waits for a workgroup that
+// has not started.
+__device__ __forceinline__ uint32_t osPartOf(uint32_t n, uint32_t grid, uint32_t partMin, uint32_t resSlots)
+{
+  const uint32_t cap = min(grid, resSlots);
+  if(partMin <= 1024u && (n + 1023u) / 1024u <= cap)
+    return 1024u;
+  if(partMin <= 2048u && (n + 2047u) / 2048u <= cap)
+    return 2048u;
+  return kOsPart;
+}
 
 #ifndef MGS_OS_WAVES
 #define MGS_OS_WAVES 4
@@ -556,7 +577,8 @@ __global__ __launch_bounds__(kThreads, MGS_OS_WAVES) void k_os_pass(const OsPass
         s_rv[(uint32_t)plan->remapVals[i] - base] = (uint8_t)i;
     }
   __syncthreads();
-  const uint32_t parts = (uint32_t)(((uint64_t)n + kOsPart - 1u) / kOsPart);
+  const uint32_t part  = osPartOf(n, gridDim.x - (IN == 3 ? kOsFoldWgs : 0u), a.partMin, a.resSlots);  // wave-uniform, the same in every workgroup
+  const uint32_t parts = (uint32_t)(((uint64_t)n + part - 1u) / part);
   if(p >= parts)
     return;
   const bool finalOut = a.finalMode == 1 || (a.finalMode == 2 && remapped);
@@ -571,7 +593,7 @@ __global__ __launch_bounds__(kThreads, MGS_OS_WAVES) void k_os_pass(const OsPass
 
   // ---- load: wave w owns a contiguous quarter of the partition, lane-interleaved, so (wave, round, lane) is memory order.
   // The rounds adapt to the element count (the last partition is ragged).
-  const uint32_t count = (uint32_t)min((uint64_t)kOsPart, (uint64_t)n - (uint64_t)p * kOsPart);
+  const uint32_t count = (uint32_t)min((uint64_t)part, (uint64_t)n - (uint64_t)p * part);
   const uint32_t rounds = (count + kThreads - 1u) / kThreads;  // per wave: `rounds` rounds of 64 keys
   const uint32_t wofs   = w * 64u * rounds;
   uint32_t       key[kKpt], val[kKpt];
@@ -586,7 +608,7 @@ __global__ __launch_bounds__(kThreads, MGS_OS_WAVES) void k_os_pass(const OsPass
     uint32_t* s_src = reinterpret_cast<uint32_t*>(s_pair);       // [4096] pair index (slot * 2048 + entry) of every position of the partition
     uint32_t* s_cpw = s_src + kOsPart + (uint32_t)w * 264u;      // [257] this wave's prefix of chunkSum[.][d] over a tile of chunks
     constexpr uint32_t kCpTile = 256;                            // chunks per tile: four per lane
-    const uint32_t a0 = p * kOsPart, e0 = a0 + count;
+    const uint32_t a0 = p * part, e0 = a0 + count;
     // D: lane l holds digit-0 values 4 l .. 4 l + 3
     const uint32_t tk[4] = {tot0q.x, tot0q.y, tot0q.z, tot0q.w};
     uint32_t       d     = 256u;
@@ -729,12 +751,12 @@ __global__ __launch_bounds__(kThreads, MGS_OS_WAVES) void k_os_pass(const OsPass
       const uint32_t idx = min(wofs + (uint32_t)i * 64u + lane, count - 1u);
       if(IN == 2)
       {
-        key[i] = a.srcKeys[(size_t)p * kOsPart + idx];
-        val[i] = a.srcVals[(size_t)p * kOsPart + idx];
+        key[i] = a.srcKeys[(size_t)p * part + idx];
+        val[i] = a.srcVals[(size_t)p * part + idx];
       }
       else
       {
-        const uint2 kv = IN == 3 ? a.srcPairs[srcAt[IN == 3 ? i : 0]] : a.srcPairs[(size_t)p * kOsPart + idx];
+        const uint2 kv = IN == 3 ? a.srcPairs[srcAt[IN == 3 ? i : 0]] : a.srcPairs[(size_t)p * part + idx];
         key[i] = kv.x;
         val[i] = kv.y;
       }
@@ -1008,9 +1030,32 @@ __global__ void k_os_plan_clear(OsPlan* plan)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Grid of a pass (and rows of its look-back words): partitions of kOsPart pairs for the largest count, and — round 6 — at least
+// as many workgroups as 1024-pair partitions of that count, up to kOsSmallGrid, so that a sort of few keys can spread over the chip
+// (osPartOf).  Workgroups beyond the partitions exit after the set-up.
+constexpr uint32_t kOsSmallGrid = 1024;
+// MGS_OS_PART_MIN=1024 | 2048 switches the device-side choice on (default: the fixed kOsPart).  Measured in round 6 on one box,
+// alternating (profiles/r6_a_sort_part_ab.log, r6_a_os_trace_strip*.log): a middle strip's sort 64.5 us at 78-212 partitions of
+// 4096 vs 64.8 us at 313-846 of 1024; train-sized 54.6 vs 54.6; garden and configs[4] never choose the small size.  What the
+// smaller partitions save in the table's expansion and the ranking (pass 1: 11.8 -> 5.8 us, 4.6 -> 2.7 us per workgroup) they pay
+// in the look-back (publish .. level 2: 5.4 -> 10.3 us: four times the members to wait for): a pass of few keys is its chain of
+// dependent round trips (~16-20 us) whatever the partition size.  Kept as an A/B knob, off by default.
+static uint32_t osPartMinEnv()
+{
+  static const uint32_t v = [] {
+    const char* e = std::getenv("MGS_OS_PART_MIN");
+    const int   x = e ? std::atoi(e) : 0;
+    return (x == 1024 || x == 2048) ? (uint32_t)x : kOsPart;
+  }();
+  return v;
+}
 uint32_t osSortMaxParts(uint32_t maxElems)
 {
-  return (uint32_t)(((uint64_t)maxElems + kOsPart - 1u) / kOsPart);
+  const uint32_t big = (uint32_t)(((uint64_t)maxElems + kOsPart - 1u) / kOsPart);
+  if(osPartMinEnv() >= kOsPart)
+    return big;
+  const uint32_t small = (uint32_t)std::min<uint64_t>(((uint64_t)maxElems + 1023u) / 1024u, kOsSmallGrid);
+  return std::max(big, small);
 }
 size_t osSortStatusWords(uint32_t maxParts)
 {  // per buffer: partition rows [partition][digit] (rounded up to whole groups) followed by group rows [group][digit]
@@ -1029,6 +1074,18 @@ void launchOsSort(hipStream_t stream, const OsLaunch& L)
     return;  // (the callers reject / re-route 2^30 pairs and more: a prefix would wrap inside its status word)
   const bool     frame    = L.pairs0 != nullptr;  // the project kernels' slots of pairs + their histograms / records
   const uint32_t maxParts = osSortMaxParts(L.maxElems);
+  // the device-side choice of the partition size (osPartOf): off unless MGS_OS_PART_MIN asks for it (osPartMinEnv above)
+  static uint32_t       devSlots[64] = {};
+  int                   dev = 0;
+  (void)hipGetDevice(&dev);
+  if(dev >= 0 && dev < 64 && devSlots[dev] == 0u)
+  {
+    int cus = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    devSlots[dev] = (uint32_t)std::max(cus, 1) * (uint32_t)MGS_OS_WAVES;
+  }
+  const uint32_t partMin  = L.partMin ? L.partMin : osPartMinEnv();
+  const uint32_t resSlots = L.resSlots ? L.resSlots : ((dev >= 0 && dev < 64) ? devSlots[dev] : 1024u);
   const uint32_t sWords   = (uint32_t)osSortStatusWords(maxParts);
   // Three sets of look-back words: pass 0 uses set 0, pass 1 set 1, pass 2 set 2, pass 3 set 1 again.  Every set is zero when its
   // pass starts: pass 0 clears sets 1 and 2 (whatever the previous sort left there, whether its pass 3 ran or not), pass 1
@@ -1085,6 +1142,8 @@ void launchOsSort(hipStream_t stream, const OsLaunch& L)
     a.nPtr    = L.nPtr;
     a.ctr     = L.ctr;
     a.pass    = pass;
+    a.partMin  = partMin;
+    a.resSlots = resSlots;
     a.dstKeys = L.outKeys;
     a.dstVals = L.outVals;
     // stand-alone: pass 0 -> A, 1 -> B, 2 -> A, 3 -> the result.  Frame: pass 1 reads the project kernels' slots, which live in B,

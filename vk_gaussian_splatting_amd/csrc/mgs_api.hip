@@ -2495,9 +2495,14 @@ Rccl& rccl()
 {
   static Rccl R = [] {
     Rccl r;
-    for(const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-      if((r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL)))
-        break;
+    // MGS_RCCL_LIB=path: load THIS library instead (and nothing else if it fails) — the seam of the test double that lets several
+    // ranks share one GPU (tests/helpers/fake_rccl.cpp); never set in production, never a fallback
+    if(const char* forced = std::getenv("MGS_RCCL_LIB"))
+      r.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    else
+      for(const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        if((r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL)))
+          break;
     if(!r.lib)
       return r;
     auto sym = [&](const char* n) { return dlsym(r.lib, n); };

@@ -107,6 +107,8 @@ struct OsLaunch
   uint32_t*       status   = nullptr;  // 3 x osSortStatusWords(osSortMaxParts(...)) words, zero on first use
   FrameCounters*  ctr      = nullptr;  // errorFlags |= kErrSpinTimeout if a look-back wait ever gives up
   bool            allowRemap = true;
+  uint32_t        partMin    = 0;      // smallest partition size the passes may choose on the device (k_osort.hip: osPartOf); 0 = MGS_OS_PART_MIN or, by default, kOsPart = fixed
+  uint32_t        resSlots   = 0;      // workgroups of a pass the device holds at once; 0 = 4 per CU of the current device (126 VGPRs, 36-40 KB of LDS)
 };
 
 // the per-frame sort state of one context, contiguous so that the frame's first kernel zeroes it in one sweep
