@@ -281,6 +281,9 @@ def main():
             for c in range(K):
                 scenes[c].set_strip_rows(bounds)
     my_rows = (bounds[rank], bounds[rank + 1]) if world > 1 else (0, 0)
+    # what the untimed calibration / counter frames of this rank render: its strip — or, for a rank whose strip is EMPTY (it renders
+    # nothing in the timed frames and only joins the exchange), the whole frame, so that its stage times and counters exist at all
+    own_rows = my_rows if my_rows[1] > my_rows[0] else (0, 0)
     Rmax = multigpu.padded_strip_rows(bounds) if world > 1 else 0
     strips = [torch.zeros((Rmax, W, 4), dtype=torch.float16, device="cuda") if world > 1 and not gather_mode.startswith("libmgs")
               else None for _ in range(K)]
@@ -318,7 +321,7 @@ def main():
     for i in range(8):
         pc = poses[i % 64]
         pc.collect_timings = 2
-        pc.strip_row_begin, pc.strip_row_end = my_rows
+        pc.strip_row_begin, pc.strip_row_end = own_rows
         with torch.cuda.stream(streams[0]):
             scenes[0].render(pc)
         torch.cuda.synchronize()
@@ -379,7 +382,7 @@ def main():
         pp = poses[(args.warmup + args.steps - 1 - i) % 64]
         # counters are per pose; re-render untimed to read them back (outside the timed region)
         pp.collect_timings = 0
-        pp.strip_row_begin, pp.strip_row_end = my_rows  # N>1: this rank's strip (what the stage times describe)
+        pp.strip_row_begin, pp.strip_row_end = own_rows  # N>1: this rank's strip (what the stage times describe)
         o = scene.render(pp, want_stats=True)
         counts.append((o.frustum_count, o.sorted_count, o.tile_pairs, o.error_flags, o.shaded_count, o.scanned_entries, o.escape_count))
         pp.collect_timings = 2 if args.stage_events else 0

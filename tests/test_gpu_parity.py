@@ -171,6 +171,7 @@ def test_key_sort_variants_are_bit_identical_to_the_stable_sort():
     assert out["default"] == out["ballotmasks"]
 
 
+
 def test_key_sort_oversubscribed_by_a_co_running_kernel():
     """The look-back of k_os_pass waits for lower-numbered workgroups and leans on the dispatcher starting a 1-D grid in index
     order (k_osort.hip header); all partitions of a frame-sized sort are usually resident at once, which hides the question.
@@ -183,9 +184,12 @@ def test_key_sort_oversubscribed_by_a_co_running_kernel():
     here = os.path.dirname(os.path.abspath(__file__))
     if not os.path.exists(os.path.join(here, "helpers", "libcuhog.so")):
         pytest.skip("tests/helpers/libcuhog.so not built (python __graft_entry__.py)")
-    r = subprocess.run([sys.executable, os.path.join(here, "_child_hog.py")], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "HOG_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
-    print([l for l in r.stdout.splitlines() if l.startswith("HOG_OK")])
+    # (round 6: also with plain digits in every frame — MGS_SORT_REMAP=0: four look-back passes per frame instead of two)
+    for extra in ({}, {"MGS_SORT_REMAP": "0"}):
+        r = subprocess.run([sys.executable, os.path.join(here, "_child_hog.py")], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, **extra))
+        assert r.returncode == 0 and "HOG_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+        print(extra, [l for l in r.stdout.splitlines() if l.startswith("HOG_OK")])
 
 
 def test_upload_transform_matches_oracle_bitwise(scene_small, ob):

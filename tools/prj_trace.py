@@ -36,5 +36,13 @@ for pose in poses:
     for i, n in enumerate(names):
         print(f"  {n:42s} median {np.median(ph[:, i]):6.2f} us   total {ph[:, i].sum():8.0f} workgroup-us")
     print("  survivors per workgroup (frustum / sorted) median:", np.median(b[:, 6]), np.median(b[:, 7]))
+    M, oc, dur = b[:, 6], b[:, 7], en - st
+    print(f"  candidates M per workgroup p10/50/90/max {np.percentile(M, [10, 50, 90, 100])}; sorted per workgroup p10/50/90/max {np.percentile(oc, [10, 50, 90, 100])}")
+    print(f"  workgroups with M == 0: {(M == 0).sum()} ({(M == 0).mean():.2%}); with no sorted pair: {(oc == 0).sum()} ({(oc == 0).mean():.2%}); "
+          f"M <= 256: {(M <= 256).mean():.2%}; sum M {M.sum()} sum sorted {oc.sum()}")
+    for lo, hi in ((0, 1), (1, 65), (65, 257), (257, 1025), (1025, 4096)):
+        sel = (M >= lo) & (M < hi)
+        if sel.any():
+            print(f"    M in [{lo}, {hi}): {sel.sum():5d} workgroups, duration median {np.median(dur[sel]):6.1f} us, phases " + " ".join(f"{np.median(ph[sel, i]):5.1f}" for i in range(5)))
     ts = np.linspace(0, en.max(), 25)
     print("  resident over time:", [int(((st <= x) & (en > x)).sum()) for x in ts])

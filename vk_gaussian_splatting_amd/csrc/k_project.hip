@@ -377,6 +377,12 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
     atomicAdd(&frameStatSlotFromOs(osPlan, part)[2], M);  // (sort_plan.h: 32 slots on 32 lines, not the counters' one line)
 
   MGS_PRJ_STAMP(3)
+  if(M == 0u)
+  {  // nothing of this partition survives the dist stage (a strip of the multi-GPU partition: 18 % of the workgroups that pass the
+     // box test, profiles/r6_b_prj_trace_strip.log): the slot is empty — no front end, no hand-over (four barriers, 3 us)
+    emitEmptySlot<kPrjThreads>(slotCount, slotHist2, top16Rec, part);
+    return;
+  }
   if constexpr(!FULL)
   {
     // sort-only hook: survivors of the dist stage, exactly dist.comp.slang's (key, id) stream
@@ -402,6 +408,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
     }
     static_assert(kPrjItems == 8, "RideCodes holds eight rounds");
     RideCodes      codes;
+    bool           anySurvivor = false;
     const uint32_t rideShift = (uint32_t)A.f.rideShift;
     for(uint32_t j0 = 0; j0 < M; j0 += kPrjThreads)
     {
@@ -431,6 +438,7 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
           if(rideShift == 0u || code == A.f.rideEscape)
             rect[gidOk] = pr.rect;
           s_li[j] |= 0x8000u;  // own entry only: no race
+          anySurvivor = true;
         }
       }
       // the id rides in the pitch's third (padding) quad: a separate 1 KB array was what kept the workgroup above 26 KB of LDS
@@ -454,8 +462,25 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
     for(uint32_t j0 = (M + kPrjThreads - 1u) / kPrjThreads * kPrjThreads; j0 < (uint32_t)kPrjPart; j0 += kPrjThreads)
       codes.push(0u);
     // ---- the survivors, grouped by the low byte of their keys, into the partition's slot (slot_emit.h) ----
-    __syncthreads();  // phase 2 is over: s_rec is free
+    // (phase 2 is over behind this barrier: s_rec is free.  The barrier also tells whether ANY candidate survived the front end: in a
+    //  strip 37 % of the workgroups hand nothing to the sort — every candidate's footprint misses the rows — and skip the hand-over)
+    const bool anyOut = __syncthreads_or(anySurvivor ? 1 : 0) != 0;
     MGS_PRJ_STAMP(4)
+    if(!anyOut)
+    {
+      emitEmptySlot<kPrjThreads>(slotCount, slotHist2, top16Rec, part);
+#ifdef MGS_PRJ_TRACE
+      MGS_PRJ_STAMP(5)
+      if(threadIdx.x == 0 && g_prjTrace)
+      {
+        uint64_t* o = g_prjTrace + (size_t)blockIdx.x * 8;
+        for(int i = 0; i < 6; ++i) o[i] = trc[i];
+        o[6] = M;
+        o[7] = 0;
+      }
+#endif
+      return;
+    }
     if(rideShift != 0u)
     {  // the codes leave their registers for the hand-over, which deals the candidates out anew (wave-contiguous)
       uint16_t* s_code = reinterpret_cast<uint16_t*>(s_raw);
