@@ -208,7 +208,7 @@ __device__ uint64_t* g_prjTrace = nullptr;
 #define MGS_PRJ_STAMP(i)
 #endif
 template <bool FULL>
-__global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __restrict__ Ap, FrameCounters* __restrict__ ctr,
+__global__ __launch_bounds__(kPrjThreads, 6) void k_project(const FrameArgs* __restrict__ Ap, FrameCounters* __restrict__ ctr,
                                                          uint2* __restrict__ slotPairs, uint32_t* __restrict__ slotCount,
                                                          SplatRec* __restrict__ rec, uint32_t* __restrict__ rect,
                                                          uint32_t* __restrict__ slotHist2,
@@ -255,6 +255,10 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   const PartitionBox pbox = partitionLoad(I, part - I.blockBegin);  // ahead of the centres (partition_cull.h)
   // ---- phase 1: key + frustum cull for 8 splats per thread -------------------------------------------
   float px[kPrjItems], py[kPrjItems], pz[kPrjItems];
+  // strips (multi-GPU): every splat's own footprint bound needs its largest axis (4 B per splat, requested beside the centres: a
+  // load behind the dist stage would be one more dependent trip) — round 6, below
+  const bool stripMode = FULL && A.f.partitionCull && (A.f.stripRow1 - A.f.stripRow0) < A.f.tilesY;
+  [[maybe_unused]] float msc[kPrjItems];
 #pragma unroll
   for(int it = 0; it < kPrjItems; ++it)
   {
@@ -263,6 +267,12 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
     px[it] = I.centers[3 * (size_t)li];
     py[it] = I.centers[3 * (size_t)li + 1];
     pz[it] = I.centers[3 * (size_t)li + 2];
+    if constexpr(FULL)
+    {
+      msc[it] = 0.0f;
+      if(stripMode)  // uniform
+        msc[it] = I.maxScale[li];
+    }
   }
   // the partition as a whole (partition_cull.h; behind the centres' loads, which are in flight either way): bit 0 no splat of
   // it can survive the cull / reach the strip, bit 1 every centre passes the frustum test, bit 2 all centres finite
@@ -290,8 +300,15 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
   // strips (multi-GPU): a splat whose centre lies further from this device's rows than the partition's footprint bound R
   // (partition_cull.h; valid for every splat of the partition) cannot reach them — dropped here, before the projection.
   // The exact footprint-vs-strip test of phase 2 would reject it anyway: the sorted set is unchanged.
-  const bool  stripPre = FULL && A.f.partitionCull && (A.f.stripRow1 - A.f.stripRow0) < A.f.tilesY;
+  // Round 6: the bound is the SPLAT'S OWN — R_i = s (k_i f S sqrt(8) sigma_i / z_i + 3.2) with its own view depth z_i, its own
+  // k_i = sqrt(2 + (x/z)^2 + (y/z)^2) (||J||_F = k f / z) and sigma_i = its largest axis (sqrt(lambda_max(Sigma3D)) exactly) — capped
+  // by the partition's R (the same expression at the box's nearest corner with the partition's largest trace).  On a middle
+  // strip of eight the partition's bound let 2.03 M candidates into the front end for 0.87 M that reach the rows
+  // (profiles/r6_b_prj_trace_strip.log).
+  const bool  stripPre = stripMode;
   const float stripR   = stripPre ? partRadius : 3.0e38f;
+  const float stripK   = fmaxf(fabsf(A.f.focal[0]), fabsf(A.f.focal[1])) * I.modelScale * 2.8284271247461903f;
+  const bool  gutFish  = A.f.cameraModel == 1 && A.f.pipeline == 1;  // (this kernel is the 3DGS one: never; kept for the rule's sake)
   const float stripY0  = (float)(A.f.stripRow0 * kTilePx), stripY1 = (float)min(A.f.stripRow1 * kTilePx, A.f.height);
   const bool  insideFast = (pflag & 2u) != 0u && A.f.cullMode == 1 && !stripPre;
 #pragma unroll
@@ -347,7 +364,19 @@ __global__ __launch_bounds__(kPrjThreads) void k_project(const FrameArgs* __rest
         v = false;
       if(stripPre)
       {
-        const float R = stripR;
+        float R = stripR;
+        if constexpr(FULL)
+        {
+          const float zv = -vp[2];  // view depth (the camera looks down -z)
+          if(zv > 1.0e-4f && !gutFish)
+          {
+            const float iz = fastRcp(zv), qx = vp[0] * iz, qy = vp[1] * iz;
+            const float kk = fastSqrt(2.0f + qx * qx + qy * qy);
+            float       Ri = A.f.splatScale * (kk * stripK * msc[it] * iz + 3.2f);
+            Ri             = fminf(Ri, 2897.0f * A.f.splatScale) * 1.01f + 2.0f;  // both bases are clamped at 2048 px
+            R              = fminf(R, Ri);  // (a NaN Ri leaves the partition's bound)
+          }
+        }
         const float ypx = (ny + 1.0f) * 0.5f * (float)A.f.height;
         if(ypx + R < stripY0 || ypx - R > stripY1)
           v = false;
