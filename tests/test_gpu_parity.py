@@ -172,6 +172,33 @@ def test_key_sort_variants_are_bit_identical_to_the_stable_sort():
 
 
 
+@pytest.mark.parametrize("kind", ["thin", "opaque"])
+def test_adaptive_bin_size_is_scheduling_only_and_follows_the_scan_ratio(kind):
+    """Round 6: a frame context picks 128x128-px bins instead of 256x128 when its regions scan most of their lists (sampled every
+    32nd frame: scanned entries / (list entries x regions per bin) > 0.025 AND more than 900 entries walked per region; mgs_api.hip: BinPolicy).  A 72-frame sequence with the
+    policy (default) and without (MGS_BIN_ADAPT=0): the SAME frames bit for bit; on the translucent scene the number of list entries
+    changes at the frame the policy is applied (24 frames in) and stays changed, on the opaque one it never does."""
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_child_binpolicy.py")
+    out = {}
+    for mode, extra in (("adaptive", {}), ("fixed", {"MGS_BIN_ADAPT": "0"})):
+        r = subprocess.run([sys.executable, child, kind], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        sha = [l for l in r.stdout.splitlines() if l.startswith("FRAMES_SHA1")]
+        pairs = [int(x) for x in [l for l in r.stdout.splitlines() if l.startswith("PAIRS")][0].split()[1:]]
+        out[mode] = (sha, pairs)
+    assert out["adaptive"][0] and out["adaptive"][0] == out["fixed"][0], "the bin size must not show in a frame"
+    fx, ad = out["fixed"][1], out["adaptive"][1]
+    assert len(set(fx)) == 1, fx  # the same pose every fourth frame: the same lists
+    print(kind, "list entries of pose 0 over the sequence:", ad)
+    if kind == "thin":
+        assert ad[:6] == fx[:6] and ad[7] != fx[7] and len(set(ad[7:])) == 1, (ad, fx)  # frames 0..20 as before; from frame 24 on the finer bins
+        assert ad[7] > fx[7]  # finer bins: more (bin, splat) entries
+    else:
+        assert ad == fx, (ad, fx)
+
+
 def test_key_sort_oversubscribed_by_a_co_running_kernel():
     """The look-back of k_os_pass waits for lower-numbered workgroups and leans on the dispatcher starting a 1-D grid in index
     order (k_osort.hip header); all partitions of a frame-sized sort are usually resident at once, which hides the question.

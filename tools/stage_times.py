@@ -17,12 +17,17 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--strip", type=int, nargs=2, default=None)
 ap.add_argument("--scene", default="garden")
 ap.add_argument("--frames", type=int, default=32)
+ap.add_argument("--skip", type=int, default=4, help="untimed frames in front (the adaptive bin size settles after 24)")
 ap.add_argument("--tag", default="")
 ap.add_argument("--graph", action="store_true", help="also report frames/s of graph-replayed frames (no stage events)")
 a = ap.parse_args()
 sc = synth.make_scene(a.splats, seed=0xC0FFEE + 2)
 if a.scene == "fog":
     sc["opacity"] = (sc["opacity"] - 2.5).astype(np.float32)
+elif a.scene == "sparse":
+    r = np.linalg.norm(sc["positions"], axis=1)
+    keep = (r >= 4.0) | (np.random.default_rng(7).random(a.splats) < 0.10)
+    sc = {k: np.ascontiguousarray(v[keep]) for k, v in sc.items()}
 ss = mgs.SplatSet.from_arrays(**sc)
 scene = mgs.Scene(0)
 for q in range(a.instances):
@@ -46,12 +51,12 @@ for i in range(64):
         p.strip_row_begin, p.strip_row_end = a.strip
     poses.append(p)
 rows = []
-for i in range(4 + a.frames):
+for i in range(a.skip + a.frames):
     p = poses[i % 64]
     p.collect_timings = 2
     scene.render(p)
     scene.sync()
-    if i >= 4:
+    if i >= a.skip:
         rows.append(scene.timings_all(0))
 ms = np.array(rows, np.float64).mean(axis=0)
 o = scene.render(poses[0], want_stats=True)

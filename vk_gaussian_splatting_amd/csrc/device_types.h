@@ -172,13 +172,13 @@ static_assert(sizeof(GutRec) == 96, "six 16-byte vectors");
 // device-resident counters of one frame
 struct FrameCounters
 {
-  uint32_t frustumCount;   // survivors of the dist-stage cull
+  uint32_t frustumCount;   // (zero since round 5: the dist stage's survivors are counted in the statistics lines, sort_plan.h: frameStatSlot)
   uint32_t sortedCount;    // V: elements handed to the radix sort
   uint32_t pairCount;      // D: (tile, splat) records
   uint32_t errorFlags;
-  uint32_t stagedSlots[8];   // compositor statistics, spread over 8 words (one per XCD-ish) to keep the atomics apart
-  uint32_t scannedSlots[8];
-  uint32_t pad[11];
+  // (the compositors' statistics — staged records, scanned entries — and the project kernels' frustum survivors are counted on 32
+  //  lines of their own since round 5: sort_plan.h, frameStatSlot)
+  uint32_t pad[27];
 };
 
 }  // namespace mgs

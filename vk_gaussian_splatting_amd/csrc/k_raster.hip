@@ -511,12 +511,15 @@ __global__ __launch_bounds__(256) void k_dbin_scan(const SortPlan* __restrict__ 
   const uint32_t chunks = (n + kDbChunk - 1) / kDbChunk;
   uint32_t*      row    = binHist + (size_t)blockIdx.x * pStride;
   uint32_t       carry  = 0;
-  for(uint32_t base = 0; base < chunks; base += 2048)
+  // 16 values per thread: a garden-sized frame's ~4 080 chunks are ONE trip of loads, one block scan, one trip of stores (8 per
+  // thread were two dependent rounds of that: the kernel is its latency)
+  constexpr int kPer = 16;
+  for(uint32_t base = 0; base < chunks; base += 256 * kPer)
   {
-    const uint32_t p0 = base + t * 8;
-    uint32_t       v[8], sum = 0;
+    const uint32_t p0 = base + t * kPer;
+    uint32_t       v[kPer], sum = 0;
 #pragma unroll
-    for(int i = 0; i < 8; ++i)
+    for(int i = 0; i < kPer; ++i)
     {
       v[i] = (p0 + i < chunks) ? row[p0 + i] : 0u;
       sum += v[i];
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(256) void k_dbin_scan(const SortPlan* __restrict__ 
     uint32_t chunk;
     uint32_t run = carry + blockExclusiveScan256(sum, s_tmp, &chunk);
 #pragma unroll
-    for(int i = 0; i < 8; ++i)
+    for(int i = 0; i < kPer; ++i)
     {
       if(p0 + i < chunks)
         row[p0 + i] = run;
@@ -707,6 +710,9 @@ __global__ __launch_bounds__(256) void k_dbin_emit(const uint32_t* __restrict__ 
     if(t == 0)
     {
       ctr->pairCount = (uint32_t)min(D64, (uint64_t)capacity);
+      // (round 6) ... and beside the compositor's statistics (sort_plan.h: frameStatSlot, slot 0 word 4), so that ONE small copy
+      // tells the host how much of their lists the regions scan: the adaptive bin size's input (mgs_api.hip: BinPolicy)
+      const_cast<uint32_t*>(&plan->ghist[0][0])[4] = (uint32_t)min(D64, (uint64_t)capacity);
       if(D64 > capacity)
         atomicOr(&ctr->errorFlags, kErrPairOverflow);
     }

@@ -340,6 +340,7 @@ struct MgsScene_t
   // last frame
   MgsFrameParams lastParams{};
   bool           haveFrame = false, lastTimed = false, lastWasSortOnly = false;
+  int            lastBinShift[2] = {4, 3};  // the last frame's bin size (the adaptive policy may pick another one for the next frame)
   int            lastRide[5] = {0, 0, 0, 0, 0};  // the last frame's rideShift, code bits, binsX, binsY, 1 if the GPU key sort ran (mgs_frame_download_projected)
   bool           lastListsPartial = false;  // the last frame came from mgs_render_gathered: its bin lists cover this rank's rows only
   size_t         imageBytes = 0, imageRowBytes = 0;
@@ -355,6 +356,26 @@ struct MgsScene_t
   ncclComm_t            comm = nullptr;
   int                   commRank = 0, commWorld = 1;
   std::vector<int32_t>  stripBounds;  // [world + 1] tile rows; empty = equal strips
+
+  // Adaptive bin size (round 6).  A region walks its bin's list until its pixels saturate; where regions never
+  // saturate (sparse or translucent scenes) every region re-scans the WHOLE list of a 256x128-px bin, and 128x128-px bins halve
+  // that — measured in round 5: train-sized composite 137 -> 124 us for +6 us of binning, fog -2 %, the benchmark scene +4.6 %
+  // (its regions stop after a few hundred entries whatever the list's length).  The signal is the fraction of the list entries
+  // the regions look at, scanned / (D x regions per bin): 0.008 on the benchmark scene, 0.034 fog, 0.056 sparse, 0.077 train-sized.
+  // Sampled every 32nd frame of a context (one 4 KB device-to-host copy of the statistics lines behind the frame), applied eight
+  // frames later — by frame count, not by when the copy lands, so that a sequence renders the same way every time.  Scheduling
+  // only: frames do not depend on the bin size (test_binning_paths_bit_identical).  MGS_BIN_ADAPT=0 turns it off; MGS_BIN_SHIFT wins.
+  struct BinPolicy
+  {
+    int        fine = 0;           // 1: 128x128-px bins (where the frame allows: <= 256 bins)
+    uint32_t   frames = 0;         // eligible frames rendered by this context
+    bool       pending = false;    // a sample is in flight / waiting to be applied
+    int        sampledFine = 0, sampledRegions = 64;
+    uint32_t   sampledRegionCount = 1;  // 32x16-px regions of the sampled frame (its strip)
+    hipEvent_t ev = nullptr;
+    uint32_t*  host = nullptr;     // pinned, kFrameStatSlots x 32 words
+    float      lastRatio = 0.0f;
+  } binPolicy;
 
   CpuSorter             cpu;
   std::vector<float>    cpuDistances;  // distances of the consumed sort (swapped out under the sorter's lock, like the indices)
@@ -755,6 +776,8 @@ void mgs_scene_destroy(MgsScene s)
   s->rsPairA.release(); s->rsPairB.release(); s->rsStatus.release(); s->rsOsPlan.release();
   if(s->hCtr) (void)hipHostFree(s->hCtr);
   if(s->hPlans) (void)hipHostFree(s->hPlans);
+  if(s->binPolicy.host) (void)hipHostFree(s->binPolicy.host);
+  if(s->binPolicy.ev) (void)hipEventDestroy(s->binPolicy.ev);
   for(int k = 0; k < MgsScene_t::kUpRing; ++k)
     if(s->upBuf[k])
     {
@@ -1577,6 +1600,13 @@ static void chooseRide(MgsScene s, FrameConst& F, bool cpuMode)
 }
 
 
+// the frames the adaptive bin size applies to: the default compositing mode of the 3DGS pipeline with the GPU sort
+static const bool kBinAdapt = [] { const char* e = std::getenv("MGS_BIN_ADAPT"); return (e ? std::atoi(e) != 0 : true) && std::getenv("MGS_BIN_SHIFT") == nullptr; }();
+static bool binPolicyEligible(const MgsFrameParams* p)
+{
+  return kBinAdapt && p->alpha_mode != MGS_ALPHA_SUM && p->pipeline == MGS_PIPELINE_3DGS && p->sort_mode == MGS_SORT_GPU_RADIX && p->surface_outputs == 0;
+}
+
 static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
 {
   if(p->width <= 0 || p->height <= 0 || p->width > 8192 || p->height > 8192)
@@ -1629,6 +1659,8 @@ static int buildFrameArgs(MgsScene s, const MgsFrameParams* p, FrameArgs& A)
     bsx = 3;
     bsy = 2;
   }
+  else if(binPolicyEligible(p) && s->binPolicy.fine)
+    bsx = bsy = 3;  // 128x128 px: this context's regions scan most of their lists (BinPolicy)
   if(const char* e = std::getenv("MGS_BIN_SHIFT"))
     std::sscanf(e, "%d,%d", &bsx, &bsy);
   else
@@ -2002,6 +2034,29 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
   if(int wrc = ensureWorkingSet(s))
     return wrc;
   HIPCHK(hipSetDevice(s->device));
+  // adaptive bin size: a sample taken 8 eligible frames ago is applied now (BinPolicy)
+  const bool policyFrame = binPolicyEligible(p);
+  if(policyFrame && s->binPolicy.pending && (s->binPolicy.frames & 31u) == 24u)
+  {
+    MgsScene_t::BinPolicy& B = s->binPolicy;
+    HIPCHK(hipEventSynchronize(B.ev));  // (eight frames of this context's stream ago: long done)
+    uint64_t scanned = 0;
+    for(uint32_t i = 0; i < kFrameStatSlots; ++i)
+      scanned += B.host[32u * i + 1u];
+    const uint64_t D = B.host[4];
+    B.pending        = false;
+    if(D > 0)
+    {
+      B.lastRatio = (float)((double)scanned / ((double)D * (double)B.sampledRegions));
+      // ... and how far a region walks in absolute terms: one stage-A round is 512 entries, and a region that saturates inside its
+      // first round or two (686 entries on the benchmark scene; 1 140-2 570 on the sparse / train-sized / fog scenes) has nothing
+      // to gain from a shorter list, however short the list is (a small scene's lists are a few rounds long: its ratio is high for
+      // that reason alone)
+      const float perRegion = (float)((double)scanned / (double)B.sampledRegionCount);
+      // (under the finer bins a saturating region's share of its — shorter — list is about twice what it is under the coarse ones)
+      B.fine = B.sampledFine ? ((B.lastRatio > 0.030f && perRegion > 450.0f) ? 1 : 0) : ((B.lastRatio > 0.025f && perRegion > 900.0f) ? 1 : 0);
+    }
+  }
   FrameArgs A;
   int       rc = buildFrameArgs(s, p, A);
   if(rc != MGS_OK)
@@ -2266,6 +2321,32 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
     if(rc != MGS_OK)
       return rc;
   }
+  if(policyFrame && kDirectBin && directBinningSupported(F.binsX, F.binsY))
+  {  // adaptive bin size: every 32nd eligible frame leaves a copy of its statistics lines (4 KB) for the frame eight later
+    MgsScene_t::BinPolicy& B = s->binPolicy;
+    if((B.frames & 31u) == 16u && !B.pending)
+    {
+      if(!B.host)
+      {
+        if(hipHostMalloc((void**)&B.host, kFrameStatSlots * 32u * sizeof(uint32_t)) != hipSuccess || hipEventCreateWithFlags(&B.ev, hipEventDisableTiming) != hipSuccess)
+        {
+          (void)hipGetLastError();
+          if(B.host) (void)hipHostFree(B.host);
+          B.host = nullptr;
+        }
+      }
+      if(B.host)
+      {
+        HIPCHK(hipMemcpyAsync(B.host, &s->plans.p->keys.ghist[0][0], kFrameStatSlots * 32u * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(B.ev, st));
+        B.pending        = true;
+        B.sampledFine    = (F.binShiftX == 3 && F.binShiftY == 3) ? 1 : 0;
+        B.sampledRegions = (1 << (F.binShiftX - 1)) * (1 << F.binShiftY);
+        B.sampledRegionCount = (uint32_t)std::max(1, ((F.tilesX + 1) / 2) * (F.stripRow1 - F.stripRow0));
+      }
+    }
+    ++B.frames;
+  }
   // the counters stay on the device; mgs_frame_stats fetches them when somebody asks (two API calls per frame less
   // on the submitting thread, which spends ~6 us per call)
   HIPCHK(hipGetLastError());
@@ -2282,6 +2363,8 @@ static int mgs_render_impl(MgsScene s, const MgsFrameParams* p, MgsFrameOut* out
       ++codeBits;
     const int lr[5] = {F.rideShift, codeBits, F.binsX, F.binsY, cpuModeOuter ? 0 : 1};
     std::memcpy(s->lastRide, lr, sizeof(lr));
+    s->lastBinShift[0] = F.binShiftX;
+    s->lastBinShift[1] = F.binShiftY;
   }
   if(timed)
     ++s->frameIndex;
@@ -2774,7 +2857,12 @@ int mgs_frame_row_costs(MgsScene s, uint32_t* cost, size_t rows)
     int       rc = buildFrameArgs(s, &s->lastParams, A);
     if(rc != MGS_OK)
       return rc;
-    const FrameConst& F = A.f;
+    FrameConst& F = A.f;
+    // the lists are those of the LAST frame: its bin grid, not the one the adaptive policy would pick for the next frame
+    F.binShiftX = s->lastBinShift[0];
+    F.binShiftY = s->lastBinShift[1];
+    F.binsX     = (F.tilesX + (1 << F.binShiftX) - 1) >> F.binShiftX;
+    F.binsY     = (F.tilesY + (1 << F.binShiftY) - 1) >> F.binShiftY;
     if(rows < (size_t)F.tilesY)
     {
       setError("mgs_frame_row_costs: need one entry per 16-pixel tile row");
