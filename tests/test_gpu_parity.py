@@ -145,7 +145,8 @@ def test_key_sort_variants_are_bit_identical_to_the_stable_sort():
     the generic reduce-then-scan kernels instead of the key sort's (MGS_RAW_SORT=generic), without the bin rectangles'
     ride through the sort (MGS_RECT_RIDE=0), with the codes split between the key's low byte and the id's spare bits as scenes
     beyond 8 M splats have them (MGS_RIDE_SPLIT=2), and with the project kernel's partitions in storage order instead of
-    fullest-slot-first (MGS_PRJ_ORDER=0), the binning's masks by ballots instead of the transpose (MGS_DB_TRANSPOSE=0).  Sizes around the partition and
+    fullest-slot-first (MGS_PRJ_ORDER=0), the binning's masks by ballots instead of the transpose (MGS_DB_TRANSPOSE=0), the sort passes'
+    level-2 look-back as the chain of group prefixes instead of the counted sums (MGS_OS_FLAT=0).  Sizes around the partition and
     look-back group boundaries, distributions with giant runs / few values / many exponents, and whole frames — every sorted
     stream must equal the stable sort bit for bit, every frame must be the same frame"""
     import subprocess
@@ -155,7 +156,8 @@ def test_key_sort_variants_are_bit_identical_to_the_stable_sort():
     for mode, env_extra in (("default", {}), ("plain", {"MGS_SORT_REMAP": "0"}), ("generic", {"MGS_RAW_SORT": "generic"}),
                             ("gather", {"MGS_RECT_RIDE": "0"}), ("nohistory", {"MGS_BIN_HISTORY": "0"}),
                             ("split", {"MGS_RIDE_SPLIT": "2"}), ("storageorder", {"MGS_PRJ_ORDER": "0"}),
-                            ("fullproducts", {"MGS_EXACT_SHORTCUTS": "0"}), ("ballotmasks", {"MGS_DB_TRANSPOSE": "0"})):
+                            ("fullproducts", {"MGS_EXACT_SHORTCUTS": "0"}), ("ballotmasks", {"MGS_DB_TRANSPOSE": "0"}),
+                            ("chain", {"MGS_OS_FLAT": "0"})):
         r = subprocess.run([sys.executable, child], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
         assert "SORTS_OK" in r.stdout, r.stdout[-3000:]
@@ -169,6 +171,9 @@ def test_key_sort_variants_are_bit_identical_to_the_stable_sort():
     assert out["default"] == out["fullproducts"]
     # ballotmasks: the binning's column / row masks by ballots instead of the bit-matrix transpose (k_dbin_count): the same lists
     assert out["default"] == out["ballotmasks"]
+    # chain: the sort passes' level-2 look-back as the chain of group prefixes of rounds 3-5 instead of round 6's counted sums
+    # (k_osort.hip: flat level 2; sorts of more than 1 024 partitions always take the chain)
+    assert out["default"] == out["chain"]
 
 
 
@@ -212,7 +217,7 @@ def test_key_sort_oversubscribed_by_a_co_running_kernel():
     if not os.path.exists(os.path.join(here, "helpers", "libcuhog.so")):
         pytest.skip("tests/helpers/libcuhog.so not built (python __graft_entry__.py)")
     # (round 6: also with plain digits in every frame — MGS_SORT_REMAP=0: four look-back passes per frame instead of two)
-    for extra in ({}, {"MGS_SORT_REMAP": "0"}):
+    for extra in ({}, {"MGS_SORT_REMAP": "0"}, {"MGS_OS_FLAT": "0"}):  # (the last: the chain of group prefixes instead of round 6's counted sums)
         r = subprocess.run([sys.executable, os.path.join(here, "_child_hog.py")], capture_output=True, text=True, timeout=600,
                            env=dict(os.environ, **extra))
         assert r.returncode == 0 and "HOG_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

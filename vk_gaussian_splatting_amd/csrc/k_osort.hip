@@ -506,6 +506,7 @@ struct OsPassArgs
   // 2048 pairs when that many partitions still fit the grid and one residency wave of the chip, else kOsPart.
   uint32_t        partMin;    // smallest partition size allowed (kOsPart: the fixed size of rounds 3-5; A/B)
   uint32_t        resSlots;   // workgroups of this kernel the chip holds at once
+  uint32_t        flatLookback;  // 1: sorts of at most 32 groups resolve the groups before a partition from COUNTED SUMS instead of the chain of group prefixes (below; MGS_OS_FLAT)
 };
 
 // A sort of few keys used to run on few workgroups: a strip's 0.32 M keys were 78 partitions of 4096 on 256 CUs, a train-sized
@@ -562,21 +563,6 @@ __global__ __launch_bounds__(kThreads, MGS_OS_WAVES) void k_os_pass(const OsPass
       foldTop16<kThreads>(plan, a.top16Count, a.allowRemap, blockIdx.x - (gridDim.x - kOsFoldWgs), reinterpret_cast<uint32_t*>(s_pair), s_tmp);
       return;
     }
-  for(int i = t; i < kWaves * 256; i += kThreads)
-    (&s_whist[0][0])[i] = 0;
-  const bool useRemap = REMAP && remapped;
-  if constexpr(REMAP)
-    if(useRemap)
-    {  // every entry holds the largest rank first: a value outside the table (padding keys) sorts behind every real key
-      const uint32_t count = plan->remapCount, base = plan->remapBase;
-      const uint32_t fill  = plan->remapPadRank * 0x01010101u;
-      for(int i = t; i < (int)kRemapSpan / 4; i += kThreads)
-        reinterpret_cast<uint32_t*>(s_rv)[i] = fill;
-      __syncthreads();
-      for(uint32_t i = t; i < count; i += kThreads)
-        s_rv[(uint32_t)plan->remapVals[i] - base] = (uint8_t)i;
-    }
-  __syncthreads();
   const uint32_t part  = osPartOf(n, gridDim.x - (IN == 3 ? kOsFoldWgs : 0u), a.partMin, a.resSlots);  // wave-uniform, the same in every workgroup
   const uint32_t parts = (uint32_t)(((uint64_t)n + part - 1u) / part);
   if(p >= parts)
@@ -598,11 +584,62 @@ __global__ __launch_bounds__(kThreads, MGS_OS_WAVES) void k_os_pass(const OsPass
   const uint32_t wofs   = w * 64u * rounds;
   uint32_t       key[kKpt], val[kKpt];
   MGS_OS_STAMP(1)
+  [[maybe_unused]] uint32_t srcAt[IN == 3 ? kKpt : 1];
+  auto loadPairs = [&]() {
+    // clamped, not predicated: a predicated load becomes a branch + wait and serialises the fetches
+#pragma unroll
+    for(int i = 0; i < kKpt; ++i)
+    {
+      key[i] = 0xFFFFFFFFu;
+      val[i] = 0u;
+      if((uint32_t)i < rounds)  // wave-uniform
+      {
+        const uint32_t idx = min(wofs + (uint32_t)i * 64u + lane, count - 1u);
+        if(IN == 2)
+        {
+          key[i] = a.srcKeys[(size_t)p * part + idx];
+          val[i] = a.srcVals[(size_t)p * part + idx];
+        }
+        else
+        {
+          const uint2 kv = IN == 3 ? a.srcPairs[srcAt[IN == 3 ? i : 0]] : a.srcPairs[(size_t)p * part + idx];
+          key[i] = kv.x;
+          val[i] = kv.y;
+        }
+      }
+    }
+#pragma unroll
+    for(int i = 0; i < kKpt; ++i)
+      if(wofs + (uint32_t)i * 64u + lane >= count)
+      {
+        key[i] = 0xFFFFFFFFu;
+        val[i] = 0u;
+      }
+  };
+  // (round 6) a pass over contiguous input requests its pairs BEFORE it sets up its LDS (the zeroed wave histograms, the rank table
+  // and their two barriers: 1.9 us of the workgroup's life that the loads' round trip used to follow); the first pass of a frame
+  // cannot — its source table is built in LDS first
+  if constexpr(IN != 3)
+    loadPairs();
+  for(int i = t; i < kWaves * 256; i += kThreads)
+    (&s_whist[0][0])[i] = 0;
+  const bool useRemap = REMAP && remapped;
+  if constexpr(REMAP)
+    if(useRemap)
+    {  // every entry holds the largest rank first: a value outside the table (padding keys) sorts behind every real key
+      const uint32_t count = plan->remapCount, base = plan->remapBase;
+      const uint32_t fill  = plan->remapPadRank * 0x01010101u;
+      for(int i = t; i < (int)kRemapSpan / 4; i += kThreads)
+        reinterpret_cast<uint32_t*>(s_rv)[i] = fill;
+      __syncthreads();
+      for(uint32_t i = t; i < count; i += kThreads)
+        s_rv[(uint32_t)plan->remapVals[i] - base] = (uint8_t)i;
+    }
+  __syncthreads();
   // IN 3: the source table of the virtual pass 0 (header of OsPassArgs).  s_pair is not in use before the re-order: its first
   // half holds the table.  Everything that locates the runs — the digit bases D, the prefix over the chunks — is computed by
   // EVERY WAVE FOR ITSELF (identical results, a few dozen loads each): the construction has no workgroup barrier except the
   // one before the table is read (with block-wide scans it had nine, 8 us per digit value; profiles/r4_c_os_trace.log).
-  [[maybe_unused]] uint32_t srcAt[IN == 3 ? kKpt : 1];
   if constexpr(IN == 3)
   {
     uint32_t* s_src = reinterpret_cast<uint32_t*>(s_pair);       // [4096] pair index (slot * 2048 + entry) of every position of the partition
@@ -740,35 +777,8 @@ __global__ __launch_bounds__(kThreads, MGS_OS_WAVES) void k_os_pass(const OsPass
     for(int i = 0; i < kKpt; ++i)
       srcAt[i] = min(s_src[min(wofs + (uint32_t)i * 64u + lane, count - 1u)], a.srcLimit);
   }
-  // clamped, not predicated: a predicated load becomes a branch + wait and serialises the fetches
-#pragma unroll
-  for(int i = 0; i < kKpt; ++i)
-  {
-    key[i] = 0xFFFFFFFFu;
-    val[i] = 0u;
-    if((uint32_t)i < rounds)  // wave-uniform
-    {
-      const uint32_t idx = min(wofs + (uint32_t)i * 64u + lane, count - 1u);
-      if(IN == 2)
-      {
-        key[i] = a.srcKeys[(size_t)p * part + idx];
-        val[i] = a.srcVals[(size_t)p * part + idx];
-      }
-      else
-      {
-        const uint2 kv = IN == 3 ? a.srcPairs[srcAt[IN == 3 ? i : 0]] : a.srcPairs[(size_t)p * part + idx];
-        key[i] = kv.x;
-        val[i] = kv.y;
-      }
-    }
-  }
-#pragma unroll
-  for(int i = 0; i < kKpt; ++i)
-    if(wofs + (uint32_t)i * 64u + lane >= count)
-    {
-      key[i] = 0xFFFFFFFFu;
-      val[i] = 0u;
-    }
+  if constexpr(IN == 3)
+    loadPairs();
   const int      shift = 8 * a.pass;
   const uint32_t rbase = plan->remapBase;
   uint32_t       rd[kKpt];  // digit << 16 | rank inside the wave (one register per key)
@@ -786,6 +796,19 @@ __global__ __launch_bounds__(kThreads, MGS_OS_WAVES) void k_os_pass(const OsPass
   // bits that tell the digits of this pass apart: 8, or — sorting on the rank of key >> 16 — as many as the largest rank has
   [[maybe_unused]] const int rankBits = (REMAP && useRemap) ? 32 - __builtin_clz(plan->remapPadRank | 1u) : 8;
   MGS_OS_STAMP(2)
+  // Round 6 — flat level 2 (sorts of at most 32 groups = 1 024 partitions: a frame's).  The chain of rounds 3-5 — a group's last
+  // member folds its rows, publishes the group total, looks back over the group totals, publishes the inclusive prefix; every
+  // other member polls that word — is three dependent round trips that START when the last member has ranked its keys, the moment
+  // everybody else starts waiting: the partitions of a pass run in step (15-24 polls per workgroup, 5.2-7.3 us in "re-order +
+  // level 2": profiles/r6_l_os_trace_flat0.log).  Instead every partition ADDS its counts to its group's row — one fire-and-forget
+  // atomic per digit; the word carries the sum (< 2^20: 32 x 4096) and, above it, how many partitions have added — and reads the
+  // rows of ALL groups before its own (<= 31 words per digit thread, requested behind the level-1 fold, consumed behind the LDS
+  // re-order); a row counts once 32 partitions have arrived.  No last member, no dependent trips: polls per workgroup 23 -> 1 and
+  // 15 -> 0, "re-order + level 2" 7.3 -> 2.5 and 5.2 -> 2.4 us (profiles/r6_l_os_trace_flat1.log).  (Publishing the counts BEFORE the
+  // ranking as well — an LDS histogram, one atomic per key — was measured on top: no polls left to remove, and the histogram costs
+  // the ranking phase +1 us / +2.3 us even on four copies per wave: the rank pass has 5-8 digit values — dropped.)
+  const uint32_t groupsAll = (parts + kOsGroup - 1u) / kOsGroup;
+  const bool     flat      = a.flatLookback != 0u && groupsAll <= 32u;
 
   // ---- (the look-back is software-pipelined with the rest of the pass: level 1 is issued right after the partition's own
   // counts are published, behind the ranking, and consumed behind the scans; level 2 travels behind the LDS re-order) ----
@@ -838,6 +861,8 @@ __global__ __launch_bounds__(kThreads, MGS_OS_WAVES) void k_os_pass(const OsPass
   const uint32_t padDigit = (REMAP && useRemap) ? plan->remapPadRank : 255u;
   const uint32_t myCount  = tot - (((uint32_t)t == padDigit) ? rounds * kThreads - count : 0u);
   stAgent(&a.status[(size_t)p * 256u + t], kAgg | myCount);
+  if(flat)
+    __hip_atomic_fetch_add(&a.gstatus[(size_t)g * 256u + t], myCount | (1u << 20), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // Level 1 by rows: the counts a member published are one 1 KB row (256 digits).  Wave w folds the rows w, w + 4, ... of the
   // members before me for four digits per lane (lane l: digits 4 l .. 4 l + 3);
   // the four waves' partial sums meet in LDS.  Issued now, consumed behind the scans.
@@ -893,7 +918,7 @@ __global__ __launch_bounds__(kThreads, MGS_OS_WAVES) void k_os_pass(const OsPass
   // first inclusive prefix) and publishes the inclusive prefix — so that the 31 other members, which fold behind their scans
   // and need that one word behind their LDS re-order, find it there.  It finishes ~3 us behind them instead of all of them
   // waiting ~5 us for it.
-  const bool lastMember = m == kOsGroup - 1u;
+  const bool lastMember = !flat && m == kOsGroup - 1u;
   if(lastMember)
   {
     foldRows();
@@ -942,6 +967,19 @@ __global__ __launch_bounds__(kThreads, MGS_OS_WAVES) void k_os_pass(const OsPass
   const uint32_t below = scan256(plan->total[a.pass][t], s_tmp);
   if(!lastMember)
     foldRows();
+  // flat level 2: the counted sums of the groups before mine, thread t == digit t, all requested now (the registers of the
+  // level-1 rows are free), consumed behind the re-order
+  uint32_t gl[31];
+  if(flat)
+  {
+#pragma unroll
+    for(uint32_t k = 0; k < 31u; ++k)
+    {
+      gl[k] = 32u << 20;
+      if(k < g)
+        gl[k] = ldAgent(&a.gstatus[(size_t)k * 256u + t]);
+    }
+  }
   __syncthreads();  // everybody has read the partial sums: s_pair may be overwritten
   MGS_OS_STAMP(4)
   // ---- re-order through LDS so that equal digits are contiguous ----
@@ -953,7 +991,22 @@ __global__ __launch_bounds__(kThreads, MGS_OS_WAVES) void k_os_pass(const OsPass
       const uint32_t pos = (uint32_t)s_loff[d] + (uint32_t)s_whist[w][d] + (rd[i] & 0xFFFFu);
       s_pair[pos]        = make_uint2(key[i], val[i]);
     }
-  if(!lastMember && g > 0u)
+  if(flat)
+  {
+#pragma unroll
+    for(uint32_t k = 0; k < 31u; ++k)
+      if(k < g)
+      {
+        while((gl[k] >> 20) != kOsGroup && !bad)
+        {
+          gl[k] = ldAgent(&a.gstatus[(size_t)k * 256u + t]);
+          if(++spins > kSpinMax)
+            bad = true;
+        }
+        base += gl[k] & 0xFFFFFu;
+      }
+  }
+  else if(!lastMember && g > 0u)
   {  // the inclusive prefix of the previous group is one word
     uint32_t v;
     while(((v = ldAgent(&a.gstatus[(size_t)(g - 1u) * 256u + t])) >> 30) != 2u)
@@ -1144,6 +1197,8 @@ void launchOsSort(hipStream_t stream, const OsLaunch& L)
     a.pass    = pass;
     a.partMin  = partMin;
     a.resSlots = resSlots;
+    static const uint32_t kFlat = [] { const char* e = std::getenv("MGS_OS_FLAT"); return e ? (uint32_t)std::atoi(e) : 1u; }();
+    a.flatLookback = kFlat;
     a.dstKeys = L.outKeys;
     a.dstVals = L.outVals;
     // stand-alone: pass 0 -> A, 1 -> B, 2 -> A, 3 -> the result.  Frame: pass 1 reads the project kernels' slots, which live in B,
