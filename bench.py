@@ -193,7 +193,8 @@ def main():
     scene.commit(args.sh_format, args.rgba_format)
     for c in range(K):
         sc_k = scene if c == 0 else scene.frame_context()
-        st_k = torch.cuda.Stream()        # a real (non-null) stream shared by this context's renderer and RCCL
+        st_k = torch.cuda.Stream()        # a real (non-null) stream shared by this context's renderer and RCCL (equal priorities: a high-priority context
+                                          # starves the others — 3 800 -> 3 630 frames/s, profiles/r6_q_prio.log)
         sc_k.set_stream(st_k.cuda_stream)
         scenes.append(sc_k)
         streams.append(st_k)
@@ -362,6 +363,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t1
     intervals = np.array([done_ev[i].elapsed_time(done_ev[i + 1]) for i in range(args.steps - 1)], np.float64) if args.steps > 2 else np.zeros(1)
+    if os.environ.get("MGS_BENCH_DUMP_INTERVALS"):  # debugging aid: the completion intervals of the timed frames, in order
+        print("INTERVALS", " ".join("%.3f" % x for x in intervals[:64]), file=sys.stderr)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
