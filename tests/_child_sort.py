@@ -23,7 +23,7 @@ def check(k, v, name):
 # sizes around the structural thresholds: one partition (4096), one look-back group (32 partitions = 131072), one window of
 # groups (16 groups = 2 M), strip-sized, multi-million
 for n in [0, 1, 2, 255, 256, 257, 4095, 4096, 4097, 8191, 8193, 40_000, 131_071, 131_072, 131_073, 262_145, 2_097_152, 2_097_153,
-          2_500_000, 5_000_011]:
+          2_500_000, 4_190_208, 4_194_304, 4_194_305, 5_000_011]:  # (1 023 / 1 024 partitions: the largest sorts of the flat level 2; 1 025: the chain)
     rng = np.random.default_rng(n)
     check(rng.integers(0, 2**32, n, dtype=np.uint32), rng.integers(0, 2**32, n, dtype=np.uint32), f"n={n}")
 rng = np.random.default_rng(99)
@@ -50,6 +50,11 @@ n2 = 6_000_000
 k2 = np.full(n2, 5, np.uint32)
 k2[rng.integers(0, n2, 1000)] = rng.integers(0, 2**32, 1000, dtype=np.uint32)
 check(k2, np.arange(n2, dtype=np.uint32), "6 M keys, one value")
+# ... and over exactly 32 full groups: every counted sum of the flat level 2 carries its largest value (32 x 4096 in one digit)
+n3 = 4_194_304
+k3 = np.full(n3, 0x3F7FFFFF, np.uint32)
+k3[rng.integers(0, n3, 1000)] = rng.integers(0, 2**32, 1000, dtype=np.uint32)
+check(k3, np.arange(n3, dtype=np.uint32)[::-1].copy(), "4 M keys, one value, 1 024 partitions")
 print("SORTS_OK")
 
 # frames: the in-frame key sort feeds binning and compositing
