@@ -157,7 +157,7 @@ def test_key_sort_variants_are_bit_identical_to_the_stable_sort():
                             ("gather", {"MGS_RECT_RIDE": "0"}), ("nohistory", {"MGS_BIN_HISTORY": "0"}),
                             ("split", {"MGS_RIDE_SPLIT": "2"}), ("storageorder", {"MGS_PRJ_ORDER": "0"}),
                             ("fullproducts", {"MGS_EXACT_SHORTCUTS": "0"}), ("ballotmasks", {"MGS_DB_TRANSPOSE": "0"}),
-                            ("chain", {"MGS_OS_FLAT": "0"})):
+                            ("chain", {"MGS_OS_FLAT": "0"}), ("fixedpart", {"MGS_OS_PART_MIN": "4096"}), ("part1024", {"MGS_OS_PART_MIN": "1024"})):
         r = subprocess.run([sys.executable, child], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
         assert "SORTS_OK" in r.stdout, r.stdout[-3000:]
@@ -174,6 +174,8 @@ def test_key_sort_variants_are_bit_identical_to_the_stable_sort():
     # chain: the sort passes' level-2 look-back as the chain of group prefixes of rounds 3-5 instead of round 6's counted sums
     # (k_osort.hip: flat level 2; sorts of more than 1 024 partitions always take the chain)
     assert out["default"] == out["chain"]
+    # fixedpart / part1024: the sort's partitions fixed at 4 096 pairs / chosen on the device down to 1 024 (default: down to 1 536)
+    assert out["default"] == out["fixedpart"] == out["part1024"]
 
 
 

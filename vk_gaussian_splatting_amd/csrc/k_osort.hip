@@ -502,8 +502,7 @@ struct OsPassArgs
   int             pass;
   int             digitMode;  // 0 plain byte `pass`; 1 pass 2: rank of key >> 16 when the plan says remap, else plain; 2 pass 3: exits when remapped
   int             finalMode;  // 0 writes pairs; 1 writes the result; 2 writes the result iff the plan says remap (pass 2)
-  // Round 6 (A/B knob, off by default): the partition size chosen ON THE DEVICE from the element count (osPartOf below) — 1024 or
-  // 2048 pairs when that many partitions still fit the grid and one residency wave of the chip, else kOsPart.
+  // Round 6: the partition size chosen ON THE DEVICE from the element count (osPartOf below): ~384 partitions between partMin and kOsPart
   uint32_t        partMin;    // smallest partition size allowed (kOsPart: the fixed size of rounds 3-5; A/B)
   uint32_t        resSlots;   // workgroups of this kernel the chip holds at once
   uint32_t        flatLookback;  // 1: sorts of at most 32 groups resolve the groups before a partition from COUNTED SUMS instead of the chain of group prefixes (below; MGS_OS_FLAT)
@@ -511,18 +510,26 @@ struct OsPassArgs
 
 // A sort of few keys used to run on few workgroups: a strip's 0.32 M keys were 78 partitions of 4096 on 256 CUs, a train-sized
 // frame's 0.74 M were 181 (64 us and 54 us, a third of a strip's frame).  The rounds of a partition adapt to its element
-// count anyway (the ragged last one), so the SAME kernel takes partitions of 1024 or 2048 pairs: every workgroup derives the size
-// from n (device-side count, identical for all) and the grid the host launched — no host-side guess, nothing in the graph key.
-// Smaller partitions are taken only while all of them are resident at once: the look-back then never waits for a workgroup that
-// has not started.
+// count anyway (the ragged last one), so the SAME kernel takes smaller partitions: every workgroup derives the size from n
+// (device-side count, identical for all) and the grid the host launched — no host-side guess, nothing in the graph key.  The size:
+// ~384 partitions, in steps of 512 pairs, between partMin (1 536) and 4 096 — so every sort above 1.5 M keys keeps 4 096 — and only
+// while all partitions are resident at once.  Round 6's first measurement of this (with the CHAIN as level 2 of the look-back) found
+// no gain: what small partitions saved in the table's expansion and the ranking they paid in the look-back (four times the
+// members and groups to wait for).  With the flat level 2 nothing waits, and the smaller partitions pay: same box x3 alternating
+// (profiles/r6_x2_sort_part_adaptive_ab.log), sort of a top strip of eight 72.2 -> 51.1 us (its frame +14 %), a middle strip 62.0
+// -> 58.2, a 400 K-splat scene 52.6 -> 42.2, train-sized 52.0 -> 49.1, sparse 54.7 -> 52.0; 1.3 M keys and more: unchanged.
+// (Fixed 2 048 instead: within 2 us of this rule on every workload, 5 us worse on the top strip; 2 048 for a 2 M-key sort — 980
+// partitions — is 6 us WORSE than 4 096: profiles/r6_x_sort_part_sweep.log, r6_x3_sort_part_rules.log.)  MGS_OS_PART_MIN=4096: the
+// fixed size of rounds 3-5 (A/B; the variants test runs it).
 __device__ __forceinline__ uint32_t osPartOf(uint32_t n, uint32_t grid, uint32_t partMin, uint32_t resSlots)
 {
-  const uint32_t cap = min(grid, resSlots);
-  if(partMin <= 1024u && (n + 1023u) / 1024u <= cap)
-    return 1024u;
-  if(partMin <= 2048u && (n + 2047u) / 2048u <= cap)
-    return 2048u;
-  return kOsPart;
+  if(partMin >= kOsPart)
+    return kOsPart;
+  // ~384 partitions, in steps of 512 pairs, between partMin and kOsPart (round 6, with the flat level 2: below)
+  const uint32_t cap  = min(grid, resSlots);
+  const uint32_t want = ((n / 384u + 511u) / 512u) * 512u;
+  const uint32_t part = min(max(want, partMin), kOsPart);
+  return (n + part - 1u) / part <= cap ? part : kOsPart;
 }
 
 #ifndef MGS_OS_WAVES
@@ -1087,18 +1094,14 @@ __global__ void k_os_plan_clear(OsPlan* plan)
 // as many workgroups as 1024-pair partitions of that count, up to kOsSmallGrid, so that a sort of few keys can spread over the chip
 // (osPartOf).  Workgroups beyond the partitions exit after the set-up.
 constexpr uint32_t kOsSmallGrid = 1024;
-// MGS_OS_PART_MIN=1024 | 2048 switches the device-side choice on (default: the fixed kOsPart).  Measured in round 6 on one box,
-// alternating (profiles/r6_a_sort_part_ab.log, r6_a_os_trace_strip*.log): a middle strip's sort 64.5 us at 78-212 partitions of
-// 4096 vs 64.8 us at 313-846 of 1024; train-sized 54.6 vs 54.6; garden and configs[4] never choose the small size.  What the
-// smaller partitions save in the table's expansion and the ranking (pass 1: 11.8 -> 5.8 us, 4.6 -> 2.7 us per workgroup) they pay
-// in the look-back (publish .. level 2: 5.4 -> 10.3 us: four times the members to wait for): a pass of few keys is its chain of
-// dependent round trips (~16-20 us) whatever the partition size.  Kept as an A/B knob, off by default.
+// MGS_OS_PART_MIN = the smallest partition size the passes may choose on the device (osPartOf above; a multiple of 256 in
+// [1024, 4096]; default 1 536; 4096 = the fixed size of rounds 3-5).
 static uint32_t osPartMinEnv()
 {
   static const uint32_t v = [] {
     const char* e = std::getenv("MGS_OS_PART_MIN");
     const int   x = e ? std::atoi(e) : 0;
-    return (x == 1024 || x == 2048) ? (uint32_t)x : kOsPart;
+    return (x >= 1024 && x <= (int)kOsPart && x % 256 == 0) ? (uint32_t)x : 1536u;
   }();
   return v;
 }
