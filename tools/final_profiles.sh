@@ -1,6 +1,6 @@
 #!/bin/bash
 # everything behind profiles/${TAG}_*: run on the GPU box (gpurun), results land in gpurun_out/ (copy to profiles/ afterwards)
-export TAG=${TAG:-r5_z}; R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out
+export TAG=${TAG:-r6_z}; R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out
 python bench.py 2>/dev/null | grep '^{' | tail -1 > gpurun_out/${TAG}_bench_if3.json
 python bench.py --inflight 1 2>/dev/null | grep '^{' | tail -1 > gpurun_out/${TAG}_bench_if1.json
 bash tools/collect_profiles.sh > gpurun_out/${TAG}_collect.log 2>&1
