@@ -373,9 +373,9 @@ def main():
         fence()
     # Pre-roll (untimed, like the warm-up): the calibration frames above are synchronous — the GPU idles between them and falls
     # out of its sustained clocks, and a timed region of 20 frames (5 ms) that starts there reads 6-9 % low (round 6:
-    # 3 430-3 560 frames/s against 3 720-3 870 at 128 steps; profiles/r6_p_warmup.log).  MGS_BENCH_PREROLL dense frames through the
+    # 3 430-3 560 frames/s against 3 720-3 870 at 128 steps; profiles/r6_p_warmup.log).  MGS_BENCH_PREROLL (default 128) dense frames through the
     # same step() as the timed ones put the device where a running renderer has it; then the fence, then the K timed frames.
-    preroll = int(os.environ.get("MGS_BENCH_PREROLL", "48"))
+    preroll = int(os.environ.get("MGS_BENCH_PREROLL", "128"))
     for i in range(preroll):
         step(args.warmup + i)
     fence()
